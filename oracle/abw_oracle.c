@@ -1,0 +1,502 @@
+/* TEST INFRASTRUCTURE — NOT part of the product path.  See abw_oracle.h for scope and pinning.
+ *
+ * Plain-C restatement of the reference's algorithms, deliberately written the way the REFERENCE
+ * computes (rolling decimal keys; sort + sweep with TP/FP bookkeeping) and not the way the HIP
+ * kernels do (2-bit codes + suffix marginals; histograms + scans), so that agreement between the
+ * two is evidence and not tautology.
+ */
+#include "abw_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---------------------------------------------------------------------------------------- */
+/* mer table — reference src/abawaca-build.cpp:75-100                                        */
+/* ---------------------------------------------------------------------------------------- */
+static int mer_block_offset(int k) { return k == 1 ? 0 : k == 2 ? 4 : k == 3 ? 20 : 84; }
+
+void abw_or_mer_table(int32_t mer2dim[ABW_OR_NMERS])
+{
+    /* ids are handed out in enumeration order (k = 1..4, lexicographic A<C<G<T) to the first of
+     * {mer, reverse complement} that appears (:79-86); the other one re-uses the id. */
+    int32_t next_id = 0;
+    for (int i = 0; i < ABW_OR_NMERS; i++) mer2dim[i] = -1;
+    for (int k = 1; k <= 4; k++) {
+        int off = mer_block_offset(k), n = 1 << (2 * k);
+        for (int m = 0; m < n; m++) {
+            int rc = 0;
+            for (int i = 0; i < k; i++) {             /* digit i (from least significant) */
+                int dgt = (m >> (2 * i)) & 3;
+                rc = (rc << 2) | (3 - dgt);           /* complement, reversed */
+            }
+            if (mer2dim[off + rc] >= 0) mer2dim[off + m] = mer2dim[off + rc];
+            else mer2dim[off + m] = next_id++;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* DNAString upper-casing — reference src/String.cpp:37-51                                   */
+/* ---------------------------------------------------------------------------------------- */
+int abw_or_upcase(uint8_t* seq, uint64_t len)
+{
+    for (uint64_t i = 0; i < len; i++) {
+        uint8_t c = seq[i];
+        if (c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N') continue;
+        if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 'a' + 'A');   /* toupper, C locale */
+        seq[i] = c;
+        if (c == 'N') return -1;                                   /* :47-49 throws */
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* segmentation — reference src/abawaca-build.cpp:198-228                                    */
+/* ---------------------------------------------------------------------------------------- */
+uint64_t abw_or_segments(const uint8_t* seq, uint64_t len, uint32_t window,
+                         uint64_t* start, uint64_t* end, uint64_t cap)
+{
+    uint64_t Ns = 0;
+    for (uint64_t i = 0; i < len; i++) Ns += (seq[i] == 'N');      /* Bio::Ns, String.cpp:134-146 */
+    uint64_t nsegments = (len - Ns) / window;                       /* :202 */
+    if (nsegments == 0) nsegments = 1;                              /* :204-205 */
+    uint64_t nbps = (len - Ns) / nsegments;                         /* :206 */
+    uint64_t nbps_segment = 0, sit = 0, n = 0;
+    for (uint64_t it = 0; it < len; it++) {                         /* :209-225 */
+        if (seq[it] != 'N') nbps_segment++;
+        if (nbps_segment == nbps) {
+            if (n < cap) { start[n] = sit + 1; end[n] = it + 1; }   /* :216, 1-based inclusive */
+            n++;
+            sit = it + 1;
+            nbps_segment = 0;
+        }
+    }
+    return n;                                                       /* tail dropped, :227 */
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* signature — reference src/abawaca-build.cpp:103-174                                       */
+/* ---------------------------------------------------------------------------------------- */
+static int dec_digit(uint8_t c)
+{
+    switch (c) { case 'A': return 2; case 'C': return 3; case 'G': return 4; case 'T': return 5; default: return 0; }
+}
+
+void abw_or_signature(const uint8_t* seg, uint64_t len, double dims[ABW_OR_NDIMS],
+                      uint32_t* counts, uint32_t* totals)
+{
+    static int32_t mer2dim[ABW_OR_NMERS];
+    static int have_table = 0;
+    if (!have_table) { abw_or_mer_table(mer2dim); have_table = 1; }
+
+    for (int i = 0; i < ABW_OR_NDIMS; i++) dims[i] = 0.0;
+    if (counts) memset(counts, 0, ABW_OR_NMERS * sizeof(uint32_t));
+    if (totals) memset(totals, 0, 4 * sizeof(uint32_t));
+
+    int factor = 10, N_limit = 1;                                   /* :112-113 */
+    for (int k = 1; k <= 4; k++, N_limit *= 10, factor *= 10) {     /* :114 */
+        if (len < (uint64_t)k) continue;                            /* :116-117 */
+        uint32_t cnt[6000];                                         /* indexed by decimal key <= 5555 */
+        memset(cnt, 0, sizeof(cnt));
+        int key = 0, total = 0;
+        uint64_t pos = 0;
+        while (pos < (uint64_t)k) {                                 /* first mer, :124-133 */
+            key *= 10;
+            int dgt = dec_digit(seg[pos++]);
+            if (dgt) key += dgt; else key = 0;
+        }
+        if (key > N_limit) { cnt[key]++; total++; }                 /* :134-137 */
+        while (pos < len) {                                         /* :139-155 */
+            key *= 10;
+            key = key % factor;
+            int dgt = dec_digit(seg[pos++]);
+            if (dgt) key += dgt; else key = 0;
+            if (key > N_limit) { cnt[key]++; total++; }
+        }
+        if (totals) totals[k - 1] = (uint32_t)total;
+        for (int key2 = 0; key2 < 6000; key2++) {                   /* :157-172 (map order is irrelevant:   */
+            if (!cnt[key2]) continue;                               /*  each dim gets at most two addends)  */
+            int m = 0, ok = 1;
+            for (int p = factor / 10; p > 0; p /= 10) {             /* decode the k digits */
+                int dg = (key2 / p) % 10;
+                if (dg < 2 || dg > 5) { ok = 0; break; }
+                m = (m << 2) | (dg - 2);
+            }
+            if (!ok) continue;                                      /* cannot happen for key > N_limit */
+            if (counts) counts[mer_block_offset(k) + m] = cnt[key2];
+            dims[mer2dim[mer_block_offset(k) + m]] += (total != 0) ? ((double)cnt[key2] / total) : 0;   /* :171 */
+        }
+    }
+}
+
+int32_t abw_or_milli(double x) { return (int32_t)(1000.0 * x); }   /* :603 */
+
+/* ---------------------------------------------------------------------------------------- */
+/* separator                                                                                 */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t tp, fp, tot;          /* true_positives, false_positives, total_dps_for_assigned_scafs */
+} or_stats;
+
+typedef struct { int32_t key; int32_t local; } or_kv;
+
+static int cmp_kv(const void* a, const void* b)
+{
+    int32_t x = ((const or_kv*)a)->key, y = ((const or_kv*)b)->key;
+    return (x > y) - (x < y);
+}
+
+/* ClusteringResult::is_better — reference src/ClusterSeparatorBySensitivitySpecificity.h:25-30
+ * with the base-class tie-break of src/ClusterSeparator.cpp:11-16.  dim: size_t, (size_t)-1 = none. */
+static int cr_is_better(double sens, double spec, uint64_t dim, double value,
+                        double osens, double ospec, uint64_t odim, double ovalue)
+{
+    double a = sens * spec, b = osens * ospec;
+    if (a != b) return a >= b;
+    if (dim != odim) return dim < odim;
+    return value < ovalue;
+}
+
+/* ClusterQuality::is_split_better — reference src/ClusterQuality.cpp:96-136 (symmetric in its
+ * two arguments).  side[ls] in {1,2}: cluster the node-local scaffold ls is assigned to. */
+static int gate_is_split_better(const uint8_t* side, const int32_t* node_scafs, int32_t m,
+                                const int64_t* scaf_len, const int32_t* scg_off, const int32_t* scg_ids,
+                                int32_t n_scg, int32_t* scratch /* 2*n_scg */)
+{
+    int32_t* c1 = scratch;
+    int32_t* c2 = scratch + n_scg;
+    memset(scratch, 0, sizeof(int32_t) * 2 * (size_t)n_scg);
+    int64_t size1 = 0, size2 = 0;
+    for (int32_t ls = 0; ls < m; ls++) {
+        int32_t s = node_scafs[ls];
+        if (side[ls] == 1) size1 += scaf_len[s]; else size2 += scaf_len[s];
+        if (!scg_off) continue;
+        for (int32_t e = scg_off[s]; e < scg_off[s + 1]; e++) {
+            if (side[ls] == 1) c1[scg_ids[e]]++; else c2[scg_ids[e]]++;
+        }
+    }
+    int64_t g1 = 0, g2 = 0, both = 0;
+    for (int32_t g = 0; g < n_scg; g++) {
+        g1 += c1[g] > 0; g2 += c2[g] > 0; both += (c1[g] > 0 && c2[g] > 0);
+    }
+    if (g1 == 0 || g2 == 0) return (size1 >= 500000) && (size2 >= 500000);   /* :118-120 */
+    if ((double)both / (double)(g1 < g2 ? g1 : g2) < 0.2) return 0;            /* :130-131 */
+    return 1;
+}
+
+int abw_or_separate(const int32_t* keys, int64_t N, int32_t D,
+                    const int32_t* dp2scaf, const int32_t* scaf_ndps, const int64_t* scaf_len, int32_t S,
+                    const int32_t* scg_off, const int32_t* scg_ids, int32_t n_scg,
+                    const int32_t* node_dps, int64_t n, int32_t min_ndps, int nthreads,
+                    abw_or_split* out, abw_or_dimbest* per_dim,
+                    uint8_t* dp_raw_side, uint8_t* scaf_side)
+{
+    if (n <= 0 || D <= 0) return -1;
+    /* node-local scaffold numbering */
+    int32_t* g2l = (int32_t*)malloc(sizeof(int32_t) * (size_t)S);
+    int32_t* node_scafs = (int32_t*)malloc(sizeof(int32_t) * (size_t)S);
+    int32_t* lscaf = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    if (!g2l || !node_scafs || !lscaf) return -2;
+    for (int32_t s = 0; s < S; s++) g2l[s] = -1;
+    int32_t m = 0;
+    for (int64_t i = 0; i < n; i++) {
+        int32_t s = dp2scaf[node_dps[i]];
+        if (g2l[s] < 0) { g2l[s] = m; node_scafs[m++] = s; }
+        lscaf[i] = g2l[s];
+    }
+
+    abw_or_dimbest* dimbest = per_dim ? per_dim : (abw_or_dimbest*)malloc(sizeof(abw_or_dimbest) * (size_t)D);
+    int err = 0;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+
+    /* one "thread" per dimension like reference src/ClusterSeparator.cpp:72-78 */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int32_t d = 0; d < D; d++) {
+        /* separate_dimension — reference src/ClusterSeparatorBySensitivitySpecificity.cpp:91-143 */
+        or_kv* dps = (or_kv*)malloc(sizeof(or_kv) * (size_t)n);
+        int32_t* cnt1 = (int32_t*)calloc((size_t)m, sizeof(int32_t));
+        int32_t* cnt2 = (int32_t*)calloc((size_t)m, sizeof(int32_t));
+        uint8_t* side = (uint8_t*)malloc((size_t)m);            /* which cluster the scaffold is assigned to */
+        int32_t* scratch = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(n_scg > 0 ? n_scg : 1));
+        if (!dps || !cnt1 || !cnt2 || !side || !scratch) { err = 1; free(dps); free(cnt1); free(cnt2); free(side); free(scratch); continue; }
+        or_stats s1 = {0, 0, 0}, s2 = {0, 0, 0};
+        const int32_t* col = keys + (int64_t)d * N;
+        /* :105-112 — everything starts in cluster2, every scaffold assigned to cluster2 */
+        for (int64_t i = 0; i < n; i++) {
+            dps[i].key = col[node_dps[i]];
+            dps[i].local = (int32_t)i;
+            int32_t ls = lscaf[i];
+            if (scaf_ndps[node_scafs[ls]] < 2) continue;        /* add_dp :10-11 (never true after ScafDpData.cpp:92-93) */
+            cnt2[ls]++;
+            s2.fp++;                                            /* add_dp before assign: false positive */
+        }
+        for (int32_t ls = 0; ls < m; ls++) {
+            side[ls] = 2;
+            if (scaf_ndps[node_scafs[ls]] < 2) continue;
+            s2.fp -= cnt2[ls]; s2.tp += cnt2[ls]; s2.tot += scaf_ndps[node_scafs[ls]];   /* assign_scaf :42-58 */
+        }
+        qsort(dps, (size_t)n, sizeof(or_kv), cmp_kv);           /* :114 */
+
+        int found = 0;
+        double bsens = 0, bspec = 0, bvalue = -1;
+        uint64_t bdim = (uint64_t)-1;                            /* ClusteringResult() : dimension(-1), value(-1) */
+        int32_t bkey = -1;
+        for (int64_t i = 0; i < n;) {                            /* :117-134 */
+            int32_t key = dps[i].key;
+            while (i < n && dps[i].key == key) {
+                int32_t ls = lscaf[dps[i].local];
+                int32_t tot_s = scaf_ndps[node_scafs[ls]];
+                if (tot_s >= 2) {
+                    cnt1[ls]++; if (side[ls] == 1) s1.tp++; else s1.fp++;      /* add_dp :6-21 */
+                    cnt2[ls]--; if (side[ls] == 2) s2.tp--; else s2.fp--;      /* remove_dp :24-39 */
+                    if (side[ls] == 2 && 2 * (int64_t)cnt1[ls] > tot_s) {      /* :125 */
+                        s1.fp -= cnt1[ls]; s1.tp += cnt1[ls]; s1.tot += tot_s; /* assign_scaf */
+                        s2.fp += cnt2[ls]; s2.tp -= cnt2[ls]; s2.tot -= tot_s; /* unassign_scaf :61-76 */
+                        side[ls] = 1;
+                    }
+                }
+                i++;
+            }
+            /* separate_specific :146-161 */
+            int64_t n1 = s1.tp + s1.fp, n2 = s2.tp + s2.fp;
+            if (n1 < min_ndps || n2 < min_ndps) continue;
+            const or_stats* small = (n1 < n2) ? &s1 : &s2;
+            double sens = (double)small->tp / (double)small->tot;              /* .h:75 */
+            double spec = (double)small->tp / (double)(small->tp + small->fp); /* .h:74 */
+            double value = (double)key;                          /* order-isomorphic to the .lrn double */
+            if (cr_is_better(sens, spec, (uint64_t)(d + 1), value, bsens, bspec, bdim, bvalue) &&
+                gate_is_split_better(side, node_scafs, m, scaf_len, scg_off, scg_ids, n_scg, scratch)) {
+                bsens = sens; bspec = spec; bdim = (uint64_t)(d + 1); bvalue = value; bkey = key; found = 1;
+            }
+        }
+        dimbest[d].found = found;
+        dimbest[d].key = bkey;
+        dimbest[d].sensitivity = bsens;
+        dimbest[d].specificity = bspec;
+        free(dps); free(cnt1); free(cnt2); free(side); free(scratch);
+    }
+    if (err) { free(g2l); free(node_scafs); free(lscaf); if (!per_dim) free(dimbest); return -2; }
+
+    /* global winner :137-140 — order independent (is_better is a strict total order on distinct
+     * (product, dimension, value) triples) */
+    double gsens = 0, gspec = 0, gvalue = -1;
+    uint64_t gdim = (uint64_t)-1;
+    int32_t gkey = -1;
+    for (int32_t d = 0; d < D; d++) {
+        double sens = dimbest[d].found ? dimbest[d].sensitivity : 0.0;
+        double spec = dimbest[d].found ? dimbest[d].specificity : 0.0;
+        uint64_t dim = dimbest[d].found ? (uint64_t)(d + 1) : (uint64_t)-1;
+        double value = dimbest[d].found ? (double)dimbest[d].key : -1.0;
+        if (cr_is_better(sens, spec, dim, value, gsens, gspec, gdim, gvalue)) {
+            gsens = sens; gspec = spec; gdim = dim; gvalue = value; gkey = dimbest[d].key;
+        }
+    }
+
+    memset(out, 0, sizeof(*out));
+    out->dimension = (gdim == (uint64_t)-1) ? -1 : (int32_t)gdim;
+    out->key = (gdim == (uint64_t)-1) ? -1 : gkey;
+    out->sensitivity = gsens;
+    out->specificity = gspec;
+    /* is_legal .h:31-35 */
+    out->legal = (gsens >= 0.8) && (gspec >= 0.8) && (gsens + gspec >= 1.6) && (gsens * gspec >= 0.8);
+    if (dp_raw_side) memset(dp_raw_side, 0, (size_t)n);
+    if (scaf_side) memset(scaf_side, 0, (size_t)S);
+
+    if (out->legal && gdim != (uint64_t)-1) {
+        /* reconstruct_best_clusters — reference src/ClusterSeparator.cpp:25-54 */
+        const int32_t* col = keys + (int64_t)(gdim - 1) * N;
+        int64_t le = 0, gt = 0;
+        for (int64_t i = 0; i < n; i++) {
+            int useful = scaf_ndps[dp2scaf[node_dps[i]]] > 1;
+            if (col[node_dps[i]] <= gkey) le += useful; else gt += useful;
+        }
+        int swap = gt < le;                                      /* :49-53: cluster1 = the smaller one */
+        int32_t* c1cnt = (int32_t*)calloc((size_t)m, sizeof(int32_t));
+        int32_t* c2cnt = (int32_t*)calloc((size_t)m, sizeof(int32_t));
+        uint8_t* raw = (uint8_t*)malloc((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            int in_le = col[node_dps[i]] <= gkey;
+            int c = (in_le != swap) ? 1 : 2;
+            raw[i] = (uint8_t)c;
+            if (c == 1) c1cnt[lscaf[i]]++; else c2cnt[lscaf[i]]++;
+        }
+        if (dp_raw_side) memcpy(dp_raw_side, raw, (size_t)n);    /* :87-90 */
+        /* scaffold assignment :94-101, dp moves :104-122 */
+        int64_t nd1 = 0, nd2 = 0;
+        uint8_t* fin = (uint8_t*)malloc((size_t)m);
+        for (int32_t ls = 0; ls < m; ls++) {
+            int32_t tot_s = scaf_ndps[node_scafs[ls]];
+            int a1 = (c1cnt[ls] > 0) && (2 * (int64_t)c1cnt[ls] >= tot_s);
+            int a2 = (c2cnt[ls] > 0) && (2 * (int64_t)c2cnt[ls] > tot_s);
+            /* dps of a scaffold assigned to neither stay where they are (cannot happen for whole scaffolds) */
+            if (a1) { fin[ls] = 1; nd1 += c1cnt[ls] + c2cnt[ls]; }
+            else if (a2) { fin[ls] = 2; nd2 += c1cnt[ls] + c2cnt[ls]; }
+            else { fin[ls] = 3; nd1 += c2cnt[ls]; nd2 += c1cnt[ls]; }   /* both halves swap sides (:104-122) */
+        }
+        if (nd1 >= min_ndps && nd2 >= min_ndps) {                /* :125-132 */
+            out->split = 1;
+            out->ndps1 = nd1; out->ndps2 = nd2;
+            if (scaf_side) for (int32_t ls = 0; ls < m; ls++) scaf_side[node_scafs[ls]] = fin[ls];
+        } else {
+            out->dimension = -1; out->key = -1; out->sensitivity = 0; out->specificity = 0;   /* best_separation->reset() :130 */
+            if (dp_raw_side) { /* raw sets are left filled by the reference (:87-90 ran); keep them */ }
+        }
+        free(c1cnt); free(c2cnt); free(raw); free(fin);
+    }
+    free(g2l); free(node_scafs); free(lscaf);
+    if (!per_dim) free(dimbest);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* TinyMT32 — reference tinymt32.c:62-76, tinymt32.h:70-107                                  */
+/* ---------------------------------------------------------------------------------------- */
+#define OR_MAT1 0x8f7011eeU   /* reference src/misc.cpp:29 */
+#define OR_MAT2 0xfc78ff1fU   /* :30 */
+#define OR_TMAT 0x3793fdffU   /* :31 */
+
+static void tinymt_next_state(abw_or_tinymt* t)
+{
+    uint32_t y = t->s[3];
+    uint32_t x = (t->s[0] & 0x7fffffffU) ^ t->s[1] ^ t->s[2];
+    x ^= (x << 1);
+    y ^= (y >> 1) ^ x;
+    t->s[0] = t->s[1];
+    t->s[1] = t->s[2];
+    t->s[2] = x ^ (y << 10);
+    t->s[3] = y;
+    uint32_t mask = (uint32_t)(-(int32_t)(y & 1));
+    t->s[1] ^= mask & OR_MAT1;
+    t->s[2] ^= mask & OR_MAT2;
+}
+
+void abw_or_tinymt_init(abw_or_tinymt* t, uint32_t seed)
+{
+    t->s[0] = seed; t->s[1] = OR_MAT1; t->s[2] = OR_MAT2; t->s[3] = OR_TMAT;
+    for (uint32_t i = 1; i < 8; i++)
+        t->s[i & 3] ^= i + 1812433253U * (t->s[(i - 1) & 3] ^ (t->s[(i - 1) & 3] >> 30));
+    if ((t->s[0] & 0x7fffffffU) == 0 && t->s[1] == 0 && t->s[2] == 0 && t->s[3] == 0) {
+        t->s[0] = 'T'; t->s[1] = 'I'; t->s[2] = 'N'; t->s[3] = 'Y';
+    }
+    for (int i = 0; i < 8; i++) tinymt_next_state(t);
+}
+
+uint32_t abw_or_tinymt_next(abw_or_tinymt* t)
+{
+    tinymt_next_state(t);
+    uint32_t t0 = t->s[3];
+    uint32_t t1 = t->s[0] + (t->s[2] >> 8);
+    t0 ^= t1;
+    t0 ^= (uint32_t)(-(int32_t)(t1 & 1)) & OR_TMAT;
+    return t0;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* K-means restarts (extension; semantics fixed in DESIGN.md "K-means")                      */
+/* ---------------------------------------------------------------------------------------- */
+#define KM_TILE 32
+
+static void km_scores(const float* xp, const float* c0, const float* c1, float h0, float h1, int32_t d,
+                      float* s0, float* s1)
+{
+    float a0 = -h0, a1 = -h1;
+    for (int32_t j = 0; j < d; j++) { a0 = fmaf(xp[j], c0[j], a0); a1 = fmaf(xp[j], c1[j], a1); }
+    *s0 = a0; *s1 = a1;
+}
+
+int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed, int32_t iters,
+                  int32_t groups, int nthreads, uint8_t* assign, float* centroids, double* inertia)
+{
+    if (N < 2 || d < 1 || R < 1 || groups < 1) return -1;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+    int64_t ntiles = (N + KM_TILE - 1) / KM_TILE;
+    /* total sums (shared by all restarts): tile partial in fp32 in point order, tiles into their
+     * group's fp64 accumulator in tile order, groups added in group order */
+    double* total = (double*)calloc((size_t)d, sizeof(double));
+    {
+        double* gacc = (double*)calloc((size_t)groups * d, sizeof(double));
+        for (int64_t t = 0; t < ntiles; t++) {
+            int64_t p0 = t * KM_TILE, p1 = p0 + KM_TILE < N ? p0 + KM_TILE : N;
+            double* ga = gacc + (size_t)(t % groups) * d;
+            for (int32_t j = 0; j < d; j++) {
+                float part = 0.0f;
+                for (int64_t p = p0; p < p1; p++) part = part + x[p * d + j];
+                ga[j] += (double)part;
+            }
+        }
+        for (int32_t g = 0; g < groups; g++) for (int32_t j = 0; j < d; j++) total[j] += gacc[(size_t)g * d + j];
+        free(gacc);
+    }
+    int err = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int32_t r = 0; r < R; r++) {
+        float* c = centroids + (size_t)r * 2 * d;
+        uint8_t* a = assign + (size_t)r * N;
+        double* gacc = (double*)malloc(sizeof(double) * (size_t)groups * (d + 2));
+        if (!gacc) { err = 1; continue; }
+        abw_or_tinymt t;
+        abw_or_tinymt_init(&t, base_seed + (uint32_t)r);
+        int64_t i0 = (int64_t)(abw_or_tinymt_next(&t) % (uint64_t)N);
+        int64_t i1 = i0;
+        for (int tries = 0; tries < 64 && i1 == i0; tries++) i1 = (int64_t)(abw_or_tinymt_next(&t) % (uint64_t)N);
+        memcpy(c, x + i0 * d, sizeof(float) * d);
+        memcpy(c + d, x + i1 * d, sizeof(float) * d);
+        double inert = 0;
+        for (int32_t it = 0; it <= iters; it++) {
+            /* half squared norms, fp32 fma chain */
+            float n0 = 0.0f, n1 = 0.0f;
+            for (int32_t j = 0; j < d; j++) { n0 = fmaf(c[j], c[j], n0); n1 = fmaf(c[d + j], c[d + j], n1); }
+            float h0 = 0.5f * n0, h1 = 0.5f * n1;
+            /* per group: [0..d) cluster-1 sums, [d] cluster-1 count, [d+1] inertia */
+            memset(gacc, 0, sizeof(double) * (size_t)groups * (d + 2));
+            for (int64_t tl = 0; tl < ntiles; tl++) {
+                int64_t p0 = tl * KM_TILE, p1 = p0 + KM_TILE < N ? p0 + KM_TILE : N;
+                double* ga = gacc + (size_t)(tl % groups) * (d + 2);
+                double tin = 0; int32_t cnt = 0;
+                for (int64_t p = p0; p < p1; p++) {
+                    float s0, s1;
+                    km_scores(x + p * d, c, c + d, h0, h1, d, &s0, &s1);
+                    uint8_t as = s1 > s0;                   /* tie -> cluster 0 */
+                    a[p] = as;
+                    cnt += as;
+                    float xn = 0.0f;
+                    for (int32_t j = 0; j < d; j++) xn = fmaf(x[p * d + j], x[p * d + j], xn);
+                    tin += (double)xn - 2.0 * (double)(as ? s1 : s0);
+                }
+                for (int32_t j = 0; j < d; j++) {
+                    float part = 0.0f;
+                    for (int64_t p = p0; p < p1; p++) part = fmaf((float)a[p], x[p * d + j], part);
+                    ga[j] += (double)part;
+                }
+                ga[d] += (double)cnt;
+                ga[d + 1] += tin;
+            }
+            double cnt1 = 0; inert = 0;
+            for (int32_t g = 0; g < groups; g++) { cnt1 += gacc[(size_t)g * (d + 2) + d]; inert += gacc[(size_t)g * (d + 2) + d + 1]; }
+            if (it == iters) break;                          /* last pass only assigns + scores */
+            double cnt0 = (double)N - cnt1;
+            for (int32_t j = 0; j < d; j++) {
+                double s1 = 0;
+                for (int32_t g = 0; g < groups; g++) s1 += gacc[(size_t)g * (d + 2) + j];
+                double s0 = total[j] - s1;
+                if (cnt0 > 0) c[j] = (float)(s0 / cnt0);
+                if (cnt1 > 0) c[d + j] = (float)(s1 / cnt1);
+            }
+        }
+        inertia[r] = inert;
+        free(gacc);
+    }
+    free(total);
+    return err ? -2 : 0;
+}

@@ -1,0 +1,123 @@
+/* TEST INFRASTRUCTURE — NOT part of the product path.
+ *
+ * CPU restatement ("oracle") of the abawaca binning hot path, written from the reference's
+ * behaviour, each function citing the reference file:line it follows (paths relative to
+ * /root/reference).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library — as the checker, never as the thing measured or shipped.
+ *
+ * Pinning: the restatement is checked in tests/test_oracle_golden.py against golden vectors
+ * produced by running the compiled reference in the build container
+ * (tests/golden/make_golden.py -> tests/golden/*.npz):
+ *   signature  — pinned (abawaca.lrn of reference abawaca-build, 214 segments incl. edge cases)
+ *   separator  — pinned (per-node dimension/value/specificity/sensitivity and final bins of the
+ *                reference's ClusterSeparatorBySensitivitySpecificity on 6 synthetic assemblies)
+ *   tinymt32   — pinned (upstream check32.out.txt + reference tinymt32.c for 6 seeds)
+ *   k-means    — PARITY UNPINNED: the reference contains no k-means; the
+ *                functions below define the algorithm the HIP path must reproduce.
+ */
+#ifndef ABW_ORACLE_H
+#define ABW_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABW_OR_NMERS 340   /* 4 + 16 + 64 + 256 */
+#define ABW_OR_NDIMS 180   /* 2 + 10 + 32 + 136 canonical 1..4-mers, "A" first */
+
+/* mer (k=1..4 blocks, base-4 digits A,C,G,T = 0..3, most significant first) -> canonical
+ * dimension index, numbered in order of first appearance.  reference src/abawaca-build.cpp:75-100 */
+void abw_or_mer_table(int32_t mer2dim[ABW_OR_NMERS]);
+
+/* Upper-cases like Bio::DNAString::validate_string (reference src/String.cpp:37-51).
+ * Returns 0, or -1 if a lower-case 'n' is met (the reference throws Illegal_DNAString). */
+int abw_or_upcase(uint8_t* seq, uint64_t len);
+
+/* Segmentation of one (already upper-cased) scaffold.  reference src/abawaca-build.cpp:198-228.
+ * start/end are 1-based inclusive like segment_coords (:216).  Returns the number of segments
+ * (writes at most cap of them). */
+uint64_t abw_or_segments(const uint8_t* seq, uint64_t len, uint32_t window,
+                         uint64_t* start, uint64_t* end, uint64_t cap);
+
+/* 1..4-mer signature of one segment: dims[180] as Scaf_segment::dimensions after the constructor,
+ * counts[340] the raw window counts (our numbering), totals[4] the per-k window totals.
+ * reference src/abawaca-build.cpp:103-174.  counts/totals may be NULL. */
+void abw_or_signature(const uint8_t* seg, uint64_t len, double dims[ABW_OR_NDIMS],
+                      uint32_t* counts, uint32_t* totals);
+
+/* int(1000.0*x) — the truncation of reference src/abawaca-build.cpp:603 (printed as %.3lf). */
+int32_t abw_or_milli(double x);
+
+/* ------------------------------------------------------------------------------------------
+ * Separator (reference src/ClusterSeparator.cpp:25-135,
+ *            src/ClusterSeparatorBySensitivitySpecificity.cpp:6-161, .h:25-35,
+ *            src/ClusterQuality.cpp:96-136, src/SCGdb.cpp:21-38)
+ *
+ * keys      : [D][N] int32, column-major over ALL dps (0-based dp ids); any order-preserving
+ *             integer image of the .lrn values (thousandths for abawaca-build output).
+ * dp2scaf   : [N] 0-based scaffold of each dp;  scaf_ndps [S]: ScafDpData::ndps(scaf);
+ * scaf_len  : [S] sequence length (ClusterQuality.cpp:111-115);
+ * scg_off/scg_ids : CSR scaffold -> SCG ids (SCGdb::scaf2scgs), n_scg distinct names.
+ * node_dps  : [n] the dps of this node.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t found;        /* 1 if some threshold passed size check + gate in this dimension */
+    int32_t key;          /* separating key (value) */
+    double  sensitivity;
+    double  specificity;
+} abw_or_dimbest;
+
+typedef struct {
+    int32_t split;        /* separate() returned true */
+    int32_t dimension;    /* 1-based like the reference; -1 if none / reset */
+    int32_t key;          /* separating key; -1 if none */
+    int32_t legal;        /* is_legal() of the global winner */
+    double  sensitivity;
+    double  specificity;
+    int64_t ndps1, ndps2; /* final cluster sizes (cluster1 = the smaller raw side) */
+} abw_or_split;
+
+/* Runs one node.  per_dim (may be NULL): [D] per-dimension winners.  dp_raw_side (may be NULL):
+ * [n] 1/2 = raw_dps_cluster1/2 membership (0 when no legal separation).  scaf_side (may be NULL):
+ * [S] 1/2 final cluster of every scaffold present in the node, 0 elsewhere / when not split.
+ * min_ndps is cluster_ndps_threshold (100, ClusterSeparator.h:72).  nthreads <= 0: all cores. */
+int abw_or_separate(const int32_t* keys, int64_t N, int32_t D,
+                    const int32_t* dp2scaf, const int32_t* scaf_ndps, const int64_t* scaf_len, int32_t S,
+                    const int32_t* scg_off, const int32_t* scg_ids, int32_t n_scg,
+                    const int32_t* node_dps, int64_t n, int32_t min_ndps, int nthreads,
+                    abw_or_split* out, abw_or_dimbest* per_dim,
+                    uint8_t* dp_raw_side, uint8_t* scaf_side);
+
+/* ------------------------------------------------------------------------------------------
+ * TinyMT32 (reference src/TinyMT-src-1.0.1/tinymt/tinymt32.c:62-76, tinymt32.h:70-107,168-171)
+ * with the parameter triple of reference src/misc.cpp:29-31.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { uint32_t s[4]; } abw_or_tinymt;
+void     abw_or_tinymt_init(abw_or_tinymt* t, uint32_t seed);
+uint32_t abw_or_tinymt_next(abw_or_tinymt* t);
+
+/* ------------------------------------------------------------------------------------------
+ * K-means restarts (EXTENSION, parity unpinned — see DESIGN.md "K-means").
+ * x: [N][d] fp32 row-major points; k = 2; R restarts.  Restart r seeds TinyMT32 with
+ * base_seed + r and takes as initial centroids the points  u0 % N  and  u1 % N  (u1 redrawn, at
+ * most 64 times, while it names the same point).
+ * Assign: score_c = fmaf-chain over j = 0..d-1 of x_j*c_j starting from -0.5f*|c|^2 (|c|^2 itself
+ *   an fp32 fmaf chain); a point goes to cluster 1 iff score_1 > score_0 (tie -> 0).  This is
+ *   argmin of the squared Euclidean distance with |x|^2 dropped.
+ * Update: points are cut into tiles of 32 consecutive points; per tile and dimension the cluster-1
+ *   members are summed in fp32 in point order (fmaf(a, x, acc), a in {0,1}); tile t's partial is
+ *   added in fp64 to accumulator (t % groups); the `groups` accumulators are then added in index
+ *   order.  sum_0 = total - sum_1 in fp64 (total built the same way from all points);
+ *   centroid = (float)(sum / count); an empty cluster keeps its centroid.
+ * `iters` assign+update rounds are followed by one assign-only pass; inertia[r] =
+ *   sum_p (|x_p|^2 - 2*score_best) in fp64, accumulated per tile in point order, tiles/groups as above.
+ * Outputs: assign [R][N] uint8, centroids [R][2][d] fp32, inertia [R] fp64.
+ * ------------------------------------------------------------------------------------------ */
+int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed, int32_t iters,
+                  int32_t groups, int nthreads, uint8_t* assign, float* centroids, double* inertia);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

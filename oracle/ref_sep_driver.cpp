@@ -1,0 +1,113 @@
+// TEST INFRASTRUCTURE — not part of the product path.
+//
+// A small driver of OUR OWN that links the reference's unmodified objects (ScafDpData,
+// ClusterData, SCGdb, ClusterSeparatorBySensitivitySpecificity, ...) and runs the same
+// work-list recursion as the reference's main loop (reference src/abawaca.cpp:95-197), but
+//   * takes the SCG-list path as an argument (the reference hard-codes an absolute path,
+//     src/abawaca.cpp:42, which does not exist here),
+//   * skips ClusterEsomWriter / fasta output (out of scope),
+//   * writes machine-readable results with full double precision, and the wall time of every
+//     separate() call (this is what bench.py's cpu_baseline "reference" leg reads).
+//
+// usage: ref_sep_driver <names> <fasta> <info> <lrn> <gene2scg|-> <scg.list> <ncpus> <out_prefix> [max_nodes]
+//
+// outputs:
+//   <out_prefix>.nodes.tsv        one row per visited node:
+//        id ndps split dim value specificity sensitivity child1 ndps1 child2 ndps2 usec
+//   <out_prefix>.scaf2cluster.tsv scaffold-name <tab> terminal cluster id (0 = none), ids 1..S
+//   <out_prefix>.dp2cluster.tsv   internal dp id <tab> terminal cluster id
+//   <out_prefix>.dpmap.tsv        internal dp id <tab> internal scaffold id   (the ScafDpData numbering)
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <chrono>
+#include <map>
+#include <string>
+#include "ScafDpData.h"
+#include "ClusterData.h"
+#include "ClusterSeparatorBySensitivitySpecificity.h"
+#include "Semaphore.h"
+#include "SCGdb.h"
+
+int main(int argc, const char** argv)
+{
+	if(argc < 9) {
+		fprintf(stderr, "usage: %s <names> <fasta> <info> <lrn> <gene2scg|-> <scg.list> <ncpus> <out_prefix> [max_nodes]\n", argv[0]);
+		return 2;
+	}
+	std::string names = argv[1], fasta = argv[2], info = argv[3], lrn = argv[4];
+	std::string gene2scg = strcmp(argv[5], "-") ? argv[5] : "";
+	std::string scg_list = argv[6];
+	int ncpus = atoi(argv[7]);
+	std::string prefix = argv[8];
+	size_t max_nodes = (argc > 9) ? strtoul(argv[9], NULL, 10) : (size_t)-1;
+
+	ScafDpData	scaf_db(names, fasta, info);
+	ClusterData	clustering_db(lrn, scaf_db);
+	SCGdb		scg_db(scaf_db, gene2scg, scg_list);
+	Semaphore	sem(ncpus);
+
+	FILE* fn = fopen((prefix + ".nodes.tsv").c_str(), "w");
+	FILE* fm = fopen((prefix + ".dpmap.tsv").c_str(), "w");
+	if(!fn || !fm) { perror("open output"); return 1; }
+	for(size_t dp = 1; dp <= scaf_db.ndps(); dp++)
+		fprintf(fm, "%lu\t%lu\n", dp, scaf_db.dp2scaf(dp));
+	fclose(fm);
+
+	std::map<size_t, Cluster*> work;
+	std::map<size_t, size_t> dp2cluster, scaf2cluster;
+	size_t next_id = 1, visited = 0;
+
+	Cluster* root = new Cluster(scaf_db);
+	for(size_t i = 1; i <= scaf_db.ndps(); i++) *root += i;
+	for(size_t i = 1; i <= scaf_db.nscafs(); i++) root->add_assigned_scaf(i);
+	work[next_id++] = root;
+
+	while(!work.empty() && visited < max_nodes) {
+		auto it = work.begin();
+		size_t id = it->first;
+		Cluster* cur = it->second;
+		work.erase(it);
+		visited++;
+
+		ClusterData* node_db = new ClusterData(clustering_db, cur->get_dps());
+		ClusterSeparatorBySensitivitySpecificity sep(scaf_db, scg_db, *node_db, sem);
+
+		auto t0 = std::chrono::steady_clock::now();
+		bool split = sep.separate();
+		auto t1 = std::chrono::steady_clock::now();
+		long usec = std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
+
+		if(!split || sep.get_cluster1() == NULL) {
+			fprintf(fn, "%lu\t%lu\t0\t%ld\t%.17g\t%.17g\t%.17g\t0\t0\t0\t0\t%ld\n", id, cur->ndps(),
+				(long)sep.get_separating_dimension(), sep.get_separating_value(),
+				sep.get_best_specificity(), sep.get_best_sensitivity(), usec);
+			for(auto s = cur->dps_begin(); s != cur->dps_end(); s++) dp2cluster[*s] = id;
+			for(auto s = cur->assigned_scafs_begin(); s != cur->assigned_scafs_end(); s++) scaf2cluster[*s] = id;
+		}
+		else {
+			size_t c1 = next_id++, c2 = next_id++;
+			fprintf(fn, "%lu\t%lu\t1\t%ld\t%.17g\t%.17g\t%.17g\t%lu\t%lu\t%lu\t%lu\t%ld\n", id, cur->ndps(),
+				(long)sep.get_separating_dimension(), sep.get_separating_value(),
+				sep.get_best_specificity(), sep.get_best_sensitivity(),
+				c1, sep.get_cluster1()->ndps(), c2, sep.get_cluster2()->ndps(), usec);
+			work[c1] = sep.get_cluster1();
+			work[c2] = sep.get_cluster2();
+		}
+		fflush(fn);
+		delete node_db;
+		delete cur;
+	}
+	fclose(fn);
+
+	FILE* fs = fopen((prefix + ".scaf2cluster.tsv").c_str(), "w");
+	FILE* fd = fopen((prefix + ".dp2cluster.tsv").c_str(), "w");
+	if(!fs || !fd) { perror("open output"); return 1; }
+	for(size_t i = 1; i <= scaf_db.nscafs(); i++)
+		fprintf(fs, "%s\t%lu\n", scaf_db.scaf_id2name(i).c_str(), scaf2cluster.count(i) ? scaf2cluster[i] : (size_t)0);
+	for(size_t i = 1; i <= scaf_db.ndps(); i++)
+		fprintf(fd, "%lu\t%lu\n", i, dp2cluster.count(i) ? dp2cluster[i] : (size_t)0);
+	fclose(fs);
+	fclose(fd);
+	return 0;
+}

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors by RUNNING THE REFERENCE in this container.
+
+Needs oracle/_ref/ (built by `make -C oracle ref` from the sources under /root/reference; nothing
+of the reference is copied).  The outputs (tests/golden/*.npz, *.json) are data only: inputs we
+synthesise and the numbers the reference printed for them.
+
+  signature cases : FASTA -> oracle/_ref/abawaca-build (reference src/abawaca-build.cpp) -> abawaca.lrn/.names
+  separator cases : the same .lrn/.names/.info + synthetic SCG table -> oracle/_ref/ref_sep_driver
+                    (our driver around the reference's ClusterSeparatorBySensitivitySpecificity)
+  tinymt          : oracle/_ref/tinymt_kat (reference's vendored tinymt32.c) for a few seeds
+
+usage: python tests/golden/make_golden.py            (from the repo root)
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from abawaca_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def run_build(asm, workdir, n_samples, sam_seed, cov_reads=True):
+    fasta = os.path.join(workdir, "asm.fa")
+    synth.write_fasta(fasta, asm)
+    for s in range(n_samples):
+        p = os.path.join(workdir, f"s{s}.sam")
+        if cov_reads:
+            synth.write_sam(p, asm, s, sam_seed + s, read_len=250)
+        else:
+            a = synth.Assembly(asm.names[:1], [asm.seqs[0]], asm.genome[:1], asm.gc, asm.cov * 0, [])
+            synth.write_sam(p, a, s, sam_seed + s)
+    out = os.path.join(workdir, "build")
+    os.makedirs(out, exist_ok=True)
+    subprocess.run([os.path.join(REF, "abawaca-build"), "-f", fasta, "-o", out,
+                    "-s", os.path.join(workdir, "s*.sam"), "-c", os.path.join(workdir, "s0.sam")],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return fasta, out
+
+
+def edge_assembly():
+    rng = synth.rng_for(7)
+
+    def rnd(n):
+        return synth.ACGT[rng.integers(0, 4, size=n)]
+
+    def put(a, at, text):
+        a = a.copy()
+        a[at:at + len(text)] = np.frombuffer(text.encode(), dtype=np.uint8)
+        return a
+    cases = []
+    cases.append(("e00_plain4500", rnd(4500)))
+    cases.append(("e01_len2000", rnd(2000)))
+    cases.append(("e02_len3999", rnd(3999)))
+    cases.append(("e03_len4000", rnd(4000)))
+    cases.append(("e04_len4001", rnd(4001)))
+    cases.append(("e05_short1999", rnd(1999)))
+    cases.append(("e06_short3", np.frombuffer(b"ACG", dtype=np.uint8)))
+    cases.append(("e07_short1", np.frombuffer(b"T", dtype=np.uint8)))
+    cases.append(("e08_short4", np.frombuffer(b"GATC", dtype=np.uint8)))
+    cases.append(("e09_Nhead", put(rnd(5000), 0, "N" * 37)))
+    cases.append(("e10_Ntail", put(rnd(5000), 5000 - 41, "N" * 41)))
+    cases.append(("e11_Nmid", put(put(rnd(7000), 1990, "N" * 25), 4100, "N" * 3)))
+    cases.append(("e12_Nbig", put(rnd(9000), 2500, "N" * 3000)))
+    cases.append(("e13_iupac", put(put(put(rnd(6100), 10, "R"), 2001, "YKM"), 4000, "SWBDHV")))
+    low = rnd(4400)
+    low[100:900] |= 0x20            # lower-case acgt (reference upper-cases, String.cpp:45)
+    cases.append(("e14_lower", low))
+    cases.append(("e15_polyA", np.full(4100, ord("A"), dtype=np.uint8)))
+    cases.append(("e16_allN", np.full(5, ord("N"), dtype=np.uint8)))
+    cases.append(("e17_Nscatter", put(put(put(rnd(2100), 3, "N"), 7, "N"), 2096, "NN")))
+    cases.append(("e18_len6123", rnd(6123)))
+    cases.append(("e19_dinuc", np.tile(np.frombuffer(b"AC", dtype=np.uint8), 2300)))
+    cases.append(("e20_gapstart_seg", put(rnd(4400), 2200, "N" * 10)))
+    # ends exactly on cut boundaries with N right after the cut
+    cases.append(("e21_Nafter_cut", put(rnd(6001), 2000, "NNNN")))
+    names = [c[0] for c in cases]
+    seqs = [np.ascontiguousarray(c[1]) for c in cases]
+    return synth.Assembly(names, seqs, np.zeros(len(cases), dtype=np.int64), np.array([0.5]),
+                          np.zeros((1, 1)), [])
+
+
+def sig_case(tag, asm):
+    with tempfile.TemporaryDirectory(prefix="abwgold_") as wd:
+        _fasta, out = run_build(asm, wd, 1, 99, cov_reads=False)
+        dp, header, milli = synth.read_lrn(os.path.join(out, "abawaca.lrn"))
+        rows = synth.read_names(os.path.join(out, "abawaca.names"))
+    # rows of the .lrn come in scaffold-NAME order (std::map, abawaca-build.cpp:482,596)
+    seg_scaf = np.array([asm.names.index(r[2]) for r in rows], dtype=np.int32)
+    seg_start = np.array([r[3] for r in rows], dtype=np.int64)
+    seg_end = np.array([r[4] for r in rows], dtype=np.int64)
+    blob = np.concatenate(asm.seqs) if len(asm.seqs) else np.zeros(0, dtype=np.uint8)
+    off = np.zeros(len(asm.seqs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(s) for s in asm.seqs])
+    # (the coverage column of a segment that received no read is read out of bounds by the reference,
+    #  abawaca-build.cpp:188-193 vs :179-180, so only the 179 signature columns are kept here)
+    assert milli[:, :179].max() <= 1000 and milli[:, :179].min() >= 0
+    np.savez_compressed(os.path.join(OUT, f"sig_{tag}.npz"),
+                        ascii=blob, scaf_off=off, scaf_names=np.array(asm.names),
+                        seg_scaf=seg_scaf, seg_start=seg_start, seg_end=seg_end,
+                        milli=milli[:, :179].astype(np.int16), header=np.array(header[:179]))
+    print(f"sig_{tag}: {len(asm.names)} scaffolds, {len(rows)} segments")
+
+
+def sep_case(tag, seed, n_scaf, n_genomes, gc_lo, gc_hi, jitter, n_samples=3, n_scg=30, max_nodes=64,
+             cov_sigma=0.6, use_scg=True):
+    asm = synth.make_assembly(seed, n_scaf, n_genomes, n_samples, gc_lo=gc_lo, gc_hi=gc_hi,
+                              jitter=jitter, n_scg=n_scg)
+    asm.cov[:] = np.exp(synth.rng_for(seed + 1).normal(np.log(4.0), cov_sigma, size=asm.cov.shape))
+    if not use_scg:
+        asm.scg = []
+    with tempfile.TemporaryDirectory(prefix="abwgold_") as wd:
+        fasta, out = run_build(asm, wd, n_samples, seed + 100)
+        scg = os.path.join(wd, "genes.scg")
+        synth.write_scg(scg, asm)
+        scg_list = os.path.join(wd, "scg.list")
+        synth.write_scg_list(scg_list, n_scg)
+        prefix = os.path.join(wd, "ref")
+        subprocess.run([os.path.join(REF, "ref_sep_driver"), os.path.join(out, "abawaca.names"), fasta,
+                        os.path.join(out, "abawaca.info"), os.path.join(out, "abawaca.lrn"),
+                        scg if use_scg else "-", scg_list,
+                        "8", prefix, str(max_nodes)], check=True)
+        dp, header, milli = synth.read_lrn(os.path.join(out, "abawaca.lrn"))
+        rows = synth.read_names(os.path.join(out, "abawaca.names"))
+        info = synth.read_info(os.path.join(out, "abawaca.info"))
+        nodes = np.loadtxt(prefix + ".nodes.tsv", dtype=np.float64, ndmin=2)
+        dpmap = np.loadtxt(prefix + ".dpmap.tsv", dtype=np.int64, ndmin=2)
+        s2c = [ln.rstrip("\n").split("\t") for ln in open(prefix + ".scaf2cluster.tsv")]
+        d2c = np.loadtxt(prefix + ".dp2cluster.tsv", dtype=np.int64, ndmin=2)
+    kept, dp2scaf, scaf_names = synth.scafdp_numbering(rows)
+    assert np.array_equal(dpmap[:, 1], dp2scaf), "our replay of the ScafDpData numbering disagrees with the reference"
+    assert [x[0] for x in s2c] == scaf_names
+    row_of = {int(d): i for i, d in enumerate(dp)}
+    sel = np.array([row_of[int(d)] for d in kept])
+    feat = milli[sel].T.copy()                      # [D, N] column-major, internal dp order
+    scaf_len = np.array([info[s] for s in scaf_names], dtype=np.int64)
+    sid = {s: i for i, s in enumerate(scaf_names)}
+    scg_names = sorted({b for _a, b in asm.scg})
+    pairs = set()
+    for gene, name in asm.scg:
+        sc = gene.rsplit("_", 1)[0]
+        if sc in sid:
+            pairs.add((sid[sc], scg_names.index(name)))
+    pairs = sorted(pairs)
+    np.savez_compressed(os.path.join(OUT, f"sep_{tag}.npz"),
+                        milli=feat.astype(np.int32), dp2scaf=(dp2scaf - 1).astype(np.int32),
+                        scaf_len=scaf_len, scg_scaf=np.array([p[0] for p in pairs], dtype=np.int32),
+                        scg_id=np.array([p[1] for p in pairs], dtype=np.int32), n_scg=len(scg_names),
+                        nodes=nodes, scaf2cluster=np.array([int(x[1]) for x in s2c], dtype=np.int32),
+                        dp2cluster=d2c[:, 1].astype(np.int32), header=np.array(header))
+    print(f"sep_{tag}: N={feat.shape[1]} D={feat.shape[0]} scaffolds={len(scaf_names)} nodes={len(nodes)} "
+          f"splits={int(nodes[:, 2].sum())}")
+    for r in nodes[:6]:
+        print("   node", int(r[0]), "ndps", int(r[1]), "split", int(r[2]), "dim", int(r[3]), "val", r[4], "spec", r[5], "sens", r[6])
+
+
+def tinymt_case():
+    seeds = ["1", "2", "20240", "123456789", "4294967295", "0"]
+    txt = subprocess.run([os.path.join(REF, "tinymt_kat"), "64"] + seeds, check=True,
+                         capture_output=True, text=True).stdout
+    kat = {ln.split()[0]: [int(x) for x in ln.split()[1:]] for ln in txt.strip().split("\n")}
+    # upstream's own expected output for seed 1 (reference tinymt/check32.out.txt:3-12)
+    up = [2545341989, 981918433, 3715302833, 2387538352, 3591001365, 3820442102, 2114400566, 2196103051,
+          2783359912, 764534509]
+    assert kat["1"][:10] == up
+    with open(os.path.join(OUT, "tinymt32_kat.json"), "w") as f:
+        json.dump({"mat1": 0x8f7011ee, "mat2": 0xfc78ff1f, "tmat": 0x3793fdff, "outputs": kat}, f)
+    print("tinymt32_kat:", len(kat), "seeds")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["sig", "sep", "tinymt"]
+    if "sig" in which:
+        sig_case("edge", edge_assembly())
+        sig_case("rand", synth.make_assembly(11, 40, 4, 1, frac_n_run=0.25))
+    if "sep" in which:
+        sep_case("g3", 20241, 150, 3, 0.38, 0.56, 0.012)
+        sep_case("g5", 20242, 330, 5, 0.32, 0.64, 0.015)
+        sep_case("g2noisy", 20243, 120, 2, 0.46, 0.50, 0.02)
+        sep_case("g4tight", 20244, 260, 4, 0.44, 0.56, 0.02, cov_sigma=0.12)
+        sep_case("g3noscg", 20245, 200, 3, 0.40, 0.56, 0.015, cov_sigma=0.2, use_scg=False)
+        sep_case("g6", 20246, 420, 6, 0.30, 0.66, 0.018, cov_sigma=0.3)
+    if "tinymt" in which:
+        tinymt_case()
