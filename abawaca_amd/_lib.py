@@ -1,0 +1,112 @@
+"""ctypes binding of libabawaca_hip.so (the C ABI declared in include/abawaca_hip.h).
+
+There is NO fallback: if the shared library is missing or does not load, importing this module's
+`lib()` raises.  The oracle under oracle/ is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libabawaca_hip.so")
+
+ABW_OK = 0
+ABW_ERR_ARG, ABW_ERR_HIP, ABW_ERR_CAPACITY, ABW_ERR_LOWER_N, ABW_ERR_STATE, ABW_ERR_NOMEM = -1, -2, -3, -4, -5, -6
+SIG_NDIMS, SIG_NCOLS, SIG_NMERS = 180, 179, 340
+
+# every symbol include/abawaca_hip.h declares (tests/test_abi.py checks the two lists agree)
+EXPORTS = [
+    "abw_ctx_create", "abw_ctx_destroy", "abw_ctx_set_stream", "abw_ctx_synchronize", "abw_last_error",
+    "abw_abi_version", "abw_sig_dim_names", "abw_sig_segment_host", "abw_sig_segment_dev", "abw_sig_count_dev",
+    "abw_sig_build", "abw_sep_load", "abw_sep_node", "abw_sep_dev_keys", "abw_km_run_dev", "abw_km_run",
+    "abw_km_features_from_keys", "abw_km_tinymt_selftest",
+]
+
+
+class AbwError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"abawaca_hip error {code}: {msg}")
+        self.code = code
+
+
+class DimBest(C.Structure):
+    _fields_ = [("found", C.c_int32), ("key", C.c_int32), ("sensitivity", C.c_double), ("specificity", C.c_double)]
+
+
+class Split(C.Structure):
+    _fields_ = [("split", C.c_int32), ("dimension", C.c_int32), ("key", C.c_int32), ("legal", C.c_int32),
+                ("sensitivity", C.c_double), ("specificity", C.c_double), ("ndps1", C.c_int64), ("ndps2", C.c_int64)]
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C abawaca_amd/csrc` (or __graft_entry__.build()). "
+            "abawaca_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_uint32
+    L.abw_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.abw_ctx_destroy.argtypes = [vp]
+    L.abw_ctx_destroy.restype = None
+    L.abw_ctx_set_stream.argtypes = [vp, vp]
+    L.abw_ctx_synchronize.argtypes = [vp]
+    L.abw_last_error.argtypes = [vp]
+    L.abw_last_error.restype = C.c_char_p
+    L.abw_sig_dim_names.argtypes = [C.c_char_p, u64]
+    L.abw_sig_segment_host.argtypes = [vp, vp, u64, u32, u64, vp, vp, vp, C.POINTER(u64)]
+    L.abw_sig_segment_dev.argtypes = [vp, vp, u64, vp, u64, u32, u64, vp, vp, vp, C.POINTER(u64)]
+    L.abw_sig_count_dev.argtypes = [vp, vp, u64, vp, vp, vp, vp, u64, vp, vp, vp]
+    L.abw_sig_build.argtypes = [vp, vp, vp, u64, u32, u64, vp, vp, vp, vp, vp, C.POINTER(u64)]
+    L.abw_sep_load.argtypes = [vp, vp, i32, i64, vp, vp, i32, vp, vp, i32]
+    L.abw_sep_node.argtypes = [vp, vp, i32, i32, C.POINTER(Split), vp, vp, vp]
+    L.abw_sep_dev_keys.argtypes = [vp]
+    L.abw_sep_dev_keys.restype = vp
+    L.abw_km_run_dev.argtypes = [vp, vp, i64, i32, i32, u32, i32, i32, vp, vp, vp]
+    L.abw_km_run.argtypes = [vp, vp, i64, i32, i32, u32, i32, i32, vp, vp, vp]
+    L.abw_km_features_from_keys.argtypes = [vp, vp, i32, i64, vp, vp]
+    L.abw_km_tinymt_selftest.argtypes = [vp, u32, i32, vp]
+    _LIB = L
+    return L
+
+
+class Context:
+    """Owns one abw_ctx (one GPU, one stream)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        rc = lib().abw_ctx_create(int(device), C.byref(self._h))
+        if rc != ABW_OK:
+            raise AbwError(rc, "abw_ctx_create failed (is a GPU visible?)")
+        self.device = int(device)
+
+    def check(self, rc):
+        if rc != ABW_OK:
+            raise AbwError(rc, lib().abw_last_error(self._h).decode(errors="replace"))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, hip_stream_ptr):
+        self.check(lib().abw_ctx_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def synchronize(self):
+        self.check(lib().abw_ctx_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            lib().abw_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

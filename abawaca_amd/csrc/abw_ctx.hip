@@ -1,0 +1,100 @@
+// Context management for libabawaca_hip.so.
+#include "abw_internal.h"
+#include <stdarg.h>
+
+int abw_fail(abw_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else fprintf(stderr, "abawaca_hip: %s\n", buf);
+    return code;
+}
+
+int abw_reserve(abw_ctx* ctx, abw_devbuf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return ABW_OK;
+    if (b.p) { ABW_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return abw_fail(ctx, ABW_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return ABW_OK;
+}
+
+void abw_release(abw_devbuf& b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+extern "C" {
+
+int abw_abi_version(void) { return ABW_ABI_VERSION; }
+
+int abw_ctx_create(int device, abw_ctx** out)
+{
+    if (!out) return ABW_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return abw_fail(nullptr, ABW_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count)
+        return abw_fail(nullptr, ABW_ERR_ARG, "device %d out of range [0,%d)", device, count);
+    abw_ctx* ctx = new (std::nothrow) abw_ctx();
+    if (!ctx) return ABW_ERR_NOMEM;
+    ctx->device = device;
+    abw_device_guard g(device);
+    e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return abw_fail(nullptr, ABW_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    ctx->stream = ctx->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    *out = ctx;
+    return ABW_OK;
+}
+
+void abw_sep_free(abw_ctx* ctx);   // abw_sep.hip
+
+void abw_ctx_destroy(abw_ctx* ctx)
+{
+    if (!ctx) return;
+    abw_device_guard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    abw_sep_free(ctx);
+    for (auto& b : ctx->scratch) abw_release(b);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int abw_ctx_set_stream(abw_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    abw_device_guard g(ctx->device);
+    ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return ABW_OK;
+}
+
+int abw_ctx_synchronize(abw_ctx* ctx)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    abw_device_guard g(ctx->device);
+    ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ABW_OK;
+}
+
+const char* abw_last_error(const abw_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+}  // extern "C"

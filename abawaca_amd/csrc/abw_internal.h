@@ -1,0 +1,86 @@
+// Internal definitions shared by the translation units of libabawaca_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/abawaca_hip.h"
+
+#define ABW_ABI_VERSION 1
+
+// Grow-only device buffer owned by a context.
+struct abw_devbuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+};
+
+struct abw_sep_state {
+    bool      loaded = false;
+    int32_t   D = 0;
+    int64_t   N = 0;
+    int32_t   S = 0;
+    int32_t   n_scg = 0;
+    int32_t*  d_keys = nullptr;       // [D][N] original keys
+    int32_t*  d_bins = nullptr;       // [D][N] bin index per dp (== keys for narrow dims, rank for wide)
+    int32_t*  d_scaf_first = nullptr; // [S]
+    int32_t*  d_scaf_ndps = nullptr;  // [S]
+    int64_t*  d_scaf_len = nullptr;   // [S]
+    int32_t*  d_scg_off = nullptr;    // [S+1]
+    int32_t*  d_scg_ids = nullptr;
+    int32_t*  d_T = nullptr;          // [D] bins per dimension
+    int64_t*  d_Toff = nullptr;       // [D+1] offsets into the histogram arrays
+    int32_t*  d_binval = nullptr;     // [sum T over wide dims] bin -> key (wide dims only)
+    int64_t*  d_binval_off = nullptr; // [D] offset into d_binval, -1 for narrow dims
+    std::vector<int32_t> h_T;
+    std::vector<int64_t> h_Toff;
+    std::vector<int64_t> h_binval_off;
+    std::vector<int32_t> h_binval;
+    std::vector<int32_t> h_scaf_first, h_scaf_ndps;
+    int64_t   TB = 0;                 // total bins
+    // per-node scratch
+    abw_devbuf hist;                  // 3 x int32[TB] + int64[TB]
+    abw_devbuf scg_lohi;              // 2 x int32[D][n_scg]
+    abw_devbuf node_scaf;             // int32[m]
+    abw_devbuf node_dpoff;            // int32[m+1]
+    abw_devbuf dimbest;               // per-dimension results
+    abw_devbuf nle;                   // int32[m]
+    abw_devbuf raw;                   // uint8[n]
+};
+
+struct abw_ctx {
+    int         device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    abw_sep_state sep;
+    abw_devbuf  scratch[8];           // general-purpose grow-only scratch
+    int         num_cu = 256;
+};
+
+int abw_fail(abw_ctx* ctx, int code, const char* fmt, ...);
+int abw_reserve(abw_ctx* ctx, abw_devbuf& b, size_t bytes);
+void abw_release(abw_devbuf& b);
+
+#define ABW_HIP(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return abw_fail((ctx), ABW_ERR_HIP, "%s failed: %s (%s:%d)", #call,                 \
+                            hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+
+#define ABW_LAUNCH_CHECK(ctx)                                                                   \
+    do {                                                                                        \
+        hipError_t e_ = hipGetLastError();                                                      \
+        if (e_ != hipSuccess)                                                                   \
+            return abw_fail((ctx), ABW_ERR_HIP, "kernel launch failed: %s (%s:%d)",             \
+                            hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+
+// RAII device guard: every entry point runs with the context's device current.
+struct abw_device_guard {
+    int prev = -1;
+    explicit abw_device_guard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~abw_device_guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};

@@ -1,0 +1,435 @@
+// Extension — batched k-means restarts (k = 2) over the dp feature table.
+//
+// The reference contains NO k-means; this stage is the north-star's extension and
+// its semantics are fixed by DESIGN.md "K-means" and restated on the CPU in oracle/abw_oracle.c
+// (abw_or_kmeans).  Only the RNG has a reference counterpart: TinyMT32 with the parameter triple of
+// reference src/misc.cpp:29-31 (tinymt32.c:62-76, tinymt32.h:70-107).
+//
+// Kernel design (gfx950): both halves of a Lloyd iteration are contractions and run on the f32
+// MFMA (v_mfma_f32_32x32x2_f32: exact fp32, result == a k-ordered fmaf chain, so the CPU oracle
+// reproduces every bit):
+//   scores   X[p][rc] = -0.5|c_rc|^2 + sum_j x[p][j] c[rc][j]          (points x (restarts*2))
+//   sums     S[rc][j] = sum_p member[p][rc] x[p][j]                    ((restarts*2) x dims)
+// One workgroup = 4 waves = 64 restarts; a wave owns 32 score columns (16 restarts x 2 clusters).
+// A 32-point tile of x is staged once in LDS and feeds both products; the score accumulator of the
+// first product IS the A operand of the second (column on the lane, rows in registers), so
+// memberships never leave registers.  fp32 partial sums run over one chunk of points in point
+// order, one slab per chunk; slabs are added in fp64 in chunk order by km_update_kernel.
+#include "abw_internal.h"
+#include <string.h>
+#include <vector>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr uint32_t TMT_MAT1 = 0x8f7011eeu, TMT_MAT2 = 0xfc78ff1fu, TMT_TMAT = 0x3793fdffu;   // ref misc.cpp:29-31
+
+struct TinyMT { uint32_t s[4]; };
+
+__host__ __device__ inline void tmt_next_state(TinyMT& t)          // ref tinymt32.h:70-86
+{
+    uint32_t y = t.s[3];
+    uint32_t x = (t.s[0] & 0x7fffffffu) ^ t.s[1] ^ t.s[2];
+    x ^= (x << 1);
+    y ^= (y >> 1) ^ x;
+    t.s[0] = t.s[1];
+    t.s[1] = t.s[2];
+    t.s[2] = x ^ (y << 10);
+    t.s[3] = y;
+    const uint32_t mask = (uint32_t)(-(int32_t)(y & 1));
+    t.s[1] ^= mask & TMT_MAT1;
+    t.s[2] ^= mask & TMT_MAT2;
+}
+
+__host__ __device__ inline void tmt_init(TinyMT& t, uint32_t seed)  // ref tinymt32.c:62-76
+{
+    t.s[0] = seed; t.s[1] = TMT_MAT1; t.s[2] = TMT_MAT2; t.s[3] = TMT_TMAT;
+    for (uint32_t i = 1; i < 8; i++) t.s[i & 3] ^= i + 1812433253u * (t.s[(i - 1) & 3] ^ (t.s[(i - 1) & 3] >> 30));
+    if ((t.s[0] & 0x7fffffffu) == 0 && t.s[1] == 0 && t.s[2] == 0 && t.s[3] == 0) { t.s[0] = 'T'; t.s[1] = 'I'; t.s[2] = 'N'; t.s[3] = 'Y'; }
+    for (int i = 0; i < 8; i++) tmt_next_state(t);
+}
+
+__host__ __device__ inline uint32_t tmt_next(TinyMT& t)             // ref tinymt32.h:94-107,168-171
+{
+    tmt_next_state(t);
+    uint32_t t0 = t.s[3];
+    const uint32_t t1 = t.s[0] + (t.s[2] >> 8);
+    t0 ^= t1;
+    t0 ^= (uint32_t)(-(int32_t)(t1 & 1)) & TMT_TMAT;
+    return t0;
+}
+
+__global__ void tmt_selftest_kernel(uint32_t seed, int n, uint32_t* out)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    TinyMT t;
+    tmt_init(t, seed);
+    for (int i = 0; i < n; i++) out[i] = tmt_next(t);
+}
+
+// centroid buffers: cent [Rp*2][W] fp32 (W = DT*32, zero beyond d), hneg [Rp*2]
+__global__ void km_init_kernel(const float* __restrict__ x, int64_t N, int d, int W, int R, int Rp, uint32_t base_seed,
+                               float* __restrict__ cent, float* __restrict__ hneg)
+{
+    const int r = blockIdx.x;
+    __shared__ int64_t idx[2];
+    if (threadIdx.x == 0) {
+        int64_t i0 = 0, i1 = 1 % N;
+        if (r < R) {
+            TinyMT t;
+            tmt_init(t, base_seed + (uint32_t)r);
+            i0 = (int64_t)(tmt_next(t) % (uint64_t)N);
+            i1 = i0;
+            for (int tries = 0; tries < 64 && i1 == i0; tries++) i1 = (int64_t)(tmt_next(t) % (uint64_t)N);
+        }
+        idx[0] = i0; idx[1] = i1;
+    }
+    __syncthreads();
+    for (int c = 0; c < 2; c++)
+        for (int j = threadIdx.x; j < W; j += blockDim.x)
+            cent[((int64_t)r * 2 + c) * W + j] = (j < d) ? x[(int64_t)j * N + idx[c]] : 0.0f;
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const float* c = cent + ((int64_t)r * 2 + threadIdx.x) * W;
+        float n2 = 0.0f;
+        for (int j = 0; j < d; j++) n2 = fmaf(c[j], c[j], n2);
+        hneg[r * 2 + threadIdx.x] = -(0.5f * n2);
+    }
+}
+
+constexpr int XS = 33;   // LDS row stride (floats) of the staged x tile: odd -> conflict-free both ways
+
+// row i of the score tile holds the point whose position in the fp32 summation order is rowpoint(i)
+__device__ __forceinline__ int rowpoint(int i) { return 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); }
+
+// lane l <-> lane l^1 exchange inside a quad (DPP quad_perm [1,0,3,2]); no LDS crossbar involved
+__device__ __forceinline__ float swap_pair(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+
+template <int DT, bool ASSIGN>
+__global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ x, int64_t N, int d,
+                                                     const float* __restrict__ cent, const float* __restrict__ hneg,
+                                                     int Rp, int chunk, int64_t nchunks,
+                                                     float* __restrict__ slabs, uint8_t* __restrict__ assign, int R)
+{
+    constexpr int W = DT * 32;
+    __shared__ float xs[W * XS];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int rc0 = blockIdx.y * 128 + wid * 32;             // first score column of this wave
+    // a wave past the last column (only when Rp*2 is not a multiple of 128) recomputes the last
+    // tile of columns and stores nothing: keeps every wave on one straight-line MFMA stream
+    const bool wave_active = rc0 < Rp * 2;
+    const int rc0c = wave_active ? rc0 : Rp * 2 - 32;
+    const int rc = rc0c + col;
+
+    // B operand of the score product: c[rc][j = 2s + half], resident for the whole kernel
+    float b1[16 * DT];
+#pragma unroll
+    for (int s = 0; s < 16 * DT; s++) b1[s] = cent[(int64_t)rc * W + 2 * s + half];
+    const float hn = hneg[rc];
+    const int rp = rowpoint(col);
+    const bool is_c1 = col & 1;
+    const int sp = threadIdx.x & 31;                         // staging: this thread's point within the tile
+    const int sj = threadIdx.x >> 5;                         //          and its first row
+
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        f32x16 acc2[DT];
+#pragma unroll
+        for (int t = 0; t < DT; t++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc2[t][e] = 0.0f;
+        const int64_t p_begin = ch * chunk;
+        const int64_t p_end = min(N, p_begin + chunk);
+        for (int64_t tile = p_begin; tile < p_end; tile += 32) {
+            // stage x[0..W)[tile..tile+32) -> LDS; row d is the all-ones count column.  All loads are
+            // unconditional (clamped addresses) so they issue back to back.
+            float stg[DT * 4];
+            {
+                const int64_t gp = min(tile + sp, N - 1);
+#pragma unroll
+                for (int k = 0; k < DT * 4; k++) {
+                    const int j = min(sj + 8 * k, d - 1);
+                    stg[k] = x[(int64_t)j * N + gp];
+                }
+            }
+            __syncthreads();                                  // previous tile fully consumed
+            {
+                const bool pv = tile + sp < N;
+#pragma unroll
+                for (int k = 0; k < DT * 4; k++) {
+                    const int j = sj + 8 * k;
+                    const float v = (j < d) ? (pv ? stg[k] : 0.0f) : (j == d ? 1.0f : 0.0f);
+                    xs[j * XS + sp] = v;
+                }
+            }
+            __syncthreads();
+            // scores: X[p][rc] = -h + sum_j x[p][j] c[rc][j]
+            f32x16 acc1;
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc1[e] = hn;
+#pragma unroll
+            for (int s = 0; s < 16 * DT; s++) {
+                const float a = xs[(2 * s + half) * XS + rp];
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s], acc1, 0, 0, 0);
+                if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep LDS prefetch depth (and VGPRs) bounded
+            }
+            // memberships (tie -> cluster 0), straight from the accumulator layout:
+            // register e of lane (col, half) is point q = 2e + half of the tile
+            float mem[16];
+            const int nvalid = (int)min((int64_t)32, N - tile) - half;            // point 2e + half is real iff 2e < nvalid
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float mine = acc1[e];
+                const float other = swap_pair(mine);
+                const bool a1 = is_c1 ? (mine > other) : (other > mine);          // score1 > score0
+                const bool valid = 2 * e < nvalid;
+                mem[e] = (valid && (is_c1 == a1)) ? 1.0f : 0.0f;
+                if (ASSIGN) {
+                    if (wave_active && !is_c1 && valid && (rc >> 1) < R)
+                        assign[(int64_t)(rc >> 1) * N + tile + 2 * e + half] = a1 ? 1 : 0;
+                }
+            }
+            // sums: S[rc][j] += sum_p mem[p][rc] x[p][j]
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+#pragma unroll
+                for (int t = 0; t < DT; t++) {
+                    const float b = xs[(t * 32 + col) * XS + 2 * e + half];
+                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(mem[e], b, acc2[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (wave_active) {
+            // slab[ch][rc_row][j]: C/D layout col = lane&31 -> j, row = (e&3) + 8(e>>2) + 4*half -> rc
+            float* slab = slabs + ((int64_t)ch * Rp * 2 + rc0) * W;
+#pragma unroll
+            for (int t = 0; t < DT; t++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    slab[(int64_t)row * W + t * 32 + col] = acc2[t][e];
+                }
+        }
+    }
+}
+
+// One workgroup per score column rc: adds the chunk slabs in fp64 in chunk order, then either
+// moves the centroid (update = 1) or contributes the column's part of the inertia (update = 0).
+__global__ void km_update_kernel(const float* __restrict__ slabs, int64_t nchunks, int Rp, int W, int d,
+                                 float* __restrict__ cent, float* __restrict__ hneg, int update,
+                                 double* __restrict__ col_term)
+{
+    extern __shared__ double sh[];            // [W] sums, then [W] floats of the centroid
+    const int rc = blockIdx.x;
+    float* cs = (float*)(sh + W);
+    for (int j = threadIdx.x; j < W; j += blockDim.x) {
+        double s = 0.0;
+        const float* p = slabs + (int64_t)rc * W + j;
+        const int64_t stride = (int64_t)Rp * 2 * W;
+        for (int64_t c = 0; c < nchunks; c++) s += (double)p[c * stride];
+        sh[j] = s;
+    }
+    __syncthreads();
+    const double cnt = sh[d];
+    for (int j = threadIdx.x; j < W; j += blockDim.x) {
+        float c = cent[(int64_t)rc * W + j];
+        if (update && j < d && cnt > 0.0) { c = (float)(sh[j] / cnt); cent[(int64_t)rc * W + j] = c; }
+        cs[j] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (update) {
+            float n2 = 0.0f;
+            for (int j = 0; j < d; j++) n2 = fmaf(cs[j], cs[j], n2);
+            hneg[rc] = -(0.5f * n2);
+        } else {
+            // sum_{p in cluster} |x_p - c|^2 = [sum |x_p|^2] - 2 c.S + n |c|^2 ; the bracket is added per restart
+            double dot = 0.0, n2 = 0.0;
+            for (int j = 0; j < d; j++) { dot += (double)cs[j] * sh[j]; n2 += (double)cs[j] * (double)cs[j]; }
+            col_term[rc] = cnt * n2 - 2.0 * dot;
+        }
+    }
+}
+
+// sum_p x[j][p]^2 per dimension: 256 strided fp64 partials, then a fixed butterfly
+__global__ __launch_bounds__(256) void km_x2_kernel(const float* __restrict__ x, int64_t N, double* __restrict__ x2_dim)
+{
+    __shared__ double w[4];
+    const int j = blockIdx.x;
+    const float* row = x + (int64_t)j * N;
+    double acc = 0.0;
+    for (int64_t p = threadIdx.x; p < N; p += 256) { const double v = (double)row[p]; acc += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) x2_dim[j] = (w[0] + w[1]) + (w[2] + w[3]);
+}
+
+__global__ void km_inertia_kernel(const double* __restrict__ x2_dim, int d, const double* __restrict__ col_term, int R,
+                                  double* __restrict__ inertia)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    double x2 = 0.0;
+    for (int j = 0; j < d; j++) x2 += x2_dim[j];
+    inertia[r] = (x2 + col_term[2 * r]) + col_term[2 * r + 1];
+}
+
+__global__ void km_copy_centroids_kernel(const float* __restrict__ cent, int W, int d, int R, float* __restrict__ out)
+{
+    const int64_t n = (int64_t)R * 2 * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t rc = i / d; const int j = (int)(i % d);
+        out[i] = cent[rc * W + j];
+    }
+}
+
+__global__ void km_features_kernel(const int32_t* __restrict__ keys, int64_t n, int64_t N, const float* __restrict__ scale,
+                                   float* __restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float s = scale ? scale[i / N] : 1.0f;
+        out[i] = (float)keys[i] * s;
+    }
+}
+
+template <int DT>
+void launch_step(abw_ctx* ctx, dim3 grid, const float* x, int64_t N, int d, const float* cent, const float* hneg, int Rp,
+                 int chunk, int64_t nchunks, float* slabs, uint8_t* assign, int R)
+{
+    if (assign)
+        hipLaunchKernelGGL((km_step_kernel<DT, true>), grid, dim3(256), 0, ctx->stream, x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, assign, R);
+    else
+        hipLaunchKernelGGL((km_step_kernel<DT, false>), grid, dim3(256), 0, ctx->stream, x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, assign, R);
+}
+
+}  // namespace
+
+extern "C" {
+
+int abw_km_tinymt_selftest(abw_ctx* ctx, uint32_t seed, int32_t n, uint32_t* out)
+{
+    if (!ctx || !out || n <= 0) return ABW_ERR_ARG;
+    abw_device_guard g(ctx->device);
+    int rc = abw_reserve(ctx, ctx->scratch[0], (size_t)n * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(tmt_selftest_kernel, dim3(1), dim3(64), 0, ctx->stream, seed, n, (uint32_t*)ctx->scratch[0].p);
+    ABW_LAUNCH_CHECK(ctx);
+    ABW_HIP(ctx, hipMemcpyAsync(out, ctx->scratch[0].p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ABW_OK;
+}
+
+int abw_km_features_from_keys(abw_ctx* ctx, const int32_t* d_keys, int32_t D, int64_t N, const float* scale, float* d_x)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!d_keys || !d_x || D <= 0 || N <= 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_features_from_keys: bad argument");
+    abw_device_guard g(ctx->device);
+    float* d_scale = nullptr;
+    if (scale) {
+        int rc = abw_reserve(ctx, ctx->scratch[0], (size_t)D * 4);
+        if (rc) return rc;
+        d_scale = (float*)ctx->scratch[0].p;
+        ABW_HIP(ctx, hipMemcpyAsync(d_scale, scale, (size_t)D * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    hipLaunchKernelGGL(km_features_kernel, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream, d_keys, (int64_t)D * N, N, d_scale, d_x);
+    ABW_LAUNCH_CHECK(ctx);
+    if (scale) ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `scale` is the caller's memory
+    return ABW_OK;
+}
+
+int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t R, uint32_t base_seed,
+                   int32_t iters, int32_t chunk, uint8_t* d_assign, float* d_centroids, double* d_inertia)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!d_x || N < 2 || d < 1 || R < 1 || iters < 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run_dev: bad argument");
+    if (chunk == 0) chunk = 512;
+    if (chunk < 32 || (chunk & 31)) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run_dev: chunk must be a positive multiple of 32");
+    const int DT = (d + 1 + 31) / 32;                       // dims + the count column, in 32-wide tiles
+    if (DT > 8) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run_dev: d = %d not supported (max 255)", d);
+    abw_device_guard g(ctx->device);
+    const int W = DT * 32;
+    const int Rp = (R + 15) & ~15;
+    const int64_t nchunks = (N + chunk - 1) / chunk;
+    int rc;
+    // scratch[1]: centroids + hneg + col_term + x2 ; scratch[2]: slabs
+    const size_t cent_bytes = (size_t)Rp * 2 * W * 4, hneg_bytes = (size_t)Rp * 2 * 4;
+    const size_t term_bytes = (size_t)Rp * 2 * 8, x2_bytes = (size_t)d * 8;
+    if ((rc = abw_reserve(ctx, ctx->scratch[1], cent_bytes + hneg_bytes + term_bytes + x2_bytes + 64))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[2], (size_t)nchunks * Rp * 2 * W * 4))) return rc;
+    uint8_t* base = (uint8_t*)ctx->scratch[1].p;
+    double* col_term = (double*)base;
+    double* x2_dim = (double*)(base + term_bytes);
+    float* cent = (float*)(base + term_bytes + x2_bytes);
+    float* hneg = (float*)(base + term_bytes + x2_bytes + cent_bytes);
+    float* slabs = (float*)ctx->scratch[2].p;
+    hipStream_t st = ctx->stream;
+
+    hipLaunchKernelGGL(km_init_kernel, dim3(Rp), dim3(256), 0, st, d_x, N, d, W, R, Rp, base_seed, cent, hneg);
+    ABW_LAUNCH_CHECK(ctx);
+    const unsigned gy = (unsigned)((Rp * 2 + 127) / 128);
+    unsigned gx = (unsigned)std::min<int64_t>(nchunks, (int64_t)ctx->num_cu * 8);
+    const dim3 grid(gx, gy);
+    const size_t upd_lds = (size_t)W * 8 + (size_t)W * 4;
+    for (int it = 0; it <= iters; it++) {
+        const bool last = it == iters;
+        uint8_t* asg = last ? d_assign : nullptr;
+        switch (DT) {
+            case 1: launch_step<1>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
+            case 2: launch_step<2>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
+            case 3: launch_step<3>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
+            case 4: launch_step<4>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
+            case 5: launch_step<5>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
+            case 6: launch_step<6>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
+            case 7: launch_step<7>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
+            default: launch_step<8>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
+        }
+        ABW_LAUNCH_CHECK(ctx);
+        if (last && !d_inertia) break;
+        hipLaunchKernelGGL(km_update_kernel, dim3(Rp * 2), dim3(W), upd_lds, st, slabs, nchunks, Rp, W, d, cent, hneg, last ? 0 : 1, col_term);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    if (d_inertia) {
+        hipLaunchKernelGGL(km_x2_kernel, dim3(d), dim3(256), 0, st, d_x, N, x2_dim);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(km_inertia_kernel, dim3((R + 63) / 64), dim3(64), 0, st, x2_dim, d, col_term, R, d_inertia);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    if (d_centroids) {
+        hipLaunchKernelGGL(km_copy_centroids_kernel, dim3(64), dim3(256), 0, st, cent, W, d, R, d_centroids);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    return ABW_OK;
+}
+
+int abw_km_run(abw_ctx* ctx, const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed,
+               int32_t iters, int32_t chunk, uint8_t* assign, float* centroids, double* inertia)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!x || N < 2 || d < 1 || R < 1) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run: bad argument");
+    abw_device_guard g(ctx->device);
+    int rc;
+    const size_t xb = (size_t)N * d * 4, ab = (size_t)R * N, cb = (size_t)R * 2 * d * 4, ib = (size_t)R * 8;
+    if ((rc = abw_reserve(ctx, ctx->scratch[3], xb))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[4], ab + cb + ib + 64))) return rc;
+    float* d_x = (float*)ctx->scratch[3].p;
+    double* d_in = (double*)ctx->scratch[4].p;
+    float* d_c = (float*)((uint8_t*)d_in + ib);
+    uint8_t* d_a = (uint8_t*)d_c + cb;
+    ABW_HIP(ctx, hipMemcpyAsync(d_x, x, xb, hipMemcpyHostToDevice, ctx->stream));
+    rc = abw_km_run_dev(ctx, d_x, N, d, R, base_seed, iters, chunk, assign ? d_a : nullptr, centroids ? d_c : nullptr, inertia ? d_in : nullptr);
+    if (rc) return rc;
+    if (assign) ABW_HIP(ctx, hipMemcpyAsync(assign, d_a, ab, hipMemcpyDeviceToHost, ctx->stream));
+    if (centroids) ABW_HIP(ctx, hipMemcpyAsync(centroids, d_c, cb, hipMemcpyDeviceToHost, ctx->stream));
+    if (inertia) ABW_HIP(ctx, hipMemcpyAsync(inertia, d_in, ib, hipMemcpyDeviceToHost, ctx->stream));
+    ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ABW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,681 @@
+// Stage 2 — the cluster separator: ClusterSeparator::separate() for one node of the recursion.
+//
+// Reference behaviour restated here (reference = CK7/abawaca):
+//   sweep          src/ClusterSeparatorBySensitivitySpecificity.cpp:91-161 (+ ClusterStats :6-76)
+//   tie-breaks     src/ClusterSeparatorBySensitivitySpecificity.h:25-35, src/ClusterSeparator.cpp:11-16
+//   gate           src/ClusterQuality.cpp:96-136, src/SCGdb.cpp:21-38
+//   finalisation   src/ClusterSeparator.cpp:25-135
+//
+// The reference sorts every dimension and walks the thresholds while moving dps between two
+// clusters.  All quantities it looks at after threshold t are COUNTS, so the sweep has an exact
+// integer formulation with no sort of the N points:
+//   t_s      = the (floor(n_s/2)+1)-th smallest value of scaffold s   (scaffold s flips to cluster1
+//              exactly when t reaches t_s: "2*n1_s > n_s", ...Specificity.cpp:125)
+//   size1(t) = #{p : v_p <= t}                tot1(t) = #{p : t_s(p) <= t}
+//   TP1(t)   = #{p : max(v_p, t_s(p)) <= t}   TP2(t)  = N - #{p : min(v_p, t_s(p)) <= t}
+//            and #{min <= t} = size1 + tot1 - TP1 because {max,min} = {v,t_s} as multisets
+//   gate     : per SCG g, lo_g/hi_g = min/max t_s over the node's scaffolds carrying g;
+//              |G1| = #{lo_g <= t}, |G2| = #{hi_g > t}, |G1 n G2| = #{lo_g <= t < hi_g};
+//              bp1(t) = sum of len_s over t_s <= t.
+// Kernels: (1) sep_accum — one thread per (scaffold, dimension): order statistic + histogram
+// updates, LDS-privatised per workgroup for narrow dimensions; (2) chunked scan of the histograms
+// and evaluation of every threshold; (3) per-scaffold counts for the final assignment.
+#include "abw_internal.h"
+#include <string.h>
+#include <algorithm>
+#include <thread>
+#include <limits.h>
+
+namespace {
+
+constexpr int NARROW_T = 1024;      // dimensions with keys in [0, NARROW_T) use the key itself as bin
+constexpr int SCAN_CH = 2048;       // bins per scan chunk
+constexpr int ACC_SPB = 2048;       // scaffolds per workgroup in sep_accum
+constexpr int MAX_SCG = 4096;
+
+struct DimBestDev { int32_t found; int32_t bin; double sens; double spec; double prod; };
+
+struct ChunkDesc { int32_t dim; int32_t start; int32_t len; int32_t first_chunk_of_dim; };
+
+struct SepDev {
+    const int32_t* bins; int64_t N;
+    const int32_t* scaf_first; const int32_t* scaf_ndps; const int64_t* scaf_len;
+    const int32_t* scg_off; const int32_t* scg_ids; int32_t n_scg;
+    const int32_t* T; const int64_t* Toff;
+    uint32_t* h_size; uint32_t* h_tp1; uint32_t* h_tot; unsigned long long* h_bp;
+    int32_t* scg_lo; int32_t* scg_hi;
+};
+
+// k-th smallest (0-based) of the n values at col[0..n), n > 8: binary search on the answer.
+__device__ inline int32_t select_kth_mem(const int32_t* __restrict__ col, int n, int k, int T)
+{
+    int lo = 0;
+    int bit = 1;
+    while ((bit << 1) < T && bit < (1 << 29)) bit <<= 1;
+    for (; bit > 0; bit >>= 1) {
+        const int cand = lo | bit;
+        if (cand >= T) continue;
+        int cnt = 0;
+        for (int i = 0; i < n; i++) cnt += col[i] < cand;
+        if (cnt <= k) lo = cand;
+    }
+    return lo;
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t* __restrict__ dimlist,
+                                                       const int32_t* __restrict__ node_scaf, int32_t m)
+{
+    __shared__ uint32_t s_size[USE_LDS ? NARROW_T : 1];
+    __shared__ uint32_t s_tp1[USE_LDS ? NARROW_T : 1];
+    __shared__ uint32_t s_tot[USE_LDS ? NARROW_T : 1];
+    __shared__ unsigned long long s_bp[USE_LDS ? NARROW_T : 1];
+    const int d = dimlist[blockIdx.y];
+    const int T = P.T[d];
+    const int64_t toff = P.Toff[d];
+    const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
+    if (USE_LDS) {
+        for (int t = threadIdx.x; t < T; t += 256) { s_size[t] = 0; s_tp1[t] = 0; s_tot[t] = 0; s_bp[t] = 0; }
+        __syncthreads();
+    }
+    uint32_t* g_size = P.h_size + toff;
+    uint32_t* g_tp1 = P.h_tp1 + toff;
+    uint32_t* g_tot = P.h_tot + toff;
+    unsigned long long* g_bp = P.h_bp + toff;
+
+    const int ls_end = min(m, (int)(blockIdx.x + 1) * ACC_SPB);
+    for (int ls = blockIdx.x * ACC_SPB + threadIdx.x; ls < ls_end; ls += 256) {
+        const int s = node_scaf ? node_scaf[ls] : ls;
+        const int f = P.scaf_first[s];
+        const int n = P.scaf_ndps[s];
+        const int k = n >> 1;                              // 0-based index of the flip value
+        int ts;
+        if (n <= 8) {
+            int v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (i < n) ? col[f + i] : INT_MAX;
+            ts = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int rank = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) rank += (v[j] < v[i]) || (v[j] == v[i] && j < i);
+                if (i < n && rank == k) ts = v[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (i < n) {
+                    const int mx = max(v[i], ts);
+                    if (USE_LDS) { atomicAdd(&s_size[v[i]], 1u); atomicAdd(&s_tp1[mx], 1u); }
+                    else { atomicAdd(&g_size[v[i]], 1u); atomicAdd(&g_tp1[mx], 1u); }
+                }
+            }
+        } else {
+            ts = select_kth_mem(col + f, n, k, T);
+            for (int i = 0; i < n; i++) {
+                const int v = col[f + i];
+                const int mx = max(v, ts);
+                if (USE_LDS) { atomicAdd(&s_size[v], 1u); atomicAdd(&s_tp1[mx], 1u); }
+                else { atomicAdd(&g_size[v], 1u); atomicAdd(&g_tp1[mx], 1u); }
+            }
+        }
+        if (USE_LDS) { atomicAdd(&s_tot[ts], (uint32_t)n); atomicAdd(&s_bp[ts], (unsigned long long)P.scaf_len[s]); }
+        else { atomicAdd(&g_tot[ts], (uint32_t)n); atomicAdd(&g_bp[ts], (unsigned long long)P.scaf_len[s]); }
+        if (P.n_scg > 0) {
+            for (int e = P.scg_off[s]; e < P.scg_off[s + 1]; e++) {
+                const int g = P.scg_ids[e];
+                atomicMin(&P.scg_lo[(int64_t)d * P.n_scg + g], ts);
+                atomicMax(&P.scg_hi[(int64_t)d * P.n_scg + g], ts);
+            }
+        }
+    }
+    if (USE_LDS) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < T; t += 256) {
+            const uint32_t a = s_size[t], b = s_tp1[t], c = s_tot[t];
+            const unsigned long long e = s_bp[t];
+            if (a) atomicAdd(&g_size[t], a);
+            if (b) atomicAdd(&g_tp1[t], b);
+            if (c) atomicAdd(&g_tot[t], c);
+            if (e) atomicAdd(&g_bp[t], e);
+        }
+    }
+}
+
+// ---- chunked scan + evaluation ----------------------------------------------------------------
+struct Sums { unsigned long long size, tp1, tot, bp; };
+
+__device__ __forceinline__ Sums sums_add(Sums a, Sums b) { return {a.size + b.size, a.tp1 + b.tp1, a.tot + b.tot, a.bp + b.bp}; }
+
+__device__ __forceinline__ Sums wave_incl_scan(Sums x, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        Sums y;
+        y.size = __shfl_up(x.size, o, 64); y.tp1 = __shfl_up(x.tp1, o, 64);
+        y.tot = __shfl_up(x.tot, o, 64); y.bp = __shfl_up(x.bp, o, 64);
+        if (lane >= o) x = sums_add(x, y);
+    }
+    return x;
+}
+
+// phase A: per-chunk totals
+__global__ __launch_bounds__(256) void sep_chunk_sums_kernel(SepDev P, const ChunkDesc* __restrict__ chunks, Sums* __restrict__ chunk_sums)
+{
+    __shared__ Sums wsum[4];
+    const ChunkDesc c = chunks[blockIdx.x];
+    const int64_t base = P.Toff[c.dim] + c.start;
+    Sums acc = {0, 0, 0, 0};
+    for (int t = threadIdx.x; t < c.len; t += 256) {
+        acc.size += P.h_size[base + t]; acc.tp1 += P.h_tp1[base + t]; acc.tot += P.h_tot[base + t]; acc.bp += P.h_bp[base + t];
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    acc = wave_incl_scan(acc, lane);
+    if (lane == 63) wsum[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = sums_add(sums_add(wsum[0], wsum[1]), sums_add(wsum[2], wsum[3]));
+}
+
+// phase B: exclusive scan of the chunk totals within each dimension (chunks of a dimension are
+// consecutive); one thread per dimension is plenty (<= N/2048 chunks for the widest column).
+__global__ void sep_chunk_scan_kernel(const int32_t* __restrict__ dim_first_chunk, const int32_t* __restrict__ dim_nchunks,
+                                      int32_t D, Sums* __restrict__ chunk_sums, Sums* __restrict__ dim_total)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    Sums run = {0, 0, 0, 0};
+    const int f = dim_first_chunk[d], n = dim_nchunks[d];
+    for (int i = 0; i < n; i++) { Sums v = chunk_sums[f + i]; chunk_sums[f + i] = run; run = sums_add(run, v); }
+    dim_total[d] = run;
+}
+
+struct Cand { double prod; int32_t bin; int32_t found; double sens; double spec; };
+
+__device__ __forceinline__ bool cand_better(const Cand& a, const Cand& b)   // is a better than b
+{
+    if (!a.found) return false;
+    if (!b.found) return true;
+    if (a.prod != b.prod) return a.prod > b.prod;
+    return a.bin < b.bin;                        // equal products keep the smaller threshold
+}
+
+__device__ __forceinline__ Cand cand_shfl_xor(const Cand& c, int o)
+{
+    Cand r;
+    r.prod = __shfl_xor(c.prod, o, 64); r.bin = __shfl_xor(c.bin, o, 64); r.found = __shfl_xor(c.found, o, 64);
+    r.sens = __shfl_xor(c.sens, o, 64); r.spec = __shfl_xor(c.spec, o, 64);
+    return r;
+}
+
+// phase C: rescan each chunk with its carry-in, evaluate every threshold, keep the chunk's best
+__global__ __launch_bounds__(256) void sep_eval_kernel(SepDev P, const ChunkDesc* __restrict__ chunks,
+                                                      const Sums* __restrict__ chunk_carry, const Sums* __restrict__ dim_total,
+                                                      int32_t min_ndps, Cand* __restrict__ chunk_best)
+{
+    __shared__ Sums wsum[4];
+    __shared__ Sums carry_s;
+    __shared__ int32_t s_lo[MAX_SCG], s_hi[MAX_SCG];
+    __shared__ int32_t s_ng;
+    __shared__ Cand wbest[4];
+    const ChunkDesc c = chunks[blockIdx.x];
+    const int d = c.dim;
+    const int64_t base = P.Toff[d] + c.start;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const Sums total = dim_total[d];
+    const long long n = (long long)total.size;
+    if (threadIdx.x == 0) { carry_s = chunk_carry[blockIdx.x]; s_ng = 0; }
+    __syncthreads();
+    // SCGs present in the node: lo != INT_MAX.  compact them.
+    for (int g = threadIdx.x; g < P.n_scg; g += 256) {
+        const int lo = P.scg_lo[(int64_t)d * P.n_scg + g];
+        if (lo != INT_MAX) {
+            const int slot = atomicAdd(&s_ng, 1);
+            s_lo[slot] = lo; s_hi[slot] = P.scg_hi[(int64_t)d * P.n_scg + g];
+        }
+    }
+    __syncthreads();
+    const int ng = s_ng;
+    Cand best = {0.0, 0, 0, 0.0, 0.0};
+    for (int t0 = 0; t0 < c.len; t0 += 256) {
+        const int t = t0 + threadIdx.x;
+        Sums v = {0, 0, 0, 0};
+        uint32_t here = 0;
+        if (t < c.len) {
+            here = P.h_size[base + t];
+            v.size = here; v.tp1 = P.h_tp1[base + t]; v.tot = P.h_tot[base + t]; v.bp = P.h_bp[base + t];
+        }
+        Sums x = wave_incl_scan(v, lane);
+        if (lane == 63) wsum[wid] = x;
+        __syncthreads();
+        Sums off = carry_s;
+        for (int k = 0; k < wid; k++) off = sums_add(off, wsum[k]);
+        x = sums_add(x, off);
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = x;
+        if (here) {                                                    // only values present in the node are thresholds
+            const long long size1 = (long long)x.size, tp1 = (long long)x.tp1, tot1 = (long long)x.tot;
+            const long long size2 = n - size1, tot2 = n - tot1;
+            const long long tp2 = n - (size1 + tot1 - tp1);
+            if (size1 >= min_ndps && size2 >= min_ndps) {              // ref ...Specificity.cpp:151
+                const bool small1 = size1 < size2;                     // ref :155 (tie -> cluster2)
+                const long long TP = small1 ? tp1 : tp2, TOT = small1 ? tot1 : tot2, SZ = small1 ? size1 : size2;
+                const double sens = (double)(int)TP / (double)(int)TOT;   // ref .h:75 (int fields)
+                const double spec = (double)(int)TP / (double)(int)SZ;    // ref .h:74
+                const double prod = sens * spec;
+                if (prod == prod) {                                    // NaN is never better (ref .h:28)
+                    Cand cnd = {prod, c.start + t, 1, sens, spec};
+                    if (cand_better(cnd, best)) {
+                        // gate, ref ClusterQuality.cpp:96-136
+                        const int tt = c.start + t;
+                        int cl = 0, chh = 0;
+                        for (int g = 0; g < ng; g++) { cl += s_lo[g] <= tt; chh += s_hi[g] <= tt; }
+                        const int G1 = cl, G2 = ng - chh, both = cl - chh;
+                        bool pass;
+                        if (G1 == 0 || G2 == 0) pass = (x.bp >= 500000ull) && (total.bp - x.bp >= 500000ull);
+                        else pass = !((double)both / (double)(G1 < G2 ? G1 : G2) < 0.2);
+                        if (pass) best = cnd;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { Cand other = cand_shfl_xor(best, o); if (cand_better(other, best)) best = other; }
+    if (lane == 0) wbest[wid] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Cand b = wbest[0];
+        for (int k = 1; k < 4; k++) if (cand_better(wbest[k], b)) b = wbest[k];
+        chunk_best[blockIdx.x] = b;
+    }
+}
+
+// phase D: best chunk of each dimension
+__global__ void sep_dimbest_kernel(const int32_t* __restrict__ dim_first_chunk, const int32_t* __restrict__ dim_nchunks,
+                                   int32_t D, const Cand* __restrict__ chunk_best, DimBestDev* __restrict__ out)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    Cand b = {0.0, 0, 0, 0.0, 0.0};
+    const int f = dim_first_chunk[d], n = dim_nchunks[d];
+    for (int i = 0; i < n; i++) if (cand_better(chunk_best[f + i], b)) b = chunk_best[f + i];
+    out[d].found = b.found; out[d].bin = b.bin; out[d].sens = b.sens; out[d].spec = b.spec; out[d].prod = b.prod;
+}
+
+// per-scaffold count of dps with bin <= t in the winning dimension, and the raw side of each dp
+__global__ __launch_bounds__(256) void sep_final_kernel(SepDev P, int32_t d, int32_t tbin, const int32_t* __restrict__ node_scaf,
+                                                       const int32_t* __restrict__ node_dpoff, int32_t m,
+                                                       int32_t* __restrict__ nle, uint8_t* __restrict__ raw)
+{
+    const int ls = blockIdx.x * 256 + threadIdx.x;
+    if (ls >= m) return;
+    const int s = node_scaf ? node_scaf[ls] : ls;
+    const int f = P.scaf_first[s], n = P.scaf_ndps[s];
+    const int64_t o = node_dpoff ? node_dpoff[ls] : f;
+    const int32_t* col = P.bins + (int64_t)d * P.N;
+    int c = 0;
+    for (int i = 0; i < n; i++) { const int le = col[f + i] <= tbin; c += le; raw[o + i] = (uint8_t)le; }
+    nle[ls] = c;
+}
+
+__global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+struct SepHost {
+    std::vector<int32_t> narrow_dims, wide_dims;
+    std::vector<ChunkDesc> chunks;
+    std::vector<int32_t> dim_first_chunk, dim_nchunks;
+    int32_t *d_narrow = nullptr, *d_wide = nullptr, *d_dim_first_chunk = nullptr, *d_dim_nchunks = nullptr;
+    ChunkDesc* d_chunks = nullptr;
+    Sums *d_chunk_sums = nullptr, *d_dim_total = nullptr;
+    Cand* d_chunk_best = nullptr;
+};
+
+}  // namespace
+
+struct abw_sep_extra { SepHost h; };
+static abw_sep_extra* g_extra_of(abw_ctx* ctx);
+
+// The context keeps the host-side extras in a side table keyed by the context pointer (keeps
+// abw_internal.h free of kernel-only types).
+#include <map>
+#include <mutex>
+static std::map<abw_ctx*, abw_sep_extra*> g_extras;
+static std::mutex g_extras_mtx;
+static abw_sep_extra* g_extra_of(abw_ctx* ctx)
+{
+    std::lock_guard<std::mutex> l(g_extras_mtx);
+    auto it = g_extras.find(ctx);
+    if (it != g_extras.end()) return it->second;
+    abw_sep_extra* e = new abw_sep_extra();
+    g_extras[ctx] = e;
+    return e;
+}
+
+extern "C" void abw_sep_free(abw_ctx* ctx)
+{
+    abw_sep_state& s = ctx->sep;
+    void* ptrs[] = {s.d_keys, s.d_bins, s.d_scaf_first, s.d_scaf_ndps, s.d_scaf_len, s.d_scg_off, s.d_scg_ids,
+                    s.d_T, s.d_Toff, s.d_binval, s.d_binval_off};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    s.d_keys = s.d_bins = s.d_scaf_first = s.d_scaf_ndps = s.d_scg_off = s.d_scg_ids = s.d_T = s.d_binval = nullptr;
+    s.d_scaf_len = s.d_Toff = s.d_binval_off = nullptr;
+    abw_release(s.hist); abw_release(s.scg_lohi); abw_release(s.node_scaf); abw_release(s.node_dpoff);
+    abw_release(s.dimbest); abw_release(s.nle); abw_release(s.raw);
+    s.loaded = false;
+    abw_sep_extra* e = nullptr;
+    {
+        std::lock_guard<std::mutex> l(g_extras_mtx);
+        auto it = g_extras.find(ctx);
+        if (it != g_extras.end()) { e = it->second; g_extras.erase(it); }
+    }
+    if (e) {
+        void* q[] = {e->h.d_narrow, e->h.d_wide, e->h.d_dim_first_chunk, e->h.d_dim_nchunks, e->h.d_chunks,
+                     e->h.d_chunk_sums, e->h.d_dim_total, e->h.d_chunk_best};
+        for (void* p : q) if (p) (void)hipFree(p);
+        delete e;
+    }
+}
+
+template <typename T>
+static int upload(abw_ctx* ctx, T** dst, const T* src, size_t n)
+{
+    *dst = nullptr;
+    if (n == 0) n = 1;
+    ABW_HIP(ctx, hipMalloc((void**)dst, n * sizeof(T)));
+    if (src) ABW_HIP(ctx, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return ABW_OK;
+}
+
+extern "C" {
+
+int abw_sep_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const int32_t* dp2scaf,
+                 const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
+                 int32_t n_scg)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!keys || !dp2scaf || !scaf_len || D <= 0 || N <= 0 || S <= 0 || N > INT_MAX - 16)
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: bad argument");
+    if (n_scg < 0 || n_scg > MAX_SCG) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: n_scg must be in [0,%d]", MAX_SCG);
+    if (n_scg > 0 && (!scg_off || !scg_ids)) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: null SCG table");
+    abw_device_guard g(ctx->device);
+    ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    abw_sep_free(ctx);
+    abw_sep_state& s = ctx->sep;
+    SepHost& H = g_extra_of(ctx)->h;
+
+    // scaffold layout (ref: ScafDpData.cpp:91-99 numbers dps scaffold by scaffold)
+    s.h_scaf_first.assign(S, 0);
+    s.h_scaf_ndps.assign(S, 0);
+    {
+        int32_t prev = -1;
+        for (int64_t p = 0; p < N; p++) {
+            const int32_t sc = dp2scaf[p];
+            if (sc < 0 || sc >= S || (sc != prev && sc != prev + 1))
+                return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: dp2scaf must list scaffolds 0..S-1 contiguously and ascending (dp %lld)", (long long)p);
+            if (sc != prev) s.h_scaf_first[sc] = (int32_t)p;
+            s.h_scaf_ndps[sc]++;
+            prev = sc;
+        }
+        if (prev != S - 1) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: dp2scaf covers %d scaffolds, S = %d", prev + 1, S);
+        for (int32_t sc = 0; sc < S; sc++)
+            if (s.h_scaf_ndps[sc] < 2)
+                return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: scaffold %d has %d dp(s); the reference drops such scaffolds (ScafDpData.cpp:92-93)", sc, s.h_scaf_ndps[sc]);
+    }
+    if (n_scg > 0) {
+        if (scg_off[0] != 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: scg_off[0] != 0");
+        for (int32_t sc = 0; sc < S; sc++) if (scg_off[sc + 1] < scg_off[sc]) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: scg_off not monotone");
+        for (int32_t e = 0; e < scg_off[S]; e++) if (scg_ids[e] < 0 || scg_ids[e] >= n_scg) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: scg id out of range");
+    }
+
+    // bins: narrow dimensions use the key as bin; wide ones the rank among the column's distinct keys
+    s.h_T.assign(D, 0);
+    s.h_Toff.assign(D + 1, 0);
+    s.h_binval_off.assign(D, -1);
+    std::vector<std::vector<int32_t>> uniq(D);
+    std::vector<int32_t> bins;
+    std::vector<char> is_wide(D, 0);
+    {
+        unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        auto classify_dim = [&](unsigned t) {
+            for (int32_t d = t; d < D; d += nt) {
+                const int32_t* col = keys + (int64_t)d * N;
+                int32_t mn = INT_MAX, mx = INT_MIN;
+                for (int64_t p = 0; p < N; p++) { mn = std::min(mn, col[p]); mx = std::max(mx, col[p]); }
+                if (mn >= 0 && mx < NARROW_T) { s.h_T[d] = mx + 1; continue; }
+                is_wide[d] = 1;
+                std::vector<int32_t>& u = uniq[d];
+                u.assign(col, col + N);
+                std::sort(u.begin(), u.end());
+                u.erase(std::unique(u.begin(), u.end()), u.end());
+                s.h_T[d] = (int32_t)u.size();
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(classify_dim, t);
+        for (auto& x : th) x.join();
+        bool any_wide = false;
+        for (int32_t d = 0; d < D; d++) any_wide |= is_wide[d];
+        if (any_wide) {
+            bins.assign(keys, keys + (int64_t)D * N);
+            auto rank_dim = [&](unsigned t) {
+                for (int32_t d = t; d < D; d += nt) {
+                    if (!is_wide[d]) continue;
+                    const std::vector<int32_t>& u = uniq[d];
+                    int32_t* col = bins.data() + (int64_t)d * N;
+                    for (int64_t p = 0; p < N; p++) col[p] = (int32_t)(std::lower_bound(u.begin(), u.end(), col[p]) - u.begin());
+                }
+            };
+            std::vector<std::thread> th2;
+            for (unsigned t = 0; t < nt; t++) th2.emplace_back(rank_dim, t);
+            for (auto& x : th2) x.join();
+        }
+    }
+    s.h_binval.clear();
+    H.narrow_dims.clear(); H.wide_dims.clear(); H.chunks.clear();
+    H.dim_first_chunk.assign(D, 0); H.dim_nchunks.assign(D, 0);
+    int64_t tb = 0;
+    for (int32_t d = 0; d < D; d++) {
+        s.h_Toff[d] = tb;
+        tb += s.h_T[d];
+        if (is_wide[d]) {
+            H.wide_dims.push_back(d);
+            s.h_binval_off[d] = (int64_t)s.h_binval.size();
+            s.h_binval.insert(s.h_binval.end(), uniq[d].begin(), uniq[d].end());
+        } else H.narrow_dims.push_back(d);
+        H.dim_first_chunk[d] = (int32_t)H.chunks.size();
+        for (int32_t st = 0; st < s.h_T[d]; st += SCAN_CH) {
+            ChunkDesc c = {d, st, std::min(SCAN_CH, s.h_T[d] - st), H.dim_first_chunk[d]};
+            H.chunks.push_back(c);
+        }
+        H.dim_nchunks[d] = (int32_t)H.chunks.size() - H.dim_first_chunk[d];
+    }
+    s.h_Toff[D] = tb;
+    s.TB = tb;
+    s.D = D; s.N = N; s.S = S; s.n_scg = n_scg;
+
+    int rc;
+    if ((rc = upload(ctx, &s.d_keys, keys, (size_t)D * N))) return rc;
+    if (!bins.empty()) { if ((rc = upload(ctx, &s.d_bins, bins.data(), (size_t)D * N))) return rc; }
+    if ((rc = upload(ctx, &s.d_scaf_first, s.h_scaf_first.data(), (size_t)S))) return rc;
+    if ((rc = upload(ctx, &s.d_scaf_ndps, s.h_scaf_ndps.data(), (size_t)S))) return rc;
+    if ((rc = upload(ctx, &s.d_scaf_len, scaf_len, (size_t)S))) return rc;
+    if (n_scg > 0) {
+        if ((rc = upload(ctx, &s.d_scg_off, scg_off, (size_t)S + 1))) return rc;
+        if ((rc = upload(ctx, &s.d_scg_ids, scg_ids, (size_t)scg_off[S]))) return rc;
+    }
+    if ((rc = upload(ctx, &s.d_T, s.h_T.data(), (size_t)D))) return rc;
+    if ((rc = upload(ctx, &s.d_Toff, s.h_Toff.data(), (size_t)D + 1))) return rc;
+    if ((rc = upload(ctx, &H.d_narrow, H.narrow_dims.data(), H.narrow_dims.size()))) return rc;
+    if ((rc = upload(ctx, &H.d_wide, H.wide_dims.data(), H.wide_dims.size()))) return rc;
+    if ((rc = upload(ctx, &H.d_dim_first_chunk, H.dim_first_chunk.data(), (size_t)D))) return rc;
+    if ((rc = upload(ctx, &H.d_dim_nchunks, H.dim_nchunks.data(), (size_t)D))) return rc;
+    if ((rc = upload(ctx, &H.d_chunks, H.chunks.data(), H.chunks.size()))) return rc;
+    if ((rc = upload<Sums>(ctx, &H.d_chunk_sums, nullptr, H.chunks.size()))) return rc;
+    if ((rc = upload<Sums>(ctx, &H.d_dim_total, nullptr, (size_t)D))) return rc;
+    if ((rc = upload<Cand>(ctx, &H.d_chunk_best, nullptr, H.chunks.size()))) return rc;
+    if ((rc = abw_reserve(ctx, s.hist, (size_t)tb * (4 * 3 + 8) + 64))) return rc;
+    if ((rc = abw_reserve(ctx, s.scg_lohi, (size_t)std::max<int64_t>(1, (int64_t)D * n_scg) * 8))) return rc;
+    if ((rc = abw_reserve(ctx, s.dimbest, (size_t)D * sizeof(DimBestDev)))) return rc;
+    s.loaded = true;
+    return ABW_OK;
+}
+
+const int32_t* abw_sep_dev_keys(const abw_ctx* ctx) { return (ctx && ctx->sep.loaded) ? ctx->sep.d_keys : nullptr; }
+
+int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t min_ndps,
+                 abw_split* out, abw_dimbest* per_dim, uint8_t* scaf_side, uint8_t* dp_raw_side)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    abw_sep_state& s = ctx->sep;
+    if (!s.loaded) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_node: call abw_sep_load first");
+    if (!out) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_node: null out");
+    abw_device_guard g(ctx->device);
+    SepHost& H = g_extra_of(ctx)->h;
+    hipStream_t st = ctx->stream;
+    const int32_t m = scaf_ids ? n_scaf : s.S;
+    if (m <= 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_node: empty node");
+    memset(out, 0, sizeof(*out));
+    out->dimension = -1; out->key = -1;
+
+    // node description
+    std::vector<int32_t> dpoff;
+    int64_t n = 0;
+    const int32_t* d_node_scaf = nullptr;
+    const int32_t* d_node_dpoff = nullptr;
+    int rc;
+    if (scaf_ids) {
+        dpoff.resize((size_t)m + 1);
+        std::vector<char> seen;                                     // duplicate check without O(S) work for small nodes
+        for (int32_t i = 0; i < m; i++) {
+            const int32_t sc = scaf_ids[i];
+            if (sc < 0 || sc >= s.S) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_node: scaffold id %d out of range", sc);
+            dpoff[i] = (int32_t)n;
+            n += s.h_scaf_ndps[sc];
+        }
+        dpoff[m] = (int32_t)n;
+        {
+            std::vector<int32_t> tmp(scaf_ids, scaf_ids + m);
+            std::sort(tmp.begin(), tmp.end());
+            if (std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end()) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_node: duplicate scaffold id");
+        }
+        if ((rc = abw_reserve(ctx, s.node_scaf, (size_t)m * 4))) return rc;
+        if ((rc = abw_reserve(ctx, s.node_dpoff, ((size_t)m + 1) * 4))) return rc;
+        ABW_HIP(ctx, hipMemcpyAsync(s.node_scaf.p, scaf_ids, (size_t)m * 4, hipMemcpyHostToDevice, st));
+        ABW_HIP(ctx, hipMemcpyAsync(s.node_dpoff.p, dpoff.data(), ((size_t)m + 1) * 4, hipMemcpyHostToDevice, st));
+        d_node_scaf = (const int32_t*)s.node_scaf.p;
+        d_node_dpoff = (const int32_t*)s.node_dpoff.p;
+    } else n = s.N;
+
+    SepDev P;
+    P.bins = s.d_bins ? s.d_bins : s.d_keys; P.N = s.N;
+    P.scaf_first = s.d_scaf_first; P.scaf_ndps = s.d_scaf_ndps; P.scaf_len = s.d_scaf_len;
+    P.scg_off = s.d_scg_off; P.scg_ids = s.d_scg_ids; P.n_scg = s.n_scg;
+    P.T = s.d_T; P.Toff = s.d_Toff;
+    P.h_size = (uint32_t*)s.hist.p; P.h_tp1 = P.h_size + s.TB; P.h_tot = P.h_tp1 + s.TB;
+    // 8-byte aligned start for the 64-bit histogram
+    P.h_bp = (unsigned long long*)(((uintptr_t)(P.h_tot + s.TB) + 7) & ~(uintptr_t)7);
+    P.scg_lo = (int32_t*)s.scg_lohi.p; P.scg_hi = P.scg_lo + (int64_t)s.D * s.n_scg;
+
+    ABW_HIP(ctx, hipMemsetAsync(s.hist.p, 0, (size_t)s.TB * (4 * 3 + 8) + 8, st));
+    if (s.n_scg > 0) {
+        const int64_t cnt = (int64_t)s.D * s.n_scg;
+        hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)std::min<int64_t>(1024, (cnt + 255) / 256)), dim3(256), 0, st, P.scg_lo, cnt, INT_MAX);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)std::min<int64_t>(1024, (cnt + 255) / 256)), dim3(256), 0, st, P.scg_hi, cnt, -1);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    const unsigned gx = (unsigned)((m + ACC_SPB - 1) / ACC_SPB);
+    if (!H.narrow_dims.empty()) {
+        hipLaunchKernelGGL(sep_accum_kernel<true>, dim3(gx, (unsigned)H.narrow_dims.size()), dim3(256), 0, st, P, H.d_narrow, d_node_scaf, m);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    if (!H.wide_dims.empty()) {
+        hipLaunchKernelGGL(sep_accum_kernel<false>, dim3(gx, (unsigned)H.wide_dims.size()), dim3(256), 0, st, P, H.d_wide, d_node_scaf, m);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    const unsigned nch = (unsigned)H.chunks.size();
+    hipLaunchKernelGGL(sep_chunk_sums_kernel, dim3(nch), dim3(256), 0, st, P, H.d_chunks, H.d_chunk_sums);
+    ABW_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(sep_chunk_scan_kernel, dim3((s.D + 63) / 64), dim3(64), 0, st, H.d_dim_first_chunk, H.d_dim_nchunks, s.D, H.d_chunk_sums, H.d_dim_total);
+    ABW_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(sep_eval_kernel, dim3(nch), dim3(256), 0, st, P, H.d_chunks, H.d_chunk_sums, H.d_dim_total, min_ndps, H.d_chunk_best);
+    ABW_LAUNCH_CHECK(ctx);
+    DimBestDev* d_dimbest = (DimBestDev*)s.dimbest.p;
+    hipLaunchKernelGGL(sep_dimbest_kernel, dim3((s.D + 63) / 64), dim3(64), 0, st, H.d_dim_first_chunk, H.d_dim_nchunks, s.D, H.d_chunk_best, d_dimbest);
+    ABW_LAUNCH_CHECK(ctx);
+    std::vector<DimBestDev> db((size_t)s.D);
+    ABW_HIP(ctx, hipMemcpyAsync(db.data(), d_dimbest, (size_t)s.D * sizeof(DimBestDev), hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+
+    auto key_of = [&](int32_t d, int32_t bin) -> int32_t {
+        return s.h_binval_off[d] < 0 ? bin : s.h_binval[(size_t)s.h_binval_off[d] + bin];
+    };
+    // global winner: ClusteringResult::is_better (ref ...Specificity.h:25-30 + ClusterSeparator.cpp:11-16),
+    // starting from the reset best_separation (dimension = (size_t)-1, value = -1, sens = spec = 0)
+    double gsens = 0, gspec = 0, gvalue = -1;
+    uint64_t gdim = (uint64_t)-1;
+    int32_t gbin = -1;
+    for (int32_t d = 0; d < s.D; d++) {
+        const bool f = db[d].found != 0;
+        const double sens = f ? db[d].sens : 0.0, spec = f ? db[d].spec : 0.0;
+        const uint64_t dim = f ? (uint64_t)(d + 1) : (uint64_t)-1;
+        const double value = f ? (double)key_of(d, db[d].bin) : -1.0;
+        if (per_dim) { per_dim[d].found = f; per_dim[d].key = f ? key_of(d, db[d].bin) : -1; per_dim[d].sensitivity = sens; per_dim[d].specificity = spec; }
+        const double a = sens * spec, b = gsens * gspec;
+        bool better;
+        if (a != b) better = a >= b;
+        else if (dim != gdim) better = dim < gdim;
+        else better = value < gvalue;
+        if (better) { gsens = sens; gspec = spec; gdim = dim; gvalue = value; gbin = db[d].bin; }
+    }
+    if (scaf_side) memset(scaf_side, 0, (size_t)m);
+    if (dp_raw_side) memset(dp_raw_side, 0, (size_t)n);
+    if (gdim == (uint64_t)-1) return ABW_OK;
+    const int32_t gd = (int32_t)gdim - 1;
+    out->dimension = (int32_t)gdim;
+    out->key = key_of(gd, gbin);
+    out->sensitivity = gsens; out->specificity = gspec;
+    // is_legal, ref ...Specificity.h:31-35
+    out->legal = (gsens >= 0.8) && (gspec >= 0.8) && (gsens + gspec >= 1.6) && (gsens * gspec >= 0.8);
+    if (!out->legal) return ABW_OK;                                   // reconstruct_best_clusters returns early (ref ClusterSeparator.cpp:27-28)
+
+    if ((rc = abw_reserve(ctx, s.nle, (size_t)m * 4))) return rc;
+    if ((rc = abw_reserve(ctx, s.raw, (size_t)n))) return rc;
+    hipLaunchKernelGGL(sep_final_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, gd, gbin, d_node_scaf, d_node_dpoff, m,
+                       (int32_t*)s.nle.p, (uint8_t*)s.raw.p);
+    ABW_LAUNCH_CHECK(ctx);
+    std::vector<int32_t> nle((size_t)m);
+    std::vector<uint8_t> raw((size_t)(dp_raw_side ? n : 0));
+    ABW_HIP(ctx, hipMemcpyAsync(nle.data(), s.nle.p, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+    if (dp_raw_side) ABW_HIP(ctx, hipMemcpyAsync(raw.data(), s.raw.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+
+    // ref ClusterSeparator.cpp:35-53: cluster1 is the side with fewer dps (tie: the "<=" side)
+    int64_t le = 0;
+    for (int32_t i = 0; i < m; i++) le += nle[i];
+    const int64_t gt = n - le;
+    const bool swap = gt < le;
+    if (dp_raw_side) for (int64_t i = 0; i < n; i++) dp_raw_side[i] = ((raw[i] != 0) != swap) ? 1 : 2;   // ref :87-90
+    // ref :94-122: a scaffold goes to cluster1 iff at least half of its dps are there, dps follow
+    int64_t nd1 = 0, nd2 = 0;
+    std::vector<uint8_t> side((size_t)m);
+    for (int32_t i = 0; i < m; i++) {
+        const int32_t sc = scaf_ids ? scaf_ids[i] : i;
+        const int32_t tot = s.h_scaf_ndps[sc];
+        const int32_t c1 = swap ? tot - nle[i] : nle[i];
+        if (c1 > 0 && 2 * (int64_t)c1 >= tot) { side[i] = 1; nd1 += tot; } else { side[i] = 2; nd2 += tot; }
+    }
+    if (nd1 >= min_ndps && nd2 >= min_ndps) {                          // ref :125-132
+        out->split = 1; out->ndps1 = nd1; out->ndps2 = nd2;
+        if (scaf_side) memcpy(scaf_side, side.data(), (size_t)m);
+    } else {
+        out->dimension = -1; out->key = -1; out->sensitivity = 0; out->specificity = 0;   // best_separation->reset(), ref :130
+    }
+    return ABW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,583 @@
+// Stage 1 — signature build: segmentation of scaffolds into ~window non-N bp segments and the
+// canonical 1..4-mer signature of every segment.
+//
+// Reference behaviour restated here (reference = CK7/abawaca):
+//   segmentation   src/abawaca-build.cpp:198-228  (Scaf::Scaf)
+//   counting       src/abawaca-build.cpp:103-174  (Scaf_segment::Scaf_segment)
+//   column order   src/abawaca-build.cpp:75-100   (prepare_mer_indexes)
+//   upper-casing   src/String.cpp:37-51           (DNAString::validate_string)
+//   truncation     src/abawaca-build.cpp:603      (int(1000.0*x))
+//
+// Kernel design (gfx950): one wave64 per segment.  Each lane takes aligned 16-byte pieces of the
+// segment (one coalesced 1 KiB read per wave-instruction) plus a 3-base halo, keeps a rolling
+// 8-bit 4-mer code `w` and a run mask `m` (how many of the last 4 bases are valid and in the
+// segment), and issues exactly ONE LDS atomic per valid base into a wave-private 340-counter table:
+//   run >= 4 -> 4-mer table[w]           run == 3 -> head 3-mer table[w & 63]
+//   run == 2 -> head 2-mer table[w & 15] run == 1 -> head 1-mer table[w & 3]
+// The k = 3, 2, 1 counts the reference obtains by three more passes then follow exactly from suffix
+// marginals: cnt3[s] = head3[s] + sum_x cnt4[x s], and so on down (a k-mer window that is not the
+// suffix of a valid (k+1)-mer window is precisely a "head" at the start of a valid run).
+// Finalisation divides in fp64 per mer and adds the two strands' quotients, like the reference.
+#include "abw_internal.h"
+#include <string.h>
+#include <algorithm>
+#include <thread>
+
+namespace {
+
+// "hw code" of a base: (toupper(c) >> 1) & 3  ->  A=0 C=1 T=2 G=3
+__host__ __device__ inline int hw_of_acgt(int d) { return d == 2 ? 3 : d == 3 ? 2 : d; }   // A,C,G,T=0..3 -> hw
+
+constexpr int LDS_T4 = 0, LDS_T3 = 256, LDS_T2 = 320, LDS_T1 = 336, LDS_WORDS = 352;
+
+struct SigTables {
+    uint16_t dim_a[ABW_SIG_NDIMS];      // LDS word index of the first member mer of each dimension
+    uint16_t dim_b[ABW_SIG_NDIMS];      // second member (reverse complement) or 0xFFFF for palindromes
+    uint16_t cnt_perm[ABW_SIG_NMERS];   // oracle/ABI mer index -> LDS word index
+};
+
+__constant__ SigTables c_tabs;
+
+int lds_index(int k, int mer_acgt)
+{
+    int hw = 0;
+    for (int i = k - 1; i >= 0; i--) hw = (hw << 2) | hw_of_acgt((mer_acgt >> (2 * i)) & 3);
+    const int base[5] = {0, LDS_T1, LDS_T2, LDS_T3, LDS_T4};
+    return base[k] + hw;
+}
+
+void build_tables(SigTables& t, std::vector<std::string>* names)
+{
+    // ref: prepare_mer_indexes_recursive, src/abawaca-build.cpp:75-94 — ids in enumeration order
+    // (k = 1..4, A<C<G<T) to whichever of {mer, reverse complement} shows up first.
+    int next_id = 0, off = 0;
+    for (int i = 0; i < ABW_SIG_NDIMS; i++) { t.dim_a[i] = 0xFFFF; t.dim_b[i] = 0xFFFF; }
+    for (int k = 1; k <= 4; k++) {
+        int n = 1 << (2 * k);
+        std::vector<int> id(n, -1);
+        for (int m = 0; m < n; m++) {
+            int rc = 0;
+            for (int i = 0; i < k; i++) rc = (rc << 2) | (3 - ((m >> (2 * i)) & 3));
+            if (id[rc] >= 0) {
+                id[m] = id[rc];
+                t.dim_b[id[m]] = (uint16_t)lds_index(k, m);
+            } else {
+                id[m] = next_id++;
+                t.dim_a[id[m]] = (uint16_t)lds_index(k, m);
+                if (names) {
+                    std::string s;
+                    for (int i = k - 1; i >= 0; i--) s.push_back("ACGT"[(m >> (2 * i)) & 3]);
+                    names->push_back(s);
+                }
+            }
+            t.cnt_perm[off + m] = (uint16_t)lds_index(k, m);
+        }
+        off += n;
+    }
+}
+
+const SigTables& host_tables()
+{
+    static SigTables t;
+    static bool init = false;
+    if (!init) { build_tables(t, nullptr); init = true; }
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// counting kernel
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void classify(uint32_t c, uint32_t& code, bool& valid)
+{
+    uint32_t u = c & 0xDFu;                          // toupper for letters; only 'a'..'z' can map onto 'A'..'Z'
+    code = (u >> 1) & 3u;                            // A0 C1 T2 G3
+    valid = ((0x47544341u >> (code * 8)) & 0xFFu) == u;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void sig_count_kernel(
+    const uint8_t* __restrict__ ascii, uint64_t total_len, const uint64_t* __restrict__ scaf_off,
+    const uint32_t* __restrict__ seg_scaf, const uint64_t* __restrict__ seg_start,
+    const uint64_t* __restrict__ seg_end, uint64_t n_seg,
+    double* __restrict__ dims, int32_t* __restrict__ milli, uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t lds[4][LDS_WORDS];
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    uint32_t* tab = lds[wid];
+    const uint64_t waves_total = (uint64_t)gridDim.x * 4;
+
+    for (uint64_t s = (uint64_t)blockIdx.x * 4 + wid; s < n_seg; s += waves_total) {
+        for (int i = lane; i < LDS_WORDS; i += 64) tab[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        const uint64_t sb = scaf_off[seg_scaf[s]];
+        const uint64_t seg_b = sb + seg_start[s] - 1;           // absolute, inclusive
+        const uint64_t seg_e = sb + seg_end[s];                 // absolute, exclusive
+        const uint64_t a0 = seg_b & ~(uint64_t)15;
+
+        for (uint64_t base = a0; base < seg_e; base += 1024) {
+            const uint64_t A = base + (uint64_t)lane * 16;
+            if (A < seg_e) {
+                uint32_t q[4];
+                if (A + 16 <= total_len) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(ascii + A);
+                    q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+                } else {
+                    q[0] = q[1] = q[2] = q[3] = 0;
+                    for (uint64_t i = 0; A + i < total_len; i++) q[i >> 2] |= (uint32_t)ascii[A + i] << (8 * (i & 3));
+                }
+                uint32_t halo = (A >= 4) ? *reinterpret_cast<const uint32_t*>(ascii + A - 4) : 0;
+                // positions of this piece that lie inside the segment: [lo, hi)
+                const int lo = (seg_b > A) ? (int)(seg_b - A) : 0;
+                const int hi = (seg_e - A < 16) ? (int)(seg_e - A) : 16;
+                uint32_t w = 0, m = 0;
+                // 3-base halo (positions A-3 .. A-1), in the segment iff >= seg_b
+#pragma unroll
+                for (int h = 1; h <= 3; h++) {
+                    uint32_t code; bool valid;
+                    classify((halo >> (8 * h)) & 0xFFu, code, valid);
+                    valid = valid && (A + h >= seg_b + 4) && (A >= 4);          // A - 4 + h >= seg_b
+                    w = ((w << 2) | code) & 0xFFu;
+                    m = valid ? (((m << 2) | 3u) & 0xFFu) : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    uint32_t code; bool valid;
+                    classify((q[i >> 2] >> (8 * (i & 3))) & 0xFFu, code, valid);
+                    valid = valid && (i >= lo) && (i < hi);
+                    w = ((w << 2) | code) & 0xFFu;
+                    m = valid ? (((m << 2) | 3u) & 0xFFu) : 0u;
+                    if (m) atomicAdd(&tab[(w & m) | (0x150u & ~(m << 2))], 1u);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // suffix marginals, in place: T3 += sum_x T4[x|s], T2 += sum_x T3[x|s], T1 += sum_x T2[x|s]
+        {
+            uint32_t c3 = tab[LDS_T3 + lane] + tab[LDS_T4 + lane] + tab[LDS_T4 + 64 + lane] +
+                          tab[LDS_T4 + 128 + lane] + tab[LDS_T4 + 192 + lane];
+            tab[LDS_T3 + lane] = c3;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 16) {
+            uint32_t c2 = tab[LDS_T2 + lane] + tab[LDS_T3 + lane] + tab[LDS_T3 + 16 + lane] +
+                          tab[LDS_T3 + 32 + lane] + tab[LDS_T3 + 48 + lane];
+            tab[LDS_T2 + lane] = c2;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 4) {
+            uint32_t c1 = tab[LDS_T1 + lane] + tab[LDS_T2 + lane] + tab[LDS_T2 + 4 + lane] +
+                          tab[LDS_T2 + 8 + lane] + tab[LDS_T2 + 12 + lane];
+            tab[LDS_T1 + lane] = c1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // per-k totals (number of valid windows; ref: `total`, src/abawaca-build.cpp:120,136,153)
+        uint32_t tot[4];
+        tot[3] = wave_sum(tab[LDS_T4 + lane] + tab[LDS_T4 + 64 + lane] + tab[LDS_T4 + 128 + lane] + tab[LDS_T4 + 192 + lane]);
+        tot[2] = wave_sum(tab[LDS_T3 + lane]);
+        tot[1] = wave_sum(lane < 16 ? tab[LDS_T2 + lane] : 0u);
+        tot[0] = wave_sum(lane < 4 ? tab[LDS_T1 + lane] : 0u);
+
+#pragma unroll
+        for (int rep = 0; rep < 3; rep++) {
+            const int dim = lane + 64 * rep;
+            if (dim < ABW_SIG_NDIMS) {
+                const uint32_t ia = c_tabs.dim_a[dim], ib = c_tabs.dim_b[dim];
+                const uint32_t t = ia >= LDS_T1 ? tot[0] : ia >= LDS_T2 ? tot[1] : ia >= LDS_T3 ? tot[2] : tot[3];
+                double x = 0.0;
+                if (t != 0) {
+                    // ref :171 — dimensions[idx] += double(count)/total, once per strand
+                    x = (double)tab[ia] / (double)(int)t;
+                    if (ib != 0xFFFFu) x += (double)tab[ib] / (double)(int)t;
+                }
+                if (dims) dims[s * ABW_SIG_NDIMS + dim] = x;
+                if (milli && dim > 0) milli[s * ABW_SIG_NCOLS + dim - 1] = (int)(1000.0 * x);   // ref :603
+            }
+        }
+        if (counts) {
+            for (int i = lane; i < ABW_SIG_NMERS; i += 64) counts[s * ABW_SIG_NMERS + i] = tab[c_tabs.cnt_perm[i]];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// segmentation on the device
+//   pass 1: non-'N' count of every 1 KiB block of the blob + lower-case 'n' detection
+//   pass 2: exclusive scan of the block counts (single workgroup, decoupled chunks)
+//   pass 3: per scaffold: nonN, nseg, nbps, number of segments produced
+//   pass 4: exclusive scan over scaffolds -> segment offsets
+//   pass 5: one wave per segment: locate the position of its last non-N base by rank
+// ---------------------------------------------------------------------------------------------
+constexpr int SEGBLK = 1024;
+
+__device__ __forceinline__ uint32_t count_byte_eq(uint32_t x, uint32_t pat)   // pat = byte replicated 4x
+{
+    uint32_t t = x ^ pat;
+    // exact zero-byte detector: 0x80 in every byte of t that is zero
+    uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+    return __popc(z);
+}
+
+__global__ __launch_bounds__(256) void seg_blockcount_kernel(const uint8_t* __restrict__ ascii, uint64_t total_len,
+                                                            uint32_t* __restrict__ blk_nonN, uint64_t nblk,
+                                                            int* __restrict__ flag_lower_n)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t b = wave; b < nblk; b += nwaves) {
+        const uint64_t A = b * SEGBLK + (uint64_t)lane * 16;
+        uint32_t nN = 0, nn = 0, len = 0;
+        if (A + 16 <= total_len) {
+            const uint4 v = *reinterpret_cast<const uint4*>(ascii + A);
+            nN = count_byte_eq(v.x, 0x4E4E4E4Eu) + count_byte_eq(v.y, 0x4E4E4E4Eu) + count_byte_eq(v.z, 0x4E4E4E4Eu) + count_byte_eq(v.w, 0x4E4E4E4Eu);
+            nn = count_byte_eq(v.x, 0x6E6E6E6Eu) + count_byte_eq(v.y, 0x6E6E6E6Eu) + count_byte_eq(v.z, 0x6E6E6E6Eu) + count_byte_eq(v.w, 0x6E6E6E6Eu);
+            len = 16;
+        } else {
+            for (uint64_t i = A; i < total_len; i++) { nN += ascii[i] == 'N'; nn += ascii[i] == 'n'; len++; }
+        }
+        uint32_t nonN = wave_sum(len - nN);
+        if (nn) atomicOr(flag_lower_n, 1);
+        if (lane == 0) blk_nonN[b] = nonN;
+    }
+}
+
+// exclusive scan of uint32 -> uint64, one workgroup (n is L/1024 or n_scaf: small next to the blob)
+template <typename TIN>
+__global__ __launch_bounds__(1024) void scan_exclusive_kernel(const TIN* __restrict__ in, uint64_t* __restrict__ out, uint64_t n)
+{
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry_s;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n; base += 1024) {
+        const uint64_t i = base + threadIdx.x;
+        uint64_t v = (i < n) ? (uint64_t)in[i] : 0, x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint64_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) wsum[wid] = x;
+        __syncthreads();
+        uint64_t woff = 0;
+        for (int k = 0; k < wid; k++) woff += wsum[k];
+        const uint64_t carry = carry_s;
+        if (i < n) out[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry_s;
+}
+
+// rank (number of non-N bytes) of blob prefix [0, pos): whole blocks from blk_prefix + a partial block
+__device__ __forceinline__ uint64_t prefix_nonN(const uint8_t* __restrict__ ascii, const uint64_t* __restrict__ blk_prefix,
+                                                uint64_t pos, int lane)
+{
+    const uint64_t b = pos / SEGBLK;
+    const uint64_t A = b * SEGBLK + (uint64_t)lane * 16;
+    uint32_t c = 0;
+    for (uint64_t i = A; i < A + 16 && i < pos; i++) c += ascii[i] != 'N';
+    return blk_prefix[b] + wave_sum(c);
+}
+
+struct ScafSeg { uint64_t rank0; uint64_t nbps; uint64_t nseg; };
+
+__global__ __launch_bounds__(256) void seg_scaf_kernel(const uint8_t* __restrict__ ascii, const uint64_t* __restrict__ scaf_off,
+                                                      uint64_t n_scaf, const uint64_t* __restrict__ blk_prefix, uint32_t window,
+                                                      ScafSeg* __restrict__ info, uint64_t* __restrict__ nseg_out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t s = wave; s < n_scaf; s += nwaves) {
+        const uint64_t b = scaf_off[s], e = scaf_off[s + 1];
+        const uint64_t r0 = prefix_nonN(ascii, blk_prefix, b, lane);
+        const uint64_t r1 = prefix_nonN(ascii, blk_prefix, e, lane);
+        const uint64_t nonN = r1 - r0;
+        uint64_t nsegments = nonN / window;                      // ref :202
+        if (nsegments == 0) nsegments = 1;                       // ref :204-205
+        const uint64_t nbps = nonN / nsegments;                  // ref :206
+        // ref :209-225 — a cut every nbps non-N bases; nbps == 0 cuts after every base
+        const uint64_t produced = (nbps == 0) ? (e - b) : nonN / nbps;
+        if (lane == 0) { info[s].rank0 = r0; info[s].nbps = nbps; info[s].nseg = produced; nseg_out[s] = produced; }
+    }
+}
+
+// position (absolute) of the non-N byte with 0-based global rank `rank`
+__device__ __forceinline__ uint64_t select_nonN(const uint8_t* __restrict__ ascii, uint64_t total_len,
+                                                const uint64_t* __restrict__ blk_prefix, uint64_t nblk, uint64_t rank, int lane)
+{
+    // largest block b with blk_prefix[b] <= rank
+    uint64_t lo = 0, hi = nblk;                                   // invariant: blk_prefix[lo] <= rank < blk_prefix[hi]
+    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (blk_prefix[mid] <= rank) lo = mid; else hi = mid; }
+    const uint64_t A = lo * SEGBLK + (uint64_t)lane * 16;
+    uint32_t c = 0;
+    for (uint64_t i = A; i < A + 16 && i < total_len; i++) c += ascii[i] != 'N';
+    uint32_t x = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    const uint64_t before = blk_prefix[lo] + x - c;               // non-N bytes before this lane's piece
+    uint64_t pos = ~0ull;
+    if (rank >= before && rank < before + c) {
+        uint64_t need = rank - before;
+        for (uint64_t i = A; i < A + 16; i++) if (ascii[i] != 'N') { if (need == 0) { pos = i; break; } need--; }
+    }
+    // exactly one lane found it
+    const unsigned long long ball = __ballot(pos != ~0ull);
+    const int src = __ffsll((long long)ball) - 1;
+    return __shfl(pos, src < 0 ? 0 : src, 64);
+}
+
+__global__ __launch_bounds__(256) void seg_emit_kernel(const uint8_t* __restrict__ ascii, uint64_t total_len,
+                                                      const uint64_t* __restrict__ scaf_off, uint64_t n_scaf,
+                                                      const uint64_t* __restrict__ blk_prefix, uint64_t nblk,
+                                                      const ScafSeg* __restrict__ info, const uint64_t* __restrict__ seg_off,
+                                                      uint64_t n_seg, uint32_t* __restrict__ seg_scaf,
+                                                      uint64_t* __restrict__ seg_start, uint64_t* __restrict__ seg_end)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t g = wave; g < n_seg; g += nwaves) {
+        // scaffold of segment g: largest s with seg_off[s] <= g
+        uint64_t lo = 0, hi = n_scaf;
+        while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (seg_off[mid] <= g) lo = mid; else hi = mid; }
+        const uint64_t s = lo, j = g - seg_off[s], b = scaf_off[s];
+        const ScafSeg si = info[s];
+        uint64_t st, en;                                          // 1-based inclusive within the scaffold
+        if (si.nbps == 0) { st = j + 1; en = j + 1; }
+        else {
+            // segment j ends at the ((j+1)*nbps)-th non-N base of the scaffold and starts right after
+            // the end of segment j-1 (ref :216,221-223)
+            const uint64_t pe = select_nonN(ascii, total_len, blk_prefix, nblk, si.rank0 + (j + 1) * si.nbps - 1, lane);
+            en = pe - b + 1;
+            if (j == 0) st = 1;
+            else st = select_nonN(ascii, total_len, blk_prefix, nblk, si.rank0 + j * si.nbps - 1, lane) - b + 2;
+        }
+        if (lane == 0) { seg_scaf[g] = (uint32_t)s; seg_start[g] = st; seg_end[g] = en; }
+    }
+}
+
+bool g_tables_uploaded[64] = {};
+
+int upload_tables(abw_ctx* ctx)
+{
+    if (ctx->device < 64 && g_tables_uploaded[ctx->device]) return ABW_OK;
+    const SigTables& t = host_tables();
+    ABW_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_tabs), &t, sizeof(t)));
+    if (ctx->device < 64) g_tables_uploaded[ctx->device] = true;
+    return ABW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int abw_sig_dim_names(char* buf, uint64_t buf_len)
+{
+    if (!buf) return ABW_ERR_ARG;
+    SigTables t;
+    std::vector<std::string> names;
+    build_tables(t, &names);
+    uint64_t need = 0;
+    for (auto& s : names) need += s.size() + 1;
+    if (buf_len < need) return ABW_ERR_CAPACITY;
+    char* p = buf;
+    for (auto& s : names) { memcpy(p, s.c_str(), s.size() + 1); p += s.size() + 1; }
+    return ABW_OK;
+}
+
+int abw_sig_segment_host(const uint8_t* ascii, const uint64_t* scaf_off, uint64_t n_scaf, uint32_t window,
+                         uint64_t seg_cap, uint32_t* seg_scaf, uint64_t* seg_start, uint64_t* seg_end,
+                         uint64_t* n_seg)
+{
+    if ((!ascii && n_scaf && scaf_off && scaf_off[n_scaf]) || !scaf_off || !n_seg || window == 0) return ABW_ERR_ARG;
+    // pass 1 (parallel): per scaffold non-N count -> number of segments; also the lower-case 'n' rule
+    std::vector<uint64_t> nseg(n_scaf + 1, 0), nbps_v(n_scaf, 0);
+    std::vector<int> bad(1, 0);
+    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    auto pass1 = [&](unsigned t) {
+        for (uint64_t s = t; s < n_scaf; s += nt) {
+            const uint8_t* p = ascii + scaf_off[s];
+            const uint64_t len = scaf_off[s + 1] - scaf_off[s];
+            uint64_t Ns = 0;
+            for (uint64_t i = 0; i < len; i++) { Ns += p[i] == 'N'; if (p[i] == 'n') bad[0] = 1; }
+            uint64_t nonN = len - Ns, k = nonN / window;
+            if (k == 0) k = 1;
+            const uint64_t nbps = nonN / k;
+            nbps_v[s] = nbps;
+            nseg[s] = nbps == 0 ? len : nonN / nbps;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(pass1, t);
+        for (auto& x : th) x.join();
+    }
+    if (bad[0]) return ABW_ERR_LOWER_N;
+    uint64_t total = 0;
+    for (uint64_t s = 0; s < n_scaf; s++) { uint64_t c = nseg[s]; nseg[s] = total; total += c; }
+    nseg[n_scaf] = total;
+    *n_seg = total;
+    if (total > seg_cap) return ABW_ERR_CAPACITY;
+    if (total && (!seg_scaf || !seg_start || !seg_end)) return ABW_ERR_ARG;
+    auto pass2 = [&](unsigned t) {
+        for (uint64_t s = t; s < n_scaf; s += nt) {
+            const uint8_t* p = ascii + scaf_off[s];
+            const uint64_t len = scaf_off[s + 1] - scaf_off[s], nbps = nbps_v[s];
+            uint64_t o = nseg[s], acc = 0, sit = 0;
+            for (uint64_t it = 0; it < len; it++) {                 // ref :209-225
+                if (p[it] != 'N') acc++;
+                if (acc == nbps) {
+                    seg_scaf[o] = (uint32_t)s; seg_start[o] = sit + 1; seg_end[o] = it + 1;
+                    o++; sit = it + 1; acc = 0;
+                }
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(pass2, t);
+        for (auto& x : th) x.join();
+    }
+    return ABW_OK;
+}
+
+int abw_sig_segment_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len, const uint64_t* d_scaf_off,
+                        uint64_t n_scaf, uint32_t window, uint64_t seg_cap, uint32_t* d_seg_scaf,
+                        uint64_t* d_seg_start, uint64_t* d_seg_end, uint64_t* n_seg)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!n_seg || window == 0 || (n_scaf && !d_scaf_off)) return abw_fail(ctx, ABW_ERR_ARG, "abw_sig_segment_dev: bad argument");
+    abw_device_guard g(ctx->device);
+    *n_seg = 0;
+    if (n_scaf == 0) return ABW_OK;
+    const uint64_t nblk = total_len / SEGBLK + 1;                 // + partial / empty tail block
+    // scratch[0]: blk_nonN u32[nblk] | scratch[1]: blk_prefix u64[nblk+1] | scratch[2]: ScafSeg[n_scaf]
+    // scratch[3]: nseg u64[n_scaf] | scratch[4]: seg_off u64[n_scaf+1] | scratch[5]: flag
+    int rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[0], nblk * 4))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[1], (nblk + 1) * 8))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[2], n_scaf * sizeof(ScafSeg)))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[3], n_scaf * 8))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[4], (n_scaf + 1) * 8))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[5], 64))) return rc;
+    uint32_t* blk_nonN = (uint32_t*)ctx->scratch[0].p;
+    uint64_t* blk_prefix = (uint64_t*)ctx->scratch[1].p;
+    ScafSeg* info = (ScafSeg*)ctx->scratch[2].p;
+    uint64_t* nseg = (uint64_t*)ctx->scratch[3].p;
+    uint64_t* seg_off = (uint64_t*)ctx->scratch[4].p;
+    int* flag = (int*)ctx->scratch[5].p;
+    hipStream_t st = ctx->stream;
+    ABW_HIP(ctx, hipMemsetAsync(flag, 0, 4, st));
+    const int grid = ctx->num_cu * 8;
+    hipLaunchKernelGGL(seg_blockcount_kernel, dim3(grid), dim3(256), 0, st, d_ascii, total_len, blk_nonN, nblk, flag);
+    ABW_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(scan_exclusive_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, blk_nonN, blk_prefix, nblk);
+    ABW_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(seg_scaf_kernel, dim3(grid), dim3(256), 0, st, d_ascii, d_scaf_off, n_scaf, blk_prefix, window, info, nseg);
+    ABW_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(scan_exclusive_kernel<uint64_t>, dim3(1), dim3(1024), 0, st, nseg, seg_off, n_scaf);
+    ABW_LAUNCH_CHECK(ctx);
+    uint64_t total = 0;
+    int h_flag = 0;
+    ABW_HIP(ctx, hipMemcpyAsync(&total, seg_off + n_scaf, 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    if (h_flag) return abw_fail(ctx, ABW_ERR_LOWER_N, "lower-case 'n' in sequence data (the reference throws Illegal_DNAString)");
+    *n_seg = total;
+    if (total > seg_cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "segment capacity %llu < %llu", (unsigned long long)seg_cap, (unsigned long long)total);
+    if (total == 0) return ABW_OK;
+    if (!d_seg_scaf || !d_seg_start || !d_seg_end) return abw_fail(ctx, ABW_ERR_ARG, "null segment output");
+    hipLaunchKernelGGL(seg_emit_kernel, dim3(grid), dim3(256), 0, st, d_ascii, total_len, d_scaf_off, n_scaf, blk_prefix, nblk,
+                       info, seg_off, total, d_seg_scaf, d_seg_start, d_seg_end);
+    ABW_LAUNCH_CHECK(ctx);
+    return ABW_OK;
+}
+
+int abw_sig_count_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len, const uint64_t* d_scaf_off,
+                      const uint32_t* d_seg_scaf, const uint64_t* d_seg_start, const uint64_t* d_seg_end,
+                      uint64_t n_seg, double* d_dims, int32_t* d_milli, uint32_t* d_counts)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (n_seg == 0) return ABW_OK;
+    if (!d_ascii || !d_scaf_off || !d_seg_scaf || !d_seg_start || !d_seg_end)
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_sig_count_dev: null input");
+    if (((uintptr_t)d_ascii & 15) != 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sig_count_dev: d_ascii must be 16-byte aligned");
+    abw_device_guard g(ctx->device);
+    int rc = upload_tables(ctx);
+    if (rc) return rc;
+    uint64_t blocks = (n_seg + 3) / 4;
+    const uint64_t maxb = (uint64_t)ctx->num_cu * 16;
+    if (blocks > maxb) blocks = maxb;
+    hipLaunchKernelGGL(sig_count_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, total_len, d_scaf_off,
+                       d_seg_scaf, d_seg_start, d_seg_end, n_seg, d_dims, d_milli, d_counts);
+    ABW_LAUNCH_CHECK(ctx);
+    return ABW_OK;
+}
+
+int abw_sig_build(abw_ctx* ctx, const uint8_t* ascii, const uint64_t* scaf_off, uint64_t n_scaf, uint32_t window,
+                  uint64_t seg_cap, uint32_t* seg_scaf, uint64_t* seg_start, uint64_t* seg_end,
+                  double* dims, int32_t* milli, uint64_t* n_seg)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!scaf_off || !n_seg) return abw_fail(ctx, ABW_ERR_ARG, "abw_sig_build: null argument");
+    abw_device_guard g(ctx->device);
+    *n_seg = 0;
+    if (n_scaf == 0) return ABW_OK;
+    const uint64_t total_len = scaf_off[n_scaf];
+    int rc;
+    // scratch[6]: blob (padded) + scaffold offsets ; scratch[7]: segment tables + outputs
+    const uint64_t blob_bytes = ((total_len + 15) & ~15ull) + 16;
+    const uint64_t off_bytes = (n_scaf + 1) * 8;
+    if ((rc = abw_reserve(ctx, ctx->scratch[6], blob_bytes + off_bytes))) return rc;
+    uint8_t* d_ascii = (uint8_t*)ctx->scratch[6].p;
+    uint64_t* d_off = (uint64_t*)(d_ascii + blob_bytes);
+    hipStream_t st = ctx->stream;
+    if (total_len) ABW_HIP(ctx, hipMemcpyAsync(d_ascii, ascii, total_len, hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemcpyAsync(d_off, scaf_off, off_bytes, hipMemcpyHostToDevice, st));
+    const uint64_t cap = seg_cap;
+    const uint64_t seg_bytes = cap * (4 + 8 + 8);
+    const uint64_t out_bytes = cap * ((dims ? ABW_SIG_NDIMS * 8ull : 0) + (milli ? ABW_SIG_NCOLS * 4ull : 0));
+    if ((rc = abw_reserve(ctx, ctx->scratch[7], seg_bytes + out_bytes + 64))) return rc;
+    uint64_t* d_start = (uint64_t*)ctx->scratch[7].p;
+    uint64_t* d_end = d_start + cap;
+    double* d_dims = dims ? (double*)(d_end + cap) : nullptr;
+    uint8_t* tail = (uint8_t*)(d_end + cap) + (dims ? cap * ABW_SIG_NDIMS * 8ull : 0);
+    int32_t* d_milli = milli ? (int32_t*)tail : nullptr;
+    tail += milli ? cap * ABW_SIG_NCOLS * 4ull : 0;
+    uint32_t* d_scaf = (uint32_t*)tail;
+    uint64_t n = 0;
+    rc = abw_sig_segment_dev(ctx, d_ascii, total_len, d_off, n_scaf, window, cap, d_scaf, d_start, d_end, &n);
+    *n_seg = n;
+    if (rc) return rc;
+    if (n == 0) return ABW_OK;
+    if (!seg_scaf || !seg_start || !seg_end) return abw_fail(ctx, ABW_ERR_ARG, "abw_sig_build: null segment output");
+    rc = abw_sig_count_dev(ctx, d_ascii, total_len, d_off, d_scaf, d_start, d_end, n, d_dims, d_milli, nullptr);
+    if (rc) return rc;
+    ABW_HIP(ctx, hipMemcpyAsync(seg_scaf, d_scaf, n * 4, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipMemcpyAsync(seg_start, d_start, n * 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipMemcpyAsync(seg_end, d_end, n * 8, hipMemcpyDeviceToHost, st));
+    if (dims) ABW_HIP(ctx, hipMemcpyAsync(dims, d_dims, n * ABW_SIG_NDIMS * 8ull, hipMemcpyDeviceToHost, st));
+    if (milli) ABW_HIP(ctx, hipMemcpyAsync(milli, d_milli, n * ABW_SIG_NCOLS * 4ull, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    return ABW_OK;
+}
+
+}  // extern "C"

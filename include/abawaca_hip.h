@@ -1,0 +1,172 @@
+/* abawaca_hip.h — C ABI of libabawaca_hip.so: the MI355X (gfx950) implementation of abawaca's
+ * data-parallel hot path.  Plain pointers and sizes only; nothing throws across this boundary.
+ *
+ * Citations "ref:" are into the reference tree (CK7/abawaca, paths relative to its root) and name
+ * the interface or code each entry point stands in for.  INTEGRATION.md shows the C++ that a
+ * maintainer adds on the reference side to bind them.
+ *
+ * Conventions
+ *   - every function returns ABW_OK (0) or a negative ABW_ERR_* code; abw_last_error() gives text.
+ *   - "host" pointers are ordinary memory; "dev" pointers are HIP device memory on the context's GPU.
+ *   - a context is used by one host thread at a time (ref: ClusterSeparator::separate() is called
+ *     serially from main, src/abawaca.cpp:109-112); different contexts are independent.
+ *   - work is enqueued on the context's stream; functions that return results in host memory
+ *     synchronise that stream before returning, *_dev functions do not.
+ */
+#ifndef ABAWACA_HIP_H
+#define ABAWACA_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABW_OK               0
+#define ABW_ERR_ARG         -1   /* bad argument (null pointer, size, ordering) */
+#define ABW_ERR_HIP         -2   /* a HIP runtime call failed */
+#define ABW_ERR_CAPACITY    -3   /* caller-provided output capacity too small */
+#define ABW_ERR_LOWER_N     -4   /* lower-case 'n' in a sequence (ref: src/String.cpp:45-49 throws) */
+#define ABW_ERR_STATE       -5   /* call order (e.g. abw_sep_node before abw_sep_load) */
+#define ABW_ERR_NOMEM       -6
+
+#define ABW_SIG_NDIMS  180       /* canonical 1..4-mers incl. "A" (ref: src/abawaca-build.cpp:75-100) */
+#define ABW_SIG_NCOLS  179       /* columns written to abawaca.lrn: all but "A" (ref: :585,591,602) */
+#define ABW_SIG_NMERS  340
+
+typedef struct abw_ctx abw_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* device: HIP device ordinal.  Creates a stream owned by the context. */
+int  abw_ctx_create(int device, abw_ctx** out);
+void abw_ctx_destroy(abw_ctx* ctx);
+/* Run on a caller-owned hipStream_t instead (NULL restores the context's own stream). */
+int  abw_ctx_set_stream(abw_ctx* ctx, void* hip_stream);
+int  abw_ctx_synchronize(abw_ctx* ctx);
+const char* abw_last_error(const abw_ctx* ctx);
+/* Library/ABI version, bumped on any signature change. */
+int  abw_abi_version(void);
+
+/* ---- stage 1: signature build (ref: src/abawaca-build.cpp:103-228, 595-607) ----------------- */
+
+/* Names of the 180 dimensions in the reference's order ("A","C","AA",...), NUL-separated into buf
+ * (needs >= 900 bytes).  ref: dimension_order, src/abawaca-build.cpp:69,82.  Host only. */
+int abw_sig_dim_names(char* buf, uint64_t buf_len);
+
+/* Segmentation of n_scaf scaffolds held as one concatenated ASCII blob (scaffold i =
+ * ascii[scaf_off[i] .. scaf_off[i+1])).  Replaces the loop of Scaf::Scaf (ref: :198-228) together
+ * with DNAString's upper-casing rule (ref: src/String.cpp:37-51; bytes are NOT modified, the
+ * counting kernel upper-cases on the fly).  Writes, in scaffold order, for every segment its
+ * scaffold index and 1-based inclusive [start,end] within the scaffold (ref: segment_coords, :216).
+ * Host memory in, host memory out; multi-threaded on the host.  *n_seg receives the count even when
+ * it exceeds seg_cap (then ABW_ERR_CAPACITY). */
+int abw_sig_segment_host(const uint8_t* ascii, const uint64_t* scaf_off, uint64_t n_scaf, uint32_t window,
+                         uint64_t seg_cap, uint32_t* seg_scaf, uint64_t* seg_start, uint64_t* seg_end,
+                         uint64_t* n_seg);
+
+/* Same on the GPU: d_ascii/d_scaf_off and all outputs are device pointers; *n_seg is host memory
+ * (the call synchronises).  total_len = scaf_off[n_scaf]. */
+int abw_sig_segment_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len, const uint64_t* d_scaf_off,
+                        uint64_t n_scaf, uint32_t window, uint64_t seg_cap, uint32_t* d_seg_scaf,
+                        uint64_t* d_seg_start, uint64_t* d_seg_end, uint64_t* n_seg);
+
+/* Counting + finalisation of n_seg segments: the body of Scaf_segment::Scaf_segment (ref: :103-174)
+ * for every segment at once.  Segment s covers blob bytes
+ *   [d_scaf_off[d_seg_scaf[s]] + d_seg_start[s] - 1,  d_scaf_off[d_seg_scaf[s]] + d_seg_end[s]).
+ * Outputs (each may be NULL):
+ *   d_dims   [n_seg][180] f64 — Scaf_segment::dimensions, bit-exact (ref: :171)
+ *   d_milli  [n_seg][179] i32 — int(1000.0*x) of every column but "A" (ref: :603)
+ *   d_counts [n_seg][340] u32 — raw k-mer window counts, k=1..4 blocks, base-4 A,C,G,T=0..3
+ * Asynchronous on the context's stream. */
+int abw_sig_count_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len, const uint64_t* d_scaf_off,
+                      const uint32_t* d_seg_scaf, const uint64_t* d_seg_start, const uint64_t* d_seg_end,
+                      uint64_t n_seg, double* d_dims, int32_t* d_milli, uint32_t* d_counts);
+
+/* Whole stage with host buffers: segmentation on the GPU, H2D, counting, D2H.  This is what the
+ * reference's FASTA loop (ref: src/abawaca-build.cpp:483-490) would call once per batch of
+ * scaffolds instead of constructing Scaf objects.  dims/milli may be NULL. */
+int abw_sig_build(abw_ctx* ctx, const uint8_t* ascii, const uint64_t* scaf_off, uint64_t n_scaf, uint32_t window,
+                  uint64_t seg_cap, uint32_t* seg_scaf, uint64_t* seg_start, uint64_t* seg_end,
+                  double* dims, int32_t* milli, uint64_t* n_seg);
+
+/* ---- stage 2: cluster separator (ref: src/ClusterSeparator.cpp:25-135,
+ *               src/ClusterSeparatorBySensitivitySpecificity.cpp:91-161, src/ClusterQuality.cpp:96-136)
+ *
+ * abw_sep_load puts the whole column store on the GPU once (ref: ClusterData loaded at
+ * src/abawaca.cpp:86); abw_sep_node then runs ClusterSeparator::separate() for one node of the
+ * recursion (ref: src/abawaca.cpp:109-112) given only the node's scaffold list.
+ */
+typedef struct {
+    int32_t found;          /* some threshold of this dimension passed size check and gate */
+    int32_t key;            /* its value (the caller's integer key; thousandths for abawaca.lrn) */
+    double  sensitivity;    /* ref: ClusterStats::get_sensitivity, ...Specificity.h:75 */
+    double  specificity;    /* ref: ...Specificity.h:74 */
+} abw_dimbest;
+
+typedef struct {
+    int32_t split;          /* return value of separate() (ref: ClusterSeparator.cpp:57-135) */
+    int32_t dimension;      /* get_separating_dimension(), 1-based; -1 when none/reset */
+    int32_t key;            /* get_separating_value() as integer key; -1 when none/reset */
+    int32_t legal;          /* is_best_separation_legal() of the global winner before the size check */
+    double  sensitivity;    /* get_best_sensitivity() */
+    double  specificity;    /* get_best_specificity() */
+    int64_t ndps1, ndps2;   /* final cluster1/cluster2 sizes after dps followed their scaffolds */
+} abw_split;
+
+/* keys: host [D][N] int32 column-major (dimension-major), an order-preserving integer image of the
+ * .lrn values — thousandths for abawaca-build output (ref: src/abawaca-build.cpp:603 writes
+ * 3 decimals; src/ClusterData.cpp:159 reads them back).  dp2scaf: host [N], 0-based scaffold of
+ * each dp; dps of one scaffold must be contiguous and scaffolds ascending, which is how
+ * ScafDpData numbers them (ref: src/ScafDpData.cpp:91-99).  Every scaffold needs >= 2 dps
+ * (ref: :92-93 drops the others).  scaf_len: [S] sequence lengths (ref: ClusterQuality.cpp:111-115).
+ * scg_off [S+1] / scg_ids: CSR scaffold -> SCG id in [0, n_scg) (ref: SCGdb::scaf2scgs,
+ * src/SCGdb.h:25); both may be NULL when n_scg == 0. */
+int abw_sep_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const int32_t* dp2scaf,
+                 const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
+                 int32_t n_scg);
+
+/* One node.  scaf_ids: host, the node's scaffolds (any order, no duplicates); NULL = all S
+ * scaffolds (the root, ref: init_cluster, src/abawaca.cpp:242-251).  min_ndps is
+ * cluster_ndps_threshold (100; ref: ClusterSeparator.h:72).
+ * Outputs (host; per_dim/scaf_side/dp_raw_side may be NULL):
+ *   per_dim     [D]      per-dimension winner (ref: best_dimension_separation, ...Specificity.cpp:115)
+ *   scaf_side   [n_scaf] 1/2 = scaffold assigned to cluster1/cluster2 (ref: ClusterSeparator.cpp:94-101),
+ *                        in the order of scaf_ids (ascending scaffold id when scaf_ids is NULL); 0 if !split
+ *   dp_raw_side [n dps]  1/2 = raw_dps_cluster1/2 (ref: :87-90) for the node's dps, scaffold by scaffold
+ *                        in the order of scaf_ids, dps ascending within a scaffold; 0 if no legal separation */
+int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t min_ndps,
+                 abw_split* out, abw_dimbest* per_dim, uint8_t* scaf_side, uint8_t* dp_raw_side);
+
+/* Device pointer to the resident column store [D][N] int32 (for abw_km_features_from_keys). */
+const int32_t* abw_sep_dev_keys(const abw_ctx* ctx);
+
+/* ---- extension: k-means restarts (NO counterpart in the reference, see DESIGN.md "K-means";
+ *      RNG = TinyMT32, ref: src/misc.cpp:24-36, src/TinyMT-src-1.0.1/tinymt/tinymt32.{c,h}) -------- */
+
+/* Rows needed for d_x in abw_km_run_dev: d rounded up to even, plus nothing else. */
+/* d_x: device [d][N] fp32 column-major (dimension-major) points.  k = 2.  R restarts are run
+ * together; restart r seeds TinyMT32 with base_seed + r.  chunk: points per fp32 partial sum
+ * (multiple of 32; 0 = default 1024).  Outputs are device pointers (any may be NULL):
+ *   d_assign    [R][N] u8   cluster of every point after the final assign pass
+ *   d_centroids [R][2][d] fp32
+ *   d_inertia   [R] f64     sum of squared distances to the assigned centroid
+ * Asynchronous on the context's stream. */
+int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t R, uint32_t base_seed,
+                   int32_t iters, int32_t chunk, uint8_t* d_assign, float* d_centroids, double* d_inertia);
+
+/* Host-buffer convenience: x is host [d][N]; outputs host. */
+int abw_km_run(abw_ctx* ctx, const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed,
+               int32_t iters, int32_t chunk, uint8_t* assign, float* centroids, double* inertia);
+
+/* d_x[j][p] = (float)keys[j][p] * scale[j]  (scale host [D], NULL = all ones) — turns the resident
+ * integer column store into k-means features without a second copy of the table on the host. */
+int abw_km_features_from_keys(abw_ctx* ctx, const int32_t* d_keys, int32_t D, int64_t N, const float* scale,
+                              float* d_x);
+
+/* First n outputs of the TinyMT32 stream for `seed` computed ON THE DEVICE (known-answer check
+ * against ref: tinymt/check32.out.txt).  out: host [n]. */
+int abw_km_tinymt_selftest(abw_ctx* ctx, uint32_t seed, int32_t n, uint32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABAWACA_HIP_H */

@@ -401,102 +401,103 @@ uint32_t abw_or_tinymt_next(abw_or_tinymt* t)
 /* ---------------------------------------------------------------------------------------- */
 /* K-means restarts (extension; semantics fixed in DESIGN.md "K-means")                      */
 /* ---------------------------------------------------------------------------------------- */
-#define KM_TILE 32
-
-static void km_scores(const float* xp, const float* c0, const float* c1, float h0, float h1, int32_t d,
-                      float* s0, float* s1)
+/* sum_p x[j][p]^2 : 256 strided fp64 partials per dimension, xor-butterfly inside each group of 64,
+ * then (w0 + w1) + (w2 + w3); dimensions added in index order. */
+static double km_x2(const float* x, int64_t N, int32_t d)
 {
-    float a0 = -h0, a1 = -h1;
-    for (int32_t j = 0; j < d; j++) { a0 = fmaf(xp[j], c0[j], a0); a1 = fmaf(xp[j], c1[j], a1); }
-    *s0 = a0; *s1 = a1;
+    double total = 0.0;
+    for (int32_t j = 0; j < d; j++) {
+        const float* row = x + (int64_t)j * N;
+        double part[256];
+        for (int t = 0; t < 256; t++) {
+            double acc = 0.0;
+            for (int64_t p = t; p < N; p += 256) { double v = (double)row[p]; acc += v * v; }
+            part[t] = acc;
+        }
+        double w[4];
+        for (int g = 0; g < 4; g++) {
+            double v[64], nv[64];
+            for (int l = 0; l < 64; l++) v[l] = part[g * 64 + l];
+            for (int o = 32; o > 0; o >>= 1) {
+                for (int l = 0; l < 64; l++) nv[l] = v[l] + v[l ^ o];
+                memcpy(v, nv, sizeof(v));
+            }
+            w[g] = v[0];
+        }
+        total += (w[0] + w[1]) + (w[2] + w[3]);
+    }
+    return total;
 }
 
 int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed, int32_t iters,
-                  int32_t groups, int nthreads, uint8_t* assign, float* centroids, double* inertia)
+                  int32_t chunk, int nthreads, uint8_t* assign, float* centroids, double* inertia)
 {
-    if (N < 2 || d < 1 || R < 1 || groups < 1) return -1;
+    if (N < 2 || d < 1 || R < 1 || chunk < 1) return -1;
 #ifdef _OPENMP
     if (nthreads <= 0) nthreads = omp_get_max_threads();
 #else
     nthreads = 1;
 #endif
-    int64_t ntiles = (N + KM_TILE - 1) / KM_TILE;
-    /* total sums (shared by all restarts): tile partial in fp32 in point order, tiles into their
-     * group's fp64 accumulator in tile order, groups added in group order */
-    double* total = (double*)calloc((size_t)d, sizeof(double));
-    {
-        double* gacc = (double*)calloc((size_t)groups * d, sizeof(double));
-        for (int64_t t = 0; t < ntiles; t++) {
-            int64_t p0 = t * KM_TILE, p1 = p0 + KM_TILE < N ? p0 + KM_TILE : N;
-            double* ga = gacc + (size_t)(t % groups) * d;
-            for (int32_t j = 0; j < d; j++) {
-                float part = 0.0f;
-                for (int64_t p = p0; p < p1; p++) part = part + x[p * d + j];
-                ga[j] += (double)part;
-            }
-        }
-        for (int32_t g = 0; g < groups; g++) for (int32_t j = 0; j < d; j++) total[j] += gacc[(size_t)g * d + j];
-        free(gacc);
-    }
+    const double x2 = km_x2(x, N, d);
+    const int64_t nchunks = (N + chunk - 1) / chunk;
     int err = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int32_t r = 0; r < R; r++) {
-        float* c = centroids + (size_t)r * 2 * d;
+        float* c = centroids + (size_t)r * 2 * d;                  /* [2][d] */
         uint8_t* a = assign + (size_t)r * N;
-        double* gacc = (double*)malloc(sizeof(double) * (size_t)groups * (d + 2));
-        if (!gacc) { err = 1; continue; }
+        float* part = (float*)malloc(sizeof(float) * 2 * (size_t)(d + 1));
+        double* S = (double*)malloc(sizeof(double) * 2 * (size_t)(d + 1));
+        float* xp = (float*)malloc(sizeof(float) * (size_t)d);
+        if (!part || !S || !xp) { err = 1; free(part); free(S); free(xp); continue; }
         abw_or_tinymt t;
         abw_or_tinymt_init(&t, base_seed + (uint32_t)r);
         int64_t i0 = (int64_t)(abw_or_tinymt_next(&t) % (uint64_t)N);
         int64_t i1 = i0;
         for (int tries = 0; tries < 64 && i1 == i0; tries++) i1 = (int64_t)(abw_or_tinymt_next(&t) % (uint64_t)N);
-        memcpy(c, x + i0 * d, sizeof(float) * d);
-        memcpy(c + d, x + i1 * d, sizeof(float) * d);
-        double inert = 0;
+        for (int32_t j = 0; j < d; j++) { c[j] = x[(int64_t)j * N + i0]; c[d + j] = x[(int64_t)j * N + i1]; }
         for (int32_t it = 0; it <= iters; it++) {
-            /* half squared norms, fp32 fma chain */
             float n0 = 0.0f, n1 = 0.0f;
             for (int32_t j = 0; j < d; j++) { n0 = fmaf(c[j], c[j], n0); n1 = fmaf(c[d + j], c[d + j], n1); }
-            float h0 = 0.5f * n0, h1 = 0.5f * n1;
-            /* per group: [0..d) cluster-1 sums, [d] cluster-1 count, [d+1] inertia */
-            memset(gacc, 0, sizeof(double) * (size_t)groups * (d + 2));
-            for (int64_t tl = 0; tl < ntiles; tl++) {
-                int64_t p0 = tl * KM_TILE, p1 = p0 + KM_TILE < N ? p0 + KM_TILE : N;
-                double* ga = gacc + (size_t)(tl % groups) * (d + 2);
-                double tin = 0; int32_t cnt = 0;
+            const float hn0 = -(0.5f * n0), hn1 = -(0.5f * n1);
+            for (int32_t q = 0; q < 2 * (d + 1); q++) S[q] = 0.0;
+            for (int64_t ch = 0; ch < nchunks; ch++) {
+                const int64_t p0 = ch * chunk, p1 = p0 + chunk < N ? p0 + chunk : N;
+                for (int32_t q = 0; q < 2 * (d + 1); q++) part[q] = 0.0f;
                 for (int64_t p = p0; p < p1; p++) {
-                    float s0, s1;
-                    km_scores(x + p * d, c, c + d, h0, h1, d, &s0, &s1);
-                    uint8_t as = s1 > s0;                   /* tie -> cluster 0 */
-                    a[p] = as;
-                    cnt += as;
-                    float xn = 0.0f;
-                    for (int32_t j = 0; j < d; j++) xn = fmaf(x[p * d + j], x[p * d + j], xn);
-                    tin += (double)xn - 2.0 * (double)(as ? s1 : s0);
+                    float s0 = hn0, s1 = hn1;
+                    for (int32_t j = 0; j < d; j++) {
+                        xp[j] = x[(int64_t)j * N + p];
+                        s0 = fmaf(xp[j], c[j], s0);
+                        s1 = fmaf(xp[j], c[d + j], s1);
+                    }
+                    const int as = s1 > s0;                         /* tie -> cluster 0 */
+                    a[p] = (uint8_t)as;
+                    float* pc = part + (size_t)as * (d + 1);
+                    for (int32_t j = 0; j < d; j++) pc[j] = fmaf(1.0f, xp[j], pc[j]);
+                    pc[d] = fmaf(1.0f, 1.0f, pc[d]);                /* the count column */
                 }
-                for (int32_t j = 0; j < d; j++) {
-                    float part = 0.0f;
-                    for (int64_t p = p0; p < p1; p++) part = fmaf((float)a[p], x[p * d + j], part);
-                    ga[j] += (double)part;
-                }
-                ga[d] += (double)cnt;
-                ga[d + 1] += tin;
+                for (int32_t q = 0; q < 2 * (d + 1); q++) S[q] += (double)part[q];
             }
-            double cnt1 = 0; inert = 0;
-            for (int32_t g = 0; g < groups; g++) { cnt1 += gacc[(size_t)g * (d + 2) + d]; inert += gacc[(size_t)g * (d + 2) + d + 1]; }
-            if (it == iters) break;                          /* last pass only assigns + scores */
-            double cnt0 = (double)N - cnt1;
-            for (int32_t j = 0; j < d; j++) {
-                double s1 = 0;
-                for (int32_t g = 0; g < groups; g++) s1 += gacc[(size_t)g * (d + 2) + j];
-                double s0 = total[j] - s1;
-                if (cnt0 > 0) c[j] = (float)(s0 / cnt0);
-                if (cnt1 > 0) c[d + j] = (float)(s1 / cnt1);
+            if (it < iters) {
+                for (int cl = 0; cl < 2; cl++) {
+                    const double cnt = S[(size_t)cl * (d + 1) + d];
+                    if (cnt > 0.0)
+                        for (int32_t j = 0; j < d; j++) c[(size_t)cl * d + j] = (float)(S[(size_t)cl * (d + 1) + j] / cnt);
+                }
+            } else {
+                double term[2];
+                for (int cl = 0; cl < 2; cl++) {
+                    double dot = 0.0, n2 = 0.0;
+                    for (int32_t j = 0; j < d; j++) {
+                        dot += (double)c[(size_t)cl * d + j] * S[(size_t)cl * (d + 1) + j];
+                        n2 += (double)c[(size_t)cl * d + j] * (double)c[(size_t)cl * d + j];
+                    }
+                    term[cl] = S[(size_t)cl * (d + 1) + d] * n2 - 2.0 * dot;
+                }
+                inertia[r] = (x2 + term[0]) + term[1];
             }
         }
-        inertia[r] = inert;
-        free(gacc);
+        free(part); free(S); free(xp);
     }
-    free(total);
     return err ? -2 : 0;
 }

@@ -99,23 +99,22 @@ uint32_t abw_or_tinymt_next(abw_or_tinymt* t);
 
 /* ------------------------------------------------------------------------------------------
  * K-means restarts (EXTENSION, parity unpinned — see DESIGN.md "K-means").
- * x: [N][d] fp32 row-major points; k = 2; R restarts.  Restart r seeds TinyMT32 with
+ * x: [d][N] fp32 dimension-major points; k = 2; R restarts.  Restart r seeds TinyMT32 with
  * base_seed + r and takes as initial centroids the points  u0 % N  and  u1 % N  (u1 redrawn, at
  * most 64 times, while it names the same point).
- * Assign: score_c = fmaf-chain over j = 0..d-1 of x_j*c_j starting from -0.5f*|c|^2 (|c|^2 itself
- *   an fp32 fmaf chain); a point goes to cluster 1 iff score_1 > score_0 (tie -> 0).  This is
+ * Assign: score_c = fmaf-chain over j = 0..d-1 of x_j*c_j starting from -(0.5f*|c|^2) (|c|^2 itself
+ *   an fp32 fmaf chain from 0); a point goes to cluster 1 iff score_1 > score_0 (tie -> 0): the
  *   argmin of the squared Euclidean distance with |x|^2 dropped.
- * Update: points are cut into tiles of 32 consecutive points; per tile and dimension the cluster-1
- *   members are summed in fp32 in point order (fmaf(a, x, acc), a in {0,1}); tile t's partial is
- *   added in fp64 to accumulator (t % groups); the `groups` accumulators are then added in index
- *   order.  sum_0 = total - sum_1 in fp64 (total built the same way from all points);
- *   centroid = (float)(sum / count); an empty cluster keeps its centroid.
- * `iters` assign+update rounds are followed by one assign-only pass; inertia[r] =
- *   sum_p (|x_p|^2 - 2*score_best) in fp64, accumulated per tile in point order, tiles/groups as above.
+ * Sums: points are cut into chunks of `chunk` consecutive points; per chunk, cluster and dimension
+ *   the members are summed in fp32 in point order (and counted the same way); chunk partials are
+ *   added in fp64 in chunk order.  centroid = (float)(sum / count); an empty cluster keeps its centroid.
+ * `iters` assign+update rounds are followed by one assign-only pass whose sums give
+ *   inertia[r] = (X2 + term_0) + term_1,  term_c = count_c*|c_c|^2 - 2*(c_c . sum_c)  in fp64
+ *   (j ascending), X2 = sum |x|^2 as built by km_x2() in abw_oracle.c.
  * Outputs: assign [R][N] uint8, centroids [R][2][d] fp32, inertia [R] fp64.
  * ------------------------------------------------------------------------------------------ */
 int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed, int32_t iters,
-                  int32_t groups, int nthreads, uint8_t* assign, float* centroids, double* inertia);
+                  int32_t chunk, int nthreads, uint8_t* assign, float* centroids, double* inertia);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,78 @@
+"""CPU-only checks of the C-ABI boundary: the library loads, exports every symbol the header
+declares, and its host-only entry points agree with the oracle / golden vectors."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+from abawaca_amd import _lib, signature, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "abawaca_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(abw_[a-z0-9_]+)\s*\(", header)))
+    assert declared == sorted(_lib.EXPORTS)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.abw_abi_version() >= 1
+
+
+def test_missing_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.AbwError):
+        _lib.Context(0)
+
+
+def test_dim_names_match_reference_header(golden_dir):
+    g = np.load(os.path.join(golden_dir, "sig_edge.npz"))
+    names = signature.dim_names()
+    assert names[0] == "A" and names[1:] == [str(x) for x in g["header"]]
+
+
+@pytest.mark.parametrize("case", ["sig_edge", "sig_rand"])
+def test_segment_host_matches_reference(golden_dir, case):
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    seg_scaf, st, en = signature.segment_host(g["ascii"], g["scaf_off"])
+    names = [str(x) for x in g["scaf_names"]]
+    order = sorted(range(len(names)), key=lambda i: names[i].encode())
+    idx = np.concatenate([np.flatnonzero(seg_scaf == i) for i in order])
+    assert np.array_equal(seg_scaf[idx], g["seg_scaf"].astype(np.uint32))
+    assert np.array_equal(st[idx], g["seg_start"]) and np.array_equal(en[idx], g["seg_end"])
+
+
+def test_segment_host_random_vs_oracle():
+    rng = np.random.default_rng(5)
+    seqs = []
+    for _ in range(60):
+        L = int(rng.integers(0, 9000))
+        s = synth.ACGT[rng.integers(0, 4, size=L)].copy()
+        for _k in range(int(rng.integers(0, 4))):
+            if L > 10:
+                a = int(rng.integers(0, L - 1)); b = min(L, a + int(rng.integers(1, 2500)))
+                s[a:b] = ord("N")
+        seqs.append(s)
+    blob = np.concatenate(seqs)
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    seg_scaf, st, en = signature.segment_host(blob, off)
+    exp_scaf, exp_st, exp_en = [], [], []
+    for i, s in enumerate(seqs):
+        a, b = orc.segments(s)
+        exp_scaf += [i] * len(a); exp_st += list(a); exp_en += list(b)
+    assert np.array_equal(seg_scaf, np.array(exp_scaf, dtype=np.uint32))
+    assert np.array_equal(st, np.array(exp_st)) and np.array_equal(en, np.array(exp_en))
+
+
+def test_segment_host_rejects_lowercase_n():
+    blob = np.frombuffer(b"ACGTnACGT", dtype=np.uint8)
+    with pytest.raises(_lib.AbwError) as e:
+        signature.segment_host(blob, np.array([0, 9], dtype=np.uint64))
+    assert e.value.code == _lib.ABW_ERR_LOWER_N

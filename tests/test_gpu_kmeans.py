@@ -1,0 +1,57 @@
+"""GPU checks of the k-means restart extension against its CPU restatement (oracle/abw_or_kmeans)
+and of the device TinyMT32 against the reference's known answers.  The reference has no k-means:
+parity here is "unpinned"  except for the RNG."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+from abawaca_amd import _lib, kmeans
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def test_device_tinymt_matches_reference_kat(ctx, golden_dir):
+    kat = json.load(open(os.path.join(golden_dir, "tinymt32_kat.json")))
+    for seed, outs in kat["outputs"].items():
+        assert kmeans.tinymt_selftest(ctx, int(seed), len(outs)) == outs
+
+
+def _blobs(seed, N, d, sep=4.0):
+    rng = np.random.default_rng(seed)
+    lab = rng.integers(0, 2, size=N)
+    mu = rng.normal(0, 1, size=(2, d)) * sep
+    x = (mu[lab] + rng.normal(0, 1, size=(N, d))).astype(np.float32)
+    return np.ascontiguousarray(x.T), lab
+
+
+@pytest.mark.parametrize("N,d,R,iters,chunk", [(1000, 7, 5, 4, 64), (4097, 33, 16, 6, 256), (6000, 189, 64, 3, 512),
+                                                  (333, 31, 3, 2, 32), (2500, 64, 20, 3, 128)])
+def test_kmeans_bit_exact_vs_oracle(ctx, N, d, R, iters, chunk):
+    x, _ = _blobs(N + d, N, d)
+    a, c, inert = kmeans.kmeans_restarts(ctx, x, R, base_seed=20240, iters=iters, chunk=chunk)
+    oa, oc, oi = orc.kmeans(x, R, 20240, iters, chunk)
+    assert np.array_equal(c.view(np.uint32), oc.view(np.uint32))        # centroids: identical fp32 bits
+    assert np.array_equal(a, oa)                                         # assignments identical
+    assert np.array_equal(inert, oi)                                     # fp64 inertia identical
+
+
+def test_kmeans_recovers_planted_clusters(ctx):
+    x, lab = _blobs(7, 20000, 50, sep=3.0)
+    a, c, inert = kmeans.kmeans_restarts(ctx, x, 8, base_seed=1, iters=10)
+    best = int(np.argmin(inert))
+    agree = (a[best] == lab).mean()
+    assert max(agree, 1 - agree) > 0.99
+    # inertia equals the direct sum of squared distances (fp64) within rounding
+    pts = x.T.astype(np.float64)
+    direct = ((pts - c[best][a[best]].astype(np.float64)) ** 2).sum()
+    assert abs(direct - inert[best]) / direct < 1e-6

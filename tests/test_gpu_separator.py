@@ -1,0 +1,109 @@
+"""GPU parity of the separator (abw_sep_load / abw_sep_node) against golden vectors produced by the
+reference's ClusterSeparatorBySensitivitySpecificity and against the CPU oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+from abawaca_amd import _lib, separator, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "sep_*.npz")))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _store(ctx, g):
+    S = len(g["scaf_len"])
+    off, ids = separator.scg_csr(g["scg_scaf"], g["scg_id"], S)
+    return separator.ColumnStore(ctx, g["milli"], g["dp2scaf"], g["scaf_len"], off, ids, int(g["n_scg"])), off, ids
+
+
+@pytest.mark.parametrize("path", GOLD, ids=lambda p: os.path.basename(p)[:-4])
+def test_binning_matches_reference(ctx, path):
+    g = np.load(path)
+    store, _o, _i = _store(ctx, g)
+    nodes, s2c, d2c = separator.binning(store)
+    ref = g["nodes"]
+    assert len(nodes) == len(ref)
+    for mine, r in zip(nodes, ref):
+        assert (mine["id"], mine["ndps"], mine["split"], mine["dim"]) == (int(r[0]), int(r[1]), int(r[2]), int(r[3]))
+        if mine["dim"] > 0:
+            assert mine["key"] / 1000.0 == r[4]
+        assert mine["spec"] == r[5] and mine["sens"] == r[6]                 # bit-exact doubles
+        assert (mine["c1"], mine["n1"], mine["c2"], mine["n2"]) == tuple(int(v) for v in r[7:11])
+    assert np.array_equal(s2c, g["scaf2cluster"])
+    assert np.array_equal(d2c, g["dp2cluster"])
+
+
+def _compare_node(store, scaf_ids, g_arrays, min_ndps=100):
+    keys, dp2scaf, scaf_ndps, scaf_len, off, ids, n_scg = g_arrays
+    sep = separator.ClusterSeparatorHip(store, scaf_ids)
+    sep.cluster_ndps_threshold = min_ndps
+    sep.separate()
+    all_ids = np.arange(store.S, dtype=np.int32) if scaf_ids is None else scaf_ids
+    dps = np.concatenate([np.arange(store.scaf_first[s], store.scaf_first[s] + store.scaf_ndps[s]) for s in all_ids]).astype(np.int32)
+    res, per, raw, side = orc.separate(keys, dp2scaf, scaf_ndps, scaf_len, off, ids, n_scg, dps, min_ndps)
+    mine = sep.per_dimension()
+    assert np.array_equal(mine["found"], per["found"])
+    f = per["found"] == 1
+    assert np.array_equal(mine["key"][f], per["key"][f])
+    assert np.array_equal(mine["sens"][f], per["sens"][f]) and np.array_equal(mine["spec"][f], per["spec"][f])
+    assert (sep._res.split, sep._res.dimension, sep._res.key, sep._res.legal) == (res.split, res.dimension, res.key, res.legal)
+    assert sep._res.sensitivity == res.sensitivity and sep._res.specificity == res.specificity
+    assert (sep._res.ndps1, sep._res.ndps2) == (res.ndps1, res.ndps2)
+    if res.legal and res.dimension > 0 or res.split:
+        assert np.array_equal(sep._raw, raw)
+    if res.split:
+        assert np.array_equal(sep._side, side[all_ids])
+    return res
+
+
+@pytest.mark.parametrize("path", GOLD[:3], ids=lambda p: os.path.basename(p)[:-4])
+def test_per_dimension_winners_match_oracle(ctx, path):
+    g = np.load(path)
+    store, off, ids = _store(ctx, g)
+    S = len(g["scaf_len"])
+    scaf_ndps = np.bincount(g["dp2scaf"], minlength=S).astype(np.int32)
+    arrays = (g["milli"], g["dp2scaf"], scaf_ndps, g["scaf_len"], off, ids, int(g["n_scg"]))
+    _compare_node(store, None, arrays)
+    rng = np.random.default_rng(1)
+    for frac in (0.7, 0.4):
+        sub = np.sort(rng.choice(S, size=int(S * frac), replace=False)).astype(np.int32)
+        _compare_node(store, sub, arrays)
+    # unordered scaffold list, lower size threshold
+    sub = rng.permutation(S)[: S // 2].astype(np.int32)
+    _compare_node(store, sub, arrays, min_ndps=20)
+
+
+@pytest.mark.parametrize("seed,n_scaf,G,S_cov", [(1, 3000, 6, 3), (2, 12000, 12, 10)])
+def test_synthetic_features_match_oracle(ctx, seed, n_scaf, G, S_cov):
+    """make_features tables (incl. wide coverage columns with >1024 distinct values, big scaffolds)."""
+    f = synth.make_features(seed, n_scaf, G, S_cov, n_lo=2, n_hi=14)
+    S = n_scaf
+    off, ids = separator.scg_csr(f["scg_scaf"], f["scg_id"], S)
+    store = separator.ColumnStore(ctx, f["milli"], f["dp2scaf"], f["scaf_len"], off, ids, f["n_scg"])
+    arrays = (f["milli"], f["dp2scaf"], f["scaf_ndps"], f["scaf_len"], off, ids, f["n_scg"])
+    res = _compare_node(store, None, arrays)
+    assert res.split == 1
+    # and the whole recursion gives the same bins as the oracle's
+    nodes, s2c, d2c = separator.binning(store, max_nodes=9)
+    onodes, os2c, od2c = orc.recursive_bins(f["milli"], f["dp2scaf"], f["scaf_ndps"], f["scaf_len"], off, ids, f["n_scg"], max_nodes=9)
+    assert [(a["id"], a["split"], a["dim"], a["key"], a["n1"], a["n2"]) for a in nodes] == \
+           [(b["id"], b["split"], b["dim"], b["key"], b["n1"], b["n2"]) for b in onodes]
+    assert np.array_equal(s2c, os2c) and np.array_equal(d2c, od2c)
+
+
+def test_load_rejects_bad_layout(ctx):
+    keys = np.zeros((2, 6), dtype=np.int32)
+    with pytest.raises(_lib.AbwError):      # singleton scaffold
+        separator.ColumnStore(ctx, keys, np.array([0, 0, 1, 2, 2, 2]), np.ones(3, np.int64))
+    with pytest.raises(_lib.AbwError):      # not contiguous
+        separator.ColumnStore(ctx, keys, np.array([0, 1, 0, 1, 2, 2]), np.ones(3, np.int64))

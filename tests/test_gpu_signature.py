@@ -1,0 +1,123 @@
+"""GPU parity of the signature stage, through the C ABI (abw_sig_build / _segment_dev / _count_dev)
+against the committed golden vectors of the compiled reference and against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+from abawaca_amd import _lib, signature, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _by_name_order(names, seg_scaf):
+    order = sorted(range(len(names)), key=lambda i: names[i].encode())
+    return np.concatenate([np.flatnonzero(seg_scaf == i) for i in order])
+
+
+@pytest.mark.parametrize("case", ["sig_edge", "sig_rand"])
+def test_build_matches_reference_lrn(ctx, golden_dir, case):
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    r = signature.build_signatures(ctx, g["ascii"], g["scaf_off"])
+    idx = _by_name_order([str(x) for x in g["scaf_names"]], r["seg_scaf"])
+    assert np.array_equal(r["seg_scaf"][idx], g["seg_scaf"].astype(np.uint32))
+    assert np.array_equal(r["seg_start"][idx], g["seg_start"])
+    assert np.array_equal(r["seg_end"][idx], g["seg_end"])
+    assert np.array_equal(r["milli"][idx], g["milli"].astype(np.int32))       # bit-exact vs abawaca.lrn
+
+
+def _random_assembly(seed, n, maxlen):
+    rng = np.random.default_rng(seed)
+    seqs = []
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTNRYacgtKM", dtype=np.uint8)
+    for i in range(n):
+        L = int(rng.integers(0, maxlen))
+        s = synth.ACGT[rng.integers(0, 4, size=L)].copy()
+        k = int(rng.integers(0, 4))
+        for _ in range(k):
+            if L > 20:
+                a = int(rng.integers(0, L - 1)); b = min(L, a + int(rng.integers(1, 600)))
+                s[a:b] = alphabet[rng.integers(0, len(alphabet), size=b - a)]
+        seqs.append(s)
+    blob = np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    return blob, off
+
+
+def test_build_matches_oracle_random(ctx):
+    blob, off = _random_assembly(3, 120, 12000)
+    r = signature.build_signatures(ctx, blob, off)
+    seg_scaf, st, en, dims = orc.build_signatures(blob, off)
+    assert np.array_equal(r["seg_scaf"], seg_scaf.astype(np.uint32))
+    assert np.array_equal(r["seg_start"], st) and np.array_equal(r["seg_end"], en)
+    assert np.array_equal(r["dims"].view(np.uint64), dims.view(np.uint64))     # fp64 bit patterns
+    milli = np.array([orc.milli_of(x) for x in dims])
+    assert np.array_equal(r["milli"], milli[:, 1:])
+
+
+def test_window_parameter_and_empty_inputs(ctx):
+    blob, off = _random_assembly(9, 10, 3000)
+    for window in (50, 333, 2000):
+        r = signature.build_signatures(ctx, blob, off, window=window)
+        exp = []
+        for i in range(len(off) - 1):
+            rc, s = orc.upcase(blob[int(off[i]):int(off[i + 1])])
+            a, b = orc.segments(s, window)
+            exp += [(i, int(x), int(y)) for x, y in zip(a, b)]
+        got = list(zip(r["seg_scaf"].tolist(), r["seg_start"].tolist(), r["seg_end"].tolist()))
+        assert got == exp
+    r = signature.build_signatures(ctx, np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert len(r["seg_scaf"]) == 0
+
+
+def test_lowercase_n_is_an_error(ctx):
+    blob = np.frombuffer(b"ACGT" * 600 + b"n" + b"ACGT" * 10, dtype=np.uint8)
+    with pytest.raises(_lib.AbwError) as e:
+        signature.build_signatures(ctx, blob, np.array([0, len(blob)], dtype=np.uint64))
+    assert e.value.code == _lib.ABW_ERR_LOWER_N
+
+
+def test_counts_and_device_entry_points(ctx):
+    """abw_sig_segment_dev + abw_sig_count_dev on device tensors, raw counts vs the oracle, and the
+    size-independent identities: sum of k-mer counts == number of valid windows; every row of dims
+    sums to (number of k with total > 0) within fp rounding."""
+    import torch
+    blob, off = _random_assembly(21, 300, 9000)
+    dev = torch.device("cuda:0")
+    pad = (-len(blob)) % 16 + 16
+    t_ascii = torch.from_numpy(np.concatenate([blob, np.zeros(pad, np.uint8)])).to(dev)
+    t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    cap = len(blob) // 2000 + len(off) + 16
+    t_scaf = torch.empty(cap, dtype=torch.int32, device=dev)
+    t_st = torch.empty(cap, dtype=torch.int64, device=dev)
+    t_en = torch.empty(cap, dtype=torch.int64, device=dev)
+    n = signature.segment_dev(ctx, t_ascii, len(blob), t_off, 2000, t_scaf, t_st, t_en)
+    h_scaf, h_st, h_en = signature.segment_host(blob, off)
+    assert n == len(h_scaf)
+    assert np.array_equal(t_scaf[:n].cpu().numpy().astype(np.uint32), h_scaf)
+    assert np.array_equal(t_st[:n].cpu().numpy(), h_st) and np.array_equal(t_en[:n].cpu().numpy(), h_en)
+    t_dims = torch.empty((n, 180), dtype=torch.float64, device=dev)
+    t_counts = torch.empty((n, 340), dtype=torch.int32, device=dev)
+    signature.count_dev(ctx, t_ascii, len(blob), t_off, t_scaf, t_st, t_en, n, t_dims=t_dims, t_counts=t_counts)
+    ctx.synchronize()
+    counts = t_counts.cpu().numpy().astype(np.uint32)
+    dims = t_dims.cpu().numpy()
+    for s in range(0, n, 7):
+        b = int(off[h_scaf[s]]) + int(h_st[s]) - 1
+        e = int(off[h_scaf[s]]) + int(h_en[s])
+        rc, seg = orc.upcase(blob[b:e])
+        _d, c, tot = orc.signature(seg)
+        assert np.array_equal(counts[s], c)
+        for k, (o, w) in enumerate([(0, 4), (4, 16), (20, 64), (84, 256)]):
+            assert counts[s, o:o + w].sum() == tot[k]
+    live = np.array([[(counts[s, o:o + w].sum() > 0) for (o, w) in [(0, 4), (4, 16), (20, 64), (84, 256)]] for s in range(n)])
+    assert np.allclose(dims.sum(axis=1), live.sum(axis=1), atol=1e-12)
