@@ -164,14 +164,15 @@ def tinymt_stream(seed: int, n: int):
     return [int(lib().abw_or_tinymt_next(st)) for _ in range(n)]
 
 
-def kmeans(x, R, base_seed, iters, groups, nthreads=0):
+def kmeans(x, R, base_seed, iters, chunk, nthreads=0):
+    """x: fp32 [d, N] dimension-major (same layout as the C ABI)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
-    N, d = x.shape
+    d, N = x.shape
     assign = np.empty((R, N), dtype=np.uint8)
     cent = np.empty((R, 2, d), dtype=np.float32)
     inertia = np.empty(R, dtype=np.float64)
     rc = lib().abw_or_kmeans(_p(x, C.c_float), C.c_int64(N), C.c_int32(d), C.c_int32(R), C.c_uint32(base_seed),
-                             C.c_int32(iters), C.c_int32(groups), C.c_int(nthreads),
+                             C.c_int32(iters), C.c_int32(chunk), C.c_int(nthreads),
                              _p(assign, C.c_uint8), _p(cent, C.c_float), _p(inertia, C.c_double))
     if rc != 0:
         raise RuntimeError("abw_or_kmeans failed: %d" % rc)
