@@ -18,7 +18,7 @@ SIG_NDIMS, SIG_NCOLS, SIG_NMERS = 180, 179, 340
 # every symbol include/abawaca_hip.h declares (tests/test_abi.py checks the two lists agree)
 EXPORTS = [
     "abw_ctx_create", "abw_ctx_destroy", "abw_ctx_set_stream", "abw_ctx_synchronize", "abw_last_error",
-    "abw_abi_version", "abw_sig_dim_names", "abw_sig_segment_host", "abw_sig_segment_dev", "abw_sig_count_dev",
+    "abw_abi_version", "abw_prof_enable", "abw_prof_reset", "abw_prof_read", "abw_sig_dim_names", "abw_sig_segment_host", "abw_sig_segment_dev", "abw_sig_count_dev",
     "abw_sig_build", "abw_sep_load", "abw_sep_node", "abw_sep_dev_keys", "abw_km_run_dev", "abw_km_run",
     "abw_km_features_from_keys", "abw_km_tinymt_selftest",
 ]
@@ -59,6 +59,9 @@ def lib():
     L.abw_ctx_synchronize.argtypes = [vp]
     L.abw_last_error.argtypes = [vp]
     L.abw_last_error.restype = C.c_char_p
+    L.abw_prof_enable.argtypes = [vp, C.c_int]
+    L.abw_prof_reset.argtypes = [vp]
+    L.abw_prof_read.argtypes = [vp, C.c_char_p, C.POINTER(u64), C.POINTER(C.c_double)]
     L.abw_sig_dim_names.argtypes = [C.c_char_p, u64]
     L.abw_sig_segment_host.argtypes = [vp, vp, u64, u32, u64, vp, vp, vp, C.POINTER(u64)]
     L.abw_sig_segment_dev.argtypes = [vp, vp, u64, vp, u64, u32, u64, vp, vp, vp, C.POINTER(u64)]
@@ -96,6 +99,17 @@ class Context:
 
     def set_stream(self, hip_stream_ptr):
         self.check(lib().abw_ctx_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def prof_enable(self, on=True):
+        self.check(lib().abw_prof_enable(self._h, 1 if on else 0))
+
+    def prof_reset(self):
+        self.check(lib().abw_prof_reset(self._h))
+
+    def prof_read(self, name: str):
+        n, ms = C.c_uint64(0), C.c_double(0.0)
+        self.check(lib().abw_prof_read(self._h, name.encode(), C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
 
     def synchronize(self):
         self.check(lib().abw_ctx_synchronize(self._h))

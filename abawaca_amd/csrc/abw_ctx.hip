@@ -35,7 +35,65 @@ void abw_release(abw_devbuf& b)
     b.cap = 0;
 }
 
+static hipEvent_t prof_event(abw_ctx* ctx)
+{
+    if (!ctx->prof.pool.empty()) { hipEvent_t e = ctx->prof.pool.back(); ctx->prof.pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+abw_prof_scope::abw_prof_scope(abw_ctx* c, const char* name) : ctx(c)
+{
+    if (!ctx || !ctx->prof.on) return;
+    int id = -1;
+    for (size_t i = 0; i < ctx->prof.names.size(); i++) if (ctx->prof.names[i] == name) { id = (int)i; break; }
+    if (id < 0) { id = (int)ctx->prof.names.size(); ctx->prof.names.push_back(name); }
+    hipEvent_t a = prof_event(ctx);
+    b = prof_event(ctx);
+    if (!a || !b) { b = nullptr; return; }
+    (void)hipEventRecord(a, ctx->stream);
+    ctx->prof.recs.push_back({id, a, b});
+}
+
+abw_prof_scope::~abw_prof_scope()
+{
+    if (b) (void)hipEventRecord(b, ctx->stream);
+}
+
 extern "C" {
+
+int abw_prof_enable(abw_ctx* ctx, int on)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    ctx->prof.on = on != 0;
+    return ABW_OK;
+}
+
+int abw_prof_reset(abw_ctx* ctx)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    abw_device_guard g(ctx->device);
+    ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& r : ctx->prof.recs) { ctx->prof.pool.push_back(r.a); ctx->prof.pool.push_back(r.b); }
+    ctx->prof.recs.clear();
+    return ABW_OK;
+}
+
+int abw_prof_read(abw_ctx* ctx, const char* name, uint64_t* launches, double* total_ms)
+{
+    if (!ctx || !name || !launches || !total_ms) return ABW_ERR_ARG;
+    abw_device_guard g(ctx->device);
+    ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *launches = 0; *total_ms = 0.0;
+    for (auto& r : ctx->prof.recs) {
+        if (ctx->prof.names[r.id] != name) continue;
+        float ms = 0.0f;
+        ABW_HIP(ctx, hipEventElapsedTime(&ms, r.a, r.b));
+        *launches += 1; *total_ms += ms;
+    }
+    return ABW_OK;
+}
 
 int abw_abi_version(void) { return ABW_ABI_VERSION; }
 
@@ -73,6 +131,8 @@ void abw_ctx_destroy(abw_ctx* ctx)
     abw_device_guard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     abw_sep_free(ctx);
+    for (auto& r : ctx->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (auto& b : ctx->scratch) abw_release(b);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

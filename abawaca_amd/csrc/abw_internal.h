@@ -48,8 +48,17 @@ struct abw_sep_state {
     abw_devbuf raw;                   // uint8[n]
 };
 
+struct abw_prof_rec { int id; hipEvent_t a, b; };
+struct abw_prof {
+    bool on = false;
+    std::vector<std::string> names;
+    std::vector<abw_prof_rec> recs;
+    std::vector<hipEvent_t> pool;
+};
+
 struct abw_ctx {
     int         device = 0;
+    abw_prof    prof;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -77,6 +86,14 @@ void abw_release(abw_devbuf& b);
             return abw_fail((ctx), ABW_ERR_HIP, "kernel launch failed: %s (%s:%d)",             \
                             hipGetErrorString(e_), __FILE__, __LINE__);                         \
     } while (0)
+
+// Brackets a kernel launch with events when profiling is on (see abw_prof_* in abw_ctx.hip).
+struct abw_prof_scope {
+    abw_ctx* ctx; hipEvent_t b = nullptr;
+    abw_prof_scope(abw_ctx* c, const char* name);
+    ~abw_prof_scope();
+};
+#define ABW_PROF(ctx, name) abw_prof_scope prof_scope_##__LINE__((ctx), (name))
 
 // RAII device guard: every entry point runs with the context's device current.
 struct abw_device_guard {

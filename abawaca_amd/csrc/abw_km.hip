@@ -380,6 +380,8 @@ int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t
     for (int it = 0; it <= iters; it++) {
         const bool last = it == iters;
         uint8_t* asg = last ? d_assign : nullptr;
+        {
+        ABW_PROF(ctx, "km_step");
         switch (DT) {
             case 1: launch_step<1>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
             case 2: launch_step<2>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
@@ -390,8 +392,10 @@ int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t
             case 7: launch_step<7>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
             default: launch_step<8>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
         }
+        }
         ABW_LAUNCH_CHECK(ctx);
         if (last && !d_inertia) break;
+        ABW_PROF(ctx, "km_update");
         hipLaunchKernelGGL(km_update_kernel, dim3(Rp * 2), dim3(W), upd_lds, st, slabs, nchunks, Rp, W, d, cent, hneg, last ? 0 : 1, col_term);
         ABW_LAUNCH_CHECK(ctx);
     }

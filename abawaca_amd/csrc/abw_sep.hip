@@ -589,6 +589,8 @@ int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t 
         ABW_LAUNCH_CHECK(ctx);
     }
     const unsigned gx = (unsigned)((m + ACC_SPB - 1) / ACC_SPB);
+    {
+    ABW_PROF(ctx, "sep_accum");
     if (!H.narrow_dims.empty()) {
         hipLaunchKernelGGL(sep_accum_kernel<true>, dim3(gx, (unsigned)H.narrow_dims.size()), dim3(256), 0, st, P, H.d_narrow, d_node_scaf, m);
         ABW_LAUNCH_CHECK(ctx);
@@ -597,16 +599,20 @@ int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t 
         hipLaunchKernelGGL(sep_accum_kernel<false>, dim3(gx, (unsigned)H.wide_dims.size()), dim3(256), 0, st, P, H.d_wide, d_node_scaf, m);
         ABW_LAUNCH_CHECK(ctx);
     }
+    }
     const unsigned nch = (unsigned)H.chunks.size();
+    DimBestDev* d_dimbest = (DimBestDev*)s.dimbest.p;
+    {
+    ABW_PROF(ctx, "sep_eval");
     hipLaunchKernelGGL(sep_chunk_sums_kernel, dim3(nch), dim3(256), 0, st, P, H.d_chunks, H.d_chunk_sums);
     ABW_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(sep_chunk_scan_kernel, dim3((s.D + 63) / 64), dim3(64), 0, st, H.d_dim_first_chunk, H.d_dim_nchunks, s.D, H.d_chunk_sums, H.d_dim_total);
     ABW_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(sep_eval_kernel, dim3(nch), dim3(256), 0, st, P, H.d_chunks, H.d_chunk_sums, H.d_dim_total, min_ndps, H.d_chunk_best);
     ABW_LAUNCH_CHECK(ctx);
-    DimBestDev* d_dimbest = (DimBestDev*)s.dimbest.p;
     hipLaunchKernelGGL(sep_dimbest_kernel, dim3((s.D + 63) / 64), dim3(64), 0, st, H.d_dim_first_chunk, H.d_dim_nchunks, s.D, H.d_chunk_best, d_dimbest);
     ABW_LAUNCH_CHECK(ctx);
+    }
     std::vector<DimBestDev> db((size_t)s.D);
     ABW_HIP(ctx, hipMemcpyAsync(db.data(), d_dimbest, (size_t)s.D * sizeof(DimBestDev), hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));

@@ -487,6 +487,7 @@ int abw_sig_segment_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len
     hipStream_t st = ctx->stream;
     ABW_HIP(ctx, hipMemsetAsync(flag, 0, 4, st));
     const int grid = ctx->num_cu * 8;
+    ABW_PROF(ctx, "sig_segment");
     hipLaunchKernelGGL(seg_blockcount_kernel, dim3(grid), dim3(256), 0, st, d_ascii, total_len, blk_nonN, nblk, flag);
     ABW_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(scan_exclusive_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, blk_nonN, blk_prefix, nblk);
@@ -526,6 +527,7 @@ int abw_sig_count_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len, 
     uint64_t blocks = (n_seg + 3) / 4;
     const uint64_t maxb = (uint64_t)ctx->num_cu * 16;
     if (blocks > maxb) blocks = maxb;
+    ABW_PROF(ctx, "sig_count");
     hipLaunchKernelGGL(sig_count_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, total_len, d_scaf_off,
                        d_seg_scaf, d_seg_start, d_seg_end, n_seg, d_dims, d_milli, d_counts);
     ABW_LAUNCH_CHECK(ctx);

@@ -1,0 +1,378 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the abawaca hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Headline (BASELINE.json "metric"): k-means point·iterations/s over the whole node on the workload
+of configs[1] (200k scaffolds -> ~0.8 M dps, 179 signature + 10 coverage dims, 64 restarts), plus
+the signature build in Gbp/s and the real separator in dimension·points/s as extra keys of the same
+JSON line.  A "step" is one full pass: one k-means run of `--iters` Lloyd iterations over all
+restarts, inputs already resident in HBM.  With N GPUs every rank runs its own 64 restarts on a
+replica of the points (the north-star's "restarts spread across GPUs"): weak scaling, no data-path
+collective; value = units of all ranks / max time over ranks.
+
+The JSON line also carries
+  roofline     : the dominant kernel (km_step) against the dense fp32 MFMA peak, its duration taken
+                 live from HIP events recorded by the library on its own stream (abw_prof_*)
+  cpu_baseline : the CPU restatement of the same k-means (oracle/, "port" — the reference has no
+                 k-means) on a bounded sample, on this box's host cores
+and, as secondary objects, the reference's own binaries (oracle/_ref, "reference") timed on
+bounded samples of the signature and separator workloads.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scaffolds", type=int, default=200_000)
+    ap.add_argument("--samples", type=int, default=10)
+    ap.add_argument("--restarts", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--chunk", type=int, default=512)
+    ap.add_argument("--sig-mbp", type=int, default=1000, help="signature side bench: assembly size in Mbp")
+    ap.add_argument("--no-extras", action="store_true", help="only the k-means headline")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines")
+    return ap.parse_args()
+
+
+def make_points(seed, n_scaf, n_samples, device):
+    """configs[1]-shaped feature table generated on the GPU (same model as abawaca_amd.synth.make_features:
+    per-genome GC -> expected canonical k-mer frequencies + sampling noise, truncated to thousandths;
+    coverage c_{g,s}(1+N(0,0.1))).  -> (keys int32 [D, N] on device, dp2scaf, scaf_len, genome)"""
+    import torch
+    from abawaca_amd import synth
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    G = max(2, n_scaf // 2000)
+    rng = synth.rng_for(seed)
+    mer2dim, _names = synth.canonical_mer_table()
+    gc = np.linspace(0.30, 0.70, G)
+    cov = np.exp(rng.normal(np.log(20.0), 1.0, size=(G, n_samples)))
+    genome = rng.integers(0, G, size=n_scaf).astype(np.int32)
+    ndps = rng.integers(2, 7, size=n_scaf).astype(np.int32)
+    scaf_len = (2000 * ndps + rng.integers(0, 2000, size=n_scaf)).astype(np.int64)
+    dp2scaf = np.repeat(np.arange(n_scaf, dtype=np.int32), ndps)
+    N = int(ndps.sum())
+    p_gc_s = np.clip(gc[genome] + rng.normal(0, 0.004, size=n_scaf), 0.05, 0.95)
+    p = torch.from_numpy(p_gc_s[dp2scaf]).to(device)
+    D = 179 + n_samples
+    keys = torch.empty((D, N), dtype=torch.int32, device=device)
+    col_terms = [[] for _ in range(180)]
+    off = 0
+    for k in range(1, 5):
+        for m in range(4 ** k):
+            n_gc = sum(1 for i in range(k) if ((m >> (2 * i)) & 3) in (1, 2))
+            col_terms[mer2dim[off + m]].append((n_gc, k - n_gc))
+        off += 4 ** k
+    for c in range(1, 180):
+        f = torch.zeros(N, dtype=torch.float64, device=device)
+        for n_gc, n_at in col_terms[c]:
+            f += (p / 2) ** n_gc * ((1 - p) / 2) ** n_at
+        noise = torch.randn(N, dtype=torch.float64, device=device, generator=g) * torch.sqrt(torch.clamp(f * (1 - f), min=0) / 2500.0)
+        keys[c - 1] = torch.clamp(torch.floor((f + noise) * 1000.0), 0, 1000).to(torch.int32)
+    gi = torch.from_numpy(genome[dp2scaf].astype(np.int64)).to(device)
+    for s in range(n_samples):
+        cs = torch.from_numpy(cov[:, s]).to(device)[gi] * (1.0 + 0.1 * torch.randn(N, dtype=torch.float64, device=device, generator=g))
+        keys[179 + s] = torch.floor(torch.clamp(cs, min=0) * 1000.0).to(torch.int32)
+    return keys, dp2scaf, scaf_len, genome, G
+
+
+def standardise(keys_t):
+    """k-means features: every dimension centred and scaled to unit variance (fp32, [D, N])."""
+    import torch
+    x = keys_t.to(torch.float32)
+    mu = x.mean(dim=1, keepdim=True)
+    sd = x.std(dim=1, keepdim=True).clamp_min(1e-6)
+    return ((x - mu) / sd).contiguous()
+
+
+def make_assembly_blob(seed, mbp):
+    """configs[3]-shaped assembly: 10 kbp scaffolds, iid bases with per-scaffold GC, 50-N runs in 2 %."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n_scaf = mbp * 100
+    L = 10_000
+    codes = rng.integers(0, 256, size=n_scaf * L // 4, dtype=np.uint8)      # 4 bases per random byte
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    blob = np.empty(n_scaf * L, dtype=np.uint8)
+    for sh in range(4):
+        blob[sh::4] = lut[(codes >> (2 * sh)) & 3]
+    for s in rng.choice(n_scaf, size=max(1, n_scaf // 50), replace=False):
+        at = int(s) * L + int(rng.integers(0, L - 50))
+        blob[at:at + 50] = ord("N")
+    off = (np.arange(n_scaf + 1, dtype=np.uint64) * L)
+    return blob, off
+
+
+def cpu_kmeans_baseline(x_host, R, iters, chunk):
+    import _oracle as orc
+    cores = min(16, os.cpu_count() or 1)
+    d, N = x_host.shape
+    # calibrate on a small slice, then size the sample for ~10-15 s
+    n0 = min(N, 4000)
+    t0 = time.perf_counter()
+    orc.kmeans(x_host[:, :n0].copy(), cores, 1, 1, chunk, nthreads=cores)
+    dt = max(time.perf_counter() - t0, 1e-3)
+    rate = n0 * cores * 2 / dt                         # (iters + final assign pass) units/s, rough
+    n1 = int(min(N, max(n0, rate * 12.0 / (cores * 4 * 3))))
+    Rs, its = cores * 4, 2
+    t0 = time.perf_counter()
+    orc.kmeans(x_host[:, :n1].copy(), Rs, 1, its, chunk, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return dict(value=n1 * Rs * its / dt, unit="point*iterations/s", cores=cores, kind="port",
+                sample=f"oracle abw_or_kmeans (OpenMP, {cores} threads): first {n1} points x {Rs} restarts x {its} iterations "
+                       f"(+1 assign pass, not counted) in {dt:.1f} s; the reference has no k-means")
+
+
+def cpu_signature_baseline(blob, off, mbp_sample=20):
+    exe = os.path.join(ROOT, "oracle", "_ref", "abawaca-build")
+    if not os.path.exists(exe):
+        return None
+    n_scaf = min(len(off) - 1, mbp_sample * 100)
+    end = int(off[n_scaf])
+    with tempfile.TemporaryDirectory(prefix="abwbench_") as wd:
+        fa = os.path.join(wd, "a.fa")
+        with open(fa, "wb") as f:
+            for i in range(n_scaf):
+                f.write(b">s%d\n" % i)
+                f.write(blob[int(off[i]):int(off[i + 1])].tobytes())
+                f.write(b"\n")
+        sam = os.path.join(wd, "s0.sam")
+        with open(sam, "w") as f:
+            f.write("@HD\tVN:1.0\nr0\t0\ts0\t1\t255\t50M\t*\t0\t0\t" + blob[:50].tobytes().decode() + "\t" + "I" * 50 + "\n")
+        out = os.path.join(wd, "out")
+        os.makedirs(out)
+        t0 = time.perf_counter()
+        subprocess.run([exe, "-f", fa, "-o", out, "-s", sam, "-c", sam], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dt = time.perf_counter() - t0
+    return dict(value=end / dt / 1e9, unit="Gbp/s", cores=1, kind="reference",
+                sample=f"reference abawaca-build (-O2 build of its own sources; the program is single-threaded) on the first "
+                       f"{end / 1e6:.0f} Mbp of the same assembly, whole program incl. FASTA read and .lrn write, {dt:.1f} s")
+
+
+def cpu_separator_baseline(keys_host, dp2scaf, scaf_len, n_scaf_sample=2500):
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_sep_driver")
+    if not os.path.exists(exe):
+        return None
+    S = min(n_scaf_sample, len(scaf_len))
+    n = int(np.searchsorted(dp2scaf, S))
+    D = keys_host.shape[0]
+    cores = min(40, os.cpu_count() or 1)                 # the reference caps -p at 40 (src/abawaca.cpp:328)
+    with tempfile.TemporaryDirectory(prefix="abwbench_") as wd:
+        with open(os.path.join(wd, "a.fa"), "w") as f:
+            for s in range(S):
+                f.write(f">s{s:07d}\n" + "A" * int(scaf_len[s]) + "\n")
+        with open(os.path.join(wd, "a.info"), "w") as f:
+            for s in range(S):
+                f.write(f"s{s:07d}\t{int(scaf_len[s])}\t1.000\t0.500\t0\n")
+        with open(os.path.join(wd, "a.names"), "w") as f:
+            f.write(f"% {n}\n")
+            for p in range(n):
+                s = int(dp2scaf[p])
+                f.write(f"{p + 1}\ts{s:07d}_{p}\ts{s:07d}:(1, 2000), 2000/2000 non-Ns bps\n")
+        with open(os.path.join(wd, "a.lrn"), "w") as f:
+            f.write(f"% {n}\n% {D + 1}\n% 9" + "\t1" * D + "\n% Key" + "".join(f"\td{j}" for j in range(D)) + "\n")
+            sub = keys_host[:, :n].T
+            for p in range(n):
+                f.write(str(p + 1) + "".join("\t%d.%03d" % divmod(int(v), 1000) for v in sub[p]) + "\n")
+        open(os.path.join(wd, "scg.list"), "w").write("SCG00\n")
+        prefix = os.path.join(wd, "ref")
+        subprocess.run([exe, os.path.join(wd, "a.names"), os.path.join(wd, "a.fa"), os.path.join(wd, "a.info"),
+                        os.path.join(wd, "a.lrn"), "-", os.path.join(wd, "scg.list"), str(cores), prefix, "1"],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        row = np.loadtxt(prefix + ".nodes.tsv", ndmin=2)[0]
+    usec = float(row[11])
+    return dict(value=D * n / (usec * 1e-6), unit="dimension*points/s", cores=cores, kind="reference",
+                sample=f"reference ClusterSeparatorBySensitivitySpecificity::separate() (-O2 build of its own sources, "
+                       f"-p {cores}) on the root node of the first {S} scaffolds ({n} dps x {D} dims), {usec / 1e6:.2f} s")
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+
+    from abawaca_amd import _lib, kmeans, separator, signature
+    ctx = _lib.Context(local_rank)
+
+    # ---------------- workload: configs[1] -------------------------------------------------------
+    keys_t, dp2scaf, scaf_len, genome, G = make_points(20241, args.scaffolds, args.samples, dev)
+    D, N = keys_t.shape
+    x_t = standardise(keys_t)
+    R, iters = args.restarts, args.iters
+    seed = 20240 + 1000 * rank                      # every rank its own restarts
+    t_inertia = torch.empty(R, dtype=torch.float64, device=dev)
+    t_cent = torch.empty((R, 2, D), dtype=torch.float32, device=dev)
+    t_assign = torch.empty((R, N), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        kmeans.kmeans_restarts_dev(ctx, x_t, N, D, R, seed, iters, args.chunk, t_assign, t_cent, t_inertia)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_launch, ms_launch = ctx.prof_read("km_step")
+    ctx.prof_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    units_per_step = N * R * iters
+    value = world * units_per_step * args.steps / elapsed
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---------------- roofline of the dominant kernel --------------------------------------------
+    flops_per_unit = D * 7                           # d*(3k+1), k = 2
+    ms_avg = ms_launch / max(n_launch, 1)
+    achieved = N * R * flops_per_unit / (ms_avg * 1e-3) / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_km_step.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = dict(kernel="km_step_kernel", bound="mfma", achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TFLOPS,
+                    unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                    launches=n_launch, ms_per_launch=round(ms_avg, 4),
+                    hbm_algorithmic_GBs=round((4.0 * N * D + 4.0 * R * 2 * (D + 1)) / (ms_avg * 1e-3) / 1e9, 1))
+
+    out = dict(metric="k-means point·iterations/sec (whole node) + signature build Gbp/s",
+               value=value, unit="point*iterations/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f32", data="synthetic",
+               config=dict(workload=f"configs[1]: {args.scaffolds} scaffolds -> {N} dps, 179 signature + {args.samples} coverage dims "
+                                    f"(z-scored), k=2, {R} restarts x {iters} Lloyd iterations per GPU, chunk {args.chunk}",
+                           parallelism=f"restarts x{world}" if world > 1 else "single GPU"),
+               roofline=roofline)
+
+    # ---------------- extras: real separator + signature build on this GPU -----------------------
+    keys_host = None
+    if not args.no_extras:
+        keys_host = keys_t.cpu().numpy()
+        t0 = time.perf_counter()
+        store = separator.ColumnStore(ctx, keys_host, dp2scaf, scaf_len)
+        load_s = time.perf_counter() - t0
+        sep = separator.ClusterSeparatorHip(store)
+        sep.separate()
+        ctx.prof_reset(); ctx.prof_enable(True)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            sep.separate()
+        sep_s = (time.perf_counter() - t0) / reps
+        na, msa = ctx.prof_read("sep_accum")
+        ne, mse = ctx.prof_read("sep_eval")
+        ctx.prof_enable(False)
+        alg_bytes = 4.0 * D * N + 4.0 * N + 16.0 * D * 1001
+        out["separator"] = dict(value=D * N / sep_s, unit="dimension*points/s", ms_per_node=sep_s * 1e3, node="root",
+                                split=int(sep._res.split), dimension=int(sep._res.dimension), load_s=round(load_s, 2),
+                                roofline=dict(kernel="sep_accum_kernel", bound="hbm", achieved=round(alg_bytes / (msa / na * 1e-3) / 1e9, 1),
+                                              peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg_bytes / (msa / na * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                              traffic=None, ms_per_launch=round(msa / na, 4), eval_ms=round(mse / max(ne, 1), 4)))
+        del store
+
+        blob, off = make_assembly_blob(20244, args.sig_mbp)
+        total = len(blob)
+        pad = (-total) % 16 + 16
+        t_ascii = torch.from_numpy(np.concatenate([blob, np.zeros(pad, np.uint8)])).to(dev)
+        t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+        cap = total // 2000 + len(off) + 16
+        t_scaf = torch.empty(cap, dtype=torch.int32, device=dev)
+        t_st = torch.empty(cap, dtype=torch.int64, device=dev)
+        t_en = torch.empty(cap, dtype=torch.int64, device=dev)
+        t_dims = torch.empty((cap, 180), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+
+        def sig_step():
+            n = signature.segment_dev(ctx, t_ascii, total, t_off, 2000, t_scaf, t_st, t_en)
+            signature.count_dev(ctx, t_ascii, total, t_off, t_scaf, t_st, t_en, n, t_dims=t_dims)
+            return n
+        n_seg = sig_step()
+        ctx.synchronize()
+        ctx.prof_reset(); ctx.prof_enable(True)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            sig_step()
+        ctx.synchronize()
+        sig_s = (time.perf_counter() - t0) / reps
+        nc, msc = ctx.prof_read("sig_count")
+        ns, mss = ctx.prof_read("sig_segment")
+        ctx.prof_enable(False)
+        alg = total + 1440.0 * n_seg
+        out["signature"] = dict(value=total / sig_s / 1e9, unit="Gbp/s", mbp=args.sig_mbp, segments=int(n_seg),
+                                ms_per_pass=sig_s * 1e3, resident="ASCII in HBM; segmentation + counting + fp64 finalisation timed",
+                                roofline=dict(kernel="sig_count_kernel", bound="hbm", achieved=round(alg / (msc / nc * 1e-3) / 1e9, 1),
+                                              peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg / (msc / nc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                              traffic=None, ms_per_launch=round(msc / nc, 4), segment_ms=round(mss / max(ns, 1), 4)))
+        del t_ascii, t_dims
+
+    # ---------------- CPU baselines (rank 0, N = 1 only) -------------------------------------------
+    if world == 1 and not args.no_cpu:
+        x_host = x_t[:, :min(N, 200_000)].cpu().numpy()
+        out["cpu_baseline"] = cpu_kmeans_baseline(x_host, R, iters, args.chunk)
+        out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        if not args.no_extras:
+            b = cpu_signature_baseline(blob, off)
+            if b:
+                out["signature"]["cpu_baseline"] = b
+            b = cpu_separator_baseline(keys_host, dp2scaf, scaf_len)
+            if b:
+                out["separator"]["cpu_baseline"] = b
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,6 +46,15 @@ const char* abw_last_error(const abw_ctx* ctx);
 /* Library/ABI version, bumped on any signature change. */
 int  abw_abi_version(void);
 
+/* Measurement aid (no counterpart in the reference): when on, the library brackets each of its
+ * kernel launches with HIP events recorded on the context's stream.  abw_prof_read synchronises
+ * the stream and returns, for the kernel family `name` ("sig_count", "sig_segment", "sep_accum",
+ * "sep_eval", "km_step", "km_update"), the number of launches and their summed duration since the
+ * last abw_prof_reset.  Used by bench.py for the roofline figure. */
+int  abw_prof_enable(abw_ctx* ctx, int on);
+int  abw_prof_reset(abw_ctx* ctx);
+int  abw_prof_read(abw_ctx* ctx, const char* name, uint64_t* launches, double* total_ms);
+
 /* ---- stage 1: signature build (ref: src/abawaca-build.cpp:103-228, 595-607) ----------------- */
 
 /* Names of the 180 dimensions in the reference's order ("A","C","AA",...), NUL-separated into buf
