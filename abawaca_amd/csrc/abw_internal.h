@@ -63,7 +63,7 @@ struct abw_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     abw_sep_state sep;
-    abw_devbuf  scratch[8];           // general-purpose grow-only scratch
+    abw_devbuf  scratch[12];           // general-purpose grow-only scratch
     int         num_cu = 256;
 };
 

@@ -218,9 +218,31 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
     }
 }
 
-// One workgroup per score column rc: adds the chunk slabs in fp64 in chunk order, then either
+constexpr int KM_GROUP = 32;   // chunk slabs per fp64 group partial
+
+// Level 1 of the slab reduction: group g adds its KM_GROUP consecutive chunk slabs in fp64 in chunk
+// order.  Elementwise over [Rp*2][W]; the loads of one thread are independent, only its adds chain.
+__global__ __launch_bounds__(256) void km_group_kernel(const float* __restrict__ slabs, int64_t nchunks, int64_t elems,
+                                                      double* __restrict__ gsum)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= elems) return;
+    const int64_t g = blockIdx.y;
+    const int64_t c0 = g * KM_GROUP;
+    const int n = (int)min((int64_t)KM_GROUP, nchunks - c0);
+    const float* p = slabs + c0 * elems + e;
+    float v[KM_GROUP];
+#pragma unroll
+    for (int c = 0; c < KM_GROUP; c++) v[c] = (c < n) ? p[(int64_t)c * elems] : 0.0f;
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < KM_GROUP; c++) if (c < n) s += (double)v[c];
+    gsum[g * elems + e] = s;
+}
+
+// Level 2: one workgroup per score column rc adds the group partials in group order, then either
 // moves the centroid (update = 1) or contributes the column's part of the inertia (update = 0).
-__global__ void km_update_kernel(const float* __restrict__ slabs, int64_t nchunks, int Rp, int W, int d,
+__global__ void km_update_kernel(const double* __restrict__ gsum, int64_t ngroups, int Rp, int W, int d,
                                  float* __restrict__ cent, float* __restrict__ hneg, int update,
                                  double* __restrict__ col_term)
 {
@@ -229,9 +251,9 @@ __global__ void km_update_kernel(const float* __restrict__ slabs, int64_t nchunk
     float* cs = (float*)(sh + W);
     for (int j = threadIdx.x; j < W; j += blockDim.x) {
         double s = 0.0;
-        const float* p = slabs + (int64_t)rc * W + j;
+        const double* p = gsum + (int64_t)rc * W + j;
         const int64_t stride = (int64_t)Rp * 2 * W;
-        for (int64_t c = 0; c < nchunks; c++) s += (double)p[c * stride];
+        for (int64_t c = 0; c < ngroups; c++) s += p[c * stride];
         sh[j] = s;
     }
     __syncthreads();
@@ -362,7 +384,11 @@ int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t
     const size_t cent_bytes = (size_t)Rp * 2 * W * 4, hneg_bytes = (size_t)Rp * 2 * 4;
     const size_t term_bytes = (size_t)Rp * 2 * 8, x2_bytes = (size_t)d * 8;
     if ((rc = abw_reserve(ctx, ctx->scratch[1], cent_bytes + hneg_bytes + term_bytes + x2_bytes + 64))) return rc;
-    if ((rc = abw_reserve(ctx, ctx->scratch[2], (size_t)nchunks * Rp * 2 * W * 4))) return rc;
+    const int64_t ngroups = (nchunks + KM_GROUP - 1) / KM_GROUP;
+    const int64_t elems = (int64_t)Rp * 2 * W;
+    if ((rc = abw_reserve(ctx, ctx->scratch[2], (size_t)nchunks * elems * 4))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[5], (size_t)ngroups * elems * 8))) return rc;
+    double* gsum = (double*)ctx->scratch[5].p;
     uint8_t* base = (uint8_t*)ctx->scratch[1].p;
     double* col_term = (double*)base;
     double* x2_dim = (double*)(base + term_bytes);
@@ -396,7 +422,9 @@ int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t
         ABW_LAUNCH_CHECK(ctx);
         if (last && !d_inertia) break;
         ABW_PROF(ctx, "km_update");
-        hipLaunchKernelGGL(km_update_kernel, dim3(Rp * 2), dim3(W), upd_lds, st, slabs, nchunks, Rp, W, d, cent, hneg, last ? 0 : 1, col_term);
+        hipLaunchKernelGGL(km_group_kernel, dim3((unsigned)((elems + 255) / 256), (unsigned)ngroups), dim3(256), 0, st, slabs, nchunks, elems, gsum);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(km_update_kernel, dim3(Rp * 2), dim3(W), upd_lds, st, gsum, ngroups, Rp, W, d, cent, hneg, last ? 0 : 1, col_term);
         ABW_LAUNCH_CHECK(ctx);
     }
     if (d_inertia) {

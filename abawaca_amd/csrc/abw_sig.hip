@@ -258,9 +258,22 @@ __global__ __launch_bounds__(256) void seg_blockcount_kernel(const uint8_t* __re
     }
 }
 
-// exclusive scan of uint32 -> uint64, one workgroup (n is L/1024 or n_scaf: small next to the blob)
+// exclusive scan -> uint64, three small launches: per-1024 group totals, scan of the group totals
+// (one workgroup; n/1024 entries), rescan of every group with its carry.  out has n + 1 entries.
 template <typename TIN>
-__global__ __launch_bounds__(1024) void scan_exclusive_kernel(const TIN* __restrict__ in, uint64_t* __restrict__ out, uint64_t n)
+__global__ __launch_bounds__(1024) void scan_group_totals_kernel(const TIN* __restrict__ in, uint64_t n, uint64_t* __restrict__ gtot)
+{
+    __shared__ uint64_t w[16];
+    const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+    uint64_t v = (i < n) ? (uint64_t)in[i] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint64_t t = 0; for (int k = 0; k < 16; k++) t += w[k]; gtot[blockIdx.x] = t; }
+}
+
+__global__ __launch_bounds__(1024) void scan_single_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t n)
 {
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry_s;
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(1024) void scan_exclusive_kernel(const TIN* __restr
     __syncthreads();
     for (uint64_t base = 0; base < n; base += 1024) {
         const uint64_t i = base + threadIdx.x;
-        uint64_t v = (i < n) ? (uint64_t)in[i] : 0, x = v;
+        uint64_t v = (i < n) ? in[i] : 0, x = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { uint64_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
         if (lane == 63) wsum[wid] = x;
@@ -283,6 +296,24 @@ __global__ __launch_bounds__(1024) void scan_exclusive_kernel(const TIN* __restr
         __syncthreads();
     }
     if (threadIdx.x == 0) out[n] = carry_s;
+}
+
+template <typename TIN>
+__global__ __launch_bounds__(1024) void scan_apply_kernel(const TIN* __restrict__ in, uint64_t n, const uint64_t* __restrict__ goff,
+                                                         uint64_t ngroups, uint64_t* __restrict__ out)
+{
+    __shared__ uint64_t wsum[16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+    uint64_t v = (i < n) ? (uint64_t)in[i] : 0, x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint64_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    uint64_t woff = goff[blockIdx.x];
+    for (int k = 0; k < wid; k++) woff += wsum[k];
+    if (i < n) out[i] = woff + x - v;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = goff[ngroups];
 }
 
 // rank (number of non-N bytes) of blob prefix [0, pos): whole blocks from blk_prefix + a partial block
@@ -319,59 +350,95 @@ __global__ __launch_bounds__(256) void seg_scaf_kernel(const uint8_t* __restrict
     }
 }
 
-// position (absolute) of the non-N byte with 0-based global rank `rank`
-__device__ __forceinline__ uint64_t select_nonN(const uint8_t* __restrict__ ascii, uint64_t total_len,
-                                                const uint64_t* __restrict__ blk_prefix, uint64_t nblk, uint64_t rank, int lane)
-{
-    // largest block b with blk_prefix[b] <= rank
-    uint64_t lo = 0, hi = nblk;                                   // invariant: blk_prefix[lo] <= rank < blk_prefix[hi]
-    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (blk_prefix[mid] <= rank) lo = mid; else hi = mid; }
-    const uint64_t A = lo * SEGBLK + (uint64_t)lane * 16;
-    uint32_t c = 0;
-    for (uint64_t i = A; i < A + 16 && i < total_len; i++) c += ascii[i] != 'N';
-    uint32_t x = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-    const uint64_t before = blk_prefix[lo] + x - c;               // non-N bytes before this lane's piece
-    uint64_t pos = ~0ull;
-    if (rank >= before && rank < before + c) {
-        uint64_t need = rank - before;
-        for (uint64_t i = A; i < A + 16; i++) if (ascii[i] != 'N') { if (need == 0) { pos = i; break; } need--; }
-    }
-    // exactly one lane found it
-    const unsigned long long ball = __ballot(pos != ~0ull);
-    const int src = __ffsll((long long)ball) - 1;
-    return __shfl(pos, src < 0 ? 0 : src, 64);
-}
-
+// One wave per 1 KiB block of the blob: every non-N byte knows its rank inside its scaffold
+// (block prefix + wave prefix + position in the lane's 16 bytes), and the byte whose 1-based rank k
+// is a multiple of nbps closes segment k/nbps (ref :212-224).  No search per segment.
 __global__ __launch_bounds__(256) void seg_emit_kernel(const uint8_t* __restrict__ ascii, uint64_t total_len,
                                                       const uint64_t* __restrict__ scaf_off, uint64_t n_scaf,
                                                       const uint64_t* __restrict__ blk_prefix, uint64_t nblk,
                                                       const ScafSeg* __restrict__ info, const uint64_t* __restrict__ seg_off,
-                                                      uint64_t n_seg, uint32_t* __restrict__ seg_scaf,
+                                                      uint32_t* __restrict__ seg_scaf,
                                                       uint64_t* __restrict__ seg_start, uint64_t* __restrict__ seg_end)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t g = wave; g < n_seg; g += nwaves) {
-        // scaffold of segment g: largest s with seg_off[s] <= g
-        uint64_t lo = 0, hi = n_scaf;
-        while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (seg_off[mid] <= g) lo = mid; else hi = mid; }
-        const uint64_t s = lo, j = g - seg_off[s], b = scaf_off[s];
-        const ScafSeg si = info[s];
-        uint64_t st, en;                                          // 1-based inclusive within the scaffold
-        if (si.nbps == 0) { st = j + 1; en = j + 1; }
-        else {
-            // segment j ends at the ((j+1)*nbps)-th non-N base of the scaffold and starts right after
-            // the end of segment j-1 (ref :216,221-223)
-            const uint64_t pe = select_nonN(ascii, total_len, blk_prefix, nblk, si.rank0 + (j + 1) * si.nbps - 1, lane);
-            en = pe - b + 1;
-            if (j == 0) st = 1;
-            else st = select_nonN(ascii, total_len, blk_prefix, nblk, si.rank0 + j * si.nbps - 1, lane) - b + 2;
+    for (uint64_t b = wave; b < nblk; b += nwaves) {
+        const uint64_t b_begin = b * SEGBLK;
+        const uint64_t b_end = (b_begin + SEGBLK < total_len) ? b_begin + SEGBLK : total_len;
+        if (b_begin >= b_end) continue;
+        const uint64_t A = b_begin + (uint64_t)lane * 16;
+        uint32_t bytes[4] = {0, 0, 0, 0};
+        int len = 0;
+        if (A + 16 <= total_len) {
+            const uint4 v = *reinterpret_cast<const uint4*>(ascii + A);
+            bytes[0] = v.x; bytes[1] = v.y; bytes[2] = v.z; bytes[3] = v.w; len = 16;
+        } else {
+            for (uint64_t i = A; i < total_len; i++) { bytes[(i - A) >> 2] |= (uint32_t)ascii[i] << (8 * ((i - A) & 3)); len++; }
         }
-        if (lane == 0) { seg_scaf[g] = (uint32_t)s; seg_start[g] = st; seg_end[g] = en; }
+        uint32_t c = 0;
+        for (int i = 0; i < len; i++) c += ((bytes[i >> 2] >> (8 * (i & 3))) & 0xFFu) != 'N';
+        uint32_t x = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        const uint64_t lane_rank0 = blk_prefix[b] + x - c;          // non-N bytes of the blob before this lane's piece
+        // first scaffold that reaches into this block: smallest s with scaf_off[s+1] > b_begin
+        uint64_t lo = 0, hi = n_scaf;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (scaf_off[mid + 1] > b_begin) hi = mid; else lo = mid + 1; }
+        for (uint64_t s = lo; s < n_scaf; s++) {
+            const uint64_t sb = scaf_off[s];
+            if (sb >= b_end) break;
+            const uint64_t se = scaf_off[s + 1];
+            if (se <= sb) continue;
+            const ScafSeg si = info[s];
+            if (si.nseg == 0) continue;
+            const uint64_t g0 = seg_off[s];
+            if (sb >= b_begin && lane == 0) seg_start[g0] = 1;      // ref :209 sit = seq.begin()
+            const uint64_t p0 = (A > sb) ? A : sb;                   // this lane's bytes of scaffold s: [p0, p1)
+            const uint64_t p1 = (A + (uint64_t)len < se) ? A + (uint64_t)len : se;
+            if (p0 >= p1) continue;
+            if (si.nbps == 0) {                                      // all-N scaffold: every base is a segment
+                for (uint64_t p = p0; p < p1; p++) {
+                    const uint64_t j = p - sb;
+                    seg_scaf[g0 + j] = (uint32_t)s; seg_start[g0 + j] = j + 1; seg_end[g0 + j] = j + 1;
+                }
+                continue;
+            }
+            // 1-based non-N rank inside the scaffold of the first non-N byte at or after p0
+            uint64_t before = lane_rank0;
+            for (uint64_t p = A; p < p0; p++) before += ((bytes[(p - A) >> 2] >> (8 * ((p - A) & 3))) & 0xFFu) != 'N';
+            uint64_t k = before - si.rank0 + 1;
+            uint64_t q = k / si.nbps, r = k % si.nbps;
+            for (uint64_t p = p0; p < p1; p++) {
+                if (((bytes[(p - A) >> 2] >> (8 * ((p - A) & 3))) & 0xFFu) == 'N') continue;
+                if (r == 0 && q >= 1 && q <= si.nseg) {              // byte closes segment q-1
+                    const uint64_t g = g0 + q - 1;
+                    seg_scaf[g] = (uint32_t)s;
+                    seg_end[g] = p - sb + 1;
+                    if (q < si.nseg) seg_start[g + 1] = p - sb + 2;  // ref :221-222 sit = it + 1
+                }
+                if (++r == si.nbps) { r = 0; q++; }
+            }
+        }
     }
+}
+
+// scratch[8] is used for the group totals / offsets of the two-level scan
+template <typename TIN>
+int device_scan(abw_ctx* ctx, const TIN* in, uint64_t n, uint64_t* out)
+{
+    const uint64_t ngroups = (n + 1023) / 1024;
+    int rc = abw_reserve(ctx, ctx->scratch[8], (2 * ngroups + 2) * 8);
+    if (rc) return rc;
+    uint64_t* gtot = (uint64_t*)ctx->scratch[8].p;
+    uint64_t* goff = gtot + ngroups;
+    hipLaunchKernelGGL(scan_group_totals_kernel<TIN>, dim3((unsigned)ngroups), dim3(1024), 0, ctx->stream, in, n, gtot);
+    ABW_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(1024), 0, ctx->stream, gtot, goff, ngroups);
+    ABW_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(scan_apply_kernel<TIN>, dim3((unsigned)ngroups), dim3(1024), 0, ctx->stream, in, n, goff, ngroups, out);
+    ABW_LAUNCH_CHECK(ctx);
+    return ABW_OK;
 }
 
 bool g_tables_uploaded[64] = {};
@@ -490,12 +557,10 @@ int abw_sig_segment_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len
     ABW_PROF(ctx, "sig_segment");
     hipLaunchKernelGGL(seg_blockcount_kernel, dim3(grid), dim3(256), 0, st, d_ascii, total_len, blk_nonN, nblk, flag);
     ABW_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(scan_exclusive_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, blk_nonN, blk_prefix, nblk);
-    ABW_LAUNCH_CHECK(ctx);
+    if ((rc = device_scan<uint32_t>(ctx, blk_nonN, nblk, blk_prefix))) return rc;
     hipLaunchKernelGGL(seg_scaf_kernel, dim3(grid), dim3(256), 0, st, d_ascii, d_scaf_off, n_scaf, blk_prefix, window, info, nseg);
     ABW_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(scan_exclusive_kernel<uint64_t>, dim3(1), dim3(1024), 0, st, nseg, seg_off, n_scaf);
-    ABW_LAUNCH_CHECK(ctx);
+    if ((rc = device_scan<uint64_t>(ctx, nseg, n_scaf, seg_off))) return rc;
     uint64_t total = 0;
     int h_flag = 0;
     ABW_HIP(ctx, hipMemcpyAsync(&total, seg_off + n_scaf, 8, hipMemcpyDeviceToHost, st));
@@ -507,7 +572,7 @@ int abw_sig_segment_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len
     if (total == 0) return ABW_OK;
     if (!d_seg_scaf || !d_seg_start || !d_seg_end) return abw_fail(ctx, ABW_ERR_ARG, "null segment output");
     hipLaunchKernelGGL(seg_emit_kernel, dim3(grid), dim3(256), 0, st, d_ascii, total_len, d_scaf_off, n_scaf, blk_prefix, nblk,
-                       info, seg_off, total, d_seg_scaf, d_seg_start, d_seg_end);
+                       info, seg_off, d_seg_scaf, d_seg_start, d_seg_end);
     ABW_LAUNCH_CHECK(ctx);
     return ABW_OK;
 }

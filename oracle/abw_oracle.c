@@ -401,6 +401,8 @@ uint32_t abw_or_tinymt_next(abw_or_tinymt* t)
 /* ---------------------------------------------------------------------------------------- */
 /* K-means restarts (extension; semantics fixed in DESIGN.md "K-means")                      */
 /* ---------------------------------------------------------------------------------------- */
+#define KM_GROUP 32   /* chunk partials are first added in groups of 32 consecutive chunks, then the groups */
+
 /* sum_p x[j][p]^2 : 256 strided fp64 partials per dimension, xor-butterfly inside each group of 64,
  * then (w0 + w1) + (w2 + w3); dimensions added in index order. */
 static double km_x2(const float* x, int64_t N, int32_t d)
@@ -447,8 +449,9 @@ int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base
         uint8_t* a = assign + (size_t)r * N;
         float* part = (float*)malloc(sizeof(float) * 2 * (size_t)(d + 1));
         double* S = (double*)malloc(sizeof(double) * 2 * (size_t)(d + 1));
+        double* Sg = (double*)malloc(sizeof(double) * 2 * (size_t)(d + 1));
         float* xp = (float*)malloc(sizeof(float) * (size_t)d);
-        if (!part || !S || !xp) { err = 1; free(part); free(S); free(xp); continue; }
+        if (!part || !S || !Sg || !xp) { err = 1; free(part); free(S); free(Sg); free(xp); continue; }
         abw_or_tinymt t;
         abw_or_tinymt_init(&t, base_seed + (uint32_t)r);
         int64_t i0 = (int64_t)(abw_or_tinymt_next(&t) % (uint64_t)N);
@@ -459,7 +462,7 @@ int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base
             float n0 = 0.0f, n1 = 0.0f;
             for (int32_t j = 0; j < d; j++) { n0 = fmaf(c[j], c[j], n0); n1 = fmaf(c[d + j], c[d + j], n1); }
             const float hn0 = -(0.5f * n0), hn1 = -(0.5f * n1);
-            for (int32_t q = 0; q < 2 * (d + 1); q++) S[q] = 0.0;
+            for (int32_t q = 0; q < 2 * (d + 1); q++) { S[q] = 0.0; Sg[q] = 0.0; }
             for (int64_t ch = 0; ch < nchunks; ch++) {
                 const int64_t p0 = ch * chunk, p1 = p0 + chunk < N ? p0 + chunk : N;
                 for (int32_t q = 0; q < 2 * (d + 1); q++) part[q] = 0.0f;
@@ -476,7 +479,9 @@ int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base
                     for (int32_t j = 0; j < d; j++) pc[j] = fmaf(1.0f, xp[j], pc[j]);
                     pc[d] = fmaf(1.0f, 1.0f, pc[d]);                /* the count column */
                 }
-                for (int32_t q = 0; q < 2 * (d + 1); q++) S[q] += (double)part[q];
+                for (int32_t q = 0; q < 2 * (d + 1); q++) Sg[q] += (double)part[q];
+                if ((ch % KM_GROUP) == KM_GROUP - 1 || ch == nchunks - 1)      /* group of 32 chunks complete */
+                    for (int32_t q = 0; q < 2 * (d + 1); q++) { S[q] += Sg[q]; Sg[q] = 0.0; }
             }
             if (it < iters) {
                 for (int cl = 0; cl < 2; cl++) {
@@ -497,7 +502,7 @@ int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base
                 inertia[r] = (x2 + term[0]) + term[1];
             }
         }
-        free(part); free(S); free(xp);
+        free(part); free(S); free(Sg); free(xp);
     }
     return err ? -2 : 0;
 }

@@ -107,7 +107,7 @@ uint32_t abw_or_tinymt_next(abw_or_tinymt* t);
  *   argmin of the squared Euclidean distance with |x|^2 dropped.
  * Sums: points are cut into chunks of `chunk` consecutive points; per chunk, cluster and dimension
  *   the members are summed in fp32 in point order (and counted the same way); chunk partials are
- *   added in fp64 in chunk order.  centroid = (float)(sum / count); an empty cluster keeps its centroid.
+ *   added in fp64 in chunk order inside groups of 32 consecutive chunks, then the group sums in group order.  centroid = (float)(sum / count); an empty cluster keeps its centroid.
  * `iters` assign+update rounds are followed by one assign-only pass whose sums give
  *   inertia[r] = (X2 + term_0) + term_1,  term_c = count_c*|c_c|^2 - 2*(c_c . sum_c)  in fp64
  *   (j ascending), X2 = sum |x|^2 as built by km_x2() in abw_oracle.c.
