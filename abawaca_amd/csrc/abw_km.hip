@@ -285,7 +285,15 @@ __global__ __launch_bounds__(256) void km_x2_kernel(const float* __restrict__ x,
     const int j = blockIdx.x;
     const float* row = x + (int64_t)j * N;
     double acc = 0.0;
-    for (int64_t p = threadIdx.x; p < N; p += 256) { const double v = (double)row[p]; acc += v * v; }
+    int64_t p = threadIdx.x;
+    for (; p + 7 * 256 < N; p += 8 * 256) {                  // 8 loads in flight; the adds keep their order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = row[p + u * 256];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const double w2 = (double)v[u]; acc += w2 * w2; }
+    }
+    for (; p < N; p += 256) { const double v = (double)row[p]; acc += v * v; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;

@@ -353,6 +353,19 @@ __global__ __launch_bounds__(256) void seg_scaf_kernel(const uint8_t* __restrict
 // One wave per 1 KiB block of the blob: every non-N byte knows its rank inside its scaffold
 // (block prefix + wave prefix + position in the lane's 16 bytes), and the byte whose 1-based rank k
 // is a multiple of nbps closes segment k/nbps (ref :212-224).  No search per segment.
+struct ScafCursor { uint64_t s, sb, se, g0; ScafSeg si; };
+
+__device__ __forceinline__ void cursor_load(ScafCursor& c, uint64_t s, const uint64_t* __restrict__ scaf_off,
+                                            const ScafSeg* __restrict__ info, const uint64_t* __restrict__ seg_off)
+{
+    c.s = s; c.sb = scaf_off[s]; c.se = scaf_off[s + 1]; c.si = info[s]; c.g0 = seg_off[s];
+}
+
+__device__ __forceinline__ uint32_t byte_at(uint64_t lo, uint64_t hi, int i)
+{
+    return (uint32_t)(((i < 8) ? lo : hi) >> (8 * (i & 7))) & 0xFFu;
+}
+
 __global__ __launch_bounds__(256) void seg_emit_kernel(const uint8_t* __restrict__ ascii, uint64_t total_len,
                                                       const uint64_t* __restrict__ scaf_off, uint64_t n_scaf,
                                                       const uint64_t* __restrict__ blk_prefix, uint64_t nblk,
@@ -363,62 +376,83 @@ __global__ __launch_bounds__(256) void seg_emit_kernel(const uint8_t* __restrict
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t b = wave; b < nblk; b += nwaves) {
+    // every wave walks a CONTIGUOUS run of blocks, so the scaffold cursor only moves forward
+    const uint64_t per = (nblk + nwaves - 1) / nwaves;
+    const uint64_t b_first = wave * per;
+    const uint64_t b_last = (b_first + per < nblk) ? b_first + per : nblk;
+    if (b_first >= b_last || n_scaf == 0) return;
+    ScafCursor cur;
+    {
+        // first scaffold that reaches into the first block: smallest s with scaf_off[s+1] > b_first*SEGBLK
+        uint64_t lo = 0, hi = n_scaf;
+        const uint64_t at = b_first * SEGBLK;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (scaf_off[mid + 1] > at) hi = mid; else lo = mid + 1; }
+        if (lo >= n_scaf) return;
+        cursor_load(cur, lo, scaf_off, info, seg_off);
+    }
+    for (uint64_t b = b_first; b < b_last; b++) {
         const uint64_t b_begin = b * SEGBLK;
         const uint64_t b_end = (b_begin + SEGBLK < total_len) ? b_begin + SEGBLK : total_len;
-        if (b_begin >= b_end) continue;
+        if (b_begin >= b_end) break;
         const uint64_t A = b_begin + (uint64_t)lane * 16;
-        uint32_t bytes[4] = {0, 0, 0, 0};
+        uint64_t lo8 = 0, hi8 = 0;
         int len = 0;
         if (A + 16 <= total_len) {
             const uint4 v = *reinterpret_cast<const uint4*>(ascii + A);
-            bytes[0] = v.x; bytes[1] = v.y; bytes[2] = v.z; bytes[3] = v.w; len = 16;
+            lo8 = (uint64_t)v.x | ((uint64_t)v.y << 32); hi8 = (uint64_t)v.z | ((uint64_t)v.w << 32); len = 16;
         } else {
-            for (uint64_t i = A; i < total_len; i++) { bytes[(i - A) >> 2] |= (uint32_t)ascii[i] << (8 * ((i - A) & 3)); len++; }
+            for (uint64_t i = A; i < total_len; i++) {
+                const uint64_t c8 = (uint64_t)ascii[i] << (8 * ((i - A) & 7));
+                if (i - A < 8) lo8 |= c8; else hi8 |= c8;
+                len++;
+            }
         }
-        uint32_t c = 0;
-        for (int i = 0; i < len; i++) c += ((bytes[i >> 2] >> (8 * (i & 3))) & 0xFFu) != 'N';
+        // bit i of nmask: byte i of this lane's piece is a non-N base
+        uint32_t nmask = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) nmask |= (uint32_t)(i < len && byte_at(lo8, hi8, i) != 'N') << i;
+        const uint32_t c = __popc(nmask);
         uint32_t x = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
         const uint64_t lane_rank0 = blk_prefix[b] + x - c;          // non-N bytes of the blob before this lane's piece
-        // first scaffold that reaches into this block: smallest s with scaf_off[s+1] > b_begin
-        uint64_t lo = 0, hi = n_scaf;
-        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (scaf_off[mid + 1] > b_begin) hi = mid; else lo = mid + 1; }
-        for (uint64_t s = lo; s < n_scaf; s++) {
-            const uint64_t sb = scaf_off[s];
-            if (sb >= b_end) break;
-            const uint64_t se = scaf_off[s + 1];
-            if (se <= sb) continue;
-            const ScafSeg si = info[s];
-            if (si.nseg == 0) continue;
-            const uint64_t g0 = seg_off[s];
-            if (sb >= b_begin && lane == 0) seg_start[g0] = 1;      // ref :209 sit = seq.begin()
-            const uint64_t p0 = (A > sb) ? A : sb;                   // this lane's bytes of scaffold s: [p0, p1)
-            const uint64_t p1 = (A + (uint64_t)len < se) ? A + (uint64_t)len : se;
-            if (p0 >= p1) continue;
-            if (si.nbps == 0) {                                      // all-N scaffold: every base is a segment
-                for (uint64_t p = p0; p < p1; p++) {
-                    const uint64_t j = p - sb;
-                    seg_scaf[g0 + j] = (uint32_t)s; seg_start[g0 + j] = j + 1; seg_end[g0 + j] = j + 1;
+        while (cur.se <= b_begin && cur.s + 1 < n_scaf) cursor_load(cur, cur.s + 1, scaf_off, info, seg_off);
+        for (;;) {
+            if (cur.sb >= b_end) break;
+            if (cur.se > cur.sb && cur.si.nseg != 0) {
+                const uint64_t sb = cur.sb, se = cur.se, g0 = cur.g0;
+                if (sb >= b_begin && lane == 0) seg_start[g0] = 1;   // ref :209 sit = seq.begin()
+                const uint64_t p0 = (A > sb) ? A : sb;               // this lane's bytes of the scaffold: [p0, p1)
+                const uint64_t p1 = (A + (uint64_t)len < se) ? A + (uint64_t)len : se;
+                if (p0 < p1) {
+                    const int i0 = (int)(p0 - A), i1 = (int)(p1 - A);
+                    if (cur.si.nbps == 0) {                          // all-N scaffold: every base is a segment
+                        for (int i = i0; i < i1; i++) {
+                            const uint64_t j = A + i - sb;
+                            seg_scaf[g0 + j] = (uint32_t)cur.s; seg_start[g0 + j] = j + 1; seg_end[g0 + j] = j + 1;
+                        }
+                    } else {
+                        // 1-based non-N rank inside the scaffold of the first non-N byte at or after p0
+                        const uint64_t before = lane_rank0 + __popc(nmask & ((1u << i0) - 1u));
+                        const uint64_t k = before - cur.si.rank0 + 1;
+                        uint64_t q = k / cur.si.nbps, r = k % cur.si.nbps;
+                        uint32_t todo = nmask & ~((1u << i0) - 1u) & ((1u << i1) - 1u);
+                        while (todo) {
+                            const int i = __ffs(todo) - 1;
+                            todo &= todo - 1;
+                            if (r == 0 && q >= 1 && q <= cur.si.nseg) {   // this base closes segment q-1
+                                const uint64_t g = g0 + q - 1, rel = A + i - sb;
+                                seg_scaf[g] = (uint32_t)cur.s;
+                                seg_end[g] = rel + 1;
+                                if (q < cur.si.nseg) seg_start[g + 1] = rel + 2;   // ref :221-222 sit = it + 1
+                            }
+                            if (++r == cur.si.nbps) { r = 0; q++; }
+                        }
+                    }
                 }
-                continue;
             }
-            // 1-based non-N rank inside the scaffold of the first non-N byte at or after p0
-            uint64_t before = lane_rank0;
-            for (uint64_t p = A; p < p0; p++) before += ((bytes[(p - A) >> 2] >> (8 * ((p - A) & 3))) & 0xFFu) != 'N';
-            uint64_t k = before - si.rank0 + 1;
-            uint64_t q = k / si.nbps, r = k % si.nbps;
-            for (uint64_t p = p0; p < p1; p++) {
-                if (((bytes[(p - A) >> 2] >> (8 * ((p - A) & 3))) & 0xFFu) == 'N') continue;
-                if (r == 0 && q >= 1 && q <= si.nseg) {              // byte closes segment q-1
-                    const uint64_t g = g0 + q - 1;
-                    seg_scaf[g] = (uint32_t)s;
-                    seg_end[g] = p - sb + 1;
-                    if (q < si.nseg) seg_start[g + 1] = p - sb + 2;  // ref :221-222 sit = it + 1
-                }
-                if (++r == si.nbps) { r = 0; q++; }
-            }
+            if (cur.se >= b_end || cur.s + 1 >= n_scaf) break;       // the scaffold continues past this block
+            cursor_load(cur, cur.s + 1, scaf_off, info, seg_off);
         }
     }
 }

@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--samples", type=int, default=10)
     ap.add_argument("--restarts", type=int, default=64)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--chunk", type=int, default=512)
+    ap.add_argument("--chunk", type=int, default=0, help="points per fp32 partial sum; 0 = fill 3 rounds of 256 CUs evenly")
     ap.add_argument("--sig-mbp", type=int, default=1000, help="signature side bench: assembly size in Mbp")
     ap.add_argument("--no-extras", action="store_true", help="only the k-means headline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines")
@@ -229,6 +229,9 @@ def main():
     D, N = keys_t.shape
     x_t = standardise(keys_t)
     R, iters = args.restarts, args.iters
+    if args.chunk == 0:
+        tiles = (N + 31) // 32
+        args.chunk = 32 * max(1, -(-tiles // (3 * 256)))
     seed = 20240 + 1000 * rank                      # every rank its own restarts
     t_inertia = torch.empty(R, dtype=torch.float64, device=dev)
     t_cent = torch.empty((R, 2, D), dtype=torch.float32, device=dev)
