@@ -254,3 +254,37 @@ def make_features(seed: int, n_scaf: int, n_genomes: int, n_samples: int,
     return dict(milli=milli, dp2scaf=dp2scaf, scaf_ndps=ndps, scaf_len=scaf_len, genome=genome,
                 scg_scaf=np.asarray(scg_scaf, dtype=np.int32), scg_id=np.asarray(scg_id, dtype=np.int32),
                 n_scg=n_scg, names=names[1:] + [f"sample{s}" for s in range(n_samples)])
+
+
+def write_build_dir(wd: str, milli, dp2scaf, scaf_len, scg_scaf=(), scg_id=(), n_scg=0):
+    """Writes the files abawaca reads (reference src/abawaca.cpp:298-315) for a feature table:
+    a.names / a.lrn / a.info / a.fa / genes.scg / scg.list.  Scaffold i is named s%07d so that the
+    byte-wise name order of ScafDpData (reference src/ScafDpData.cpp:91-99) equals the index order."""
+    milli = np.asarray(milli)
+    D, N = milli.shape
+    S = len(scaf_len)
+    with open(os.path.join(wd, "a.fa"), "w") as f:
+        for s in range(S):
+            f.write(f">s{s:07d}\n" + "A" * int(scaf_len[s]) + "\n")
+    with open(os.path.join(wd, "a.info"), "w") as f:
+        for s in range(S):
+            f.write(f"s{s:07d}\t{int(scaf_len[s])}\t1.000\t0.500\t0\n")
+    with open(os.path.join(wd, "a.names"), "w") as f:
+        f.write(f"% {N}\n")
+        for p in range(N):
+            s = int(dp2scaf[p])
+            f.write(f"{p + 1}\ts{s:07d}_{p}\ts{s:07d}:(1, 2000), 2000/2000 non-Ns bps\n")
+    with open(os.path.join(wd, "a.lrn"), "w") as f:
+        f.write(f"% {N}\n% {D + 1}\n% 9" + "\t1" * D + "\n% Key" + "".join(f"\td{j}" for j in range(D)) + "\n")
+        rows = milli.T
+        for p in range(N):
+            f.write(str(p + 1) + "".join("\t%d.%03d" % divmod(int(v), 1000) for v in rows[p]) + "\n")
+    with open(os.path.join(wd, "genes.scg"), "w") as f:
+        for k, (s, g) in enumerate(zip(scg_scaf, scg_id)):
+            f.write(f"s{int(s):07d}_{k + 1}\tSCG{int(g):03d}\n")
+    with open(os.path.join(wd, "scg.list"), "w") as f:
+        for g in range(max(1, int(n_scg))):
+            f.write(f"SCG{g:03d}\n")
+    return dict(names=os.path.join(wd, "a.names"), fasta=os.path.join(wd, "a.fa"), info=os.path.join(wd, "a.info"),
+                lrn=os.path.join(wd, "a.lrn"), scg=os.path.join(wd, "genes.scg") if len(scg_scaf) else "-",
+                scg_list=os.path.join(wd, "scg.list"))

@@ -1,0 +1,168 @@
+// See ClusterSeparatorHip.h.  Host-side adapter between the reference's data model (ScafDpData,
+// ClusterData, SCGdb, Cluster) and the C ABI of libabawaca_hip.so (include/abawaca_hip.h).
+#include "ClusterSeparatorHip.h"
+#include "abawaca_hip.h"
+#include <algorithm>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+// One resident column store per process: the root ClusterData is uploaded the first time a
+// separator is asked to work (reference src/abawaca.cpp:86 loads it once, too).
+struct HipStore {
+	abw_ctx*				ctx = NULL;
+	const ScafDpData*			scaf_db = NULL;
+	size_t					N = 0, D = 0, S = 0;
+	std::vector<std::vector<double> >	values;		// [D] sorted distinct values: key -> .lrn value
+	std::vector<std::string>		dim_names;
+};
+HipStore g_store;
+
+void fail(const std::string& what)
+{
+	std::string msg = what;
+	if(g_store.ctx) msg += std::string(": ") + abw_last_error(g_store.ctx);
+	throw std::runtime_error(msg);
+}
+
+void load_store(const ScafDpData& scaf_db, const SCGdb& scg_db, const ClusterData& root)
+{
+	HipStore& st = g_store;
+	if(!st.ctx && abw_ctx_create(0, &st.ctx) != ABW_OK)
+		throw std::runtime_error("ClusterSeparatorHip: no MI355X / HIP device available");
+	const size_t N = scaf_db.ndps(), D = root.ndimensions(), S = scaf_db.nscafs();
+	if(root.ndps() != N)
+		throw std::invalid_argument("ClusterSeparatorHip: the first node must hold every datapoint (root of the recursion)");
+	st.scaf_db = &scaf_db; st.N = N; st.D = D; st.S = S;
+	st.values.assign(D, std::vector<double>());
+	st.dim_names.assign(D, "");
+
+	// keys: rank of every value among the column's distinct values (order-preserving, exact for any
+	// .lrn; for abawaca-build's 3-decimal output the table has <= 1001 entries per signature column)
+	std::vector<int32_t> keys(D * N);
+	for(size_t d = 0; d < D; d++) {
+		const Dimension& dim = root.get_dimension(d + 1);
+		st.dim_names[d] = dim.get_dimension_name();
+		std::vector<double>& u = st.values[d];
+		u.assign(dim.get_values().begin(), dim.get_values().end());	// std::set<double>: sorted, distinct
+		for(auto it = dim.begin(); it != dim.end(); it++) {
+			const size_t key = std::lower_bound(u.begin(), u.end(), it->value) - u.begin();
+			keys[d * N + (it->dp - 1)] = (int32_t)key;
+		}
+	}
+	std::vector<int32_t> dp2scaf(N);
+	for(size_t dp = 1; dp <= N; dp++) dp2scaf[dp - 1] = (int32_t)scaf_db.dp2scaf(dp) - 1;
+	std::vector<int64_t> scaf_len(S);
+	for(size_t s = 1; s <= S; s++) scaf_len[s - 1] = (int64_t)scaf_db.get_scaf(s)->get_seq_size();
+	// scaffold -> SCG ids through SCGdb's public interface
+	std::map<std::string, int32_t> scg_id;
+	std::vector<int32_t> scg_off(S + 1, 0), scg_ids;
+	for(size_t s = 1; s <= S; s++) {
+		std::set<size_t> one; one.insert(s);
+		std::map<std::string, size_t> found;
+		scg_db.get_scg2count(one, found);
+		for(auto it = found.begin(); it != found.end(); it++) {
+			auto ins = scg_id.insert(std::pair<std::string, int32_t>(it->first, (int32_t)scg_id.size()));
+			scg_ids.push_back(ins.first->second);
+		}
+		scg_off[s] = (int32_t)scg_ids.size();
+	}
+	const int32_t n_scg = (int32_t)scg_id.size();
+	if(abw_sep_load(st.ctx, keys.data(), (int32_t)D, (int64_t)N, dp2scaf.data(), scaf_len.data(), (int32_t)S,
+			n_scg ? scg_off.data() : NULL, n_scg ? scg_ids.data() : NULL, n_scg) != ABW_OK)
+		fail("ClusterSeparatorHip: abw_sep_load failed");
+}
+
+}	// namespace
+
+//////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
+ClusterSeparatorHip::ClusterSeparatorHip(const ScafDpData& scaf_db, const SCGdb& scg_db, const ClusterData& clustering_db, Semaphore& threads_semaphore) :
+	ClusterSeparator(scaf_db, scg_db, clustering_db, threads_semaphore, new Result())
+{}
+
+//////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
+void ClusterSeparatorHip::shutdown()
+{
+	if(g_store.ctx) abw_ctx_destroy(g_store.ctx);
+	g_store = HipStore();
+}
+
+//////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
+ostream& operator << (ostream& os, ClusterSeparatorHip& cs)
+{
+	// same text as reference src/ClusterSeparatorBySensitivitySpecificity.cpp:79-88
+	os << " Best separation:\t" << "dimension " << cs.get_separating_dimension() << " ("
+		<< cs.clustering_db.get_dimension(cs.get_separating_dimension()).get_dimension_name() << ")\t"
+		<< "Value " << cs.get_separating_value() << "\t"
+		<< "Specificity " << cs.get_best_specificity() << "\t"
+		<< "Sensitivity " << cs.get_best_sensitivity();
+	return os;
+}
+
+//////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
+bool ClusterSeparatorHip::separate()
+{
+	// reference src/ClusterSeparator.cpp:59-67
+	if(this->cluster1 != NULL) delete(this->cluster1);
+	if(this->cluster2 != NULL) delete(this->cluster2);
+	this->cluster1 = this->cluster2 = NULL;
+	this->best_separation->reset();
+	this->raw_dps_cluster1.clear();
+	this->raw_dps_cluster2.clear();
+
+	if(g_store.ctx == NULL || g_store.scaf_db != &scaf_db)
+		load_store(scaf_db, scg_db, clustering_db);
+	HipStore& st = g_store;
+
+	// the node as a list of whole scaffolds (separate() always hands whole scaffolds to its children,
+	// reference src/ClusterSeparator.cpp:94-122)
+	const unordered_set<size_t>& dps = clustering_db.datapoints();
+	std::map<size_t, size_t> per_scaf;
+	for(auto it = dps.begin(); it != dps.end(); it++) per_scaf[scaf_db.dp2scaf(*it)]++;
+	std::vector<int32_t> scaf_ids;
+	for(auto it = per_scaf.begin(); it != per_scaf.end(); it++) {
+		if(it->second != scaf_db.ndps(it->first))
+			throw std::invalid_argument("ClusterSeparatorHip: node holds only part of scaffold " + scaf_db.scaf_id2name(it->first));
+		scaf_ids.push_back((int32_t)it->first - 1);
+	}
+	const int32_t m = (int32_t)scaf_ids.size();
+	abw_split out;
+	std::vector<uint8_t> side(m), raw(dps.size());
+	if(abw_sep_node(st.ctx, scaf_ids.data(), m, (int32_t)this->cluster_ndps_threshold, &out, NULL, side.data(), raw.data()) != ABW_OK)
+		fail("ClusterSeparatorHip: abw_sep_node failed");
+
+	Result* best = static_cast<Result*>(best_separation);
+	if(out.dimension > 0)
+		best->set((size_t)out.dimension, st.values[out.dimension - 1][out.key], out.sensitivity, out.specificity, out.legal != 0);
+	if(!out.legal || out.dimension <= 0)
+		return false;								// reference src/ClusterSeparator.cpp:83-84
+
+	// raw sets (reference :87-90): dps listed scaffold by scaffold, ascending dp id inside a scaffold
+	std::vector<std::vector<size_t> > scaf_dps(m);
+	{
+		std::map<size_t, size_t> pos;
+		for(int32_t i = 0; i < m; i++) pos[(size_t)scaf_ids[i] + 1] = i;
+		for(auto it = dps.begin(); it != dps.end(); it++) scaf_dps[pos[scaf_db.dp2scaf(*it)]].push_back(*it);
+		for(int32_t i = 0; i < m; i++) std::sort(scaf_dps[i].begin(), scaf_dps[i].end());
+	}
+	size_t k = 0;
+	for(int32_t i = 0; i < m; i++)
+		for(size_t j = 0; j < scaf_dps[i].size(); j++, k++)
+			(raw[k] == 1 ? raw_dps_cluster1 : raw_dps_cluster2).insert(scaf_dps[i][j]);
+
+	if(!out.split) {								// reference :125-132
+		best->reset();
+		return false;
+	}
+	this->cluster1 = new Cluster(scaf_db);
+	this->cluster2 = new Cluster(scaf_db);
+	for(int32_t i = 0; i < m; i++) {
+		Cluster* c = (side[i] == 1) ? this->cluster1 : this->cluster2;
+		for(size_t j = 0; j < scaf_dps[i].size(); j++) *c += scaf_dps[i][j];
+		c->add_assigned_scaf((size_t)scaf_ids[i] + 1);
+	}
+	return true;
+}

@@ -1,0 +1,43 @@
+// ClusterSeparatorHip — the reference-side binding of libabawaca_hip.so's separator.
+//
+// This is the file a maintainer of CK7/abawaca adds to src/ (see INTEGRATION.md): a subclass of the
+// reference's abstract ClusterSeparator (reference src/ClusterSeparator.h:15-75) with the constructor
+// argument list of ClusterSeparatorBySensitivitySpecificity (reference
+// src/ClusterSeparatorBySensitivitySpecificity.h:48-50), so that the only change in main is the type
+// name at reference src/abawaca.cpp:109.  It includes the reference's headers; it contains none of
+// the reference's code.
+#ifndef CLUSTERSEPARATORHIP_H
+#define CLUSTERSEPARATORHIP_H
+
+#include "ClusterSeparator.h"
+
+class ClusterSeparatorHip : public ClusterSeparator {
+protected:
+	// same fields and rules as ClusterSeparatorBySensitivitySpecificity::ClusteringResult
+	// (reference ...Specificity.h:13-46); the rules themselves are evaluated on the GPU / in the library.
+	class Result : public ClusterSeparator::ClusteringResult {
+	public:
+		Result() : ClusterSeparator::ClusteringResult(), sensitivity(0), specificity(0), legal(false)	{}
+		void	reset()						{sensitivity = specificity = 0; legal = false; ClusterSeparator::ClusteringResult::reset();}
+		void	set(size_t d, double v, double sens, double spec, bool l)	{dimension = d; value = v; sensitivity = sens; specificity = spec; legal = l;}
+		bool	is_better(const ClusterSeparator::ClusteringResult&) const	{return false;}	// comparisons happen in the library
+		bool	is_legal() const				{return legal;}
+		void	print_separation_params(ostream& os) const	{ClusterSeparator::ClusteringResult::print_separation_params(os); os << ", Specificity: " << specificity << ", sensitivity:" << sensitivity;}
+		double	sensitivity, specificity;
+		bool	legal;
+	};
+public:
+	ClusterSeparatorHip(const ScafDpData& scaf_db, const SCGdb& scg_db, const ClusterData& clustering_db, Semaphore& threads_semaphore);
+	bool		separate() override;
+	double		get_best_sensitivity() const		{return static_cast<Result*>(best_separation)->sensitivity;}
+	double		get_best_specificity() const		{return static_cast<Result*>(best_separation)->specificity;}
+	friend ostream&	operator << (ostream& os, ClusterSeparatorHip& cs);
+	// Releases the GPU context and the resident column store (optional; call once at program end).
+	static void	shutdown();
+protected:
+	void		separate_dimension(size_t) override	{}	// separate() is replaced as a whole
+};
+
+ostream& operator << (ostream& os, ClusterSeparatorHip& cs);
+
+#endif // CLUSTERSEPARATORHIP_H

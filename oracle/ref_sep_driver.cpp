@@ -26,6 +26,12 @@
 #include "ScafDpData.h"
 #include "ClusterData.h"
 #include "ClusterSeparatorBySensitivitySpecificity.h"
+#ifdef ABW_USE_HIP_SEPARATOR		// same driver, separator swapped for the GPU drop-in (integration/ClusterSeparatorHip.h)
+#include "ClusterSeparatorHip.h"
+#define SEPARATOR_CLASS ClusterSeparatorHip
+#else
+#define SEPARATOR_CLASS ClusterSeparatorBySensitivitySpecificity
+#endif
 #include "Semaphore.h"
 #include "SCGdb.h"
 
@@ -71,7 +77,7 @@ int main(int argc, const char** argv)
 		visited++;
 
 		ClusterData* node_db = new ClusterData(clustering_db, cur->get_dps());
-		ClusterSeparatorBySensitivitySpecificity sep(scaf_db, scg_db, *node_db, sem);
+		SEPARATOR_CLASS sep(scaf_db, scg_db, *node_db, sem);
 
 		auto t0 = std::chrono::steady_clock::now();
 		bool split = sep.separate();

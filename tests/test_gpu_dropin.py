@@ -1,0 +1,43 @@
+"""The drop-in itself: the reference's own objects (ScafDpData, ClusterData, SCGdb, Cluster) driven by
+the same work-list loop, once with the reference's ClusterSeparatorBySensitivitySpecificity and once
+with integration/ClusterSeparatorHip calling libabawaca_hip.so.  Both drivers are built by
+oracle/Makefile into oracle/_ref/ (from the reference's sources where they lie; nothing copied) and
+travel to the GPU box as binaries.  Outputs must be identical text, timing column aside."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from abawaca_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "ref_sep_driver")
+HIP = os.path.join(ROOT, "oracle", "_ref", "hip_sep_driver")
+
+
+def _run(exe, files, prefix):
+    subprocess.run([exe, files["names"], files["fasta"], files["info"], files["lrn"], files["scg"], files["scg_list"],
+                    "8", prefix], check=True, timeout=300)
+    nodes = [ln.split("\t")[:11] for ln in open(prefix + ".nodes.tsv").read().strip().split("\n")]
+    return nodes, open(prefix + ".scaf2cluster.tsv").read(), open(prefix + ".dp2cluster.tsv").read()
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HIP)), reason="oracle/_ref drivers not built")
+@pytest.mark.parametrize("case", ["sep_g4tight", "sep_g3noscg", "sep_g6"])
+def test_reference_main_loop_with_hip_separator(golden_dir, case):
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    with tempfile.TemporaryDirectory(prefix="abwdrop_") as wd:
+        files = synth.write_build_dir(wd, g["milli"], g["dp2scaf"], g["scaf_len"], g["scg_scaf"], g["scg_id"], int(g["n_scg"]))
+        ref = _run(REF, files, os.path.join(wd, "ref"))
+        hip = _run(HIP, files, os.path.join(wd, "hip"))
+    assert ref[0] == hip[0]          # per node: id ndps split dim value spec sens children sizes (%.17g text)
+    assert ref[1] == hip[1] and ref[2] == hip[2]
+    # and the reference run on these regenerated files reproduces the committed golden nodes
+    gold = g["nodes"]
+    assert len(ref[0]) == len(gold)
+    for row, r in zip(ref[0], gold):
+        assert [int(row[0]), int(row[1]), int(row[2]), int(row[3])] == [int(r[0]), int(r[1]), int(r[2]), int(r[3])]
+        assert float(row[4]) == r[4] and float(row[5]) == r[5] and float(row[6]) == r[6]
