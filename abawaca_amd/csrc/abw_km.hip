@@ -116,7 +116,11 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
                                                      float* __restrict__ slabs, uint8_t* __restrict__ assign, int R)
 {
     constexpr int W = DT * 32;
-    __shared__ float xs[W * XS];
+    constexpr int NBUF = (DT <= 6) ? 2 : 1;                  // x-tile buffers that fit beside the centroids in 160 KiB
+    constexpr int NS = 16 * DT;                              // k-steps of the score product
+    // centroid operand of the score product, [wave][j][col]: lanes 0-31 read one 128-B row, conflict-free
+    __shared__ float cs[4 * W * 32];
+    __shared__ float xs[NBUF][W * XS];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
     const int rc0 = blockIdx.y * 128 + wid * 32;             // first score column of this wave
@@ -125,96 +129,148 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
     const bool wave_active = rc0 < Rp * 2;
     const int rc0c = wave_active ? rc0 : Rp * 2 - 32;
     const int rc = rc0c + col;
-
-    // B operand of the score product: c[rc][j = 2s + half], resident for the whole kernel
-    float b1[16 * DT];
-#pragma unroll
-    for (int s = 0; s < 16 * DT; s++) b1[s] = cent[(int64_t)rc * W + 2 * s + half];
+    {
+        // each wave fills its own [j][col] slice; column-major reads of cent are L2-resident (<= 100 KB)
+        float* mine = cs + wid * W * 32;
+        for (int i = lane; i < W * 32; i += 64) {
+            const int j = i >> 5, c = i & 31;
+            mine[i] = cent[(int64_t)(rc0c + c) * W + j];
+        }
+    }
+    const float* bop = cs + wid * W * 32 + half * 32 + col;  // + 64*s for k-step s
     const float hn = hneg[rc];
     const int rp = rowpoint(col);
     const bool is_c1 = col & 1;
     const int sp = threadIdx.x & 31;                         // staging: this thread's point within the tile
     const int sj = threadIdx.x >> 5;                         //          and its first row
 
-    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        f32x16 acc2[DT];
+    float stg[DT * 4];
+    auto stage_load = [&](int64_t tile) {                    // all loads unconditional (clamped), issued back to back
+        const int64_t gp = min(tile + sp, N - 1);
 #pragma unroll
-        for (int t = 0; t < DT; t++)
+        for (int k = 0; k < DT * 4; k++) {
+            const int j = min(sj + 8 * k, d - 1);
+            stg[k] = x[(int64_t)j * N + gp];
+        }
+    };
+    auto stage_store = [&](float* buf, int64_t tile) {       // row d is the all-ones count column
+        const bool pv = tile + sp < N;
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc2[t][e] = 0.0f;
-        const int64_t p_begin = ch * chunk;
-        const int64_t p_end = min(N, p_begin + chunk);
-        for (int64_t tile = p_begin; tile < p_end; tile += 32) {
-            // stage x[0..W)[tile..tile+32) -> LDS; row d is the all-ones count column.  All loads are
-            // unconditional (clamped addresses) so they issue back to back.
-            float stg[DT * 4];
-            {
-                const int64_t gp = min(tile + sp, N - 1);
+        for (int k = 0; k < DT * 4; k++) {
+            const int j = sj + 8 * k;
+            buf[j * XS + sp] = (j < d) ? (pv ? stg[k] : 0.0f) : (j == d ? 1.0f : 0.0f);
+        }
+    };
+
+    int64_t ch = blockIdx.x;
+    if (ch >= nchunks) return;
+    int64_t tile = ch * chunk;
+    int64_t p_end = min(N, tile + chunk);
+    int cur = 0;
+    stage_load(tile);
+    stage_store(xs[0], tile);
+    __syncthreads();
+
+    f32x16 acc2[DT];
 #pragma unroll
-                for (int k = 0; k < DT * 4; k++) {
-                    const int j = min(sj + 8 * k, d - 1);
-                    stg[k] = x[(int64_t)j * N + gp];
+    for (int t = 0; t < DT; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc2[t][e] = 0.0f;
+
+    for (;;) {
+        // position of the next tile of this workgroup (same chunk, or the first tile of its next chunk)
+        int64_t ntile = tile + 32, nch = ch, np_end = p_end;
+        if (ntile >= p_end) { nch = ch + gridDim.x; ntile = nch * chunk; np_end = min(N, ntile + chunk); }
+        const bool have_next = nch < nchunks;
+        if (NBUF == 2 && have_next) stage_load(ntile);       // in flight during the whole compute phase
+
+        const float* xt = xs[cur];
+        // ---- scores: X[p][rc] = -h + sum_j x[p][j] c[rc][j]; operands read 8 k-steps ahead ------------
+        f32x16 acc1;
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc1[e] = hn;
+        {
+            const float* aop = xt + half * XS + rp;          // + 2*XS*s for k-step s
+            float a[2][8], b[2][8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { a[0][u] = aop[2 * XS * u]; b[0][u] = bop[64 * u]; }
+#pragma unroll
+            for (int bt = 0; bt < NS / 8; bt++) {
+                if (bt + 1 < NS / 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        a[(bt + 1) & 1][u] = aop[2 * XS * (8 * (bt + 1) + u)];
+                        b[(bt + 1) & 1][u] = bop[64 * (8 * (bt + 1) + u)];
+                    }
                 }
-            }
-            __syncthreads();                                  // previous tile fully consumed
-            {
-                const bool pv = tile + sp < N;
+                __builtin_amdgcn_sched_barrier(0);           // next batch's LDS reads stay ahead of this batch's MFMAs
 #pragma unroll
-                for (int k = 0; k < DT * 4; k++) {
-                    const int j = sj + 8 * k;
-                    const float v = (j < d) ? (pv ? stg[k] : 0.0f) : (j == d ? 1.0f : 0.0f);
-                    xs[j * XS + sp] = v;
-                }
-            }
-            __syncthreads();
-            // scores: X[p][rc] = -h + sum_j x[p][j] c[rc][j]
-            f32x16 acc1;
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc1[e] = hn;
-#pragma unroll
-            for (int s = 0; s < 16 * DT; s++) {
-                const float a = xs[(2 * s + half) * XS + rp];
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s], acc1, 0, 0, 0);
-                if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep LDS prefetch depth (and VGPRs) bounded
-            }
-            // memberships (tie -> cluster 0), straight from the accumulator layout:
-            // register e of lane (col, half) is point q = 2e + half of the tile
-            float mem[16];
-            const int nvalid = (int)min((int64_t)32, N - tile) - half;            // point 2e + half is real iff 2e < nvalid
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const float mine = acc1[e];
-                const float other = swap_pair(mine);
-                const bool a1 = is_c1 ? (mine > other) : (other > mine);          // score1 > score0
-                const bool valid = 2 * e < nvalid;
-                mem[e] = (valid && (is_c1 == a1)) ? 1.0f : 0.0f;
-                if (ASSIGN) {
-                    if (wave_active && !is_c1 && valid && (rc >> 1) < R)
-                        assign[(int64_t)(rc >> 1) * N + tile + 2 * e + half] = a1 ? 1 : 0;
-                }
-            }
-            // sums: S[rc][j] += sum_p mem[p][rc] x[p][j]
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-#pragma unroll
-                for (int t = 0; t < DT; t++) {
-                    const float b = xs[(t * 32 + col) * XS + 2 * e + half];
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(mem[e], b, acc2[t], 0, 0, 0);
-                }
+                for (int u = 0; u < 8; u++)
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[bt & 1][u], b[bt & 1][u], acc1, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (wave_active) {
-            // slab[ch][rc_row][j]: C/D layout col = lane&31 -> j, row = (e&3) + 8(e>>2) + 4*half -> rc
-            float* slab = slabs + ((int64_t)ch * Rp * 2 + rc0) * W;
+        // ---- memberships (tie -> cluster 0), straight from the accumulator layout:
+        //      register e of lane (col, half) is point q = 2e + half of the tile
+        float mem[16];
+        const int nvalid = (int)min((int64_t)32, N - tile) - half;                // point 2e + half is real iff 2e < nvalid
 #pragma unroll
-            for (int t = 0; t < DT; t++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-                    slab[(int64_t)row * W + t * 32 + col] = acc2[t][e];
-                }
+        for (int e = 0; e < 16; e++) {
+            const float mine = acc1[e];
+            const float other = swap_pair(mine);
+            const bool a1 = is_c1 ? (mine > other) : (other > mine);              // score1 > score0
+            const bool valid = 2 * e < nvalid;
+            mem[e] = (valid && (is_c1 == a1)) ? 1.0f : 0.0f;
+            if (ASSIGN) {
+                if (wave_active && !is_c1 && valid && (rc >> 1) < R)
+                    assign[(int64_t)(rc >> 1) * N + tile + 2 * e + half] = a1 ? 1 : 0;
+            }
         }
+        // ---- sums: S[rc][j] += sum_p mem[p][rc] x[p][j]; operands read one point pair ahead ------------
+        {
+            const float* sop = xt + col * XS + half;         // + 32*XS*t + 2*e
+            float bb[2][DT];
+#pragma unroll
+            for (int t = 0; t < DT; t++) bb[0][t] = sop[32 * XS * t];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                if (e + 1 < 16) {
+#pragma unroll
+                    for (int t = 0; t < DT; t++) bb[(e + 1) & 1][t] = sop[32 * XS * t + 2 * (e + 1)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < DT; t++)
+                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(mem[e], bb[e & 1][t], acc2[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- end of a chunk: one fp32 slab, C/D layout col = lane&31 -> j, row = (e&3) + 8(e>>2) + 4*half -> rc
+        if (nch != ch) {
+            if (wave_active) {
+                float* slab = slabs + ((int64_t)ch * Rp * 2 + rc0) * W;
+#pragma unroll
+                for (int t = 0; t < DT; t++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+                        slab[(int64_t)row * W + t * 32 + col] = acc2[t][e];
+                        acc2[t][e] = 0.0f;
+                    }
+            }
+        }
+        if (!have_next) break;
+        if (NBUF == 2) {
+            stage_store(xs[cur ^ 1], ntile);                 // the other buffer was last read one barrier ago
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();                                 // everyone done reading the only buffer
+            stage_load(ntile);
+            stage_store(xs[0], ntile);
+            __syncthreads();
+        }
+        tile = ntile; ch = nch; p_end = np_end;
     }
 }
 
@@ -382,7 +438,7 @@ int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t
     if (chunk == 0) chunk = 512;
     if (chunk < 32 || (chunk & 31)) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run_dev: chunk must be a positive multiple of 32");
     const int DT = (d + 1 + 31) / 32;                       // dims + the count column, in 32-wide tiles
-    if (DT > 8) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run_dev: d = %d not supported (max 255)", d);
+    if (DT > 7) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run_dev: d = %d not supported (max 222)", d);
     abw_device_guard g(ctx->device);
     const int W = DT * 32;
     const int Rp = (R + 15) & ~15;
@@ -423,8 +479,7 @@ int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t
             case 4: launch_step<4>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
             case 5: launch_step<5>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
             case 6: launch_step<6>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
-            case 7: launch_step<7>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
-            default: launch_step<8>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
+            default: launch_step<7>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
         }
         }
         ABW_LAUNCH_CHECK(ctx);
