@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libabawaca_hip.so")
+LIB_PATH = os.environ.get("ABW_LIB_PATH") or os.path.join(_HERE, "libabawaca_hip.so")   # override: kernel experiments only
 
 ABW_OK = 0
 ABW_ERR_ARG, ABW_ERR_HIP, ABW_ERR_CAPACITY, ABW_ERR_LOWER_N, ABW_ERR_STATE, ABW_ERR_NOMEM = -1, -2, -3, -4, -5, -6

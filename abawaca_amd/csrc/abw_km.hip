@@ -16,6 +16,7 @@
 // memberships never leave registers.  fp32 partial sums run over one chunk of points in point
 // order, one slab per chunk; slabs are added in fp64 in chunk order by km_update_kernel.
 #include "abw_internal.h"
+#include <type_traits>
 #include <string.h>
 #include <vector>
 
@@ -104,11 +105,34 @@ constexpr int XS = 33;   // LDS row stride (floats) of the staged x tile: odd ->
 __device__ __forceinline__ int rowpoint(int i) { return 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); }
 
 // lane l <-> lane l^1 exchange inside a quad (DPP quad_perm [1,0,3,2]); no LDS crossbar involved
+// Score-product MFMAs with the accumulator pinned to VGPRs: its consumer is VALU code (membership),
+// and left to itself the allocator parks it in the AGPRs of the sums accumulators, paying 64 copies
+// per tile.  Inline asm is invisible to the hazard recogniser: mfma_v_done() supplies the 18 wait
+// states a 16-pass MFMA result needs before VALU may read it.
+__device__ __forceinline__ void mfma_v_first(f32x16& c, float a, float b)
+{
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_v(f32x16& c, float a, float b)
+{
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_v_done(f32x16& c0, f32x16& c1)
+{
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c0), "+v"(c1));
+}
+
 __device__ __forceinline__ float swap_pair(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
 }
 
+#ifdef ABW_KM_TIMING
+__device__ unsigned long long km_tim[10];
+#define KM_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define KM_T(i) do { } while (0)
+#endif
 template <int DT, bool ASSIGN>
 __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ x, int64_t N, int d,
                                                      const float* __restrict__ cent, const float* __restrict__ hneg,
@@ -118,7 +142,8 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
     constexpr int W = DT * 32;
     constexpr int NBUF = (DT <= 6) ? 2 : 1;                  // x-tile buffers that fit beside the centroids in 160 KiB
     constexpr int NS = 16 * DT;                              // k-steps of the score product
-    // centroid operand of the score product, [wave][j][col]: lanes 0-31 read one 128-B row, conflict-free
+    // centroid operand of the score product, [wave][j][col]: lanes 0-31 read one 128-B row, conflict-free.
+    // Row d holds -0.5|c|^2: it meets the all-ones row d of the x tile, so the score chain ends with it.
     __shared__ float cs[4 * W * 32];
     __shared__ float xs[NBUF][W * XS];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -130,149 +155,186 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
     const int rc0c = wave_active ? rc0 : Rp * 2 - 32;
     const int rc = rc0c + col;
     {
-        // each wave fills its own [j][col] slice; column-major reads of cent are L2-resident (<= 100 KB)
         float* mine = cs + wid * W * 32;
         for (int i = lane; i < W * 32; i += 64) {
             const int j = i >> 5, c = i & 31;
-            mine[i] = cent[(int64_t)(rc0c + c) * W + j];
+            mine[i] = (j == d) ? hneg[rc0c + c] : cent[(int64_t)(rc0c + c) * W + j];
         }
     }
     const float* bop = cs + wid * W * 32 + half * 32 + col;  // + 64*s for k-step s
-    const float hn = hneg[rc];
     const int rp = rowpoint(col);
     const bool is_c1 = col & 1;
+    const float thr = is_c1 ? 0.0f : __int_as_float(0x80000001);
     const int sp = threadIdx.x & 31;                         // staging: this thread's point within the tile
     const int sj = threadIdx.x >> 5;                         //          and its first row
+    // rows >= d of both buffers never change: row d all ones (count column / meets -0.5|c|^2), the rest zero
+    for (int b = 0; b < NBUF; b++)
+        for (int i = threadIdx.x; i < (W - d) * 32; i += 256)
+            xs[b][(d + (i >> 5)) * XS + (i & 31)] = (i < 32) ? 1.0f : 0.0f;
 
+#ifdef ABW_KM_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+    // Staging of the next tile: thread (sp, sj) moves rows sj, sj+8, ... of point sp.  The global loads
+    // and LDS stores are issued a few at a time between the MFMA batches of the current tile (all four
+    // waves share one texture-address unit: 96 loads issued back to back stall the waves ~1400 cycles).
     float stg[DT * 4];
-    auto stage_load = [&](int64_t tile) {                    // all loads unconditional (clamped), issued back to back
-        const int64_t gp = min(tile + sp, N - 1);
-#pragma unroll
-        for (int k = 0; k < DT * 4; k++) {
-            const int j = min(sj + 8 * k, d - 1);
-            stg[k] = x[(int64_t)j * N + gp];
-        }
-    };
-    auto stage_store = [&](float* buf, int64_t tile) {       // row d is the all-ones count column
-        const bool pv = tile + sp < N;
-#pragma unroll
-        for (int k = 0; k < DT * 4; k++) {
-            const int j = sj + 8 * k;
-            buf[j * XS + sp] = (j < d) ? (pv ? stg[k] : 0.0f) : (j == d ? 1.0f : 0.0f);
-        }
-    };
+    const float* ldp = x;                                    // set per tile: x + clamped point
+    auto load_k = [&](int k) { stg[k] = ldp[(int64_t)min(sj + 8 * k, d - 1) * N]; };   // unconditional (clamped row)
+    // Rows >= d must keep their constants, so a store aimed at one is bent into the padding column
+    // (32) of this thread's last real row instead of being branched around: one v_min per store.
+    const int trash = 8 * XS * max(0, (d - 1 - sj) >> 3) + 32 - sp;
+    const int first = (sj < d) ? 0 : trash;
+    float* stq = xs[0] + sj * XS + sp;                       // set per tile: destination buffer
+    auto store_k = [&](int k) { stq[k == 0 ? first : min(8 * k * XS, trash)] = stg[k]; };
 
-    int64_t ch = blockIdx.x;
-    if (ch >= nchunks) return;
-    int64_t tile = ch * chunk;
-    int64_t p_end = min(N, tile + chunk);
-    int cur = 0;
-    stage_load(tile);
-    stage_store(xs[0], tile);
-    __syncthreads();
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const int64_t p_begin = ch * chunk;
+        const int64_t p_end = min(N, p_begin + chunk);
+        int cur = 0;
+        KM_T(0);
+        __syncthreads();                                      // previous chunk's last tile fully consumed
+        ldp = x + min(p_begin + sp, N - 1);                   // a point past N re-reads the last one; its membership is 0
+        stq = xs[0] + sj * XS + sp;
+#pragma unroll
+        for (int k = 0; k < DT * 4; k++) load_k(k);
+#pragma unroll
+        for (int k = 0; k < DT * 4; k++) store_k(k);
+        __syncthreads();
+        f32x16 acc2[DT];
+#pragma unroll
+        for (int t = 0; t < DT; t++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc2[t][e] = 0.0f;
+        KM_T(1);
 
-    f32x16 acc2[DT];
+        for (int64_t tile = p_begin; tile < p_end; tile += 32) {
+            const bool have_next = tile + 32 < p_end;
+            // two buffers: the next tile is fetched and stored while this one is computed; on the last
+            // tile of a chunk the same code re-fetches the current tile into the idle buffer (harmless)
+            ldp = x + min((have_next ? tile + 32 : tile) + sp, N - 1);
+            stq = xs[cur ^ 1] + sj * XS + sp;
+            const float* xt = xs[cur];
+            const float* sop = xt + col * XS + half;         // sums operand: + 32*XS*t + 2*e
+            float bb[2][DT];
+            KM_T(2);
+            // ---- scores: X[p][rc] = sum_j x[p][j] c[rc][j] - 0.5|c|^2; operands read 8 k-steps ahead -------
+            // Two chains: k-steps alternate between them, so that no MFMA waits for the one before it
+            // (a dependent MFMA that does not follow its producer back to back issues ~13 cycles late).
+            f32x16 acc1, acc1b;
+            {
+                // One wave per SIMD: whatever is issued between two MFMAs has to fit into the 64 cycles
+                // the first one runs, so the next batch's LDS reads and the staging loads are dealt out
+                // one or two per MFMA instead of in a block (a block of ~16 costs a bubble per batch).
+                const float* aop = xt + half * XS + rp;      // + 2*XS*s for k-step s
+                float a[2][8], b[2][8];
 #pragma unroll
-    for (int t = 0; t < DT; t++)
+                for (int u = 0; u < 8; u++) { a[0][u] = aop[2 * XS * u]; b[0][u] = bop[64 * u]; }
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc2[t][e] = 0.0f;
-
-    for (;;) {
-        // position of the next tile of this workgroup (same chunk, or the first tile of its next chunk)
-        int64_t ntile = tile + 32, nch = ch, np_end = p_end;
-        if (ntile >= p_end) { nch = ch + gridDim.x; ntile = nch * chunk; np_end = min(N, ntile + chunk); }
-        const bool have_next = nch < nchunks;
-        if (NBUF == 2 && have_next) stage_load(ntile);       // in flight during the whole compute phase
-
-        const float* xt = xs[cur];
-        // ---- scores: X[p][rc] = -h + sum_j x[p][j] c[rc][j]; operands read 8 k-steps ahead ------------
-        f32x16 acc1;
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc1[e] = hn;
-        {
-            const float* aop = xt + half * XS + rp;          // + 2*XS*s for k-step s
-            float a[2][8], b[2][8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { a[0][u] = aop[2 * XS * u]; b[0][u] = bop[64 * u]; }
-#pragma unroll
-            for (int bt = 0; bt < NS / 8; bt++) {
-                if (bt + 1 < NS / 8) {
+                for (int bt = 0; bt < NS / 8; bt++) {
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
-                        a[(bt + 1) & 1][u] = aop[2 * XS * (8 * (bt + 1) + u)];
-                        b[(bt + 1) & 1][u] = bop[64 * (8 * (bt + 1) + u)];
+                        const int s1 = 8 * (bt + 1) + (u & ~1);          // k-step pair fetched behind this MFMA
+                        if (bt + 1 < NS / 8) {
+                            if (!(u & 1)) { a[(bt + 1) & 1][u] = aop[2 * XS * s1]; a[(bt + 1) & 1][u + 1] = aop[2 * XS * (s1 + 1)]; }
+                            else          { b[(bt + 1) & 1][u - 1] = bop[64 * s1]; b[(bt + 1) & 1][u] = bop[64 * (s1 + 1)]; }
+                        } else if (u < DT) {
+                            bb[0][u] = sop[32 * XS * u];                 // first operands of the sums product
+                        }
+                        if (NBUF == 2 && u == 2) load_k(2 * bt);
+                        if (NBUF == 2 && u == 6) load_k(2 * bt + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (bt == 0 && u < 2) mfma_v_first((u & 1) ? acc1b : acc1, a[0][u], b[0][u]);
+                        else                  mfma_v((u & 1) ? acc1b : acc1, a[bt & 1][u], b[bt & 1][u]);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);           // next batch's LDS reads stay ahead of this batch's MFMAs
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[bt & 1][u], b[bt & 1][u], acc1, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        // ---- memberships (tie -> cluster 0), straight from the accumulator layout:
-        //      register e of lane (col, half) is point q = 2e + half of the tile
-        float mem[16];
-        const int nvalid = (int)min((int64_t)32, N - tile) - half;                // point 2e + half is real iff 2e < nvalid
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const float mine = acc1[e];
-            const float other = swap_pair(mine);
-            const bool a1 = is_c1 ? (mine > other) : (other > mine);              // score1 > score0
-            const bool valid = 2 * e < nvalid;
-            mem[e] = (valid && (is_c1 == a1)) ? 1.0f : 0.0f;
-            if (ASSIGN) {
-                if (wave_active && !is_c1 && valid && (rc >> 1) < R)
-                    assign[(int64_t)(rc >> 1) * N + tile + 2 * e + half] = a1 ? 1 : 0;
-            }
-        }
-        // ---- sums: S[rc][j] += sum_p mem[p][rc] x[p][j]; operands read one point pair ahead ------------
-        {
-            const float* sop = xt + col * XS + half;         // + 32*XS*t + 2*e
-            float bb[2][DT];
-#pragma unroll
-            for (int t = 0; t < DT; t++) bb[0][t] = sop[32 * XS * t];
+            // ---- memberships (tie -> cluster 0), straight from the accumulator layout:
+            //      register e of lane (col, half) is point q = 2e + half of the tile.
+            //      score = chain0 + chain1.  cluster-1 column: member iff mine > other; cluster-0 column:
+            //      member iff mine >= other.  fp32 subtraction (denormals on) is zero only for equal
+            //      operands, so both read "mine - other > thr" with thr = 0 resp. the largest negative number.
+            // ---- sums: S[rc][j] += sum_p mem[p][rc] x[p][j]; operands read one point pair ahead; on the
+            //      common path membership e+1 is computed in the shadow of the MFMAs of point pair e.
+            KM_T(3);
+            const int nv = (int)min((int64_t)32, N - tile);                       // real points in this tile
+            float mem[16], sc = 0.0f, df = 0.0f;
+            auto member = [&](int e) {                                           // from df of point pair e
+                const bool valid = 2 * e + half < nv;
+                if (ASSIGN) {
+                    // a cluster-0 lane holds score0 - score1: cluster 1 wins iff that is negative
+                    if (wave_active && !is_c1 && valid && (rc >> 1) < R)
+                        assign[(int64_t)(rc >> 1) * N + tile + 2 * e + half] = (df < 0.0f) ? 1 : 0;
+                }
+                return (valid && df > thr) ? 1.0f : 0.0f;
+            };
+            mfma_v_done(acc1, acc1b);
+            sc = acc1[0] + acc1b[0];
+            df = sc - swap_pair(sc);
+            mem[0] = member(0);
+            KM_T(4);
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                if (e + 1 < 16) {
 #pragma unroll
-                    for (int t = 0; t < DT; t++) bb[(e + 1) & 1][t] = sop[32 * XS * t + 2 * (e + 1)];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < DT; t++)
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(mem[e], bb[e & 1][t], acc2[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // ---- end of a chunk: one fp32 slab, C/D layout col = lane&31 -> j, row = (e&3) + 8(e>>2) + 4*half -> rc
-        if (nch != ch) {
-            if (wave_active) {
-                float* slab = slabs + ((int64_t)ch * Rp * 2 + rc0) * W;
-#pragma unroll
-                for (int t = 0; t < DT; t++)
-#pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-                        slab[(int64_t)row * W + t * 32 + col] = acc2[t][e];
-                        acc2[t][e] = 0.0f;
+                for (int t = 0; t < DT; t++) {
+                    if (e + 1 < 16) bb[(e + 1) & 1][t] = sop[32 * XS * t + 2 * (e + 1)];
+                    if (NBUF == 2 && t == (DT > 1 ? 1 : 0) && 2 * e < DT * 4) store_k(2 * e);
+                    if (NBUF == 2 && t == (DT > 3 ? 3 : DT - 1) && 2 * e + 1 < DT * 4) store_k(2 * e + 1);
+                    if (e + 1 < 16) {
+                        if (t == 0) sc = acc1[e + 1] + acc1b[e + 1];
+                        if (t == (DT >= 5 ? 2 : 0)) df = sc - swap_pair(sc);
+                        if (t == (DT >= 5 ? 4 : 0)) mem[e + 1] = member(e + 1);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(mem[e], bb[e & 1][t], acc2[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+            KM_T(5);
+            if (NBUF == 2) {
+                __syncthreads();                             // next tile stored by all; this one read by all
+                cur ^= 1;
+            } else if (have_next) {
+                __syncthreads();                             // everyone done reading the only buffer
+                ldp = x + min(tile + 32 + sp, N - 1);
+                stq = xs[0] + sj * XS + sp;
+#pragma unroll
+                for (int k = 0; k < DT * 4; k++) load_k(k);
+#pragma unroll
+                for (int k = 0; k < DT * 4; k++) store_k(k);
+                __syncthreads();
+            }
+            KM_T(6);
         }
-        if (!have_next) break;
-        if (NBUF == 2) {
-            stage_store(xs[cur ^ 1], ntile);                 // the other buffer was last read one barrier ago
-            __syncthreads();
-            cur ^= 1;
-        } else {
-            __syncthreads();                                 // everyone done reading the only buffer
-            stage_load(ntile);
-            stage_store(xs[0], ntile);
-            __syncthreads();
+        if (wave_active) {
+            // slab[ch][rc_row][j]: C/D layout col = lane&31 -> j, row = (e&3) + 8(e>>2) + 4*half -> rc
+            float* slab = slabs + ((int64_t)ch * Rp * 2 + rc0) * W;
+#pragma unroll
+            for (int t = 0; t < DT; t++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    slab[(int64_t)row * W + t * 32 + col] = acc2[t][e];
+                }
         }
-        tile = ntile; ch = nch; p_end = np_end;
     }
+#ifdef ABW_KM_TIMING
+    KM_T(7);
+    if (threadIdx.x == 0 && blockIdx.x == 7)
+    {   for (int i = 0; i < 8; i++) atomicAdd(&km_tim[i], tacc[i]);
+        atomicAdd(&km_tim[8], __builtin_amdgcn_s_memrealtime() - r0_); }
+#endif
 }
+#ifdef ABW_KM_TIMING
+extern "C" void abw_dbg_km_timing(unsigned long long* out)
+{
+    unsigned long long z[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(km_tim), sizeof(z));
+    hipMemcpyToSymbol(HIP_SYMBOL(km_tim), z, sizeof(z));
+}
+#endif
 
 constexpr int KM_GROUP = 32;   // chunk slabs per fp64 group partial
 

@@ -467,13 +467,19 @@ int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base
                 const int64_t p0 = ch * chunk, p1 = p0 + chunk < N ? p0 + chunk : N;
                 for (int32_t q = 0; q < 2 * (d + 1); q++) part[q] = 0.0f;
                 for (int64_t p = p0; p < p1; p++) {
-                    float s0 = hn0, s1 = hn1;
+                    /* Two fmaf chains per score: dimension pairs (j>>1) alternate between them, the
+                     * -0.5|c|^2 term sits at position j = d (against an implicit x_d = 1), and the
+                     * score is their fp32 sum.  (The GPU issues the pairs as alternating MFMA k-steps
+                     * into two accumulators so that no MFMA waits for its predecessor.) */
+                    float s0[2] = { 0.0f, 0.0f }, s1[2] = { 0.0f, 0.0f };
                     for (int32_t j = 0; j < d; j++) {
                         xp[j] = x[(int64_t)j * N + p];
-                        s0 = fmaf(xp[j], c[j], s0);
-                        s1 = fmaf(xp[j], c[d + j], s1);
+                        s0[(j >> 1) & 1] = fmaf(xp[j], c[j], s0[(j >> 1) & 1]);
+                        s1[(j >> 1) & 1] = fmaf(xp[j], c[d + j], s1[(j >> 1) & 1]);
                     }
-                    const int as = s1 > s0;                         /* tie -> cluster 0 */
+                    s0[(d >> 1) & 1] = fmaf(1.0f, hn0, s0[(d >> 1) & 1]);
+                    s1[(d >> 1) & 1] = fmaf(1.0f, hn1, s1[(d >> 1) & 1]);
+                    const int as = (s1[0] + s1[1]) > (s0[0] + s0[1]);   /* tie -> cluster 0 */
                     a[p] = (uint8_t)as;
                     float* pc = part + (size_t)as * (d + 1);
                     for (int32_t j = 0; j < d; j++) pc[j] = fmaf(1.0f, xp[j], pc[j]);

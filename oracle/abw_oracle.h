@@ -102,8 +102,8 @@ uint32_t abw_or_tinymt_next(abw_or_tinymt* t);
  * x: [d][N] fp32 dimension-major points; k = 2; R restarts.  Restart r seeds TinyMT32 with
  * base_seed + r and takes as initial centroids the points  u0 % N  and  u1 % N  (u1 redrawn, at
  * most 64 times, while it names the same point).
- * Assign: score_c = fmaf-chain over j = 0..d-1 of x_j*c_j starting from -(0.5f*|c|^2) (|c|^2 itself
- *   an fp32 fmaf chain from 0); a point goes to cluster 1 iff score_1 > score_0 (tie -> 0): the
+ * Assign: score_c = chain0 + chain1 (fp32), two fmaf chains from 0 over j = 0..d with
+ *   x_d := 1, c_d := -(0.5f*|c|^2) (|c|^2 itself an fp32 fmaf chain from 0), j going to chain (j>>1)&1; a point goes to cluster 1 iff score_1 > score_0 (tie -> 0): the
  *   argmin of the squared Euclidean distance with |x|^2 dropped.
  * Sums: points are cut into chunks of `chunk` consecutive points; per chunk, cluster and dimension
  *   the members are summed in fp32 in point order (and counted the same way); chunk partials are
