@@ -20,7 +20,7 @@ EXPORTS = [
     "abw_ctx_create", "abw_ctx_destroy", "abw_ctx_set_stream", "abw_ctx_synchronize", "abw_last_error",
     "abw_abi_version", "abw_prof_enable", "abw_prof_reset", "abw_prof_read", "abw_sig_dim_names", "abw_sig_segment_host", "abw_sig_segment_dev", "abw_sig_count_dev",
     "abw_sig_build", "abw_sep_load", "abw_sep_node", "abw_sep_dev_keys", "abw_km_run_dev", "abw_km_run",
-    "abw_km_features_from_keys", "abw_km_tinymt_selftest",
+    "abw_km_features_from_keys", "abw_km_tinymt_selftest", "abw_km_auto_chunk",
 ]
 
 
@@ -75,6 +75,8 @@ def lib():
     L.abw_km_run.argtypes = [vp, vp, i64, i32, i32, u32, i32, i32, vp, vp, vp]
     L.abw_km_features_from_keys.argtypes = [vp, vp, i32, i64, vp, vp]
     L.abw_km_tinymt_selftest.argtypes = [vp, u32, i32, vp]
+    L.abw_km_auto_chunk.argtypes = [vp, i64, i32]
+    L.abw_km_auto_chunk.restype = i32
     _LIB = L
     return L
 

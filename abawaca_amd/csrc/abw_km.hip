@@ -5,24 +5,27 @@
 // (abw_or_kmeans).  Only the RNG has a reference counterpart: TinyMT32 with the parameter triple of
 // reference src/misc.cpp:29-31 (tinymt32.c:62-76, tinymt32.h:70-107).
 //
-// Kernel design (gfx950): both halves of a Lloyd iteration are contractions and run on the f32
-// MFMA (v_mfma_f32_32x32x2_f32: exact fp32, result == a k-ordered fmaf chain, so the CPU oracle
-// reproduces every bit):
-//   scores   X[p][rc] = -0.5|c_rc|^2 + sum_j x[p][j] c[rc][j]          (points x (restarts*2))
-//   sums     S[rc][j] = sum_p member[p][rc] x[p][j]                    ((restarts*2) x dims)
-// One workgroup = 4 waves = 64 restarts; a wave owns 32 score columns (16 restarts x 2 clusters).
-// A 32-point tile of x is staged once in LDS and feeds both products; the score accumulator of the
-// first product IS the A operand of the second (column on the lane, rows in registers), so
-// memberships never leave registers.  fp32 partial sums run over one chunk of points in point
-// order, one slab per chunk; slabs are added in fp64 in chunk order by km_update_kernel.
+// Kernel design (gfx950).  With k = 2 a Lloyd iteration needs, per restart, ONE dot product per point
+// and the sums of ONE cluster:
+//   discriminant  g[p][r] = sum_j x[p][j] D[r][j] + e[r],  D = c1 - c0,  e = 0.5|c0|^2 - 0.5|c1|^2
+//                 point p joins cluster 1 iff g > 0 (tie -> cluster 0)
+//   sums          S1[r][j] = sum_p [g[p][r] > 0] x[p][j]  (j = d: the count);  S0 = T - S1 with the
+//                 restart-independent totals T[j] = sum_p x[p][j] computed once per call.
+// Both are contractions and run on the f32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32, result == a
+// k-ordered fmaf chain, so the CPU oracle reproduces every bit).  A wave owns 32 restarts; a
+// workgroup of 4 waves is CW column tiles x PT = 4/CW point lanes, each point lane walking its own
+// chunk of points.  A 32-point tile of x is staged once in LDS and feeds both products; the
+// accumulator of the first product IS the A operand of the second (restart on the lane, points in
+// registers), so memberships never leave registers.  fp32 partial sums run over one chunk of points
+// in point order, one slab per chunk; slabs are added in fp64 in chunk order (km_group / km_update).
 #include "abw_internal.h"
-#include <type_traits>
 #include <string.h>
 #include <vector>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
 
 constexpr uint32_t TMT_MAT1 = 0x8f7011eeu, TMT_MAT2 = 0xfc78ff1fu, TMT_TMAT = 0x3793fdffu;   // ref misc.cpp:29-31
 
@@ -69,9 +72,21 @@ __global__ void tmt_selftest_kernel(uint32_t seed, int n, uint32_t* out)
     for (int i = 0; i < n; i++) out[i] = tmt_next(t);
 }
 
-// centroid buffers: cent [Rp*2][W] fp32 (W = DT*32, zero beyond d), hneg [Rp*2]
+// Buffers: cent [Rp*2][W] fp32 centroids (W = DT*32, zero beyond d); dT [W][Rp] fp32, the
+// discriminant operand, dimension-major: row j < d holds D[.][j], row d holds e[.], rows > d zero.
+__device__ inline void km_discriminant(const float* c0, const float* c1, int d, int W, int Rp, int r, float* dT, int tid, int nthr)
+{
+    for (int j = tid; j < W; j += nthr)
+        if (j != d) dT[(int64_t)j * Rp + r] = (j < d) ? c1[j] - c0[j] : 0.0f;
+    if (tid == 0) {
+        float n0 = 0.0f, n1 = 0.0f;
+        for (int j = 0; j < d; j++) { n0 = fmaf(c0[j], c0[j], n0); n1 = fmaf(c1[j], c1[j], n1); }
+        dT[(int64_t)d * Rp + r] = 0.5f * n0 - 0.5f * n1;
+    }
+}
+
 __global__ void km_init_kernel(const float* __restrict__ x, int64_t N, int d, int W, int R, int Rp, uint32_t base_seed,
-                               float* __restrict__ cent, float* __restrict__ hneg)
+                               float* __restrict__ cent, float* __restrict__ dT)
 {
     const int r = blockIdx.x;
     __shared__ int64_t idx[2];
@@ -91,21 +106,15 @@ __global__ void km_init_kernel(const float* __restrict__ x, int64_t N, int d, in
         for (int j = threadIdx.x; j < W; j += blockDim.x)
             cent[((int64_t)r * 2 + c) * W + j] = (j < d) ? x[(int64_t)j * N + idx[c]] : 0.0f;
     __syncthreads();
-    if (threadIdx.x < 2) {
-        const float* c = cent + ((int64_t)r * 2 + threadIdx.x) * W;
-        float n2 = 0.0f;
-        for (int j = 0; j < d; j++) n2 = fmaf(c[j], c[j], n2);
-        hneg[r * 2 + threadIdx.x] = -(0.5f * n2);
-    }
+    km_discriminant(cent + (int64_t)r * 2 * W, cent + ((int64_t)r * 2 + 1) * W, d, W, Rp, r, dT, threadIdx.x, blockDim.x);
 }
 
 constexpr int XS = 33;   // LDS row stride (floats) of the staged x tile: odd -> conflict-free both ways
 
-// row i of the score tile holds the point whose position in the fp32 summation order is rowpoint(i)
+// row i of the discriminant tile holds the point whose position in the fp32 summation order is rowpoint(i)
 __device__ __forceinline__ int rowpoint(int i) { return 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); }
 
-// lane l <-> lane l^1 exchange inside a quad (DPP quad_perm [1,0,3,2]); no LDS crossbar involved
-// Score-product MFMAs with the accumulator pinned to VGPRs: its consumer is VALU code (membership),
+// Discriminant MFMAs with the accumulator pinned to VGPRs: its consumer is VALU code (membership),
 // and left to itself the allocator parks it in the AGPRs of the sums accumulators, paying 64 copies
 // per tile.  Inline asm is invisible to the hazard recogniser: mfma_v_done() supplies the 18 wait
 // states a 16-pass MFMA result needs before VALU may read it.
@@ -122,85 +131,103 @@ __device__ __forceinline__ void mfma_v_done(f32x16& c0, f32x16& c1)
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c0), "+v"(c1));
 }
 
-__device__ __forceinline__ float swap_pair(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
-}
-
 #ifdef ABW_KM_TIMING
 __device__ unsigned long long km_tim[10];
 #define KM_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tprev; tprev = t_; } while (0)
 #else
 #define KM_T(i) do { } while (0)
 #endif
-template <int DT, bool ASSIGN>
+
+template <int DT, int CW> struct KmCfg {
+    static constexpr int W = DT * 32;
+    static constexpr int PT = 4 / CW;                        // point lanes (chunks walked side by side)
+    static constexpr int CS_FLOATS = CW * W * 32;            // discriminant operand [ct][j][col]
+    static constexpr int TILE_FLOATS = W * XS;               // one staged x tile
+    // two buffers per point lane when they fit beside the operand in 160 KiB, else one
+    static constexpr int NBUF = ((CS_FLOATS + PT * 2 * TILE_FLOATS) * 4 <= 160 * 1024) ? 2 : 1;
+};
+
+template <int DT, int CW, bool ASSIGN>
 __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ x, int64_t N, int d,
-                                                     const float* __restrict__ cent, const float* __restrict__ hneg,
-                                                     int Rp, int chunk, int64_t nchunks,
+                                                     const float* __restrict__ dT, int Rp, int chunk, int64_t nchunks,
                                                      float* __restrict__ slabs, uint8_t* __restrict__ assign, int R)
 {
-    constexpr int W = DT * 32;
-    constexpr int NBUF = (DT <= 6) ? 2 : 1;                  // x-tile buffers that fit beside the centroids in 160 KiB
-    constexpr int NS = 16 * DT;                              // k-steps of the score product
-    // centroid operand of the score product, [wave][j][col]: lanes 0-31 read one 128-B row, conflict-free.
-    // Row d holds -0.5|c|^2: it meets the all-ones row d of the x tile, so the score chain ends with it.
-    __shared__ float cs[4 * W * 32];
-    __shared__ float xs[NBUF][W * XS];
+    using C = KmCfg<DT, CW>;
+    constexpr int W = C::W, PT = C::PT, NBUF = C::NBUF;
+    constexpr int NS = 16 * DT;                              // k-steps of the discriminant product = MFMAs of either product
+    __shared__ float cs[C::CS_FLOATS];
+    __shared__ float xs[PT * NBUF][C::TILE_FLOATS];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
-    const int rc0 = blockIdx.y * 128 + wid * 32;             // first score column of this wave
-    // a wave past the last column (only when Rp*2 is not a multiple of 128) recomputes the last
-    // tile of columns and stores nothing: keeps every wave on one straight-line MFMA stream
-    const bool wave_active = rc0 < Rp * 2;
-    const int rc0c = wave_active ? rc0 : Rp * 2 - 32;
-    const int rc = rc0c + col;
-    {
-        float* mine = cs + wid * W * 32;
-        for (int i = lane; i < W * 32; i += 64) {
-            const int j = i >> 5, c = i & 31;
-            mine[i] = (j == d) ? hneg[rc0c + c] : cent[(int64_t)(rc0c + c) * W + j];
-        }
+    const int ct = wid % CW, pl = wid / CW;                  // this wave's column tile and point lane
+    const int r0 = ((int)blockIdx.y * CW + ct) * 32;         // first restart of this wave
+    // a wave past the last restart tile recomputes the last one and stores nothing: keeps every
+    // wave on one straight-line MFMA stream and inside the workgroup barriers
+    const bool wave_cols = r0 < Rp;
+    for (int i = threadIdx.x; i < CW * W * 32; i += 256) {
+        const int t = i / (W * 32), j = (i >> 5) % W, c = i & 31;
+        cs[i] = dT[(int64_t)j * Rp + min(((int)blockIdx.y * CW + t) * 32, Rp - 32) + c];
     }
-    const float* bop = cs + wid * W * 32 + half * 32 + col;  // + 64*s for k-step s
+    const float* bop = cs + ct * W * 32 + half * 32 + col;   // + 64*s for k-step s
     const int rp = rowpoint(col);
-    const bool is_c1 = col & 1;
-    const float thr = is_c1 ? 0.0f : __int_as_float(0x80000001);
-    const int sp = threadIdx.x & 31;                         // staging: this thread's point within the tile
-    const int sj = threadIdx.x >> 5;                         //          and its first row
-    // rows >= d of both buffers never change: row d all ones (count column / meets -0.5|c|^2), the rest zero
-    for (int b = 0; b < NBUF; b++)
-        for (int i = threadIdx.x; i < (W - d) * 32; i += 256)
-            xs[b][(d + (i >> 5)) * XS + (i & 31)] = (i < 32) ? 1.0f : 0.0f;
+    const int sq = threadIdx.x & 7;                          // staging: this thread's point quad within a tile
+    const int sr = threadIdx.x >> 3;                         //          and its first row (then every 32nd)
 
 #ifdef ABW_KM_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
     const unsigned long long r0_ = __builtin_amdgcn_s_memrealtime();
 #endif
-    // Staging of the next tile: thread (sp, sj) moves rows sj, sj+8, ... of point sp.  The global loads
-    // and LDS stores are issued a few at a time between the MFMA batches of the current tile (all four
-    // waves share one texture-address unit: 96 loads issued back to back stall the waves ~1400 cycles).
-    float stg[DT * 4];
-    const float* ldp = x;                                    // set per tile: x + clamped point
-    auto load_k = [&](int k) { stg[k] = ldp[(int64_t)min(sj + 8 * k, d - 1) * N]; };   // unconditional (clamped row)
-    // Rows >= d must keep their constants, so a store aimed at one is bent into the padding column
-    // (32) of this thread's last real row instead of being branched around: one v_min per store.
-    const int trash = 8 * XS * max(0, (d - 1 - sj) >> 3) + 32 - sp;
-    const int first = (sj < d) ? 0 : trash;
-    float* stq = xs[0] + sj * XS + sp;                       // set per tile: destination buffer
-    auto store_k = [&](int k) { stq[k == 0 ? first : min(8 * k * XS, trash)] = stg[k]; };
+    // Staging of the next tiles (one per point lane): thread (sq, sr) moves points 4sq..4sq+3 of rows
+    // sr, sr+32, ... of every lane's tile with one 16-byte load each (rows of x start at any 4-byte
+    // boundary, so the loads are unaligned ones).  Loads and LDS stores are issued one at a time
+    // between the MFMAs of the current tile: the four waves share one texture-address unit, and a
+    // block of loads issued back to back stalls them for its whole length.
+    // Rows >= d exist only in LDS: row d is all ones (the count column, and it meets e[r] in the
+    // discriminant), rows above are zero; only the last row group can hold them.
+    constexpr int NL = PT * DT;                              // staging loads (and stores) per thread per step
+    f32x4u stg[NL];
+    const float* ldp[PT];                                    // per point lane: x + first point of the quad being fetched
+    float* stq[PT];                                          // per point lane: destination buffer + (sr, 4sq)
+    auto load_k = [&](int k) { stg[k] = *(const f32x4u*)(ldp[k / DT] + (int64_t)min(sr + 32 * (k % DT), d - 1) * N); };
+    auto store_k = [&](int k) {
+        const int kk = k % DT;
+        f32x4u v = stg[k];
+        if (kk == DT - 1) {
+            const int row = sr + 32 * kk;
+            const float cst = (row == d) ? 1.0f : 0.0f;
+            if (row >= d) v = f32x4u{cst, cst, cst, cst};
+        }
+        float* q = stq[k / DT] + 32 * kk * XS;
+        q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
+    };
+    // A tile that would run past its chunk's end (only the last tile of the data can) is moved back to
+    // end there: every load stays inside x, and the points in front of the original start -- already
+    // consumed by the previous tile -- are masked out like points of no chunk at all.
+    auto tile_origin = [&](int64_t t0, int64_t end) { return min(t0, end - 32); };
 
-    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        const int64_t p_begin = ch * chunk;
-        const int64_t p_end = min(N, p_begin + chunk);
+    const int64_t nsteps_total = (nchunks + PT - 1) / PT;    // chunk groups: point lane q of group g walks chunk g*PT + q
+    for (int64_t cg = blockIdx.x; cg < nsteps_total; cg += gridDim.x) {
+        int64_t pb[PT], pe[PT];
+#pragma unroll
+        for (int q = 0; q < PT; q++) {
+            pb[q] = min(N, (cg * PT + q) * chunk);           // a lane without a chunk gets an empty range at N
+            pe[q] = min(N, pb[q] + chunk);
+        }
+        const int64_t ch = cg * PT + pl;                      // this wave's chunk
+        const int64_t p_begin = pb[pl], p_end = pe[pl];
+        const int ntiles = (int)((pe[0] - pb[0] + 31) >> 5);  // lane 0 always has the longest chunk of the group
         int cur = 0;
         KM_T(0);
-        __syncthreads();                                      // previous chunk's last tile fully consumed
-        ldp = x + min(p_begin + sp, N - 1);                   // a point past N re-reads the last one; its membership is 0
-        stq = xs[0] + sj * XS + sp;
+        __syncthreads();                                      // previous group's last tiles fully consumed
 #pragma unroll
-        for (int k = 0; k < DT * 4; k++) load_k(k);
+        for (int q = 0; q < PT; q++) {
+            ldp[q] = x + tile_origin(pb[q], pe[q]) + 4 * sq;
+            stq[q] = xs[q * NBUF] + sr * XS + 4 * sq;
+        }
 #pragma unroll
-        for (int k = 0; k < DT * 4; k++) store_k(k);
+        for (int k = 0; k < NL; k++) load_k(k);
+#pragma unroll
+        for (int k = 0; k < NL; k++) store_k(k);
         __syncthreads();
         f32x16 acc2[DT];
 #pragma unroll
@@ -209,17 +236,21 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
             for (int e = 0; e < 16; e++) acc2[t][e] = 0.0f;
         KM_T(1);
 
-        for (int64_t tile = p_begin; tile < p_end; tile += 32) {
-            const bool have_next = tile + 32 < p_end;
-            // two buffers: the next tile is fetched and stored while this one is computed; on the last
-            // tile of a chunk the same code re-fetches the current tile into the idle buffer (harmless)
-            ldp = x + min((have_next ? tile + 32 : tile) + sp, N - 1);
-            stq = xs[cur ^ 1] + sj * XS + sp;
-            const float* xt = xs[cur];
+        for (int ti = 0; ti < ntiles; ti++) {
+            const bool have_next = ti + 1 < ntiles;
+            const int64_t tile = p_begin + 32 * (int64_t)ti;  // this wave's tile
+            // two buffers: the next tiles are fetched and stored while these are computed; on the last
+            // step of a group the same code re-fetches the current tiles into the idle buffers (harmless)
+#pragma unroll
+            for (int q = 0; q < PT; q++) {
+                ldp[q] = x + tile_origin(pb[q] + 32 * (int64_t)(have_next ? ti + 1 : ti), pe[q]) + 4 * sq;
+                stq[q] = xs[q * NBUF + (NBUF == 2 ? (cur ^ 1) : 0)] + sr * XS + 4 * sq;
+            }
+            const float* xt = xs[pl * NBUF + (NBUF == 2 ? cur : 0)];
             const float* sop = xt + col * XS + half;         // sums operand: + 32*XS*t + 2*e
             float bb[2][DT];
             KM_T(2);
-            // ---- scores: X[p][rc] = sum_j x[p][j] c[rc][j] - 0.5|c|^2; operands read 8 k-steps ahead -------
+            // ---- discriminant: g[p][r] = sum_j x[p][j] D[r][j] + e[r]; operands read 8 k-steps ahead.
             // Two chains: k-steps alternate between them, so that no MFMA waits for the one before it
             // (a dependent MFMA that does not follow its producer back to back issues ~13 cycles late).
             f32x16 acc1, acc1b;
@@ -235,15 +266,15 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
                 for (int bt = 0; bt < NS / 8; bt++) {
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
-                        const int s1 = 8 * (bt + 1) + (u & ~1);          // k-step pair fetched behind this MFMA
+                        const int m = 8 * bt + u;                        // index of this MFMA
+                        const int s1 = 8 * (bt + 1) + (u & ~1);          // k-step pair fetched behind it
                         if (bt + 1 < NS / 8) {
                             if (!(u & 1)) { a[(bt + 1) & 1][u] = aop[2 * XS * s1]; a[(bt + 1) & 1][u + 1] = aop[2 * XS * (s1 + 1)]; }
                             else          { b[(bt + 1) & 1][u - 1] = bop[64 * s1]; b[(bt + 1) & 1][u] = bop[64 * (s1 + 1)]; }
                         } else if (u < DT) {
                             bb[0][u] = sop[32 * XS * u];                 // first operands of the sums product
                         }
-                        if (NBUF == 2 && u == 2) load_k(2 * bt);
-                        if (NBUF == 2 && u == 6) load_k(2 * bt + 1);
+                        if (NBUF == 2 && (m * PT) % 16 == 0) load_k(m * PT / 16);
                         __builtin_amdgcn_sched_barrier(0);
                         if (bt == 0 && u < 2) mfma_v_first((u & 1) ? acc1b : acc1, a[0][u], b[0][u]);
                         else                  mfma_v((u & 1) ? acc1b : acc1, a[bt & 1][u], b[bt & 1][u]);
@@ -251,42 +282,35 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
                     }
                 }
             }
-            // ---- memberships (tie -> cluster 0), straight from the accumulator layout:
-            //      register e of lane (col, half) is point q = 2e + half of the tile.
-            //      score = chain0 + chain1.  cluster-1 column: member iff mine > other; cluster-0 column:
-            //      member iff mine >= other.  fp32 subtraction (denormals on) is zero only for equal
-            //      operands, so both read "mine - other > thr" with thr = 0 resp. the largest negative number.
-            // ---- sums: S[rc][j] += sum_p mem[p][rc] x[p][j]; operands read one point pair ahead; on the
-            //      common path membership e+1 is computed in the shadow of the MFMAs of point pair e.
+            // ---- memberships, straight from the accumulator layout: register e of lane (col, half) is
+            //      point q = 2e + half of the tile, restart r0 + col.  g = chain0 + chain1; member of
+            //      cluster 1 iff g > 0.
+            // ---- sums: S1[r][j] += sum_p mem[p][r] x[p][j]; operands read one point pair ahead;
+            //      membership e+1 is computed in the shadow of the MFMAs of point pair e.
             KM_T(3);
-            const int nv = (int)min((int64_t)32, N - tile);                       // real points in this tile
-            float mem[16], sc = 0.0f, df = 0.0f;
-            auto member = [&](int e) {                                           // from df of point pair e
-                const bool valid = 2 * e + half < nv;
+            const int64_t tile0 = tile_origin(tile, p_end);                       // where the staged tile really starts
+            const int skip = (int)min((int64_t)32, tile - tile0);                 // its leading points that are not ours
+            float mem[16];
+            auto member = [&](int e) {
+                const bool valid = 2 * e + half >= skip;
+                const bool in1 = acc1[e] + acc1b[e] > 0.0f;
                 if (ASSIGN) {
-                    // a cluster-0 lane holds score0 - score1: cluster 1 wins iff that is negative
-                    if (wave_active && !is_c1 && valid && (rc >> 1) < R)
-                        assign[(int64_t)(rc >> 1) * N + tile + 2 * e + half] = (df < 0.0f) ? 1 : 0;
+                    if (wave_cols && valid && r0 + col < R)
+                        assign[(int64_t)(r0 + col) * N + tile0 + 2 * e + half] = in1 ? 1 : 0;
                 }
-                return (valid && df > thr) ? 1.0f : 0.0f;
+                return (valid && in1) ? 1.0f : 0.0f;
             };
             mfma_v_done(acc1, acc1b);
-            sc = acc1[0] + acc1b[0];
-            df = sc - swap_pair(sc);
             mem[0] = member(0);
             KM_T(4);
 #pragma unroll
             for (int e = 0; e < 16; e++) {
 #pragma unroll
                 for (int t = 0; t < DT; t++) {
+                    const int m = e * DT + t;
                     if (e + 1 < 16) bb[(e + 1) & 1][t] = sop[32 * XS * t + 2 * (e + 1)];
-                    if (NBUF == 2 && t == (DT > 1 ? 1 : 0) && 2 * e < DT * 4) store_k(2 * e);
-                    if (NBUF == 2 && t == (DT > 3 ? 3 : DT - 1) && 2 * e + 1 < DT * 4) store_k(2 * e + 1);
-                    if (e + 1 < 16) {
-                        if (t == 0) sc = acc1[e + 1] + acc1b[e + 1];
-                        if (t == (DT >= 5 ? 2 : 0)) df = sc - swap_pair(sc);
-                        if (t == (DT >= 5 ? 4 : 0)) mem[e + 1] = member(e + 1);
-                    }
+                    if (NBUF == 2 && (m * PT) % 16 == 0) store_k(m * PT / 16);
+                    if (e + 1 < 16 && t == 0) mem[e + 1] = member(e + 1);
                     __builtin_amdgcn_sched_barrier(0);
                     acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(mem[e], bb[e & 1][t], acc2[t], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -294,23 +318,21 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
             }
             KM_T(5);
             if (NBUF == 2) {
-                __syncthreads();                             // next tile stored by all; this one read by all
+                __syncthreads();                             // next tiles stored by all; these read by all
                 cur ^= 1;
             } else if (have_next) {
-                __syncthreads();                             // everyone done reading the only buffer
-                ldp = x + min(tile + 32 + sp, N - 1);
-                stq = xs[0] + sj * XS + sp;
+                __syncthreads();                             // everyone done reading the only buffers
 #pragma unroll
-                for (int k = 0; k < DT * 4; k++) load_k(k);
+                for (int k = 0; k < NL; k++) load_k(k);
 #pragma unroll
-                for (int k = 0; k < DT * 4; k++) store_k(k);
+                for (int k = 0; k < NL; k++) store_k(k);
                 __syncthreads();
             }
             KM_T(6);
         }
-        if (wave_active) {
-            // slab[ch][rc_row][j]: C/D layout col = lane&31 -> j, row = (e&3) + 8(e>>2) + 4*half -> rc
-            float* slab = slabs + ((int64_t)ch * Rp * 2 + rc0) * W;
+        if (wave_cols && ch < nchunks) {
+            // slab[ch][r][j]: C/D layout col = lane&31 -> j, row = (e&3) + 8(e>>2) + 4*half -> restart
+            float* slab = slabs + ((int64_t)ch * Rp + r0) * W;
 #pragma unroll
             for (int t = 0; t < DT; t++)
 #pragma unroll
@@ -322,9 +344,10 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
     }
 #ifdef ABW_KM_TIMING
     KM_T(7);
-    if (threadIdx.x == 0 && blockIdx.x == 7)
-    {   for (int i = 0; i < 8; i++) atomicAdd(&km_tim[i], tacc[i]);
-        atomicAdd(&km_tim[8], __builtin_amdgcn_s_memrealtime() - r0_); }
+    if (threadIdx.x == 0 && blockIdx.x == 7) {
+        for (int i = 0; i < 8; i++) atomicAdd(&km_tim[i], tacc[i]);
+        atomicAdd(&km_tim[8], __builtin_amdgcn_s_memrealtime() - r0_);
+    }
 #endif
 }
 #ifdef ABW_KM_TIMING
@@ -339,7 +362,7 @@ extern "C" void abw_dbg_km_timing(unsigned long long* out)
 constexpr int KM_GROUP = 32;   // chunk slabs per fp64 group partial
 
 // Level 1 of the slab reduction: group g adds its KM_GROUP consecutive chunk slabs in fp64 in chunk
-// order.  Elementwise over [Rp*2][W]; the loads of one thread are independent, only its adds chain.
+// order.  Elementwise over [Rp][W]; the loads of one thread are independent, only its adds chain.
 __global__ __launch_bounds__(256) void km_group_kernel(const float* __restrict__ slabs, int64_t nchunks, int64_t elems,
                                                       double* __restrict__ gsum)
 {
@@ -358,41 +381,83 @@ __global__ __launch_bounds__(256) void km_group_kernel(const float* __restrict__
     gsum[g * elems + e] = s;
 }
 
-// Level 2: one workgroup per score column rc adds the group partials in group order, then either
-// moves the centroid (update = 1) or contributes the column's part of the inertia (update = 0).
-__global__ void km_update_kernel(const double* __restrict__ gsum, int64_t ngroups, int Rp, int W, int d,
-                                 float* __restrict__ cent, float* __restrict__ hneg, int update,
+// Totals T[j] = sum_p x[p][j], once per call: per chunk an fp64 sum in point order (one workgroup per
+// chunk stages 32-point tiles through LDS so that global reads stay coalesced) ...
+__global__ __launch_bounds__(256) void km_totals_chunk_kernel(const float* __restrict__ x, int64_t N, int d, int chunk,
+                                                             int64_t nchunks, double* __restrict__ tchunk)
+{
+    __shared__ float tile[32][257];                          // [point][dimension], 256 dimensions per pass at most
+    const int sp = threadIdx.x & 31, sj = threadIdx.x >> 5;
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const int64_t p0 = ch * chunk, p1 = min(N, p0 + chunk);
+        double acc = 0.0;
+        for (int64_t t0 = p0; t0 < p1; t0 += 32) {
+            const int nv = (int)min((int64_t)32, p1 - t0);
+            __syncthreads();
+            for (int j = sj; j < d; j += 8) tile[sp][j] = x[(int64_t)j * N + min(t0 + sp, N - 1)];
+            __syncthreads();
+            if ((int)threadIdx.x < d)
+                for (int p = 0; p < nv; p++) acc += (double)tile[p][threadIdx.x];
+        }
+        if ((int)threadIdx.x < d) tchunk[ch * d + threadIdx.x] = acc;
+    }
+}
+
+// ... then chunk partials in groups of KM_GROUP, groups in order; T[d] = N (the count column).
+__global__ void km_totals_kernel(const double* __restrict__ tchunk, int64_t nchunks, int d, int64_t N, double* __restrict__ tot)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > d) return;
+    if (j == d) { tot[d] = (double)N; return; }
+    double s = 0.0;
+    for (int64_t c0 = 0; c0 < nchunks; c0 += KM_GROUP) {
+        double g = 0.0;
+        const int64_t c1 = min(nchunks, c0 + KM_GROUP);
+        for (int64_t c = c0; c < c1; c++) g += tchunk[c * d + j];
+        s += g;
+    }
+    tot[j] = s;
+}
+
+// Level 2: one workgroup per restart adds the group partials of cluster 1 in group order, derives
+// cluster 0 from the totals, then either moves both centroids and rebuilds the discriminant row
+// (update = 1) or contributes the restart's two inertia terms (update = 0).
+__global__ void km_update_kernel(const double* __restrict__ gsum, int64_t ngroups, const double* __restrict__ tot,
+                                 int Rp, int W, int d, float* __restrict__ cent, float* __restrict__ dT, int update,
                                  double* __restrict__ col_term)
 {
-    extern __shared__ double sh[];            // [W] sums, then [W] floats of the centroid
-    const int rc = blockIdx.x;
-    float* cs = (float*)(sh + W);
+    extern __shared__ double sh[];            // [2][W] sums of cluster 0 / 1, then [2][W] floats of the centroids
+    const int r = blockIdx.x;
+    double* s0 = sh; double* s1 = sh + W;
+    float* c0 = (float*)(sh + 2 * W); float* c1 = c0 + W;
     for (int j = threadIdx.x; j < W; j += blockDim.x) {
         double s = 0.0;
-        const double* p = gsum + (int64_t)rc * W + j;
-        const int64_t stride = (int64_t)Rp * 2 * W;
+        const double* p = gsum + (int64_t)r * W + j;
+        const int64_t stride = (int64_t)Rp * W;
         for (int64_t c = 0; c < ngroups; c++) s += p[c * stride];
-        sh[j] = s;
+        s1[j] = s;
+        s0[j] = (j <= d) ? tot[j] - s : 0.0;
     }
     __syncthreads();
-    const double cnt = sh[d];
+    const double n0 = s0[d], n1 = s1[d];
     for (int j = threadIdx.x; j < W; j += blockDim.x) {
-        float c = cent[(int64_t)rc * W + j];
-        if (update && j < d && cnt > 0.0) { c = (float)(sh[j] / cnt); cent[(int64_t)rc * W + j] = c; }
-        cs[j] = c;
+        float v0 = cent[((int64_t)r * 2) * W + j], v1 = cent[((int64_t)r * 2 + 1) * W + j];
+        if (update && j < d) {                // an empty cluster keeps its centroid
+            if (n0 > 0.0) { v0 = (float)(s0[j] / n0); cent[((int64_t)r * 2) * W + j] = v0; }
+            if (n1 > 0.0) { v1 = (float)(s1[j] / n1); cent[((int64_t)r * 2 + 1) * W + j] = v1; }
+        }
+        c0[j] = v0; c1[j] = v1;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        if (update) {
-            float n2 = 0.0f;
-            for (int j = 0; j < d; j++) n2 = fmaf(cs[j], cs[j], n2);
-            hneg[rc] = -(0.5f * n2);
-        } else {
-            // sum_{p in cluster} |x_p - c|^2 = [sum |x_p|^2] - 2 c.S + n |c|^2 ; the bracket is added per restart
-            double dot = 0.0, n2 = 0.0;
-            for (int j = 0; j < d; j++) { dot += (double)cs[j] * sh[j]; n2 += (double)cs[j] * (double)cs[j]; }
-            col_term[rc] = cnt * n2 - 2.0 * dot;
-        }
+    if (update) {
+        km_discriminant(c0, c1, d, W, Rp, r, dT, threadIdx.x, blockDim.x);
+    } else if (threadIdx.x < 2) {
+        // sum_{p in cluster} |x_p - c|^2 = [sum |x_p|^2] - 2 c.S + n |c|^2 ; the bracket is added per restart
+        const float* c = threadIdx.x ? c1 : c0;
+        const double* s = threadIdx.x ? s1 : s0;
+        double dot = 0.0, n2 = 0.0;
+        for (int j = 0; j < d; j++) { dot += (double)c[j] * s[j]; n2 += (double)c[j] * (double)c[j]; }
+        col_term[2 * r + threadIdx.x] = s[d] * n2 - 2.0 * dot;
     }
 }
 
@@ -447,14 +512,32 @@ __global__ void km_features_kernel(const int32_t* __restrict__ keys, int64_t n, 
     }
 }
 
-template <int DT>
-void launch_step(abw_ctx* ctx, dim3 grid, const float* x, int64_t N, int d, const float* cent, const float* hneg, int Rp,
-                 int chunk, int64_t nchunks, float* slabs, uint8_t* assign, int R)
+struct StepArgs {
+    const float* x; int64_t N; int d; const float* dT; int Rp; int chunk; int64_t nchunks; float* slabs; uint8_t* assign; int R;
+};
+
+template <int DT, int CW>
+void launch_step_cw(abw_ctx* ctx, const StepArgs& a)
 {
-    if (assign)
-        hipLaunchKernelGGL((km_step_kernel<DT, true>), grid, dim3(256), 0, ctx->stream, x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, assign, R);
+    constexpr int PT = 4 / CW;
+    const unsigned gy = (unsigned)((a.Rp / 32 + CW - 1) / CW);
+    const unsigned gx = (unsigned)std::min<int64_t>((a.nchunks + PT - 1) / PT, (int64_t)ctx->num_cu * 8);
+    const dim3 grid(gx, gy);
+    if (a.assign)
+        hipLaunchKernelGGL((km_step_kernel<DT, CW, true>), grid, dim3(256), 0, ctx->stream, a.x, a.N, a.d, a.dT, a.Rp, a.chunk, a.nchunks, a.slabs, a.assign, a.R);
     else
-        hipLaunchKernelGGL((km_step_kernel<DT, false>), grid, dim3(256), 0, ctx->stream, x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, assign, R);
+        hipLaunchKernelGGL((km_step_kernel<DT, CW, false>), grid, dim3(256), 0, ctx->stream, a.x, a.N, a.d, a.dT, a.Rp, a.chunk, a.nchunks, a.slabs, a.assign, a.R);
+}
+
+// Column tiles per workgroup: as many as there are restart tiles (up to 4), the remaining waves
+// become point lanes, so that all four SIMDs work whatever R is.
+template <int DT>
+void launch_step(abw_ctx* ctx, const StepArgs& a)
+{
+    const int tiles = a.Rp / 32;
+    if (tiles >= 3)      launch_step_cw<DT, 4>(ctx, a);
+    else if (tiles == 2) launch_step_cw<DT, 2>(ctx, a);
+    else                 launch_step_cw<DT, 1>(ctx, a);
 }
 
 }  // namespace
@@ -492,56 +575,83 @@ int abw_km_features_from_keys(abw_ctx* ctx, const int32_t* d_keys, int32_t D, in
     return ABW_OK;
 }
 
+int32_t abw_km_auto_chunk(const abw_ctx* ctx, int64_t N, int32_t R)
+{
+    if (!ctx || N < 1 || R < 1) return 0;
+    // workgroups that run side by side: one per compute unit (the step kernel takes ~150 KiB of LDS);
+    // each walks PT chunks at once and covers CW restart tiles (see launch_step)
+    const int tiles_r = (R + 31) / 32;
+    const int cw = tiles_r >= 3 ? 4 : tiles_r;
+    const int pt = 4 / cw, gy = (tiles_r + cw - 1) / cw;
+    const int64_t slots = std::max<int64_t>(1, (int64_t)ctx->num_cu / gy) * pt;
+    const int64_t tiles = (N + 31) / 32;
+    for (int64_t rounds = 1;; rounds++) {
+        const int64_t per = (tiles + slots * rounds - 1) / (slots * rounds);
+        if (per <= 64) return (int32_t)(32 * std::max<int64_t>(1, per));
+    }
+}
+
 int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t R, uint32_t base_seed,
                    int32_t iters, int32_t chunk, uint8_t* d_assign, float* d_centroids, double* d_inertia)
 {
     if (!ctx) return ABW_ERR_ARG;
-    if (!d_x || N < 2 || d < 1 || R < 1 || iters < 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run_dev: bad argument");
-    if (chunk == 0) chunk = 512;
+    if (!d_x || N < 32 || d < 1 || R < 1 || iters < 0)
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run_dev: bad argument (needs d_x, N >= 32 points, d >= 1, R >= 1, iters >= 0)");
+    if (chunk == 0) chunk = abw_km_auto_chunk(ctx, N, R);
     if (chunk < 32 || (chunk & 31)) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run_dev: chunk must be a positive multiple of 32");
     const int DT = (d + 1 + 31) / 32;                       // dims + the count column, in 32-wide tiles
     if (DT > 7) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run_dev: d = %d not supported (max 222)", d);
     abw_device_guard g(ctx->device);
     const int W = DT * 32;
-    const int Rp = (R + 15) & ~15;
+    const int Rp = (R + 31) & ~31;
     const int64_t nchunks = (N + chunk - 1) / chunk;
     int rc;
-    // scratch[1]: centroids + hneg + col_term + x2 ; scratch[2]: slabs
-    const size_t cent_bytes = (size_t)Rp * 2 * W * 4, hneg_bytes = (size_t)Rp * 2 * 4;
-    const size_t term_bytes = (size_t)Rp * 2 * 8, x2_bytes = (size_t)d * 8;
-    if ((rc = abw_reserve(ctx, ctx->scratch[1], cent_bytes + hneg_bytes + term_bytes + x2_bytes + 64))) return rc;
+    // scratch[1]: col_term + x2 + totals + centroids + discriminant operand ; scratch[2]: slabs ;
+    // scratch[5]: fp64 group sums, and (before the first step) the per-chunk totals
+    const size_t cent_bytes = (size_t)Rp * 2 * W * 4, dt_bytes = (size_t)Rp * W * 4;
+    const size_t term_bytes = (size_t)Rp * 2 * 8, x2_bytes = (size_t)d * 8, tot_bytes = (size_t)W * 8;
+    if ((rc = abw_reserve(ctx, ctx->scratch[1], term_bytes + x2_bytes + tot_bytes + cent_bytes + dt_bytes + 64))) return rc;
     const int64_t ngroups = (nchunks + KM_GROUP - 1) / KM_GROUP;
-    const int64_t elems = (int64_t)Rp * 2 * W;
+    const int64_t elems = (int64_t)Rp * W;
     if ((rc = abw_reserve(ctx, ctx->scratch[2], (size_t)nchunks * elems * 4))) return rc;
-    if ((rc = abw_reserve(ctx, ctx->scratch[5], (size_t)ngroups * elems * 8))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[5], std::max((size_t)ngroups * elems * 8, (size_t)nchunks * d * 8)))) return rc;
     double* gsum = (double*)ctx->scratch[5].p;
     uint8_t* base = (uint8_t*)ctx->scratch[1].p;
     double* col_term = (double*)base;
     double* x2_dim = (double*)(base + term_bytes);
-    float* cent = (float*)(base + term_bytes + x2_bytes);
-    float* hneg = (float*)(base + term_bytes + x2_bytes + cent_bytes);
+    double* tot = (double*)(base + term_bytes + x2_bytes);
+    float* cent = (float*)(base + term_bytes + x2_bytes + tot_bytes);
+    float* dT = (float*)(base + term_bytes + x2_bytes + tot_bytes + cent_bytes);
     float* slabs = (float*)ctx->scratch[2].p;
     hipStream_t st = ctx->stream;
 
-    hipLaunchKernelGGL(km_init_kernel, dim3(Rp), dim3(256), 0, st, d_x, N, d, W, R, Rp, base_seed, cent, hneg);
+    hipLaunchKernelGGL(km_init_kernel, dim3(Rp), dim3(256), 0, st, d_x, N, d, W, R, Rp, base_seed, cent, dT);
     ABW_LAUNCH_CHECK(ctx);
-    const unsigned gy = (unsigned)((Rp * 2 + 127) / 128);
-    unsigned gx = (unsigned)std::min<int64_t>(nchunks, (int64_t)ctx->num_cu * 8);
-    const dim3 grid(gx, gy);
-    const size_t upd_lds = (size_t)W * 8 + (size_t)W * 4;
+    {
+        ABW_PROF(ctx, "km_totals");
+        double* tchunk = gsum;                              // consumed before the first group reduction overwrites it
+        hipLaunchKernelGGL(km_totals_chunk_kernel, dim3((unsigned)std::min<int64_t>(nchunks, (int64_t)ctx->num_cu * 8)), dim3(256), 0, st,
+                           d_x, N, d, chunk, nchunks, tchunk);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(km_totals_kernel, dim3((d + 1 + 63) / 64), dim3(64), 0, st, tchunk, nchunks, d, N, tot);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    const StepArgs sa = { d_x, N, d, dT, Rp, chunk, nchunks, slabs, nullptr, R };
+    const size_t upd_lds = (size_t)W * 16 + (size_t)W * 8;
     for (int it = 0; it <= iters; it++) {
         const bool last = it == iters;
-        uint8_t* asg = last ? d_assign : nullptr;
+        StepArgs a = sa;
+        a.assign = last ? d_assign : nullptr;
         {
         ABW_PROF(ctx, "km_step");
         switch (DT) {
-            case 1: launch_step<1>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
-            case 2: launch_step<2>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
-            case 3: launch_step<3>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
-            case 4: launch_step<4>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
-            case 5: launch_step<5>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
-            case 6: launch_step<6>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
-            default: launch_step<7>(ctx, grid, d_x, N, d, cent, hneg, Rp, chunk, nchunks, slabs, asg, R); break;
+            case 1: launch_step<1>(ctx, a); break;
+            case 2: launch_step<2>(ctx, a); break;
+            case 3: launch_step<3>(ctx, a); break;
+            case 4: launch_step<4>(ctx, a); break;
+            case 5: launch_step<5>(ctx, a); break;
+            case 6: launch_step<6>(ctx, a); break;
+            default: launch_step<7>(ctx, a); break;
         }
         }
         ABW_LAUNCH_CHECK(ctx);
@@ -549,7 +659,7 @@ int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t
         ABW_PROF(ctx, "km_update");
         hipLaunchKernelGGL(km_group_kernel, dim3((unsigned)((elems + 255) / 256), (unsigned)ngroups), dim3(256), 0, st, slabs, nchunks, elems, gsum);
         ABW_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(km_update_kernel, dim3(Rp * 2), dim3(W), upd_lds, st, gsum, ngroups, Rp, W, d, cent, hneg, last ? 0 : 1, col_term);
+        hipLaunchKernelGGL(km_update_kernel, dim3(Rp), dim3(W), upd_lds, st, gsum, ngroups, tot, Rp, W, d, cent, dT, last ? 0 : 1, col_term);
         ABW_LAUNCH_CHECK(ctx);
     }
     if (d_inertia) {
@@ -569,7 +679,7 @@ int abw_km_run(abw_ctx* ctx, const float* x, int64_t N, int32_t d, int32_t R, ui
                int32_t iters, int32_t chunk, uint8_t* assign, float* centroids, double* inertia)
 {
     if (!ctx) return ABW_ERR_ARG;
-    if (!x || N < 2 || d < 1 || R < 1) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run: bad argument");
+    if (!x || N < 32 || d < 1 || R < 1) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run: bad argument (needs x, N >= 32 points, d >= 1, R >= 1)");
     abw_device_guard g(ctx->device);
     int rc;
     const size_t xb = (size_t)N * d * 4, ab = (size_t)R * N, cb = (size_t)R * 2 * d * 4, ib = (size_t)R * 8;

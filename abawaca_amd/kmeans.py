@@ -27,6 +27,11 @@ def kmeans_restarts(ctx: Context, x_dn: np.ndarray, R: int, base_seed: int, iter
     return assign, cent, inertia
 
 
+def auto_chunk(ctx: Context, N: int, R: int) -> int:
+    """The chunk length the library picks for chunk = 0 on this device (abw_km_auto_chunk)."""
+    return int(lib().abw_km_auto_chunk(ctx.handle, int(N), int(R)))
+
+
 def kmeans_restarts_dev(ctx: Context, t_x, N: int, d: int, R: int, base_seed: int, iters: int, chunk: int = 0,
                         t_assign=None, t_centroids=None, t_inertia=None):
     """Device-resident variant: t_x is a torch float32 tensor of shape [d, N] on the context's GPU.

@@ -151,10 +151,15 @@ const int32_t* abw_sep_dev_keys(const abw_ctx* ctx);
 /* ---- extension: k-means restarts (NO counterpart in the reference, see DESIGN.md "K-means";
  *      RNG = TinyMT32, ref: src/misc.cpp:24-36, src/TinyMT-src-1.0.1/tinymt/tinymt32.{c,h}) -------- */
 
-/* Rows needed for d_x in abw_km_run_dev: d rounded up to even, plus nothing else. */
-/* d_x: device [d][N] fp32 column-major (dimension-major) points.  k = 2.  R restarts are run
+/* The chunk length abw_km_run_dev uses when it is passed chunk = 0: the multiple of 32 (at most
+ * 2048) that cuts N points into an even number of rounds over the device's compute units for R
+ * restarts.  Results depend on the chunk (it bounds the fp32 partial sums), so a caller that wants
+ * bit-reproducible output across devices passes an explicit chunk instead.  (No reference counterpart.) */
+int32_t abw_km_auto_chunk(const abw_ctx* ctx, int64_t N, int32_t R);
+
+/* d_x: device [d][N] fp32 dimension-major points, d <= 222.  k = 2.  R restarts are run
  * together; restart r seeds TinyMT32 with base_seed + r.  chunk: points per fp32 partial sum
- * (multiple of 32; 0 = default 1024).  Outputs are device pointers (any may be NULL):
+ * (multiple of 32; 0 = abw_km_auto_chunk).  Outputs are device pointers (any may be NULL):
  *   d_assign    [R][N] u8   cluster of every point after the final assign pass
  *   d_centroids [R][2][d] fp32
  *   d_inertia   [R] f64     sum of squared distances to the assigned centroid

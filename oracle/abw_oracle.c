@@ -431,6 +431,26 @@ static double km_x2(const float* x, int64_t N, int32_t d)
     return total;
 }
 
+/* T[j] = sum_p x[j][p]: fp64 in point order inside a chunk, chunk partials added in groups of KM_GROUP,
+ * groups in order.  T[d] = N. */
+static void km_totals(const float* x, int64_t N, int32_t d, int32_t chunk, double* T)
+{
+    const int64_t nchunks = (N + chunk - 1) / chunk;
+    for (int32_t j = 0; j < d; j++) {
+        const float* row = x + (int64_t)j * N;
+        double s = 0.0, g = 0.0;
+        for (int64_t ch = 0; ch < nchunks; ch++) {
+            const int64_t p0 = ch * chunk, p1 = p0 + chunk < N ? p0 + chunk : N;
+            double acc = 0.0;
+            for (int64_t p = p0; p < p1; p++) acc += (double)row[p];
+            g += acc;
+            if ((ch % KM_GROUP) == KM_GROUP - 1 || ch == nchunks - 1) { s += g; g = 0.0; }
+        }
+        T[j] = s;
+    }
+    T[d] = (double)N;
+}
+
 int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed, int32_t iters,
                   int32_t chunk, int nthreads, uint8_t* assign, float* centroids, double* inertia)
 {
@@ -442,16 +462,19 @@ int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base
 #endif
     const double x2 = km_x2(x, N, d);
     const int64_t nchunks = (N + chunk - 1) / chunk;
+    double* T = (double*)malloc(sizeof(double) * (size_t)(d + 1));
+    if (!T) return -2;
+    km_totals(x, N, d, chunk, T);
     int err = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int32_t r = 0; r < R; r++) {
         float* c = centroids + (size_t)r * 2 * d;                  /* [2][d] */
         uint8_t* a = assign + (size_t)r * N;
-        float* part = (float*)malloc(sizeof(float) * 2 * (size_t)(d + 1));
-        double* S = (double*)malloc(sizeof(double) * 2 * (size_t)(d + 1));
-        double* Sg = (double*)malloc(sizeof(double) * 2 * (size_t)(d + 1));
-        float* xp = (float*)malloc(sizeof(float) * (size_t)d);
-        if (!part || !S || !Sg || !xp) { err = 1; free(part); free(S); free(Sg); free(xp); continue; }
+        float* part = (float*)malloc(sizeof(float) * (size_t)(d + 1));       /* cluster 1 only */
+        double* S = (double*)malloc(sizeof(double) * 2 * (size_t)(d + 1));   /* [2][d+1], S[0] derived */
+        double* Sg = (double*)malloc(sizeof(double) * (size_t)(d + 1));
+        float* D = (float*)malloc(sizeof(float) * (size_t)(d + 1));
+        if (!part || !S || !Sg || !D) { err = 1; free(part); free(S); free(Sg); free(D); continue; }
         abw_or_tinymt t;
         abw_or_tinymt_init(&t, base_seed + (uint32_t)r);
         int64_t i0 = (int64_t)(abw_or_tinymt_next(&t) % (uint64_t)N);
@@ -459,36 +482,35 @@ int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base
         for (int tries = 0; tries < 64 && i1 == i0; tries++) i1 = (int64_t)(abw_or_tinymt_next(&t) % (uint64_t)N);
         for (int32_t j = 0; j < d; j++) { c[j] = x[(int64_t)j * N + i0]; c[d + j] = x[(int64_t)j * N + i1]; }
         for (int32_t it = 0; it <= iters; it++) {
+            /* k = 2: one linear discriminant per restart.  D = c1 - c0 (fp32), and at position d
+             * (against an implicit x_d = 1) e = 0.5|c0|^2 - 0.5|c1|^2, the norms fp32 fmaf chains. */
             float n0 = 0.0f, n1 = 0.0f;
-            for (int32_t j = 0; j < d; j++) { n0 = fmaf(c[j], c[j], n0); n1 = fmaf(c[d + j], c[d + j], n1); }
-            const float hn0 = -(0.5f * n0), hn1 = -(0.5f * n1);
-            for (int32_t q = 0; q < 2 * (d + 1); q++) { S[q] = 0.0; Sg[q] = 0.0; }
+            for (int32_t j = 0; j < d; j++) { n0 = fmaf(c[j], c[j], n0); n1 = fmaf(c[d + j], c[d + j], n1); D[j] = c[d + j] - c[j]; }
+            D[d] = 0.5f * n0 - 0.5f * n1;
+            double* S1 = S + (d + 1);
+            for (int32_t q = 0; q <= d; q++) { S1[q] = 0.0; Sg[q] = 0.0; }
             for (int64_t ch = 0; ch < nchunks; ch++) {
                 const int64_t p0 = ch * chunk, p1 = p0 + chunk < N ? p0 + chunk : N;
-                for (int32_t q = 0; q < 2 * (d + 1); q++) part[q] = 0.0f;
+                for (int32_t q = 0; q <= d; q++) part[q] = 0.0f;
                 for (int64_t p = p0; p < p1; p++) {
-                    /* Two fmaf chains per score: dimension pairs (j>>1) alternate between them, the
-                     * -0.5|c|^2 term sits at position j = d (against an implicit x_d = 1), and the
-                     * score is their fp32 sum.  (The GPU issues the pairs as alternating MFMA k-steps
-                     * into two accumulators so that no MFMA waits for its predecessor.) */
-                    float s0[2] = { 0.0f, 0.0f }, s1[2] = { 0.0f, 0.0f };
-                    for (int32_t j = 0; j < d; j++) {
-                        xp[j] = x[(int64_t)j * N + p];
-                        s0[(j >> 1) & 1] = fmaf(xp[j], c[j], s0[(j >> 1) & 1]);
-                        s1[(j >> 1) & 1] = fmaf(xp[j], c[d + j], s1[(j >> 1) & 1]);
-                    }
-                    s0[(d >> 1) & 1] = fmaf(1.0f, hn0, s0[(d >> 1) & 1]);
-                    s1[(d >> 1) & 1] = fmaf(1.0f, hn1, s1[(d >> 1) & 1]);
-                    const int as = (s1[0] + s1[1]) > (s0[0] + s0[1]);   /* tie -> cluster 0 */
+                    /* Two fmaf chains: dimension pairs (j>>1) alternate between them, position d
+                     * included; g is their fp32 sum.  (The GPU issues the pairs as alternating MFMA
+                     * k-steps into two accumulators so that no MFMA waits for its predecessor.) */
+                    float g[2] = { 0.0f, 0.0f };
+                    for (int32_t j = 0; j < d; j++) g[(j >> 1) & 1] = fmaf(x[(int64_t)j * N + p], D[j], g[(j >> 1) & 1]);
+                    g[(d >> 1) & 1] = fmaf(1.0f, D[d], g[(d >> 1) & 1]);
+                    const int as = (g[0] + g[1]) > 0.0f;             /* tie -> cluster 0 */
                     a[p] = (uint8_t)as;
-                    float* pc = part + (size_t)as * (d + 1);
-                    for (int32_t j = 0; j < d; j++) pc[j] = fmaf(1.0f, xp[j], pc[j]);
-                    pc[d] = fmaf(1.0f, 1.0f, pc[d]);                /* the count column */
+                    if (as) {
+                        for (int32_t j = 0; j < d; j++) part[j] = fmaf(1.0f, x[(int64_t)j * N + p], part[j]);
+                        part[d] = fmaf(1.0f, 1.0f, part[d]);        /* the count column */
+                    }
                 }
-                for (int32_t q = 0; q < 2 * (d + 1); q++) Sg[q] += (double)part[q];
+                for (int32_t q = 0; q <= d; q++) Sg[q] += (double)part[q];
                 if ((ch % KM_GROUP) == KM_GROUP - 1 || ch == nchunks - 1)      /* group of 32 chunks complete */
-                    for (int32_t q = 0; q < 2 * (d + 1); q++) { S[q] += Sg[q]; Sg[q] = 0.0; }
+                    for (int32_t q = 0; q <= d; q++) { S1[q] += Sg[q]; Sg[q] = 0.0; }
             }
+            for (int32_t q = 0; q <= d; q++) S[q] = T[q] - S1[q];     /* cluster 0 = totals - cluster 1 */
             if (it < iters) {
                 for (int cl = 0; cl < 2; cl++) {
                     const double cnt = S[(size_t)cl * (d + 1) + d];
@@ -508,7 +530,8 @@ int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base
                 inertia[r] = (x2 + term[0]) + term[1];
             }
         }
-        free(part); free(S); free(Sg); free(xp);
+        free(part); free(S); free(Sg); free(D);
     }
+    free(T);
     return err ? -2 : 0;
 }

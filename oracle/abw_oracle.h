@@ -102,12 +102,16 @@ uint32_t abw_or_tinymt_next(abw_or_tinymt* t);
  * x: [d][N] fp32 dimension-major points; k = 2; R restarts.  Restart r seeds TinyMT32 with
  * base_seed + r and takes as initial centroids the points  u0 % N  and  u1 % N  (u1 redrawn, at
  * most 64 times, while it names the same point).
- * Assign: score_c = chain0 + chain1 (fp32), two fmaf chains from 0 over j = 0..d with
- *   x_d := 1, c_d := -(0.5f*|c|^2) (|c|^2 itself an fp32 fmaf chain from 0), j going to chain (j>>1)&1; a point goes to cluster 1 iff score_1 > score_0 (tie -> 0): the
- *   argmin of the squared Euclidean distance with |x|^2 dropped.
- * Sums: points are cut into chunks of `chunk` consecutive points; per chunk, cluster and dimension
- *   the members are summed in fp32 in point order (and counted the same way); chunk partials are
- *   added in fp64 in chunk order inside groups of 32 consecutive chunks, then the group sums in group order.  centroid = (float)(sum / count); an empty cluster keeps its centroid.
+ * Assign (k = 2, one linear discriminant per restart): D_j = c1_j - c0_j (fp32) for j < d and
+ *   D_d = 0.5f*|c0|^2 - 0.5f*|c1|^2 (the norms fp32 fmaf chains from 0) against x_d := 1;
+ *   g = chain0 + chain1 (fp32), two fmaf chains from 0 over j = 0..d, j going to chain (j>>1)&1;
+ *   a point goes to cluster 1 iff g > 0 (tie -> 0): the nearer centroid in exact arithmetic.
+ * Sums: points are cut into chunks of `chunk` consecutive points; per chunk and dimension the
+ *   members of cluster 1 are summed in fp32 in point order (and counted the same way); chunk
+ *   partials are added in fp64 in chunk order inside groups of 32 consecutive chunks, then the
+ *   group sums in group order.  Cluster 0 is totals minus cluster 1 (fp64), the totals T_j built as
+ *   in km_totals() in abw_oracle.c, T_d = N.  centroid = (float)(sum / count); an empty cluster
+ *   keeps its centroid.
  * `iters` assign+update rounds are followed by one assign-only pass whose sums give
  *   inertia[r] = (X2 + term_0) + term_1,  term_c = count_c*|c_c|^2 - 2*(c_c . sum_c)  in fp64
  *   (j ascending), X2 = sum |x|^2 as built by km_x2() in abw_oracle.c.
