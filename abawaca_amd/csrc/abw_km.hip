@@ -26,6 +26,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
+typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1))); // 16-byte access at any alignment
 
 constexpr uint32_t TMT_MAT1 = 0x8f7011eeu, TMT_MAT2 = 0xfc78ff1fu, TMT_TMAT = 0x3793fdffu;   // ref misc.cpp:29-31
 
@@ -129,6 +130,16 @@ __device__ __forceinline__ void mfma_v(f32x16& c, float a, float b)
 __device__ __forceinline__ void mfma_v_done(f32x16& c0, f32x16& c1)
 {
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c0), "+v"(c1));
+}
+
+// bit i of the low half -> bit 2i
+__device__ __forceinline__ uint32_t spread16(uint32_t v)
+{
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
 }
 
 #ifdef ABW_KM_TIMING
@@ -291,13 +302,11 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
             const int64_t tile0 = tile_origin(tile, p_end);                       // where the staged tile really starts
             const int skip = (int)min((int64_t)32, tile - tile0);                 // its leading points that are not ours
             float mem[16];
+            uint32_t abits = 0;                               // ASSIGN: bit e = point 2e+half of the tile is in cluster 1
             auto member = [&](int e) {
                 const bool valid = 2 * e + half >= skip;
                 const bool in1 = acc1[e] + acc1b[e] > 0.0f;
-                if (ASSIGN) {
-                    if (wave_cols && valid && r0 + col < R)
-                        assign[(int64_t)(r0 + col) * N + tile0 + 2 * e + half] = in1 ? 1 : 0;
-                }
+                if (ASSIGN) abits |= in1 ? (1u << e) : 0u;
                 return (valid && in1) ? 1.0f : 0.0f;
             };
             mfma_v_done(acc1, acc1b);
@@ -315,6 +324,19 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
                     acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(mem[e], bb[e & 1][t], acc2[t], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            if (ASSIGN) {
+                // One 16-byte store per lane: lane (col, half) writes points 16*half .. +15 of restart
+                // r0+col.  Points of the tile that are not ours (skip) are written too: whoever owns
+                // them computes the same discriminant from the same inputs, so the bytes are identical.
+                const uint32_t other = (uint32_t)__shfl_xor((int)abits, 32, 64);
+                const uint32_t M = spread16(half ? other : abits) | (spread16(half ? abits : other) << 1);
+                const uint32_t m16 = (M >> (16 * half)) & 0xFFFFu;
+                u32x4u out;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; w4++) out[w4] = (((m16 >> (4 * w4)) & 0xFu) * 0x00204081u) & 0x01010101u;
+                if (wave_cols && r0 + col < R)
+                    *(u32x4u*)(assign + (int64_t)(r0 + col) * N + tile0 + 16 * half) = out;
             }
             KM_T(5);
             if (NBUF == 2) {
@@ -381,44 +403,6 @@ __global__ __launch_bounds__(256) void km_group_kernel(const float* __restrict__
     gsum[g * elems + e] = s;
 }
 
-// Totals T[j] = sum_p x[p][j], once per call: per chunk an fp64 sum in point order (one workgroup per
-// chunk stages 32-point tiles through LDS so that global reads stay coalesced) ...
-__global__ __launch_bounds__(256) void km_totals_chunk_kernel(const float* __restrict__ x, int64_t N, int d, int chunk,
-                                                             int64_t nchunks, double* __restrict__ tchunk)
-{
-    __shared__ float tile[32][257];                          // [point][dimension], 256 dimensions per pass at most
-    const int sp = threadIdx.x & 31, sj = threadIdx.x >> 5;
-    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        const int64_t p0 = ch * chunk, p1 = min(N, p0 + chunk);
-        double acc = 0.0;
-        for (int64_t t0 = p0; t0 < p1; t0 += 32) {
-            const int nv = (int)min((int64_t)32, p1 - t0);
-            __syncthreads();
-            for (int j = sj; j < d; j += 8) tile[sp][j] = x[(int64_t)j * N + min(t0 + sp, N - 1)];
-            __syncthreads();
-            if ((int)threadIdx.x < d)
-                for (int p = 0; p < nv; p++) acc += (double)tile[p][threadIdx.x];
-        }
-        if ((int)threadIdx.x < d) tchunk[ch * d + threadIdx.x] = acc;
-    }
-}
-
-// ... then chunk partials in groups of KM_GROUP, groups in order; T[d] = N (the count column).
-__global__ void km_totals_kernel(const double* __restrict__ tchunk, int64_t nchunks, int d, int64_t N, double* __restrict__ tot)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > d) return;
-    if (j == d) { tot[d] = (double)N; return; }
-    double s = 0.0;
-    for (int64_t c0 = 0; c0 < nchunks; c0 += KM_GROUP) {
-        double g = 0.0;
-        const int64_t c1 = min(nchunks, c0 + KM_GROUP);
-        for (int64_t c = c0; c < c1; c++) g += tchunk[c * d + j];
-        s += g;
-    }
-    tot[j] = s;
-}
-
 // Level 2: one workgroup per restart adds the group partials of cluster 1 in group order, derives
 // cluster 0 from the totals, then either moves both centroids and rebuilds the discriminant row
 // (update = 1) or contributes the restart's two inertia terms (update = 0).
@@ -461,27 +445,33 @@ __global__ void km_update_kernel(const double* __restrict__ gsum, int64_t ngroup
     }
 }
 
-// sum_p x[j][p]^2 per dimension: 256 strided fp64 partials, then a fixed butterfly
-__global__ __launch_bounds__(256) void km_x2_kernel(const float* __restrict__ x, int64_t N, double* __restrict__ x2_dim)
+// Per dimension j, once per call: T[j] = sum_p x[j][p] and sum_p x[j][p]^2, each as 256 strided fp64
+// partials followed by a fixed butterfly.  tot[d] = N (the count column of the totals).
+__global__ __launch_bounds__(256) void km_moments_kernel(const float* __restrict__ x, int64_t N, int d,
+                                                        double* __restrict__ tot, double* __restrict__ x2_dim)
 {
-    __shared__ double w[4];
+    __shared__ double w[2][4];
     const int j = blockIdx.x;
     const float* row = x + (int64_t)j * N;
-    double acc = 0.0;
+    double a1 = 0.0, a2 = 0.0;
     int64_t p = threadIdx.x;
-    for (; p + 7 * 256 < N; p += 8 * 256) {                  // 8 loads in flight; the adds keep their order
-        float v[8];
+    for (; p + 15 * 256 < N; p += 16 * 256) {                // 16 loads in flight; the adds keep their order
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = row[p + u * 256];
+        for (int u = 0; u < 16; u++) v[u] = row[p + u * 256];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const double w2 = (double)v[u]; acc += w2 * w2; }
+        for (int u = 0; u < 16; u++) { const double w2 = (double)v[u]; a1 += w2; a2 += w2 * w2; }
     }
-    for (; p < N; p += 256) { const double v = (double)row[p]; acc += v * v; }
+    for (; p < N; p += 256) { const double v = (double)row[p]; a1 += v; a2 += v * v; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;
+    for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+    if ((threadIdx.x & 63) == 0) { w[0][threadIdx.x >> 6] = a1; w[1][threadIdx.x >> 6] = a2; }
     __syncthreads();
-    if (threadIdx.x == 0) x2_dim[j] = (w[0] + w[1]) + (w[2] + w[3]);
+    if (threadIdx.x == 0) {
+        tot[j] = (w[0][0] + w[0][1]) + (w[0][2] + w[0][3]);
+        x2_dim[j] = (w[1][0] + w[1][1]) + (w[1][2] + w[1][3]);
+        if (j == 0) tot[d] = (double)N;
+    }
 }
 
 __global__ void km_inertia_kernel(const double* __restrict__ x2_dim, int d, const double* __restrict__ col_term, int R,
@@ -607,14 +597,14 @@ int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t
     const int64_t nchunks = (N + chunk - 1) / chunk;
     int rc;
     // scratch[1]: col_term + x2 + totals + centroids + discriminant operand ; scratch[2]: slabs ;
-    // scratch[5]: fp64 group sums, and (before the first step) the per-chunk totals
+    // scratch[5]: fp64 group sums
     const size_t cent_bytes = (size_t)Rp * 2 * W * 4, dt_bytes = (size_t)Rp * W * 4;
     const size_t term_bytes = (size_t)Rp * 2 * 8, x2_bytes = (size_t)d * 8, tot_bytes = (size_t)W * 8;
     if ((rc = abw_reserve(ctx, ctx->scratch[1], term_bytes + x2_bytes + tot_bytes + cent_bytes + dt_bytes + 64))) return rc;
     const int64_t ngroups = (nchunks + KM_GROUP - 1) / KM_GROUP;
     const int64_t elems = (int64_t)Rp * W;
     if ((rc = abw_reserve(ctx, ctx->scratch[2], (size_t)nchunks * elems * 4))) return rc;
-    if ((rc = abw_reserve(ctx, ctx->scratch[5], std::max((size_t)ngroups * elems * 8, (size_t)nchunks * d * 8)))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[5], (size_t)ngroups * elems * 8))) return rc;
     double* gsum = (double*)ctx->scratch[5].p;
     uint8_t* base = (uint8_t*)ctx->scratch[1].p;
     double* col_term = (double*)base;
@@ -628,12 +618,8 @@ int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t
     hipLaunchKernelGGL(km_init_kernel, dim3(Rp), dim3(256), 0, st, d_x, N, d, W, R, Rp, base_seed, cent, dT);
     ABW_LAUNCH_CHECK(ctx);
     {
-        ABW_PROF(ctx, "km_totals");
-        double* tchunk = gsum;                              // consumed before the first group reduction overwrites it
-        hipLaunchKernelGGL(km_totals_chunk_kernel, dim3((unsigned)std::min<int64_t>(nchunks, (int64_t)ctx->num_cu * 8)), dim3(256), 0, st,
-                           d_x, N, d, chunk, nchunks, tchunk);
-        ABW_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(km_totals_kernel, dim3((d + 1 + 63) / 64), dim3(64), 0, st, tchunk, nchunks, d, N, tot);
+        ABW_PROF(ctx, "km_moments");
+        hipLaunchKernelGGL(km_moments_kernel, dim3(d), dim3(256), 0, st, d_x, N, d, tot, x2_dim);
         ABW_LAUNCH_CHECK(ctx);
     }
     const StepArgs sa = { d_x, N, d, dT, Rp, chunk, nchunks, slabs, nullptr, R };
@@ -663,8 +649,6 @@ int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t
         ABW_LAUNCH_CHECK(ctx);
     }
     if (d_inertia) {
-        hipLaunchKernelGGL(km_x2_kernel, dim3(d), dim3(256), 0, st, d_x, N, x2_dim);
-        ABW_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(km_inertia_kernel, dim3((R + 63) / 64), dim3(64), 0, st, x2_dim, d, col_term, R, d_inertia);
         ABW_LAUNCH_CHECK(ctx);
     }

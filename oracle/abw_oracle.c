@@ -403,52 +403,40 @@ uint32_t abw_or_tinymt_next(abw_or_tinymt* t)
 /* ---------------------------------------------------------------------------------------- */
 #define KM_GROUP 32   /* chunk partials are first added in groups of 32 consecutive chunks, then the groups */
 
-/* sum_p x[j][p]^2 : 256 strided fp64 partials per dimension, xor-butterfly inside each group of 64,
- * then (w0 + w1) + (w2 + w3); dimensions added in index order. */
-static double km_x2(const float* x, int64_t N, int32_t d)
+/* Per dimension: T[j] = sum_p x[j][p] and sum_p x[j][p]^2, each as 256 strided fp64 partials,
+ * xor-butterfly inside each group of 64, then (w0 + w1) + (w2 + w3).  T[d] = N.  Returns X2 = the
+ * squares summed over dimensions in index order. */
+static double km_butterfly(const double* part)
+{
+    double w[4];
+    for (int g = 0; g < 4; g++) {
+        double v[64], nv[64];
+        for (int l = 0; l < 64; l++) v[l] = part[g * 64 + l];
+        for (int o = 32; o > 0; o >>= 1) {
+            for (int l = 0; l < 64; l++) nv[l] = v[l] + v[l ^ o];
+            memcpy(v, nv, sizeof(v));
+        }
+        w[g] = v[0];
+    }
+    return (w[0] + w[1]) + (w[2] + w[3]);
+}
+
+static double km_moments(const float* x, int64_t N, int32_t d, double* T)
 {
     double total = 0.0;
     for (int32_t j = 0; j < d; j++) {
         const float* row = x + (int64_t)j * N;
-        double part[256];
+        double p1[256], p2[256];
         for (int t = 0; t < 256; t++) {
-            double acc = 0.0;
-            for (int64_t p = t; p < N; p += 256) { double v = (double)row[p]; acc += v * v; }
-            part[t] = acc;
+            double a1 = 0.0, a2 = 0.0;
+            for (int64_t p = t; p < N; p += 256) { double v = (double)row[p]; a1 += v; a2 += v * v; }
+            p1[t] = a1; p2[t] = a2;
         }
-        double w[4];
-        for (int g = 0; g < 4; g++) {
-            double v[64], nv[64];
-            for (int l = 0; l < 64; l++) v[l] = part[g * 64 + l];
-            for (int o = 32; o > 0; o >>= 1) {
-                for (int l = 0; l < 64; l++) nv[l] = v[l] + v[l ^ o];
-                memcpy(v, nv, sizeof(v));
-            }
-            w[g] = v[0];
-        }
-        total += (w[0] + w[1]) + (w[2] + w[3]);
-    }
-    return total;
-}
-
-/* T[j] = sum_p x[j][p]: fp64 in point order inside a chunk, chunk partials added in groups of KM_GROUP,
- * groups in order.  T[d] = N. */
-static void km_totals(const float* x, int64_t N, int32_t d, int32_t chunk, double* T)
-{
-    const int64_t nchunks = (N + chunk - 1) / chunk;
-    for (int32_t j = 0; j < d; j++) {
-        const float* row = x + (int64_t)j * N;
-        double s = 0.0, g = 0.0;
-        for (int64_t ch = 0; ch < nchunks; ch++) {
-            const int64_t p0 = ch * chunk, p1 = p0 + chunk < N ? p0 + chunk : N;
-            double acc = 0.0;
-            for (int64_t p = p0; p < p1; p++) acc += (double)row[p];
-            g += acc;
-            if ((ch % KM_GROUP) == KM_GROUP - 1 || ch == nchunks - 1) { s += g; g = 0.0; }
-        }
-        T[j] = s;
+        T[j] = km_butterfly(p1);
+        total += km_butterfly(p2);
     }
     T[d] = (double)N;
+    return total;
 }
 
 int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed, int32_t iters,
@@ -460,11 +448,10 @@ int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base
 #else
     nthreads = 1;
 #endif
-    const double x2 = km_x2(x, N, d);
     const int64_t nchunks = (N + chunk - 1) / chunk;
     double* T = (double*)malloc(sizeof(double) * (size_t)(d + 1));
     if (!T) return -2;
-    km_totals(x, N, d, chunk, T);
+    const double x2 = km_moments(x, N, d, T);
     int err = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int32_t r = 0; r < R; r++) {

@@ -110,11 +110,11 @@ uint32_t abw_or_tinymt_next(abw_or_tinymt* t);
  *   members of cluster 1 are summed in fp32 in point order (and counted the same way); chunk
  *   partials are added in fp64 in chunk order inside groups of 32 consecutive chunks, then the
  *   group sums in group order.  Cluster 0 is totals minus cluster 1 (fp64), the totals T_j built as
- *   in km_totals() in abw_oracle.c, T_d = N.  centroid = (float)(sum / count); an empty cluster
+ *   in km_moments() in abw_oracle.c, T_d = N.  centroid = (float)(sum / count); an empty cluster
  *   keeps its centroid.
  * `iters` assign+update rounds are followed by one assign-only pass whose sums give
  *   inertia[r] = (X2 + term_0) + term_1,  term_c = count_c*|c_c|^2 - 2*(c_c . sum_c)  in fp64
- *   (j ascending), X2 = sum |x|^2 as built by km_x2() in abw_oracle.c.
+ *   (j ascending), X2 = sum |x|^2 as built by km_moments() in abw_oracle.c.
  * Outputs: assign [R][N] uint8, centroids [R][2][d] fp32, inertia [R] fp64.
  * ------------------------------------------------------------------------------------------ */
 int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed, int32_t iters,
