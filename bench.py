@@ -126,14 +126,15 @@ def cpu_kmeans_baseline(x_host, R, iters, chunk):
     import _oracle as orc
     cores = min(16, os.cpu_count() or 1)
     d, N = x_host.shape
-    # calibrate on a small slice, then size the sample for ~10-15 s
+    # calibrate on a small slice, then size the sample (points first, then iterations) for ~12 s
     n0 = min(N, 4000)
     t0 = time.perf_counter()
     orc.kmeans(x_host[:, :n0].copy(), cores, 1, 1, chunk, nthreads=cores)
     dt = max(time.perf_counter() - t0, 1e-3)
-    rate = n0 * cores * 2 / dt                         # (iters + final assign pass) units/s, rough
-    n1 = int(min(N, max(n0, rate * 12.0 / (cores * 4 * 3))))
-    Rs, its = cores * 4, 2
+    rate = n0 * cores * 2 / dt                         # point*restart passes per second (1 iteration + assign pass)
+    Rs = cores * 4
+    n1 = int(min(N, max(n0, rate * 12.0 / (Rs * 3))))
+    its = int(min(40, max(2, round(rate * 12.0 / (n1 * Rs)) - 1)))
     t0 = time.perf_counter()
     orc.kmeans(x_host[:, :n1].copy(), Rs, 1, its, chunk, nthreads=cores)
     dt = time.perf_counter() - t0
@@ -142,7 +143,7 @@ def cpu_kmeans_baseline(x_host, R, iters, chunk):
                        f"(+1 assign pass, not counted) in {dt:.1f} s; the reference has no k-means")
 
 
-def cpu_signature_baseline(blob, off, mbp_sample=20):
+def cpu_signature_baseline(blob, off, mbp_sample=200):
     exe = os.path.join(ROOT, "oracle", "_ref", "abawaca-build")
     if not os.path.exists(exe):
         return None
@@ -168,7 +169,7 @@ def cpu_signature_baseline(blob, off, mbp_sample=20):
                        f"{end / 1e6:.0f} Mbp of the same assembly, whole program incl. FASTA read and .lrn write, {dt:.1f} s")
 
 
-def cpu_separator_baseline(keys_host, dp2scaf, scaf_len, n_scaf_sample=2500):
+def cpu_separator_baseline(keys_host, dp2scaf, scaf_len, n_scaf_sample=12000):
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_sep_driver")
     if not os.path.exists(exe):
         return None
@@ -190,9 +191,9 @@ def cpu_separator_baseline(keys_host, dp2scaf, scaf_len, n_scaf_sample=2500):
                 f.write(f"{p + 1}\ts{s:07d}_{p}\ts{s:07d}:(1, 2000), 2000/2000 non-Ns bps\n")
         with open(os.path.join(wd, "a.lrn"), "w") as f:
             f.write(f"% {n}\n% {D + 1}\n% 9" + "\t1" * D + "\n% Key" + "".join(f"\td{j}" for j in range(D)) + "\n")
-            sub = keys_host[:, :n].T
-            for p in range(n):
-                f.write(str(p + 1) + "".join("\t%d.%03d" % divmod(int(v), 1000) for v in sub[p]) + "\n")
+            import pandas as pd
+            df = pd.DataFrame(keys_host[:, :n].T / 1000.0, index=np.arange(1, n + 1))
+            df.to_csv(f, sep="\t", header=False, float_format="%.3f", lineterminator="\n")
         open(os.path.join(wd, "scg.list"), "w").write("SCG00\n")
         prefix = os.path.join(wd, "ref")
         subprocess.run([exe, os.path.join(wd, "a.names"), os.path.join(wd, "a.fa"), os.path.join(wd, "a.info"),
@@ -221,7 +222,7 @@ def main():
         dist = dist_mod
         dist.init_process_group("nccl", device_id=dev)
 
-    from abawaca_amd import _lib, kmeans, separator, signature
+    from abawaca_amd import _lib, kmeans, multi, separator, signature
     ctx = _lib.Context(local_rank)
 
     # ---------------- workload: configs[1] -------------------------------------------------------
@@ -231,7 +232,9 @@ def main():
     R, iters = args.restarts, args.iters
     if args.chunk == 0:
         args.chunk = kmeans.auto_chunk(ctx, N, R)   # what the library itself picks for chunk = 0
-    seed = 20240 + 1000 * rank                      # every rank its own restarts
+    # weak scaling: the job is world*R restarts, rank k owns restart ids [k*R, (k+1)*R) (abawaca_amd/multi.py)
+    first_restart, _n = multi.restart_range(world * R, rank, world)
+    seed = multi.rank_seed(20240, first_restart)
     t_inertia = torch.empty(R, dtype=torch.float64, device=dev)
     t_cent = torch.empty((R, 2, D), dtype=torch.float32, device=dev)
     t_assign = torch.empty((R, N), dtype=torch.uint8, device=dev)
@@ -260,10 +263,11 @@ def main():
     n_launch, ms_launch = ctx.prof_read("km_step")
     ctx.prof_enable(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = multi.max_elapsed(elapsed, dist, dev)
+        winner = multi.best_restart(t_inertia, first_restart, dist, dev)   # the job's result: (restart id, inertia, owner)
         dist.barrier()
+    else:
+        winner = multi.best_restart(t_inertia.cpu(), first_restart)
     units_per_step = N * R * iters
     value = world * units_per_step * args.steps / elapsed
 
@@ -302,7 +306,7 @@ def main():
                config=dict(workload=f"configs[1]: {args.scaffolds} scaffolds -> {N} dps, 179 signature + {args.samples} coverage dims "
                                     f"(z-scored), k=2, {R} restarts x {iters} Lloyd iterations per GPU, chunk {args.chunk}",
                            parallelism=f"restarts x{world}" if world > 1 else "single GPU"),
-               roofline=roofline)
+               roofline=roofline, best_restart=dict(id=int(winner[0]), inertia=float(winner[1]), rank=int(winner[2])))
 
     # ---------------- extras: real separator + signature build on this GPU -----------------------
     keys_host = None
