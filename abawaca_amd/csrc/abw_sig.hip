@@ -28,7 +28,10 @@ namespace {
 // "hw code" of a base: (toupper(c) >> 1) & 3  ->  A=0 C=1 T=2 G=3
 __host__ __device__ inline int hw_of_acgt(int d) { return d == 2 ? 3 : d == 3 ? 2 : d; }   // A,C,G,T=0..3 -> hw
 
-constexpr int LDS_T4 = 0, LDS_T3 = 256, LDS_T2 = 320, LDS_T1 = 336, LDS_WORDS = 352;
+// Wave-private counter table.  A window whose valid run has length r (1..4, r = 4: a full 4-mer) and
+// whose last r bases have code w & m (m = 4^r - 1) counts at word (w & m) + 510 - 2m:
+//   T4 [0,256)   T3 [384,448)   T2 [480,496)   T1 [504,508)
+constexpr int LDS_T4 = 0, LDS_T3 = 384, LDS_T2 = 480, LDS_T1 = 504, LDS_WORDS = 512, LDS_BIAS = 510;
 
 struct SigTables {
     uint16_t dim_a[ABW_SIG_NDIMS];      // LDS word index of the first member mer of each dimension
@@ -87,18 +90,54 @@ const SigTables& host_tables()
 // ---------------------------------------------------------------------------------------------
 // counting kernel
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void classify(uint32_t c, uint32_t& code, bool& valid)
+// Four bases at once (one dword of ASCII, lowest address = oldest base = byte 0).
+//   pack:  the four 2-bit codes, oldest base in the highest bits (A0 C1 T2 G3 = (toupper(c) >> 1) & 3)
+//   valid: four bits, oldest base in the highest bit; a base is valid iff toupper(c) is one of ACGT
+__device__ __forceinline__ void classify4(uint32_t q, uint32_t& pack, uint32_t& valid)
 {
-    uint32_t u = c & 0xDFu;                          // toupper for letters; only 'a'..'z' can map onto 'A'..'Z'
-    code = (u >> 1) & 3u;                            // A0 C1 T2 G3
-    valid = ((0x47544341u >> (code * 8)) & 0xFFu) == u;
+    const uint32_t u = q & 0xDFDFDFDFu;                      // toupper for letters; only 'a'..'z' can map onto 'A'..'Z'
+    const uint32_t c = (u >> 1) & 0x03030303u;
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, c);   // byte i = "ACTG"[code i]
+    const uint32_t diff = u ^ expect;
+    const uint32_t z = ~(((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff | 0x7F7F7F7Fu);   // 0x80 where the byte matched
+    const uint32_t y = (c << 6) | (c >> 4);
+    pack = (y & 0xF0u) | ((y >> 20) & 0x0Fu);
+    valid = (((z >> 7) * 0x08040201u) >> 24) & 0xFu;
 }
 
+// sum over the 64 lanes without touching LDS: butterflies inside each row of 16 (DPP), rows by readlane
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);   // row_mirror
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// double(n) / double(t) for integers, bit-identical to the IEEE division the reference performs
+// (ref :171): this is the compiler's own fp64 division sequence (reciprocal + two Newton steps,
+// quotient, one correction) with the reciprocal part hoisted -- a lane's dimensions share few
+// totals -- and without the range scaling that integer operands below 2^32 never trigger.
+struct Recip { double d, r; };
+__device__ __forceinline__ Recip recip_of(uint32_t t)
+{
+    Recip R;
+    R.d = (double)(int)t;
+    double r = __builtin_amdgcn_rcp(R.d);
+    double e = __builtin_fma(-R.d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-R.d, r, 1.0);
+    R.r = __builtin_fma(r, e, r);
+    return R;
+}
+__device__ __forceinline__ double quot(uint32_t n, const Recip& R)
+{
+    const double nn = (double)n;
+    const double q = nn * R.r;
+    const double e = __builtin_fma(-R.d, q, nn);
+    return __builtin_fma(e, R.r, q);
 }
 
 __global__ __launch_bounds__(256) void sig_count_kernel(
@@ -107,14 +146,25 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
     const uint64_t* __restrict__ seg_end, uint64_t n_seg,
     double* __restrict__ dims, int32_t* __restrict__ milli, uint32_t* __restrict__ counts)
 {
-    __shared__ uint32_t lds[4][LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][LDS_WORDS];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
     uint32_t* tab = lds[wid];
+    uint32_t* tabb = tab + LDS_BIAS;
     const uint64_t waves_total = (uint64_t)gridDim.x * 4;
+    // this lane's (up to) three dimensions: table words of the two strands and which total divides them
+    uint32_t dim_ia[3], dim_ib[3], dim_k[3];
+#pragma unroll
+    for (int rep = 0; rep < 3; rep++) {
+        const int dim = min(lane + 64 * rep, ABW_SIG_NDIMS - 1);
+        dim_ia[rep] = c_tabs.dim_a[dim];
+        dim_ib[rep] = c_tabs.dim_b[dim];
+        dim_k[rep] = dim_ia[rep] >= LDS_T1 ? 0 : dim_ia[rep] >= LDS_T2 ? 1 : dim_ia[rep] >= LDS_T3 ? 2 : 3;
+    }
 
     for (uint64_t s = (uint64_t)blockIdx.x * 4 + wid; s < n_seg; s += waves_total) {
-        for (int i = lane; i < LDS_WORDS; i += 64) tab[i] = 0;
+        *reinterpret_cast<uint4*>(tab + 4 * lane) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(tab + 256 + 4 * lane) = make_uint4(0, 0, 0, 0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
@@ -134,28 +184,35 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
                     q[0] = q[1] = q[2] = q[3] = 0;
                     for (uint64_t i = 0; A + i < total_len; i++) q[i >> 2] |= (uint32_t)ascii[A + i] << (8 * (i & 3));
                 }
-                uint32_t halo = (A >= 4) ? *reinterpret_cast<const uint32_t*>(ascii + A - 4) : 0;
-                // positions of this piece that lie inside the segment: [lo, hi)
-                const int lo = (seg_b > A) ? (int)(seg_b - A) : 0;
-                const int hi = (seg_e - A < 16) ? (int)(seg_e - A) : 16;
-                uint32_t w = 0, m = 0;
-                // 3-base halo (positions A-3 .. A-1), in the segment iff >= seg_b
-#pragma unroll
-                for (int h = 1; h <= 3; h++) {
-                    uint32_t code; bool valid;
-                    classify((halo >> (8 * h)) & 0xFFu, code, valid);
-                    valid = valid && (A + h >= seg_b + 4) && (A >= 4);          // A - 4 + h >= seg_b
-                    w = ((w << 2) | code) & 0xFFu;
-                    m = valid ? (((m << 2) | 3u) & 0xFFu) : 0u;
-                }
+                const uint32_t halo = (A >= 4) ? *reinterpret_cast<const uint32_t*>(ascii + A - 4) : 0;
+                // Window t = 0..18 is the base at A - 3 + t (3-base halo, then the 16 bases of this
+                // piece).  Code stream S (2 bits per base) and validity stream V (1 bit per base),
+                // both with the newest base in the lowest bits: base t sits at bit 18 - t of V.
+                uint32_t ph, vh, p0, v0, p1, v1, p2, v2, p3, v3;
+                classify4(halo, ph, vh);
+                classify4(q[0], p0, v0);
+                classify4(q[1], p1, v1);
+                classify4(q[2], p2, v2);
+                classify4(q[3], p3, v3);
+                const uint32_t S_lo = (p0 << 24) | (p1 << 16) | (p2 << 8) | p3;
+                const uint32_t S_hi = ph & 0x3Fu;
+                uint32_t V = ((vh & 7u) << 16) | (v0 << 12) | (v1 << 8) | (v2 << 4) | v3;
+                // only bases inside [seg_b, seg_e) count, as window members too (ref :105-173 works on
+                // the segment's own substring): t in [tl, th)
+                const int tl = (int)min((int64_t)19, max((int64_t)0, (int64_t)(seg_b - A) + 3));
+                const int th = (int)min((int64_t)19, max((int64_t)0, (int64_t)(seg_e - A) + 3));
+                V &= ((1u << (19 - tl)) - 1u) & ~((1u << (19 - th)) - 1u);
+                const uint32_t Vn = ~V;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
-                    uint32_t code; bool valid;
-                    classify((q[i >> 2] >> (8 * (i & 3))) & 0xFFu, code, valid);
-                    valid = valid && (i >= lo) && (i < hi);
-                    w = ((w << 2) | code) & 0xFFu;
-                    m = valid ? (((m << 2) | 3u) & 0xFFu) : 0u;
-                    if (m) atomicAdd(&tab[(w & m) | (0x150u & ~(m << 2))], 1u);
+                    const int sh = 15 - i;                                       // bit of base i in V
+                    const uint32_t cur = __builtin_amdgcn_ubfe(V, sh, 1);        // 1 iff this base is valid
+                    const uint32_t sel = __builtin_amdgcn_ubfe(Vn, sh + 1, 3);   // which of the 3 bases before it are NOT
+                    // run length r = 1 + (valid bases directly before, up to 3) -> m = 4^r - 1, by byte table
+                    const uint32_t m = __builtin_amdgcn_perm(0x030F033Fu, 0x030F03FFu, sel) & 0xFFu;
+                    const uint32_t w = (sh <= 12) ? __builtin_amdgcn_ubfe(S_lo, 2 * sh, 8)
+                                                  : (__builtin_amdgcn_alignbit(S_hi, S_lo, 2 * sh) & 0xFFu);
+                    atomicAdd(&tabb[(int)(w & m) - 2 * (int)m], cur);            // adds 0 for an invalid base
                 }
             }
         }
@@ -163,23 +220,23 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
         __builtin_amdgcn_wave_barrier();
 
         // suffix marginals, in place: T3 += sum_x T4[x|s], T2 += sum_x T3[x|s], T1 += sum_x T2[x|s]
-        {
-            uint32_t c3 = tab[LDS_T3 + lane] + tab[LDS_T4 + lane] + tab[LDS_T4 + 64 + lane] +
-                          tab[LDS_T4 + 128 + lane] + tab[LDS_T4 + 192 + lane];
-            tab[LDS_T3 + lane] = c3;
-        }
+        const uint32_t t4 = tab[LDS_T4 + lane] + tab[LDS_T4 + 64 + lane] + tab[LDS_T4 + 128 + lane] + tab[LDS_T4 + 192 + lane];
+        const uint32_t c3 = tab[LDS_T3 + lane] + t4;
+        tab[LDS_T3 + lane] = c3;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        uint32_t c2 = 0;
         if (lane < 16) {
-            uint32_t c2 = tab[LDS_T2 + lane] + tab[LDS_T3 + lane] + tab[LDS_T3 + 16 + lane] +
-                          tab[LDS_T3 + 32 + lane] + tab[LDS_T3 + 48 + lane];
+            c2 = tab[LDS_T2 + lane] + tab[LDS_T3 + lane] + tab[LDS_T3 + 16 + lane] +
+                 tab[LDS_T3 + 32 + lane] + tab[LDS_T3 + 48 + lane];
             tab[LDS_T2 + lane] = c2;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        uint32_t c1 = 0;
         if (lane < 4) {
-            uint32_t c1 = tab[LDS_T1 + lane] + tab[LDS_T2 + lane] + tab[LDS_T2 + 4 + lane] +
-                          tab[LDS_T2 + 8 + lane] + tab[LDS_T2 + 12 + lane];
+            c1 = tab[LDS_T1 + lane] + tab[LDS_T2 + lane] + tab[LDS_T2 + 4 + lane] +
+                 tab[LDS_T2 + 8 + lane] + tab[LDS_T2 + 12 + lane];
             tab[LDS_T1 + lane] = c1;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -187,22 +244,22 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
 
         // per-k totals (number of valid windows; ref: `total`, src/abawaca-build.cpp:120,136,153)
         uint32_t tot[4];
-        tot[3] = wave_sum(tab[LDS_T4 + lane] + tab[LDS_T4 + 64 + lane] + tab[LDS_T4 + 128 + lane] + tab[LDS_T4 + 192 + lane]);
-        tot[2] = wave_sum(tab[LDS_T3 + lane]);
-        tot[1] = wave_sum(lane < 16 ? tab[LDS_T2 + lane] : 0u);
-        tot[0] = wave_sum(lane < 4 ? tab[LDS_T1 + lane] : 0u);
+        tot[3] = wave_sum(t4);
+        tot[2] = wave_sum(c3);
+        tot[1] = wave_sum(c2);
+        tot[0] = wave_sum(c1);
 
 #pragma unroll
         for (int rep = 0; rep < 3; rep++) {
             const int dim = lane + 64 * rep;
             if (dim < ABW_SIG_NDIMS) {
-                const uint32_t ia = c_tabs.dim_a[dim], ib = c_tabs.dim_b[dim];
-                const uint32_t t = ia >= LDS_T1 ? tot[0] : ia >= LDS_T2 ? tot[1] : ia >= LDS_T3 ? tot[2] : tot[3];
+                const uint32_t t = dim_k[rep] == 0 ? tot[0] : dim_k[rep] == 1 ? tot[1] : dim_k[rep] == 2 ? tot[2] : tot[3];
                 double x = 0.0;
                 if (t != 0) {
                     // ref :171 — dimensions[idx] += double(count)/total, once per strand
-                    x = (double)tab[ia] / (double)(int)t;
-                    if (ib != 0xFFFFu) x += (double)tab[ib] / (double)(int)t;
+                    const Recip R = recip_of(t);
+                    x = quot(tab[dim_ia[rep]], R);
+                    if (dim_ib[rep] != 0xFFFFu) x += quot(tab[dim_ib[rep]], R);
                 }
                 if (dims) dims[s * ABW_SIG_NDIMS + dim] = x;
                 if (milli && dim > 0) milli[s * ABW_SIG_NCOLS + dim - 1] = (int)(1000.0 * x);   // ref :603
