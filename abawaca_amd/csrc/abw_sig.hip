@@ -29,9 +29,9 @@ namespace {
 __host__ __device__ inline int hw_of_acgt(int d) { return d == 2 ? 3 : d == 3 ? 2 : d; }   // A,C,G,T=0..3 -> hw
 
 // Wave-private counter table.  A window whose valid run has length r (1..4, r = 4: a full 4-mer) and
-// whose last r bases have code w & m (m = 4^r - 1) counts at word (w & m) + 510 - 2m:
-//   T4 [0,256)   T3 [384,448)   T2 [480,496)   T1 [504,508)
-constexpr int LDS_T4 = 0, LDS_T3 = 384, LDS_T2 = 480, LDS_T1 = 504, LDS_WORDS = 512, LDS_BIAS = 510;
+// whose last r bases have code w & m (m = 4^r - 1) counts at word (w & m) + 2*(255 - m):
+//   T4 [0,256)   T3 [384,448)   T2 [480,496)   T1 [504,508)   word 508: always zero
+constexpr int LDS_T4 = 0, LDS_T3 = 384, LDS_T2 = 480, LDS_T1 = 504, LDS_ZERO = 508, LDS_WORDS = 512;
 
 struct SigTables {
     uint16_t dim_a[ABW_SIG_NDIMS];      // LDS word index of the first member mer of each dimension
@@ -91,19 +91,21 @@ const SigTables& host_tables()
 // counting kernel
 // ---------------------------------------------------------------------------------------------
 // Four bases at once (one dword of ASCII, lowest address = oldest base = byte 0).
-//   pack:  the four 2-bit codes, oldest base in the highest bits (A0 C1 T2 G3 = (toupper(c) >> 1) & 3)
-//   valid: four bits, oldest base in the highest bit; a base is valid iff toupper(c) is one of ACGT
-__device__ __forceinline__ void classify4(uint32_t q, uint32_t& pack, uint32_t& valid)
+//   codes: byte i = 2-bit code of base i (A0 C1 T2 G3 = (toupper(c) >> 1) & 3)
+//   match: byte i = 0x80 iff toupper(c) is one of ACGT (a valid base), else 0
+// Both are turned into bit streams by v_dot4_u32_u8 with power-of-two weights (a 4-way gather).
+__device__ __forceinline__ void classify4(uint32_t q, uint32_t& codes, uint32_t& match)
 {
     const uint32_t u = q & 0xDFDFDFDFu;                      // toupper for letters; only 'a'..'z' can map onto 'A'..'Z'
-    const uint32_t c = (u >> 1) & 0x03030303u;
-    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, c);   // byte i = "ACTG"[code i]
+    codes = (u >> 1) & 0x03030303u;
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, codes);   // byte i = "ACTG"[code i]
     const uint32_t diff = u ^ expect;
-    const uint32_t z = ~(((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff | 0x7F7F7F7Fu);   // 0x80 where the byte matched
-    const uint32_t y = (c << 6) | (c >> 4);
-    pack = (y & 0xF0u) | ((y >> 20) & 0x0Fu);
-    valid = (((z >> 7) * 0x08040201u) >> 24) & 0xFu;
+    match = ~(((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff | 0x7F7F7F7Fu);   // exact zero-byte detector
 }
+// oldest base (byte 0) -> highest position
+constexpr uint32_t DOT_PACK = 0x01041040u;      // codes  -> c0<<6 | c1<<4 | c2<<2 | c3
+constexpr uint32_t DOT_BITS_LO = 0x01020408u;   // match  -> 128 * (b0<<3 | b1<<2 | b2<<1 | b3)
+constexpr uint32_t DOT_BITS_HI = 0x10204080u;   // the same, 4 bits higher
 
 // sum over the 64 lanes without touching LDS: butterflies inside each row of 16 (DPP), rows by readlane
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -148,9 +150,8 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[4][LDS_WORDS];
     const int lane = threadIdx.x & 63;
-    const int wid = threadIdx.x >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: segment bookkeeping stays scalar
     uint32_t* tab = lds[wid];
-    uint32_t* tabb = tab + LDS_BIAS;
     const uint64_t waves_total = (uint64_t)gridDim.x * 4;
     // this lane's (up to) three dimensions: table words of the two strands and which total divides them
     uint32_t dim_ia[3], dim_ib[3], dim_k[3];
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
     for (int rep = 0; rep < 3; rep++) {
         const int dim = min(lane + 64 * rep, ABW_SIG_NDIMS - 1);
         dim_ia[rep] = c_tabs.dim_a[dim];
-        dim_ib[rep] = c_tabs.dim_b[dim];
+        dim_ib[rep] = c_tabs.dim_b[dim] == 0xFFFFu ? (uint32_t)LDS_ZERO : (uint32_t)c_tabs.dim_b[dim];
         dim_k[rep] = dim_ia[rep] >= LDS_T1 ? 0 : dim_ia[rep] >= LDS_T2 ? 1 : dim_ia[rep] >= LDS_T3 ? 2 : 3;
     }
 
@@ -175,6 +176,9 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
 
         for (uint64_t base = a0; base < seg_e; base += 1024) {
             const uint64_t A = base + (uint64_t)lane * 16;
+            // segment bounds relative to window 0 of lane 0 (base - 3), clamped so that 32-bit lane math is exact
+            const int rel_b = (int)max((int64_t)-(1 << 20), min((int64_t)(1 << 20), (int64_t)(seg_b - base) + 3));
+            const int rel_e = (int)max((int64_t)-(1 << 20), min((int64_t)(1 << 20), (int64_t)(seg_e - base) + 3));
             if (A < seg_e) {
                 uint32_t q[4];
                 if (A + 16 <= total_len) {
@@ -188,19 +192,23 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
                 // Window t = 0..18 is the base at A - 3 + t (3-base halo, then the 16 bases of this
                 // piece).  Code stream S (2 bits per base) and validity stream V (1 bit per base),
                 // both with the newest base in the lowest bits: base t sits at bit 18 - t of V.
-                uint32_t ph, vh, p0, v0, p1, v1, p2, v2, p3, v3;
-                classify4(halo, ph, vh);
-                classify4(q[0], p0, v0);
-                classify4(q[1], p1, v1);
-                classify4(q[2], p2, v2);
-                classify4(q[3], p3, v3);
-                const uint32_t S_lo = (p0 << 24) | (p1 << 16) | (p2 << 8) | p3;
-                const uint32_t S_hi = ph & 0x3Fu;
-                uint32_t V = ((vh & 7u) << 16) | (v0 << 12) | (v1 << 8) | (v2 << 4) | v3;
+                uint32_t ch, zh, c0, z0, c1, z1, c2, z2, c3, z3;
+                classify4(halo, ch, zh);
+                classify4(q[0], c0, z0);
+                classify4(q[1], c1, z1);
+                classify4(q[2], c2, z2);
+                classify4(q[3], c3, z3);
+                const uint32_t S_lo = (__builtin_amdgcn_udot4(c0, DOT_PACK, 0u, false) << 24) | (__builtin_amdgcn_udot4(c1, DOT_PACK, 0u, false) << 16) |
+                                      (__builtin_amdgcn_udot4(c2, DOT_PACK, 0u, false) << 8) | __builtin_amdgcn_udot4(c3, DOT_PACK, 0u, false);
+                const uint32_t S_hi = __builtin_amdgcn_udot4(ch, DOT_PACK & 0xFFFFFF00u, 0u, false);     // the halo's byte 0 is not a halo base
+                const uint32_t v_lo = __builtin_amdgcn_udot4(z3, DOT_BITS_LO, __builtin_amdgcn_udot4(z2, DOT_BITS_HI, 0u, false), false);
+                const uint32_t v_mi = __builtin_amdgcn_udot4(z1, DOT_BITS_LO, __builtin_amdgcn_udot4(z0, DOT_BITS_HI, 0u, false), false);
+                const uint32_t v_hi = __builtin_amdgcn_udot4(zh, DOT_BITS_LO & 0xFFFFFF00u, 0u, false);
+                uint32_t V = ((v_hi << 16) + (v_mi << 8) + v_lo) >> 7;
                 // only bases inside [seg_b, seg_e) count, as window members too (ref :105-173 works on
                 // the segment's own substring): t in [tl, th)
-                const int tl = (int)min((int64_t)19, max((int64_t)0, (int64_t)(seg_b - A) + 3));
-                const int th = (int)min((int64_t)19, max((int64_t)0, (int64_t)(seg_e - A) + 3));
+                const int tl = min(max(rel_b - 16 * lane, 0), 19);
+                const int th = min(max(rel_e - 16 * lane, 0), 19);
                 V &= ((1u << (19 - tl)) - 1u) & ~((1u << (19 - th)) - 1u);
                 const uint32_t Vn = ~V;
 #pragma unroll
@@ -208,59 +216,68 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
                     const int sh = 15 - i;                                       // bit of base i in V
                     const uint32_t cur = __builtin_amdgcn_ubfe(V, sh, 1);        // 1 iff this base is valid
                     const uint32_t sel = __builtin_amdgcn_ubfe(Vn, sh + 1, 3);   // which of the 3 bases before it are NOT
-                    // run length r = 1 + (valid bases directly before, up to 3) -> m = 4^r - 1, by byte table
-                    const uint32_t m = __builtin_amdgcn_perm(0x030F033Fu, 0x030F03FFu, sel) & 0xFFu;
+                    // run length r = 1 + (valid bases directly before, up to 3); byte table -> 255 - (4^r - 1)
+                    const uint32_t mi = __builtin_amdgcn_perm(0xFCF0FCC0u, 0xFCF0FC00u, sel);
                     const uint32_t w = (sh <= 12) ? __builtin_amdgcn_ubfe(S_lo, 2 * sh, 8)
                                                   : (__builtin_amdgcn_alignbit(S_hi, S_lo, 2 * sh) & 0xFFu);
-                    atomicAdd(&tabb[(int)(w & m) - 2 * (int)m], cur);            // adds 0 for an invalid base
+                    // word (w & m) + 2*(255 - m) = (w | mi) + mi with mi = 255 - m; the byte offset in one
+                    // v_add_lshl (left to itself the compiler distributes the shift: one more op per base)
+                    uint32_t boff;
+                    asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(boff) : "v"(w | mi), "v"(mi));
+                    atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tab) + boff), cur);   // adds 0 for an invalid base
                 }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        // suffix marginals, in place: T3 += sum_x T4[x|s], T2 += sum_x T3[x|s], T1 += sum_x T2[x|s]
+        // suffix marginals, in place: T3 += sum_x T4[x|s], T2 += sum_x T3[x|s], T1 += sum_x T2[x|s].
+        // Branch-free: every lane computes, lanes outside a table write the always-zero word back.
+        const uint32_t h3 = tab[LDS_T3 + lane];
         const uint32_t t4 = tab[LDS_T4 + lane] + tab[LDS_T4 + 64 + lane] + tab[LDS_T4 + 128 + lane] + tab[LDS_T4 + 192 + lane];
-        const uint32_t c3 = tab[LDS_T3 + lane] + t4;
+        const uint32_t c3 = h3 + t4;
         tab[LDS_T3 + lane] = c3;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        uint32_t c2 = 0;
-        if (lane < 16) {
-            c2 = tab[LDS_T2 + lane] + tab[LDS_T3 + lane] + tab[LDS_T3 + 16 + lane] +
-                 tab[LDS_T3 + 32 + lane] + tab[LDS_T3 + 48 + lane];
-            tab[LDS_T2 + lane] = c2;
-        }
+        const int l16 = lane & 15, l4 = lane & 3;
+        const uint32_t h2 = (lane < 16) ? tab[LDS_T2 + l16] : 0u;
+        const uint32_t c2 = (lane < 16) ? h2 + tab[LDS_T3 + l16] + tab[LDS_T3 + 16 + l16] + tab[LDS_T3 + 32 + l16] + tab[LDS_T3 + 48 + l16] : 0u;
+        tab[(lane < 16) ? LDS_T2 + lane : LDS_ZERO] = c2;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        uint32_t c1 = 0;
-        if (lane < 4) {
-            c1 = tab[LDS_T1 + lane] + tab[LDS_T2 + lane] + tab[LDS_T2 + 4 + lane] +
-                 tab[LDS_T2 + 8 + lane] + tab[LDS_T2 + 12 + lane];
-            tab[LDS_T1 + lane] = c1;
-        }
+        const uint32_t h1 = (lane < 4) ? tab[LDS_T1 + l4] : 0u;
+        const uint32_t c1 = (lane < 4) ? h1 + tab[LDS_T2 + l4] + tab[LDS_T2 + 4 + l4] + tab[LDS_T2 + 8 + l4] + tab[LDS_T2 + 12 + l4] : 0u;
+        tab[(lane < 4) ? LDS_T1 + lane : LDS_ZERO] = c1;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        // per-k totals (number of valid windows; ref: `total`, src/abawaca-build.cpp:120,136,153)
+        // per-k totals (number of valid windows; ref: `total`, src/abawaca-build.cpp:120,136,153):
+        // tot4 = sum T4, tot3 = tot4 + (3-base heads), ...  Two packed reductions while every count
+        // fits 16 bits, i.e. for any segment shorter than 65536 bases.
         uint32_t tot[4];
-        tot[3] = wave_sum(t4);
-        tot[2] = wave_sum(c3);
-        tot[1] = wave_sum(c2);
-        tot[0] = wave_sum(c1);
+        if (seg_e - seg_b < 65536) {
+            const uint32_t a = wave_sum(t4 | (h3 << 16)), b = wave_sum(h2 | (h1 << 16));
+            tot[3] = a & 0xFFFFu;
+            tot[2] = tot[3] + (a >> 16);
+            tot[1] = tot[2] + (b & 0xFFFFu);
+            tot[0] = tot[1] + (b >> 16);
+        } else {
+            tot[3] = wave_sum(t4);
+            tot[2] = wave_sum(c3);
+            tot[1] = wave_sum(c2);
+            tot[0] = wave_sum(c1);
+        }
 
+        // ref :171 — dimensions[idx] += double(count)/total, once per strand.  A palindrome's second
+        // strand reads the always-zero word; an empty total divides zeros by one: both give +0.0.
+        const Recip R4 = recip_of(max(tot[3], 1u));
 #pragma unroll
         for (int rep = 0; rep < 3; rep++) {
             const int dim = lane + 64 * rep;
-            if (dim < ABW_SIG_NDIMS) {
-                const uint32_t t = dim_k[rep] == 0 ? tot[0] : dim_k[rep] == 1 ? tot[1] : dim_k[rep] == 2 ? tot[2] : tot[3];
-                double x = 0.0;
-                if (t != 0) {
-                    // ref :171 — dimensions[idx] += double(count)/total, once per strand
-                    const Recip R = recip_of(t);
-                    x = quot(tab[dim_ia[rep]], R);
-                    if (dim_ib[rep] != 0xFFFFu) x += quot(tab[dim_ib[rep]], R);
-                }
+            Recip R = R4;
+            if (rep == 0) R = recip_of(max(dim_k[0] == 0 ? tot[0] : dim_k[0] == 1 ? tot[1] : dim_k[0] == 2 ? tot[2] : tot[3], 1u));
+            const double x = quot(tab[dim_ia[rep]], R) + quot(tab[dim_ib[rep]], R);
+            if (rep < 2 || dim < ABW_SIG_NDIMS) {
                 if (dims) dims[s * ABW_SIG_NDIMS + dim] = x;
                 if (milli && dim > 0) milli[s * ABW_SIG_NCOLS + dim - 1] = (int)(1000.0 * x);   // ref :603
             }
