@@ -435,9 +435,38 @@ __device__ __forceinline__ void cursor_load(ScafCursor& c, uint64_t s, const uin
     c.s = s; c.sb = scaf_off[s]; c.se = scaf_off[s + 1]; c.si = info[s]; c.g0 = seg_off[s];
 }
 
-__device__ __forceinline__ uint32_t byte_at(uint64_t lo, uint64_t hi, int i)
+// inclusive prefix sum over the 64 lanes, DPP only (row shifts, then the two row broadcasts of gfx9)
+__device__ __forceinline__ uint32_t wave_scan(uint32_t x)
 {
-    return (uint32_t)(((i < 8) ? lo : hi) >> (8 * (i & 7))) & 0xFFu;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);    // row_shr:1, zero fill
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);    // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);    // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);    // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+// bit i (i = 0..3) set iff byte i of q is not 'N'
+__device__ __forceinline__ uint32_t nonN4(uint32_t q)
+{
+    const uint32_t t = q ^ 0x4E4E4E4Eu;
+    const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);      // 0x80 where the byte is 'N'
+    return (__builtin_amdgcn_udot4(z, 0x08040201u, 0u, false) >> 7) ^ 0xFu;
+}
+
+// index of the j-th (0-based) set bit of a 16-bit mask that has more than j bits set
+__device__ __forceinline__ int nth_set_bit16(uint32_t m, uint32_t j)
+{
+    int pos = 0;
+    uint32_t c = __popc(m & 0xFFu);
+    if (j >= c) { j -= c; pos = 8; m >>= 8; }
+    c = __popc(m & 0xFu);
+    if (j >= c) { j -= c; pos += 4; m >>= 4; }
+    c = __popc(m & 0x3u);
+    if (j >= c) { j -= c; pos += 2; m >>= 2; }
+    if (j >= (m & 1u)) pos += 1;
+    return pos;
 }
 
 __global__ __launch_bounds__(256) void seg_emit_kernel(const uint8_t* __restrict__ ascii, uint64_t total_len,
@@ -448,7 +477,8 @@ __global__ __launch_bounds__(256) void seg_emit_kernel(const uint8_t* __restrict
                                                       uint64_t* __restrict__ seg_start, uint64_t* __restrict__ seg_end)
 {
     const int lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // wave-uniform on purpose (readfirstlane): the block walk and the scaffold cursor stay in scalar registers
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint64_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     // every wave walks a CONTIGUOUS run of blocks, so the scaffold cursor only moves forward
     const uint64_t per = (nblk + nwaves - 1) / nwaves;
@@ -469,58 +499,63 @@ __global__ __launch_bounds__(256) void seg_emit_kernel(const uint8_t* __restrict
         const uint64_t b_end = (b_begin + SEGBLK < total_len) ? b_begin + SEGBLK : total_len;
         if (b_begin >= b_end) break;
         const uint64_t A = b_begin + (uint64_t)lane * 16;
-        uint64_t lo8 = 0, hi8 = 0;
-        int len = 0;
-        if (A + 16 <= total_len) {
-            const uint4 v = *reinterpret_cast<const uint4*>(ascii + A);
-            lo8 = (uint64_t)v.x | ((uint64_t)v.y << 32); hi8 = (uint64_t)v.z | ((uint64_t)v.w << 32); len = 16;
-        } else {
-            for (uint64_t i = A; i < total_len; i++) {
-                const uint64_t c8 = (uint64_t)ascii[i] << (8 * ((i - A) & 7));
-                if (i - A < 8) lo8 |= c8; else hi8 |= c8;
-                len++;
-            }
-        }
-        // bit i of nmask: byte i of this lane's piece is a non-N base
+        // bit i of nmask: byte i of this lane's piece exists and is a non-N base
         uint32_t nmask = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) nmask |= (uint32_t)(i < len && byte_at(lo8, hi8, i) != 'N') << i;
+        int len = 0;
+        if (b_begin + SEGBLK <= total_len) {
+            const uint4 v = *reinterpret_cast<const uint4*>(ascii + A);
+            nmask = nonN4(v.x) | (nonN4(v.y) << 4) | (nonN4(v.z) << 8) | (nonN4(v.w) << 12);
+            len = 16;
+        } else {
+            for (uint64_t i = A; i < total_len && i < A + 16; i++) { nmask |= (uint32_t)(ascii[i] != 'N') << (i - A); len++; }
+        }
         const uint32_t c = __popc(nmask);
-        uint32_t x = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-        const uint64_t lane_rank0 = blk_prefix[b] + x - c;          // non-N bytes of the blob before this lane's piece
+        const uint32_t x = wave_scan(c);
+        const uint64_t blk_rank = blk_prefix[b];                    // non-N bytes of the blob before this block
+        const uint32_t lane_before = x - c;                         // ... and inside the block before this lane's piece
         while (cur.se <= b_begin && cur.s + 1 < n_scaf) cursor_load(cur, cur.s + 1, scaf_off, info, seg_off);
         for (;;) {
             if (cur.sb >= b_end) break;
             if (cur.se > cur.sb && cur.si.nseg != 0) {
-                const uint64_t sb = cur.sb, se = cur.se, g0 = cur.g0;
+                const uint64_t sb = cur.sb, se = cur.se, g0 = cur.g0, nbps = cur.si.nbps;
                 if (sb >= b_begin && lane == 0) seg_start[g0] = 1;   // ref :209 sit = seq.begin()
                 const uint64_t p0 = (A > sb) ? A : sb;               // this lane's bytes of the scaffold: [p0, p1)
                 const uint64_t p1 = (A + (uint64_t)len < se) ? A + (uint64_t)len : se;
-                if (p0 < p1) {
-                    const int i0 = (int)(p0 - A), i1 = (int)(p1 - A);
-                    if (cur.si.nbps == 0) {                          // all-N scaffold: every base is a segment
-                        for (int i = i0; i < i1; i++) {
-                            const uint64_t j = A + i - sb;
-                            seg_scaf[g0 + j] = (uint32_t)cur.s; seg_start[g0 + j] = j + 1; seg_end[g0 + j] = j + 1;
-                        }
-                    } else {
-                        // 1-based non-N rank inside the scaffold of the first non-N byte at or after p0
-                        const uint64_t before = lane_rank0 + __popc(nmask & ((1u << i0) - 1u));
-                        const uint64_t k = before - cur.si.rank0 + 1;
-                        uint64_t q = k / cur.si.nbps, r = k % cur.si.nbps;
-                        uint32_t todo = nmask & ~((1u << i0) - 1u) & ((1u << i1) - 1u);
-                        while (todo) {
-                            const int i = __ffs(todo) - 1;
-                            todo &= todo - 1;
-                            if (r == 0 && q >= 1 && q <= cur.si.nseg) {   // this base closes segment q-1
-                                const uint64_t g = g0 + q - 1, rel = A + i - sb;
+                if (nbps == 0) {                                     // all-N scaffold: every base is a segment
+                    for (uint64_t p = p0; p < p1; p++) {
+                        const uint64_t j = p - sb;
+                        seg_scaf[g0 + j] = (uint32_t)cur.s; seg_start[g0 + j] = j + 1; seg_end[g0 + j] = j + 1;
+                    }
+                } else {
+                    // (uniform) 1-based rank inside the scaffold of the first of its non-N bytes that lies in
+                    // this block, as quotient and remainder by nbps: one division per (block, scaffold)
+                    const uint64_t kb = ((blk_rank > cur.si.rank0) ? blk_rank - cur.si.rank0 : 0) + 1;
+                    uint64_t qb, rb;
+                    if (((kb | nbps) >> 32) == 0) { qb = (uint32_t)kb / (uint32_t)nbps; rb = (uint32_t)kb % (uint32_t)nbps; }
+                    else { qb = kb / nbps; rb = kb % nbps; }
+                    if (p0 < p1) {
+                        const int i0 = (int)(p0 - A), i1 = (int)(p1 - A);
+                        const uint32_t todo = nmask & ~((1u << i0) - 1u) & ((1u << i1) - 1u);
+                        const uint32_t cnt = __popc(todo);
+                        // rank of this lane's first such byte = kb + delta; bytes of the block in front of the
+                        // scaffold (when it starts inside the block) are not counted in kb
+                        const uint64_t first_rank = blk_rank + lane_before + __popc(nmask & ((1u << i0) - 1u)) - cur.si.rank0 + 1;
+                        const uint64_t delta = first_rank - kb;                    // < 1024
+                        uint64_t r = rb + delta, q = qb;
+                        if (nbps >= 2048) { if (r >= nbps) { r -= nbps; q++; } }
+                        else { q += r / nbps; r = r % nbps; }
+                        // first cut at or after this byte: the byte whose rank is a multiple of nbps
+                        uint64_t j = (r == 0) ? 0 : nbps - r;                       // 0-based among this lane's bytes
+                        uint64_t qc = (r == 0) ? q : q + 1;
+                        while (j < cnt) {
+                            if (qc >= 1 && qc <= cur.si.nseg) {                     // this base closes segment qc-1
+                                const int i = nth_set_bit16(todo, (uint32_t)j);
+                                const uint64_t g = g0 + qc - 1, rel = A + i - sb;
                                 seg_scaf[g] = (uint32_t)cur.s;
                                 seg_end[g] = rel + 1;
-                                if (q < cur.si.nseg) seg_start[g + 1] = rel + 2;   // ref :221-222 sit = it + 1
+                                if (qc < cur.si.nseg) seg_start[g + 1] = rel + 2;   // ref :221-222 sit = it + 1
                             }
-                            if (++r == cur.si.nbps) { r = 0; q++; }
+                            j += nbps; qc++;
                         }
                     }
                 }
