@@ -56,8 +56,20 @@ struct abw_prof {
     std::vector<hipEvent_t> pool;
 };
 
+// k-means run in progress (abw_km_shard_* phase API; abw_km_run_dev drives the same phases itself)
+struct abw_km_state {
+    bool active = false;
+    const float* x = nullptr;
+    int64_t N = 0, first = 0, N_total = 0, nchunks = 0, ngroups = 0, elems = 0;
+    int d = 0, R = 0, Rp = 0, W = 0, DT = 0, chunk = 0;
+    uint32_t seed = 0;
+    double *col_term = nullptr, *moments = nullptr, *sums = nullptr, *gsum = nullptr;   // moments = tot[W] then x2[d]
+    float *cent = nullptr, *dT = nullptr, *slabs = nullptr;
+};
+
 struct abw_ctx {
     int         device = 0;
+    abw_km_state km;
     abw_prof    prof;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;

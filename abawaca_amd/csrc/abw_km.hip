@@ -86,27 +86,35 @@ __device__ inline void km_discriminant(const float* c0, const float* c1, int d, 
     }
 }
 
-__global__ void km_init_kernel(const float* __restrict__ x, int64_t N, int d, int W, int R, int Rp, uint32_t base_seed,
-                               float* __restrict__ cent, float* __restrict__ dT)
+// x holds points [first, first + N) of N_total; a centroid whose seed point lives in another shard is
+// left all-zero bits here (the shards' buffers are combined by integer addition, see abw_km_shard_begin)
+__global__ void km_init_kernel(const float* __restrict__ x, int64_t N, int64_t first, int64_t N_total, int d, int W, int R,
+                               uint32_t base_seed, float* __restrict__ cent)
 {
     const int r = blockIdx.x;
     __shared__ int64_t idx[2];
     if (threadIdx.x == 0) {
-        int64_t i0 = 0, i1 = 1 % N;
+        int64_t i0 = 0, i1 = 1 % N_total;
         if (r < R) {
             TinyMT t;
             tmt_init(t, base_seed + (uint32_t)r);
-            i0 = (int64_t)(tmt_next(t) % (uint64_t)N);
+            i0 = (int64_t)(tmt_next(t) % (uint64_t)N_total);
             i1 = i0;
-            for (int tries = 0; tries < 64 && i1 == i0; tries++) i1 = (int64_t)(tmt_next(t) % (uint64_t)N);
+            for (int tries = 0; tries < 64 && i1 == i0; tries++) i1 = (int64_t)(tmt_next(t) % (uint64_t)N_total);
         }
-        idx[0] = i0; idx[1] = i1;
+        idx[0] = i0 - first; idx[1] = i1 - first;
     }
     __syncthreads();
-    for (int c = 0; c < 2; c++)
+    for (int c = 0; c < 2; c++) {
+        const bool mine = idx[c] >= 0 && idx[c] < N;
         for (int j = threadIdx.x; j < W; j += blockDim.x)
-            cent[((int64_t)r * 2 + c) * W + j] = (j < d) ? x[(int64_t)j * N + idx[c]] : 0.0f;
-    __syncthreads();
+            cent[((int64_t)r * 2 + c) * W + j] = (mine && j < d) ? x[(int64_t)j * N + idx[c]] : 0.0f;
+    }
+}
+
+__global__ void km_discriminant_kernel(const float* __restrict__ cent, int d, int W, int Rp, float* __restrict__ dT)
+{
+    const int r = blockIdx.x;
     km_discriminant(cent + (int64_t)r * 2 * W, cent + ((int64_t)r * 2 + 1) * W, d, W, Rp, r, dT, threadIdx.x, blockDim.x);
 }
 
@@ -403,10 +411,21 @@ __global__ __launch_bounds__(256) void km_group_kernel(const float* __restrict__
     gsum[g * elems + e] = s;
 }
 
-// Level 2: one workgroup per restart adds the group partials of cluster 1 in group order, derives
+// Level 2a: the group partials added in group order -> this shard's sums [Rp][W]
+__global__ __launch_bounds__(256) void km_sum_groups_kernel(const double* __restrict__ gsum, int64_t ngroups, int64_t elems,
+                                                           double* __restrict__ sums)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= elems) return;
+    double s = 0.0;
+    for (int64_t g = 0; g < ngroups; g++) s += gsum[g * elems + e];
+    sums[e] = s;
+}
+
+// Level 2b: one workgroup per restart takes the (all-shard) sums of cluster 1, derives
 // cluster 0 from the totals, then either moves both centroids and rebuilds the discriminant row
 // (update = 1) or contributes the restart's two inertia terms (update = 0).
-__global__ void km_update_kernel(const double* __restrict__ gsum, int64_t ngroups, const double* __restrict__ tot,
+__global__ void km_update_kernel(const double* __restrict__ sums, const double* __restrict__ tot,
                                  int Rp, int W, int d, float* __restrict__ cent, float* __restrict__ dT, int update,
                                  double* __restrict__ col_term)
 {
@@ -415,10 +434,7 @@ __global__ void km_update_kernel(const double* __restrict__ gsum, int64_t ngroup
     double* s0 = sh; double* s1 = sh + W;
     float* c0 = (float*)(sh + 2 * W); float* c1 = c0 + W;
     for (int j = threadIdx.x; j < W; j += blockDim.x) {
-        double s = 0.0;
-        const double* p = gsum + (int64_t)r * W + j;
-        const int64_t stride = (int64_t)Rp * W;
-        for (int64_t c = 0; c < ngroups; c++) s += p[c * stride];
+        const double s = sums[(int64_t)r * W + j];
         s1[j] = s;
         s0[j] = (j <= d) ? tot[j] - s : 0.0;
     }
@@ -581,56 +597,77 @@ int32_t abw_km_auto_chunk(const abw_ctx* ctx, int64_t N, int32_t R)
     }
 }
 
-int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t R, uint32_t base_seed,
-                   int32_t iters, int32_t chunk, uint8_t* d_assign, float* d_centroids, double* d_inertia)
+int abw_km_shard_begin(abw_ctx* ctx, const float* d_x, int64_t N_local, int64_t first_point, int64_t N_total, int32_t d,
+                       int32_t R, uint32_t base_seed, int32_t chunk, abw_km_exchange* ex)
 {
     if (!ctx) return ABW_ERR_ARG;
-    if (!d_x || N < 32 || d < 1 || R < 1 || iters < 0)
-        return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run_dev: bad argument (needs d_x, N >= 32 points, d >= 1, R >= 1, iters >= 0)");
-    if (chunk == 0) chunk = abw_km_auto_chunk(ctx, N, R);
-    if (chunk < 32 || (chunk & 31)) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run_dev: chunk must be a positive multiple of 32");
+    ctx->km.active = false;
+    if (!d_x || !ex || N_local < 32 || d < 1 || R < 1 || first_point < 0 || first_point + N_local > N_total)
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_km_shard_begin: bad argument (needs d_x, >= 32 local points inside [0, N_total), d >= 1, R >= 1)");
+    if (chunk == 0) chunk = abw_km_auto_chunk(ctx, N_local, R);
+    if (chunk < 32 || (chunk & 31)) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_shard_begin: chunk must be a positive multiple of 32");
     const int DT = (d + 1 + 31) / 32;                       // dims + the count column, in 32-wide tiles
-    if (DT > 7) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run_dev: d = %d not supported (max 222)", d);
+    if (DT > 7) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_shard_begin: d = %d not supported (max 222)", d);
     abw_device_guard g(ctx->device);
-    const int W = DT * 32;
-    const int Rp = (R + 31) & ~31;
-    const int64_t nchunks = (N + chunk - 1) / chunk;
+    abw_km_state& k = ctx->km;
+    k.x = d_x; k.N = N_local; k.first = first_point; k.N_total = N_total; k.d = d; k.R = R; k.seed = base_seed; k.chunk = chunk;
+    k.DT = DT; k.W = DT * 32; k.Rp = (R + 31) & ~31;
+    k.nchunks = (N_local + chunk - 1) / chunk;
+    k.ngroups = (k.nchunks + KM_GROUP - 1) / KM_GROUP;
+    k.elems = (int64_t)k.Rp * k.W;
     int rc;
-    // scratch[1]: col_term + x2 + totals + centroids + discriminant operand ; scratch[2]: slabs ;
-    // scratch[5]: fp64 group sums
-    const size_t cent_bytes = (size_t)Rp * 2 * W * 4, dt_bytes = (size_t)Rp * W * 4;
-    const size_t term_bytes = (size_t)Rp * 2 * 8, x2_bytes = (size_t)d * 8, tot_bytes = (size_t)W * 8;
-    if ((rc = abw_reserve(ctx, ctx->scratch[1], term_bytes + x2_bytes + tot_bytes + cent_bytes + dt_bytes + 64))) return rc;
-    const int64_t ngroups = (nchunks + KM_GROUP - 1) / KM_GROUP;
-    const int64_t elems = (int64_t)Rp * W;
-    if ((rc = abw_reserve(ctx, ctx->scratch[2], (size_t)nchunks * elems * 4))) return rc;
-    if ((rc = abw_reserve(ctx, ctx->scratch[5], (size_t)ngroups * elems * 8))) return rc;
-    double* gsum = (double*)ctx->scratch[5].p;
+    // scratch[1]: col_term + moments (totals, squares) + sums + centroids + discriminant operand ;
+    // scratch[2]: slabs ; scratch[5]: fp64 group sums
+    const size_t cent_bytes = (size_t)k.Rp * 2 * k.W * 4, dt_bytes = (size_t)k.Rp * k.W * 4;
+    const size_t term_bytes = (size_t)k.Rp * 2 * 8, mom_bytes = (size_t)(k.W + d) * 8, sums_bytes = (size_t)k.elems * 8;
+    if ((rc = abw_reserve(ctx, ctx->scratch[1], term_bytes + mom_bytes + sums_bytes + cent_bytes + dt_bytes + 64))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[2], (size_t)k.nchunks * k.elems * 4))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[5], (size_t)k.ngroups * k.elems * 8))) return rc;
     uint8_t* base = (uint8_t*)ctx->scratch[1].p;
-    double* col_term = (double*)base;
-    double* x2_dim = (double*)(base + term_bytes);
-    double* tot = (double*)(base + term_bytes + x2_bytes);
-    float* cent = (float*)(base + term_bytes + x2_bytes + tot_bytes);
-    float* dT = (float*)(base + term_bytes + x2_bytes + tot_bytes + cent_bytes);
-    float* slabs = (float*)ctx->scratch[2].p;
+    k.col_term = (double*)base;
+    k.moments = (double*)(base + term_bytes);
+    k.sums = (double*)(base + term_bytes + mom_bytes);
+    k.cent = (float*)(base + term_bytes + mom_bytes + sums_bytes);
+    k.dT = (float*)(base + term_bytes + mom_bytes + sums_bytes + cent_bytes);
+    k.slabs = (float*)ctx->scratch[2].p;
+    k.gsum = (double*)ctx->scratch[5].p;
     hipStream_t st = ctx->stream;
-
-    hipLaunchKernelGGL(km_init_kernel, dim3(Rp), dim3(256), 0, st, d_x, N, d, W, R, Rp, base_seed, cent, dT);
+    hipLaunchKernelGGL(km_init_kernel, dim3(k.Rp), dim3(256), 0, st, d_x, N_local, first_point, N_total, d, k.W, R, base_seed, k.cent);
     ABW_LAUNCH_CHECK(ctx);
     {
         ABW_PROF(ctx, "km_moments");
-        hipLaunchKernelGGL(km_moments_kernel, dim3(d), dim3(256), 0, st, d_x, N, d, tot, x2_dim);
+        ABW_HIP(ctx, hipMemsetAsync(k.moments, 0, mom_bytes, st));
+        hipLaunchKernelGGL(km_moments_kernel, dim3(d), dim3(256), 0, st, d_x, N_local, d, k.moments, k.moments + k.W);
         ABW_LAUNCH_CHECK(ctx);
     }
-    const StepArgs sa = { d_x, N, d, dT, Rp, chunk, nchunks, slabs, nullptr, R };
-    const size_t upd_lds = (size_t)W * 16 + (size_t)W * 8;
-    for (int it = 0; it <= iters; it++) {
-        const bool last = it == iters;
-        StepArgs a = sa;
-        a.assign = last ? d_assign : nullptr;
-        {
+    ex->d_init = k.cent; ex->init_count = (uint64_t)k.Rp * 2 * k.W;
+    ex->d_moments = k.moments; ex->moments_count = (uint64_t)(k.W + d);
+    ex->d_sums = k.sums; ex->sums_count = (uint64_t)k.elems;
+    k.active = true;
+    return ABW_OK;
+}
+
+int abw_km_shard_ready(abw_ctx* ctx)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!ctx->km.active) return abw_fail(ctx, ABW_ERR_STATE, "abw_km_shard_ready: no k-means run in progress");
+    abw_device_guard g(ctx->device);
+    abw_km_state& k = ctx->km;
+    hipLaunchKernelGGL(km_discriminant_kernel, dim3(k.Rp), dim3(256), 0, ctx->stream, k.cent, k.d, k.W, k.Rp, k.dT);
+    ABW_LAUNCH_CHECK(ctx);
+    return ABW_OK;
+}
+
+int abw_km_shard_step(abw_ctx* ctx, uint8_t* d_assign)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!ctx->km.active) return abw_fail(ctx, ABW_ERR_STATE, "abw_km_shard_step: no k-means run in progress");
+    abw_device_guard g(ctx->device);
+    abw_km_state& k = ctx->km;
+    const StepArgs a = { k.x, k.N, k.d, k.dT, k.Rp, k.chunk, k.nchunks, k.slabs, d_assign, k.R };
+    {
         ABW_PROF(ctx, "km_step");
-        switch (DT) {
+        switch (k.DT) {
             case 1: launch_step<1>(ctx, a); break;
             case 2: launch_step<2>(ctx, a); break;
             case 3: launch_step<3>(ctx, a); break;
@@ -639,24 +676,66 @@ int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t
             case 6: launch_step<6>(ctx, a); break;
             default: launch_step<7>(ctx, a); break;
         }
-        }
-        ABW_LAUNCH_CHECK(ctx);
-        if (last && !d_inertia) break;
-        ABW_PROF(ctx, "km_update");
-        hipLaunchKernelGGL(km_group_kernel, dim3((unsigned)((elems + 255) / 256), (unsigned)ngroups), dim3(256), 0, st, slabs, nchunks, elems, gsum);
-        ABW_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(km_update_kernel, dim3(Rp), dim3(W), upd_lds, st, gsum, ngroups, tot, Rp, W, d, cent, dT, last ? 0 : 1, col_term);
-        ABW_LAUNCH_CHECK(ctx);
     }
+    ABW_LAUNCH_CHECK(ctx);
+    ABW_PROF(ctx, "km_update");
+    hipLaunchKernelGGL(km_group_kernel, dim3((unsigned)((k.elems + 255) / 256), (unsigned)k.ngroups), dim3(256), 0, ctx->stream,
+                       k.slabs, k.nchunks, k.elems, k.gsum);
+    ABW_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(km_sum_groups_kernel, dim3((unsigned)((k.elems + 255) / 256)), dim3(256), 0, ctx->stream, k.gsum, k.ngroups, k.elems, k.sums);
+    ABW_LAUNCH_CHECK(ctx);
+    return ABW_OK;
+}
+
+int abw_km_shard_update(abw_ctx* ctx, int32_t last)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!ctx->km.active) return abw_fail(ctx, ABW_ERR_STATE, "abw_km_shard_update: no k-means run in progress");
+    abw_device_guard g(ctx->device);
+    abw_km_state& k = ctx->km;
+    ABW_PROF(ctx, "km_update");
+    const size_t upd_lds = (size_t)k.W * 16 + (size_t)k.W * 8;
+    hipLaunchKernelGGL(km_update_kernel, dim3(k.Rp), dim3(k.W), upd_lds, ctx->stream, k.sums, k.moments, k.Rp, k.W, k.d, k.cent, k.dT,
+                       last ? 0 : 1, k.col_term);
+    ABW_LAUNCH_CHECK(ctx);
+    return ABW_OK;
+}
+
+int abw_km_shard_finish(abw_ctx* ctx, float* d_centroids, double* d_inertia)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!ctx->km.active) return abw_fail(ctx, ABW_ERR_STATE, "abw_km_shard_finish: no k-means run in progress");
+    abw_device_guard g(ctx->device);
+    abw_km_state& k = ctx->km;
+    hipStream_t st = ctx->stream;
     if (d_inertia) {
-        hipLaunchKernelGGL(km_inertia_kernel, dim3((R + 63) / 64), dim3(64), 0, st, x2_dim, d, col_term, R, d_inertia);
+        hipLaunchKernelGGL(km_inertia_kernel, dim3((k.R + 63) / 64), dim3(64), 0, st, k.moments + k.W, k.d, k.col_term, k.R, d_inertia);
         ABW_LAUNCH_CHECK(ctx);
     }
     if (d_centroids) {
-        hipLaunchKernelGGL(km_copy_centroids_kernel, dim3(64), dim3(256), 0, st, cent, W, d, R, d_centroids);
+        hipLaunchKernelGGL(km_copy_centroids_kernel, dim3(64), dim3(256), 0, st, k.cent, k.W, k.d, k.R, d_centroids);
         ABW_LAUNCH_CHECK(ctx);
     }
+    k.active = false;
     return ABW_OK;
+}
+
+int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t R, uint32_t base_seed,
+                   int32_t iters, int32_t chunk, uint8_t* d_assign, float* d_centroids, double* d_inertia)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (iters < 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_run_dev: iters < 0");
+    abw_km_exchange ex;
+    int rc = abw_km_shard_begin(ctx, d_x, N, 0, N, d, R, base_seed, chunk, &ex);     // one shard: nothing to exchange
+    if (rc) return rc;
+    if ((rc = abw_km_shard_ready(ctx))) return rc;
+    for (int it = 0; it <= iters; it++) {
+        const bool last = it == iters;
+        if ((rc = abw_km_shard_step(ctx, last ? d_assign : nullptr))) return rc;
+        if (last && !d_inertia) break;
+        if ((rc = abw_km_shard_update(ctx, last ? 1 : 0))) return rc;
+    }
+    return abw_km_shard_finish(ctx, d_centroids, d_inertia);
 }
 
 int abw_km_run(abw_ctx* ctx, const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed,

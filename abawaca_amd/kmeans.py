@@ -40,3 +40,70 @@ def kmeans_restarts_dev(ctx: Context, t_x, N: int, d: int, R: int, base_seed: in
         return C.c_void_p(t.data_ptr()) if t is not None else None
     ctx.check(lib().abw_km_run_dev(ctx.handle, p(t_x), int(N), int(d), int(R), int(base_seed) & 0xFFFFFFFF, int(iters),
                                    int(chunk), p(t_assign), p(t_centroids), p(t_inertia)))
+
+
+class _DevView:
+    """Zero-copy torch view of a device buffer owned by the library (via __cuda_array_interface__)."""
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = dict(shape=(int(count),), typestr=typestr, data=(int(ptr), False), version=2)
+
+
+class KmExchange(C.Structure):
+    _fields_ = [("d_init", C.c_void_p), ("init_count", C.c_uint64), ("d_moments", C.c_void_p), ("moments_count", C.c_uint64),
+                ("d_sums", C.c_void_p), ("sums_count", C.c_uint64)]
+
+
+class ShardRun:
+    """One shard of a point-sharded k-means run (abw_km_shard_*): the caller combines `init` (int32),
+    `moments` and `sums` (fp64) over the shards between the phases -- abawaca_amd.multi has the
+    collectives; tests drive several shards from one process."""
+
+    def __init__(self, ctx: Context, t_x, N_local: int, first_point: int, N_total: int, d: int, R: int, base_seed: int, chunk: int):
+        import torch
+        self.ctx, self.R, self.N_local, self.d = ctx, R, N_local, d
+        self._x = t_x                                         # keep the points alive
+        ex = KmExchange()
+        ctx.check(lib().abw_km_shard_begin(ctx.handle, C.c_void_p(t_x.data_ptr()), int(N_local), int(first_point), int(N_total),
+                                           int(d), int(R), int(base_seed) & 0xFFFFFFFF, int(chunk), C.byref(ex)))
+        dev = t_x.device
+        self.init = torch.as_tensor(_DevView(ex.d_init, ex.init_count, "<i4"), device=dev)
+        self.moments = torch.as_tensor(_DevView(ex.d_moments, ex.moments_count, "<f8"), device=dev)
+        self.sums = torch.as_tensor(_DevView(ex.d_sums, ex.sums_count, "<f8"), device=dev)
+
+    def ready(self):
+        self.ctx.check(lib().abw_km_shard_ready(self.ctx.handle))
+
+    def step(self, t_assign=None):
+        self.ctx.check(lib().abw_km_shard_step(self.ctx.handle, C.c_void_p(t_assign.data_ptr()) if t_assign is not None else None))
+
+    def update(self, last: bool):
+        self.ctx.check(lib().abw_km_shard_update(self.ctx.handle, 1 if last else 0))
+
+    def finish(self, t_centroids=None, t_inertia=None):
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self.ctx.check(lib().abw_km_shard_finish(self.ctx.handle, p(t_centroids), p(t_inertia)))
+
+
+def kmeans_sharded_dev(ctx: Context, t_x_local, first_point: int, N_total: int, R: int, base_seed: int, iters: int,
+                       chunk: int, dist, t_assign=None, t_centroids=None, t_inertia=None):
+    """Point-sharded run over torch.distributed (RCCL on GPUs): this rank holds points
+    [first_point, first_point + N_local) as t_x_local [d, N_local] on the context's GPU.  Every rank ends
+    with the same centroids / inertia and its own slice of the assignments."""
+    import torch
+    from . import multi
+    d, N_local = t_x_local.shape
+    run = ShardRun(ctx, t_x_local, N_local, first_point, N_total, d, R, base_seed, chunk)
+    ctx.synchronize()
+    multi.combine_int_sum(run.init, dist)
+    multi.combine_ordered_sum(run.moments, dist)
+    torch.cuda.synchronize(t_x_local.device)
+    run.ready()
+    for it in range(iters + 1):
+        last = it == iters
+        run.step(t_assign if last else None)
+        ctx.synchronize()
+        multi.combine_ordered_sum(run.sums, dist)
+        torch.cuda.synchronize(t_x_local.device)
+        run.update(last)
+    run.finish(t_centroids, t_inertia)
+    return run

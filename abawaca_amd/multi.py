@@ -66,3 +66,38 @@ def max_elapsed(elapsed: float, dist=None, device=None) -> float:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---- point-sharded k-means (SURVEY §8 row e, second way): the exchange between the library's phases ----
+
+def shard_bounds(N: int, world: int) -> list[int]:
+    """Contiguous point ranges, multiples of 32 points except the last (whole MFMA tiles per shard)."""
+    per = -(-N // world)
+    per = -(-per // 32) * 32
+    b = [min(N, k * per) for k in range(world + 1)]
+    if any(b[k + 1] - b[k] < 32 for k in range(world)):
+        raise ValueError("every shard needs at least 32 points")
+    return b
+
+
+def combine_int_sum(t, dist=None):
+    """In-place integer sum over the shards of an int32 tensor (initial centroids: bit patterns of the
+    owner, zero elsewhere).  Exact and order-free."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def combine_ordered_sum(t, dist=None):
+    """In-place fp64 sum over the shards, added in shard (rank) order on every rank, so that all ranks
+    hold identical bits and the result does not depend on the collective's internal order: all-gather
+    (a few hundred KB per rank, one direct exchange per peer over xGMI) + local adds."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    import torch
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    t.copy_(parts[0])
+    for p in parts[1:]:
+        t.add_(p)
+    return t

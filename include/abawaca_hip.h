@@ -167,6 +167,39 @@ int32_t abw_km_auto_chunk(const abw_ctx* ctx, int64_t N, int32_t R);
 int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t R, uint32_t base_seed,
                    int32_t iters, int32_t chunk, uint8_t* d_assign, float* d_centroids, double* d_inertia);
 
+/* ---- k-means with the POINTS sharded over several contexts / processes / GPUs ("scaffolds
+ *      are sharded with all-reduce of the per-iteration centroid partial sums").  No reference counterpart.
+ * The library runs each shard's local part; between the phases the CALLER combines three small device
+ * buffers across the shards with whatever transport it has (abawaca_amd/multi.py: RCCL / gloo all-gather,
+ * added in shard order so that every shard holds identical bits).  abw_km_run_dev is these phases with
+ * one shard and nothing to combine.
+ *
+ *   begin   : shard owns points [first_point, first_point + N_local) of N_total, d_x = its [d][N_local] rows.
+ *             Restart r draws its two seed points from [0, N_total) exactly as the unsharded run does.
+ *   combine : d_init    -- init_count 32-bit words: fp32 bit patterns of the initial centroids, all-zero
+ *                          where another shard owns the seed point -> INTEGER sum over shards;
+ *             d_moments -- moments_count fp64 (per-dimension totals, local point count, sums of squares)
+ *                          -> fp64 sum in shard order.
+ *   ready   : builds the discriminants from the combined centroids.
+ *   per pass (iters update passes, then one final pass):
+ *     step   : local assign + cluster-1 sums -> d_sums (sums_count fp64); d_assign [R][N_local] u8 or NULL
+ *     combine: d_sums -> fp64 sum in shard order
+ *     update : last = 0 moves the centroids, last = 1 forms the inertia terms instead
+ *   finish  : d_centroids [R][2][d] fp32 and d_inertia [R] f64 (either may be NULL), identical on every shard.
+ * Asynchronous on the context's stream; the caller orders its combine steps after the library's work
+ * (abw_ctx_synchronize, or by running them on the same stream). */
+typedef struct abw_km_exchange {
+    void*    d_init;     uint64_t init_count;
+    double*  d_moments;  uint64_t moments_count;
+    double*  d_sums;     uint64_t sums_count;
+} abw_km_exchange;
+int abw_km_shard_begin(abw_ctx* ctx, const float* d_x, int64_t N_local, int64_t first_point, int64_t N_total, int32_t d,
+                       int32_t R, uint32_t base_seed, int32_t chunk, abw_km_exchange* ex);
+int abw_km_shard_ready(abw_ctx* ctx);
+int abw_km_shard_step(abw_ctx* ctx, uint8_t* d_assign);
+int abw_km_shard_update(abw_ctx* ctx, int32_t last);
+int abw_km_shard_finish(abw_ctx* ctx, float* d_centroids, double* d_inertia);
+
 /* Host-buffer convenience: x is host [d][N]; outputs host. */
 int abw_km_run(abw_ctx* ctx, const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed,
                int32_t iters, int32_t chunk, uint8_t* assign, float* centroids, double* inertia);

@@ -421,37 +421,64 @@ static double km_butterfly(const double* part)
     return (w[0] + w[1]) + (w[2] + w[3]);
 }
 
-static double km_moments(const float* x, int64_t N, int32_t d, double* T)
+/* moments of the points [b, e) of x (rows of length N); results ADDED to T[0..d] and returned (X2) */
+static double km_moments(const float* x, int64_t N, int64_t b, int64_t e, int32_t d, double* T)
 {
     double total = 0.0;
     for (int32_t j = 0; j < d; j++) {
-        const float* row = x + (int64_t)j * N;
+        const float* row = x + (int64_t)j * N + b;
         double p1[256], p2[256];
         for (int t = 0; t < 256; t++) {
             double a1 = 0.0, a2 = 0.0;
-            for (int64_t p = t; p < N; p += 256) { double v = (double)row[p]; a1 += v; a2 += v * v; }
+            for (int64_t p = t; p < e - b; p += 256) { double v = (double)row[p]; a1 += v; a2 += v * v; }
             p1[t] = a1; p2[t] = a2;
         }
-        T[j] = km_butterfly(p1);
+        T[j] += km_butterfly(p1);
         total += km_butterfly(p2);
     }
-    T[d] = (double)N;
+    T[d] += (double)(e - b);
     return total;
 }
 
 int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed, int32_t iters,
                   int32_t chunk, int nthreads, uint8_t* assign, float* centroids, double* inertia)
 {
-    if (N < 2 || d < 1 || R < 1 || chunk < 1) return -1;
+    const int64_t bounds[2] = { 0, N };
+    return abw_or_kmeans_sharded(x, N, d, R, base_seed, iters, chunk, nthreads, 1, bounds, assign, centroids, inertia);
+}
+
+int abw_or_kmeans_sharded(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed, int32_t iters,
+                          int32_t chunk, int nthreads, int32_t nshards, const int64_t* bounds,
+                          uint8_t* assign, float* centroids, double* inertia)
+{
+    if (N < 2 || d < 1 || R < 1 || chunk < 1 || nshards < 1 || !bounds || bounds[0] != 0 || bounds[nshards] != N) return -1;
 #ifdef _OPENMP
     if (nthreads <= 0) nthreads = omp_get_max_threads();
 #else
     nthreads = 1;
 #endif
-    const int64_t nchunks = (N + chunk - 1) / chunk;
-    double* T = (double*)malloc(sizeof(double) * (size_t)(d + 1));
-    if (!T) return -2;
-    const double x2 = km_moments(x, N, d, T);
+    double* T = (double*)calloc((size_t)(d + 1), sizeof(double));
+    double* x2d = (double*)calloc((size_t)d, sizeof(double));
+    if (!T || !x2d) { free(T); free(x2d); return -2; }
+    /* moments: per shard, then added in shard order -- per dimension for the squares too, the
+     * dimensions being added last (the device keeps one sum of squares per dimension) */
+    for (int32_t sh = 0; sh < nshards; sh++) {
+        double* Ts = (double*)calloc((size_t)(d + 1), sizeof(double));
+        if (!Ts) { free(T); free(x2d); return -2; }
+        for (int32_t j = 0; j < d; j++) {
+            double one[2] = { 0.0, 0.0 };
+            /* one dimension at a time through the same routine */
+            const double sq = km_moments(x + (int64_t)j * N, N, bounds[sh], bounds[sh + 1], 1, one);
+            Ts[j] = one[0];
+            x2d[j] += sq;
+        }
+        for (int32_t j = 0; j < d; j++) T[j] += Ts[j];
+        T[d] += (double)(bounds[sh + 1] - bounds[sh]);
+        free(Ts);
+    }
+    double x2 = 0.0;
+    for (int32_t j = 0; j < d; j++) x2 += x2d[j];
+    free(x2d);
     int err = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int32_t r = 0; r < R; r++) {
@@ -460,8 +487,9 @@ int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base
         float* part = (float*)malloc(sizeof(float) * (size_t)(d + 1));       /* cluster 1 only */
         double* S = (double*)malloc(sizeof(double) * 2 * (size_t)(d + 1));   /* [2][d+1], S[0] derived */
         double* Sg = (double*)malloc(sizeof(double) * (size_t)(d + 1));
+        double* Ss = (double*)malloc(sizeof(double) * (size_t)(d + 1));      /* one shard's sums */
         float* D = (float*)malloc(sizeof(float) * (size_t)(d + 1));
-        if (!part || !S || !Sg || !D) { err = 1; free(part); free(S); free(Sg); free(D); continue; }
+        if (!part || !S || !Sg || !Ss || !D) { err = 1; free(part); free(S); free(Sg); free(Ss); free(D); continue; }
         abw_or_tinymt t;
         abw_or_tinymt_init(&t, base_seed + (uint32_t)r);
         int64_t i0 = (int64_t)(abw_or_tinymt_next(&t) % (uint64_t)N);
@@ -475,27 +503,33 @@ int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base
             for (int32_t j = 0; j < d; j++) { n0 = fmaf(c[j], c[j], n0); n1 = fmaf(c[d + j], c[d + j], n1); D[j] = c[d + j] - c[j]; }
             D[d] = 0.5f * n0 - 0.5f * n1;
             double* S1 = S + (d + 1);
-            for (int32_t q = 0; q <= d; q++) { S1[q] = 0.0; Sg[q] = 0.0; }
-            for (int64_t ch = 0; ch < nchunks; ch++) {
-                const int64_t p0 = ch * chunk, p1 = p0 + chunk < N ? p0 + chunk : N;
-                for (int32_t q = 0; q <= d; q++) part[q] = 0.0f;
-                for (int64_t p = p0; p < p1; p++) {
-                    /* Two fmaf chains: dimension pairs (j>>1) alternate between them, position d
-                     * included; g is their fp32 sum.  (The GPU issues the pairs as alternating MFMA
-                     * k-steps into two accumulators so that no MFMA waits for its predecessor.) */
-                    float g[2] = { 0.0f, 0.0f };
-                    for (int32_t j = 0; j < d; j++) g[(j >> 1) & 1] = fmaf(x[(int64_t)j * N + p], D[j], g[(j >> 1) & 1]);
-                    g[(d >> 1) & 1] = fmaf(1.0f, D[d], g[(d >> 1) & 1]);
-                    const int as = (g[0] + g[1]) > 0.0f;             /* tie -> cluster 0 */
-                    a[p] = (uint8_t)as;
-                    if (as) {
-                        for (int32_t j = 0; j < d; j++) part[j] = fmaf(1.0f, x[(int64_t)j * N + p], part[j]);
-                        part[d] = fmaf(1.0f, 1.0f, part[d]);        /* the count column */
+            for (int32_t q = 0; q <= d; q++) S1[q] = 0.0;
+            for (int32_t sh = 0; sh < nshards; sh++) {
+                const int64_t sb = bounds[sh], se = bounds[sh + 1];
+                const int64_t nchunks = (se - sb + chunk - 1) / chunk;
+                for (int32_t q = 0; q <= d; q++) { Ss[q] = 0.0; Sg[q] = 0.0; }
+                for (int64_t ch = 0; ch < nchunks; ch++) {
+                    const int64_t p0 = sb + ch * chunk, p1 = p0 + chunk < se ? p0 + chunk : se;
+                    for (int32_t q = 0; q <= d; q++) part[q] = 0.0f;
+                    for (int64_t p = p0; p < p1; p++) {
+                        /* Two fmaf chains: dimension pairs (j>>1) alternate between them, position d
+                         * included; g is their fp32 sum.  (The GPU issues the pairs as alternating MFMA
+                         * k-steps into two accumulators so that no MFMA waits for its predecessor.) */
+                        float g[2] = { 0.0f, 0.0f };
+                        for (int32_t j = 0; j < d; j++) g[(j >> 1) & 1] = fmaf(x[(int64_t)j * N + p], D[j], g[(j >> 1) & 1]);
+                        g[(d >> 1) & 1] = fmaf(1.0f, D[d], g[(d >> 1) & 1]);
+                        const int as = (g[0] + g[1]) > 0.0f;             /* tie -> cluster 0 */
+                        a[p] = (uint8_t)as;
+                        if (as) {
+                            for (int32_t j = 0; j < d; j++) part[j] = fmaf(1.0f, x[(int64_t)j * N + p], part[j]);
+                            part[d] = fmaf(1.0f, 1.0f, part[d]);        /* the count column */
+                        }
                     }
+                    for (int32_t q = 0; q <= d; q++) Sg[q] += (double)part[q];
+                    if ((ch % KM_GROUP) == KM_GROUP - 1 || ch == nchunks - 1)      /* group of 32 chunks complete */
+                        for (int32_t q = 0; q <= d; q++) { Ss[q] += Sg[q]; Sg[q] = 0.0; }
                 }
-                for (int32_t q = 0; q <= d; q++) Sg[q] += (double)part[q];
-                if ((ch % KM_GROUP) == KM_GROUP - 1 || ch == nchunks - 1)      /* group of 32 chunks complete */
-                    for (int32_t q = 0; q <= d; q++) { S1[q] += Sg[q]; Sg[q] = 0.0; }
+                for (int32_t q = 0; q <= d; q++) S1[q] += Ss[q];                     /* shards in order */
             }
             for (int32_t q = 0; q <= d; q++) S[q] = T[q] - S1[q];     /* cluster 0 = totals - cluster 1 */
             if (it < iters) {
@@ -517,7 +551,7 @@ int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base
                 inertia[r] = (x2 + term[0]) + term[1];
             }
         }
-        free(part); free(S); free(Sg); free(D);
+        free(part); free(S); free(Sg); free(Ss); free(D);
     }
     free(T);
     return err ? -2 : 0;

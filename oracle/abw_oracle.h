@@ -120,6 +120,14 @@ uint32_t abw_or_tinymt_next(abw_or_tinymt* t);
 int abw_or_kmeans(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed, int32_t iters,
                   int32_t chunk, int nthreads, uint8_t* assign, float* centroids, double* inertia);
 
+/* The same run with the points cut into `nshards` contiguous shards [bounds[s], bounds[s+1]) (bounds[0] = 0,
+ * bounds[nshards] = N), as the device runs it over several GPUs: chunks restart at every shard, a shard's
+ * sums are its groups added in order, the shards' sums and moments are added in shard order.
+ * nshards = 1 is abw_or_kmeans. */
+int abw_or_kmeans_sharded(const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed, int32_t iters,
+                          int32_t chunk, int nthreads, int32_t nshards, const int64_t* bounds,
+                          uint8_t* assign, float* centroids, double* inertia);
+
 #ifdef __cplusplus
 }
 #endif

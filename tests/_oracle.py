@@ -177,3 +177,19 @@ def kmeans(x, R, base_seed, iters, chunk, nthreads=0):
     if rc != 0:
         raise RuntimeError("abw_or_kmeans failed: %d" % rc)
     return assign, cent, inertia
+
+
+def kmeans_sharded(x, R, base_seed, iters, chunk, bounds, nthreads=0):
+    """abw_or_kmeans_sharded: the points cut into contiguous shards at `bounds` (len nshards + 1)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    d, N = x.shape
+    b = np.ascontiguousarray(bounds, dtype=np.int64)
+    assign = np.empty((R, N), dtype=np.uint8)
+    cent = np.empty((R, 2, d), dtype=np.float32)
+    inertia = np.empty(R, dtype=np.float64)
+    rc = lib().abw_or_kmeans_sharded(_p(x, C.c_float), C.c_int64(N), C.c_int32(d), C.c_int32(R), C.c_uint32(base_seed),
+                                     C.c_int32(iters), C.c_int32(chunk), C.c_int(nthreads), C.c_int32(len(b) - 1),
+                                     _p(b, C.c_int64), _p(assign, C.c_uint8), _p(cent, C.c_float), _p(inertia, C.c_double))
+    if rc != 0:
+        raise RuntimeError("abw_or_kmeans_sharded failed: %d" % rc)
+    return assign, cent, inertia
