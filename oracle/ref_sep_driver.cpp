@@ -26,9 +26,12 @@
 #include "ScafDpData.h"
 #include "ClusterData.h"
 #include "ClusterSeparatorBySensitivitySpecificity.h"
-#ifdef ABW_USE_HIP_SEPARATOR		// same driver, separator swapped for the GPU drop-in (integration/ClusterSeparatorHip.h)
+#if defined(ABW_USE_HIP_SEPARATOR)	// same driver, separator swapped for the GPU drop-in (integration/ClusterSeparatorHip.h)
 #include "ClusterSeparatorHip.h"
 #define SEPARATOR_CLASS ClusterSeparatorHip
+#elif defined(ABW_USE_KMEANS_SEPARATOR)	// ... or for the k-means extension (integration/ClusterSeparatorKMeans.h)
+#include "ClusterSeparatorKMeans.h"
+#define SEPARATOR_CLASS ClusterSeparatorKMeans
 #else
 #define SEPARATOR_CLASS ClusterSeparatorBySensitivitySpecificity
 #endif
