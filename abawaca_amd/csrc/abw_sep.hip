@@ -42,7 +42,8 @@ struct SepDev {
     const int32_t* scaf_first; const int32_t* scaf_ndps; const int64_t* scaf_len;
     const int32_t* scg_off; const int32_t* scg_ids; int32_t n_scg;
     const int32_t* T; const int64_t* Toff;
-    uint32_t* h_size; uint32_t* h_tp1; uint32_t* h_tot; unsigned long long* h_bp;
+    unsigned long long* h_st;          // per bin: size (low 32 bits) and tp1 (high 32 bits), updated by one 64-bit atomic
+    uint32_t* h_tot; unsigned long long* h_bp;
     int32_t* scg_lo; int32_t* scg_hi;
 };
 
@@ -62,12 +63,17 @@ __device__ inline int32_t select_kth_mem(const int32_t* __restrict__ col, int n,
     return lo;
 }
 
+// Histogram updates of one (scaffold, dimension): per dp ONE 64-bit add of (size += 1, tp1 += [v >= t_s])
+// at bin v, where the dps below the flip value are credited to tp1 at bin t_s together with the dps
+// that sit on it (tp1 counts max(v, t_s) <= t); per scaffold tot[t_s] += n and bp[t_s] += len.
+constexpr int ACC_COPIES = 4;       // LDS copies of the (size, tp1) histogram, by lane: signature values cluster
+                                    // on a handful of bins, and same-address LDS atomics of a wave serialise
+
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t* __restrict__ dimlist,
                                                        const int32_t* __restrict__ node_scaf, int32_t m)
 {
-    __shared__ uint32_t s_size[USE_LDS ? NARROW_T : 1];
-    __shared__ uint32_t s_tp1[USE_LDS ? NARROW_T : 1];
+    __shared__ unsigned long long s_st[USE_LDS ? ACC_COPIES * NARROW_T : 1];
     __shared__ uint32_t s_tot[USE_LDS ? NARROW_T : 1];
     __shared__ unsigned long long s_bp[USE_LDS ? NARROW_T : 1];
     const int d = dimlist[blockIdx.y];
@@ -75,13 +81,18 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t*
     const int64_t toff = P.Toff[d];
     const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
     if (USE_LDS) {
-        for (int t = threadIdx.x; t < T; t += 256) { s_size[t] = 0; s_tp1[t] = 0; s_tot[t] = 0; s_bp[t] = 0; }
+        for (int t = threadIdx.x; t < T; t += 256) {
+#pragma unroll
+            for (int c = 0; c < ACC_COPIES; c++) s_st[c * NARROW_T + t] = 0;
+            s_tot[t] = 0; s_bp[t] = 0;
+        }
         __syncthreads();
     }
-    uint32_t* g_size = P.h_size + toff;
-    uint32_t* g_tp1 = P.h_tp1 + toff;
+    unsigned long long* g_st = P.h_st + toff;
     uint32_t* g_tot = P.h_tot + toff;
     unsigned long long* g_bp = P.h_bp + toff;
+    unsigned long long* my_st = USE_LDS ? s_st + (threadIdx.x & (ACC_COPIES - 1)) * NARROW_T : g_st;
+    constexpr unsigned long long BOTH = 1ull | (1ull << 32);
 
     const int ls_end = min(m, (int)(blockIdx.x + 1) * ACC_SPB);
     for (int ls = blockIdx.x * ACC_SPB + threadIdx.x; ls < ls_end; ls += 256) {
@@ -102,22 +113,26 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t*
                 for (int j = 0; j < 8; j++) rank += (v[j] < v[i]) || (v[j] == v[i] && j < i);
                 if (i < n && rank == k) ts = v[i];
             }
+            unsigned long long at_ts = 0;                  // everything that lands on bin t_s, in one add
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 if (i < n) {
-                    const int mx = max(v[i], ts);
-                    if (USE_LDS) { atomicAdd(&s_size[v[i]], 1u); atomicAdd(&s_tp1[mx], 1u); }
-                    else { atomicAdd(&g_size[v[i]], 1u); atomicAdd(&g_tp1[mx], 1u); }
+                    if (v[i] > ts) atomicAdd(&my_st[v[i]], BOTH);
+                    else if (v[i] < ts) { atomicAdd(&my_st[v[i]], 1ull); at_ts += 1ull << 32; }
+                    else at_ts += BOTH;
                 }
             }
+            atomicAdd(&my_st[ts], at_ts);
         } else {
             ts = select_kth_mem(col + f, n, k, T);
+            unsigned long long at_ts = 0;
             for (int i = 0; i < n; i++) {
                 const int v = col[f + i];
-                const int mx = max(v, ts);
-                if (USE_LDS) { atomicAdd(&s_size[v], 1u); atomicAdd(&s_tp1[mx], 1u); }
-                else { atomicAdd(&g_size[v], 1u); atomicAdd(&g_tp1[mx], 1u); }
+                if (v > ts) atomicAdd(&my_st[v], BOTH);
+                else if (v < ts) { atomicAdd(&my_st[v], 1ull); at_ts += 1ull << 32; }
+                else at_ts += BOTH;
             }
+            atomicAdd(&my_st[ts], at_ts);
         }
         if (USE_LDS) { atomicAdd(&s_tot[ts], (uint32_t)n); atomicAdd(&s_bp[ts], (unsigned long long)P.scaf_len[s]); }
         else { atomicAdd(&g_tot[ts], (uint32_t)n); atomicAdd(&g_bp[ts], (unsigned long long)P.scaf_len[s]); }
@@ -132,11 +147,13 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t*
     if (USE_LDS) {
         __syncthreads();
         for (int t = threadIdx.x; t < T; t += 256) {
-            const uint32_t a = s_size[t], b = s_tp1[t], c = s_tot[t];
+            unsigned long long a = 0;
+#pragma unroll
+            for (int c = 0; c < ACC_COPIES; c++) a += s_st[c * NARROW_T + t];
+            const uint32_t c3 = s_tot[t];
             const unsigned long long e = s_bp[t];
-            if (a) atomicAdd(&g_size[t], a);
-            if (b) atomicAdd(&g_tp1[t], b);
-            if (c) atomicAdd(&g_tot[t], c);
+            if (a) atomicAdd(&g_st[t], a);
+            if (c3) atomicAdd(&g_tot[t], c3);
             if (e) atomicAdd(&g_bp[t], e);
         }
     }
@@ -167,7 +184,8 @@ __global__ __launch_bounds__(256) void sep_chunk_sums_kernel(SepDev P, const Chu
     const int64_t base = P.Toff[c.dim] + c.start;
     Sums acc = {0, 0, 0, 0};
     for (int t = threadIdx.x; t < c.len; t += 256) {
-        acc.size += P.h_size[base + t]; acc.tp1 += P.h_tp1[base + t]; acc.tot += P.h_tot[base + t]; acc.bp += P.h_bp[base + t];
+        const unsigned long long st = P.h_st[base + t];
+        acc.size += (uint32_t)st; acc.tp1 += st >> 32; acc.tot += P.h_tot[base + t]; acc.bp += P.h_bp[base + t];
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     acc = wave_incl_scan(acc, lane);
@@ -241,8 +259,9 @@ __global__ __launch_bounds__(256) void sep_eval_kernel(SepDev P, const ChunkDesc
         Sums v = {0, 0, 0, 0};
         uint32_t here = 0;
         if (t < c.len) {
-            here = P.h_size[base + t];
-            v.size = here; v.tp1 = P.h_tp1[base + t]; v.tot = P.h_tot[base + t]; v.bp = P.h_bp[base + t];
+            const unsigned long long st = P.h_st[base + t];
+            here = (uint32_t)st;
+            v.size = here; v.tp1 = st >> 32; v.tot = P.h_tot[base + t]; v.bp = P.h_bp[base + t];
         }
         Sums x = wave_incl_scan(v, lane);
         if (lane == 63) wsum[wid] = x;
@@ -303,20 +322,57 @@ __global__ void sep_dimbest_kernel(const int32_t* __restrict__ dim_first_chunk, 
     out[d].found = b.found; out[d].bin = b.bin; out[d].sens = b.sens; out[d].spec = b.spec; out[d].prod = b.prod;
 }
 
-// per-scaffold count of dps with bin <= t in the winning dimension, and the raw side of each dp
+// per-scaffold count of dps with bin <= t in the winning dimension, the raw flag of each dp, and the
+// node's total of the counts (totals[0])
 __global__ __launch_bounds__(256) void sep_final_kernel(SepDev P, int32_t d, int32_t tbin, const int32_t* __restrict__ node_scaf,
                                                        const int32_t* __restrict__ node_dpoff, int32_t m,
-                                                       int32_t* __restrict__ nle, uint8_t* __restrict__ raw)
+                                                       int32_t* __restrict__ nle, uint8_t* __restrict__ raw,
+                                                       unsigned long long* __restrict__ totals)
 {
+    __shared__ unsigned long long blk;
+    if (threadIdx.x == 0) blk = 0;
+    __syncthreads();
     const int ls = blockIdx.x * 256 + threadIdx.x;
-    if (ls >= m) return;
-    const int s = node_scaf ? node_scaf[ls] : ls;
-    const int f = P.scaf_first[s], n = P.scaf_ndps[s];
-    const int64_t o = node_dpoff ? node_dpoff[ls] : f;
-    const int32_t* col = P.bins + (int64_t)d * P.N;
     int c = 0;
-    for (int i = 0; i < n; i++) { const int le = col[f + i] <= tbin; c += le; raw[o + i] = (uint8_t)le; }
-    nle[ls] = c;
+    if (ls < m) {
+        const int s = node_scaf ? node_scaf[ls] : ls;
+        const int f = P.scaf_first[s], n = P.scaf_ndps[s];
+        const int64_t o = node_dpoff ? node_dpoff[ls] : f;
+        const int32_t* col = P.bins + (int64_t)d * P.N;
+        for (int i = 0; i < n; i++) { const int le = col[f + i] <= tbin; c += le; raw[o + i] = (uint8_t)le; }
+        nle[ls] = c;
+    }
+    if (c) atomicAdd(&blk, (unsigned long long)c);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk) atomicAdd(&totals[0], blk);
+}
+
+// ref ClusterSeparator.cpp:35-53,87-122 on the device: cluster1 is the raw side with fewer dps (tie: the
+// "<=" side); a scaffold goes to cluster1 iff at least half of its dps are there; raw flags become 1 / 2.
+// totals: [0] = dps on the "<=" side (in), [1], [2] = dps of the scaffolds assigned to cluster1 / cluster2 (out)
+__global__ __launch_bounds__(256) void sep_assign_kernel(SepDev P, const int32_t* __restrict__ node_scaf,
+                                                        const int32_t* __restrict__ node_dpoff, int32_t m, int64_t n,
+                                                        const int32_t* __restrict__ nle, uint8_t* __restrict__ raw,
+                                                        uint8_t* __restrict__ side, unsigned long long* __restrict__ totals)
+{
+    __shared__ unsigned long long b1, b2;
+    if (threadIdx.x == 0) { b1 = 0; b2 = 0; }
+    __syncthreads();
+    const long long le = (long long)totals[0];
+    const bool swap = (long long)n - le < le;
+    const int ls = blockIdx.x * 256 + threadIdx.x;
+    if (ls < m) {
+        const int s = node_scaf ? node_scaf[ls] : ls;
+        const int f = P.scaf_first[s], tot = P.scaf_ndps[s];
+        const int64_t o = node_dpoff ? node_dpoff[ls] : f;
+        const int c1 = swap ? tot - nle[ls] : nle[ls];
+        const bool to1 = c1 > 0 && 2 * (long long)c1 >= tot;
+        side[ls] = to1 ? 1 : 2;
+        atomicAdd(to1 ? &b1 : &b2, (unsigned long long)tot);
+        for (int i = 0; i < tot; i++) raw[o + i] = ((raw[o + i] != 0) != swap) ? 1 : 2;      // ref :87-90
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { if (b1) atomicAdd(&totals[1], b1); if (b2) atomicAdd(&totals[2], b2); }
 }
 
 __global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v)
@@ -575,9 +631,7 @@ int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t 
     P.scaf_first = s.d_scaf_first; P.scaf_ndps = s.d_scaf_ndps; P.scaf_len = s.d_scaf_len;
     P.scg_off = s.d_scg_off; P.scg_ids = s.d_scg_ids; P.n_scg = s.n_scg;
     P.T = s.d_T; P.Toff = s.d_Toff;
-    P.h_size = (uint32_t*)s.hist.p; P.h_tp1 = P.h_size + s.TB; P.h_tot = P.h_tp1 + s.TB;
-    // 8-byte aligned start for the 64-bit histogram
-    P.h_bp = (unsigned long long*)(((uintptr_t)(P.h_tot + s.TB) + 7) & ~(uintptr_t)7);
+    P.h_st = (unsigned long long*)s.hist.p; P.h_bp = P.h_st + s.TB; P.h_tot = (uint32_t*)(P.h_bp + s.TB);
     P.scg_lo = (int32_t*)s.scg_lohi.p; P.scg_hi = P.scg_lo + (int64_t)s.D * s.n_scg;
 
     ABW_HIP(ctx, hipMemsetAsync(s.hist.p, 0, (size_t)s.TB * (4 * 3 + 8) + 8, st));
@@ -651,35 +705,27 @@ int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t 
 
     if ((rc = abw_reserve(ctx, s.nle, (size_t)m * 4))) return rc;
     if ((rc = abw_reserve(ctx, s.raw, (size_t)n))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[9], (size_t)m + 64))) return rc;
+    unsigned long long* d_tot = (unsigned long long*)ctx->scratch[9].p;       // 3 totals, then the scaffold sides
+    uint8_t* d_side = (uint8_t*)ctx->scratch[9].p + 32;
+    ABW_HIP(ctx, hipMemsetAsync(d_tot, 0, 24, st));
     hipLaunchKernelGGL(sep_final_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, gd, gbin, d_node_scaf, d_node_dpoff, m,
-                       (int32_t*)s.nle.p, (uint8_t*)s.raw.p);
+                       (int32_t*)s.nle.p, (uint8_t*)s.raw.p, d_tot);
     ABW_LAUNCH_CHECK(ctx);
-    std::vector<int32_t> nle((size_t)m);
-    std::vector<uint8_t> raw((size_t)(dp_raw_side ? n : 0));
-    ABW_HIP(ctx, hipMemcpyAsync(nle.data(), s.nle.p, (size_t)m * 4, hipMemcpyDeviceToHost, st));
-    if (dp_raw_side) ABW_HIP(ctx, hipMemcpyAsync(raw.data(), s.raw.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(sep_assign_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, d_node_scaf, d_node_dpoff, m, n,
+                       (const int32_t*)s.nle.p, (uint8_t*)s.raw.p, d_side, d_tot);
+    ABW_LAUNCH_CHECK(ctx);
+    unsigned long long tot3[3] = {0, 0, 0};
+    ABW_HIP(ctx, hipMemcpyAsync(tot3, d_tot, 24, hipMemcpyDeviceToHost, st));
+    if (scaf_side) ABW_HIP(ctx, hipMemcpyAsync(scaf_side, d_side, (size_t)m, hipMemcpyDeviceToHost, st));
+    if (dp_raw_side) ABW_HIP(ctx, hipMemcpyAsync(dp_raw_side, s.raw.p, (size_t)n, hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));
-
-    // ref ClusterSeparator.cpp:35-53: cluster1 is the side with fewer dps (tie: the "<=" side)
-    int64_t le = 0;
-    for (int32_t i = 0; i < m; i++) le += nle[i];
-    const int64_t gt = n - le;
-    const bool swap = gt < le;
-    if (dp_raw_side) for (int64_t i = 0; i < n; i++) dp_raw_side[i] = ((raw[i] != 0) != swap) ? 1 : 2;   // ref :87-90
-    // ref :94-122: a scaffold goes to cluster1 iff at least half of its dps are there, dps follow
-    int64_t nd1 = 0, nd2 = 0;
-    std::vector<uint8_t> side((size_t)m);
-    for (int32_t i = 0; i < m; i++) {
-        const int32_t sc = scaf_ids ? scaf_ids[i] : i;
-        const int32_t tot = s.h_scaf_ndps[sc];
-        const int32_t c1 = swap ? tot - nle[i] : nle[i];
-        if (c1 > 0 && 2 * (int64_t)c1 >= tot) { side[i] = 1; nd1 += tot; } else { side[i] = 2; nd2 += tot; }
-    }
+    const int64_t nd1 = (int64_t)tot3[1], nd2 = (int64_t)tot3[2];
     if (nd1 >= min_ndps && nd2 >= min_ndps) {                          // ref :125-132
         out->split = 1; out->ndps1 = nd1; out->ndps2 = nd2;
-        if (scaf_side) memcpy(scaf_side, side.data(), (size_t)m);
     } else {
         out->dimension = -1; out->key = -1; out->sensitivity = 0; out->specificity = 0;   // best_separation->reset(), ref :130
+        if (scaf_side) memset(scaf_side, 0, (size_t)m);
     }
     return ABW_OK;
 }

@@ -9,6 +9,7 @@ src/abawaca.cpp:95-197 around it.
 from __future__ import annotations
 
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -65,10 +66,12 @@ class ClusterSeparatorHip:
         per = (DimBest * st.D)()
         side = np.zeros(m, dtype=np.uint8)
         raw = np.zeros(n, dtype=np.uint8)
+        t0 = time.perf_counter()
         st.ctx.check(lib().abw_sep_node(st.ctx.handle,
                                         C.c_void_p(self.scaf_ids.ctypes.data) if self.scaf_ids is not None else None,
                                         m, self.cluster_ndps_threshold, C.byref(out), per,
                                         C.c_void_p(side.ctypes.data), C.c_void_p(raw.ctypes.data)))
+        self.last_call_s = time.perf_counter() - t0          # the C-ABI call alone (host buffers in and out)
         self._res, self._side, self._raw, self._ids = out, side, raw, ids
         self._per = np.array([(p.found, p.key, p.sensitivity, p.specificity) for p in per],
                              dtype=[("found", "i4"), ("key", "i4"), ("sens", "f8"), ("spec", "f8")])
