@@ -30,7 +30,13 @@ namespace {
 
 constexpr int NARROW_T = 1024;      // dimensions with keys in [0, NARROW_T) use the key itself as bin
 constexpr int SCAN_CH = 2048;       // bins per scan chunk
-constexpr int ACC_SPB = 2048;       // scaffolds per workgroup in sep_accum
+#ifndef ABW_ACC_SPB
+#define ABW_ACC_SPB 2048
+#endif
+#ifndef ABW_ACC_COPIES
+#define ABW_ACC_COPIES 1
+#endif
+constexpr int ACC_SPB = ABW_ACC_SPB;       // scaffolds per workgroup in sep_accum
 constexpr int MAX_SCG = 4096;
 
 struct DimBestDev { int32_t found; int32_t bin; double sens; double spec; double prod; };
@@ -66,14 +72,16 @@ __device__ inline int32_t select_kth_mem(const int32_t* __restrict__ col, int n,
 // Histogram updates of one (scaffold, dimension): per dp ONE 64-bit add of (size += 1, tp1 += [v >= t_s])
 // at bin v, where the dps below the flip value are credited to tp1 at bin t_s together with the dps
 // that sit on it (tp1 counts max(v, t_s) <= t); per scaffold tot[t_s] += n and bp[t_s] += len.
-constexpr int ACC_COPIES = 4;       // LDS copies of the (size, tp1) histogram, by lane: signature values cluster
-                                    // on a handful of bins, and same-address LDS atomics of a wave serialise
+constexpr int ACC_COPIES = ABW_ACC_COPIES;       // LDS copies of the (size, tp1) histograms, by lane.  Measured (r01): 1 copy 0.25 ms,
+                                    // 4 copies 0.40 ms for the 179 narrow dimensions -- zeroing and flushing cost more than
+                                    // the same-bin contention they remove
 
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t* __restrict__ dimlist,
                                                        const int32_t* __restrict__ node_scaf, int32_t m)
 {
-    __shared__ unsigned long long s_st[USE_LDS ? ACC_COPIES * NARROW_T : 1];
+    __shared__ uint32_t s_size[USE_LDS ? ACC_COPIES * NARROW_T : 1];    // LDS atomics: 32-bit ones are the fast ones
+    __shared__ uint32_t s_tp1[USE_LDS ? ACC_COPIES * NARROW_T : 1];
     __shared__ uint32_t s_tot[USE_LDS ? NARROW_T : 1];
     __shared__ unsigned long long s_bp[USE_LDS ? NARROW_T : 1];
     const int d = dimlist[blockIdx.y];
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t*
     if (USE_LDS) {
         for (int t = threadIdx.x; t < T; t += 256) {
 #pragma unroll
-            for (int c = 0; c < ACC_COPIES; c++) s_st[c * NARROW_T + t] = 0;
+            for (int c = 0; c < ACC_COPIES; c++) { s_size[c * NARROW_T + t] = 0; s_tp1[c * NARROW_T + t] = 0; }
             s_tot[t] = 0; s_bp[t] = 0;
         }
         __syncthreads();
@@ -91,7 +99,8 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t*
     unsigned long long* g_st = P.h_st + toff;
     uint32_t* g_tot = P.h_tot + toff;
     unsigned long long* g_bp = P.h_bp + toff;
-    unsigned long long* my_st = USE_LDS ? s_st + (threadIdx.x & (ACC_COPIES - 1)) * NARROW_T : g_st;
+    uint32_t* my_size = s_size + (threadIdx.x & (ACC_COPIES - 1)) * NARROW_T;
+    uint32_t* my_tp1 = s_tp1 + (threadIdx.x & (ACC_COPIES - 1)) * NARROW_T;
     constexpr unsigned long long BOTH = 1ull | (1ull << 32);
 
     const int ls_end = min(m, (int)(blockIdx.x + 1) * ACC_SPB);
@@ -105,34 +114,64 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t*
             int v[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = (i < n) ? col[f + i] : INT_MAX;
-            ts = 0;
+            {
+                // k-th smallest of the n values (the tail is padded with INT_MAX): Batcher's 19-comparator
+                // network on a copy, then the element at k = n/2 (1..4)
+                int w[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                int rank = 0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) rank += (v[j] < v[i]) || (v[j] == v[i] && j < i);
-                if (i < n && rank == k) ts = v[i];
+                for (int i = 0; i < 8; i++) w[i] = v[i];
+#define ABW_CX(a, b) { const int lo_ = min(w[a], w[b]), hi_ = max(w[a], w[b]); w[a] = lo_; w[b] = hi_; }
+                ABW_CX(0, 1) ABW_CX(2, 3) ABW_CX(4, 5) ABW_CX(6, 7)
+                ABW_CX(0, 2) ABW_CX(1, 3) ABW_CX(4, 6) ABW_CX(5, 7)
+                ABW_CX(1, 2) ABW_CX(5, 6)
+                ABW_CX(0, 4) ABW_CX(1, 5) ABW_CX(2, 6) ABW_CX(3, 7)
+                ABW_CX(2, 4) ABW_CX(3, 5)
+                ABW_CX(1, 2) ABW_CX(3, 4) ABW_CX(5, 6)
+#undef ABW_CX
+                ts = (k == 1) ? w[1] : (k == 2) ? w[2] : (k == 3) ? w[3] : w[4];
             }
-            unsigned long long at_ts = 0;                  // everything that lands on bin t_s, in one add
+            if (USE_LDS) {
+                uint32_t tp_ts = 0;                        // dps at or below the flip value: tp1 credits bin t_s
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (i < n) {
-                    if (v[i] > ts) atomicAdd(&my_st[v[i]], BOTH);
-                    else if (v[i] < ts) { atomicAdd(&my_st[v[i]], 1ull); at_ts += 1ull << 32; }
-                    else at_ts += BOTH;
+                for (int i = 0; i < 8; i++) {
+                    if (i < n) {
+                        atomicAdd(&my_size[v[i]], 1u);
+                        if (v[i] > ts) atomicAdd(&my_tp1[v[i]], 1u); else tp_ts++;
+                    }
                 }
+                atomicAdd(&my_tp1[ts], tp_ts);
+            } else {
+                unsigned long long at_ts = 0;              // everything that lands on bin t_s, in one add
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (i < n) {
+                        if (v[i] > ts) atomicAdd(&g_st[v[i]], BOTH);
+                        else if (v[i] < ts) { atomicAdd(&g_st[v[i]], 1ull); at_ts += 1ull << 32; }
+                        else at_ts += BOTH;
+                    }
+                }
+                atomicAdd(&g_st[ts], at_ts);
             }
-            atomicAdd(&my_st[ts], at_ts);
         } else {
             ts = select_kth_mem(col + f, n, k, T);
-            unsigned long long at_ts = 0;
-            for (int i = 0; i < n; i++) {
-                const int v = col[f + i];
-                if (v > ts) atomicAdd(&my_st[v], BOTH);
-                else if (v < ts) { atomicAdd(&my_st[v], 1ull); at_ts += 1ull << 32; }
-                else at_ts += BOTH;
+            if (USE_LDS) {
+                uint32_t tp_ts = 0;
+                for (int i = 0; i < n; i++) {
+                    const int v = col[f + i];
+                    atomicAdd(&my_size[v], 1u);
+                    if (v > ts) atomicAdd(&my_tp1[v], 1u); else tp_ts++;
+                }
+                atomicAdd(&my_tp1[ts], tp_ts);
+            } else {
+                unsigned long long at_ts = 0;
+                for (int i = 0; i < n; i++) {
+                    const int v = col[f + i];
+                    if (v > ts) atomicAdd(&g_st[v], BOTH);
+                    else if (v < ts) { atomicAdd(&g_st[v], 1ull); at_ts += 1ull << 32; }
+                    else at_ts += BOTH;
+                }
+                atomicAdd(&g_st[ts], at_ts);
             }
-            atomicAdd(&my_st[ts], at_ts);
         }
         if (USE_LDS) { atomicAdd(&s_tot[ts], (uint32_t)n); atomicAdd(&s_bp[ts], (unsigned long long)P.scaf_len[s]); }
         else { atomicAdd(&g_tot[ts], (uint32_t)n); atomicAdd(&g_bp[ts], (unsigned long long)P.scaf_len[s]); }
@@ -149,7 +188,7 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t*
         for (int t = threadIdx.x; t < T; t += 256) {
             unsigned long long a = 0;
 #pragma unroll
-            for (int c = 0; c < ACC_COPIES; c++) a += s_st[c * NARROW_T + t];
+            for (int c = 0; c < ACC_COPIES; c++) a += (unsigned long long)s_size[c * NARROW_T + t] | ((unsigned long long)s_tp1[c * NARROW_T + t] << 32);
             const uint32_t c3 = s_tot[t];
             const unsigned long long e = s_bp[t];
             if (a) atomicAdd(&g_st[t], a);
