@@ -285,13 +285,15 @@ def main():
     flops_per_unit = 4 * (D + 1)
     ms_avg = ms_launch / max(n_launch, 1)
     achieved = N * R * flops_per_unit / (ms_avg * 1e-3) / 1e12
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_km_step.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    # HBM bytes per launch from the committed PMC passes (profiles/pmc_r01.json; collected on this
+    # workload with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as the microarchitecture guide says)
+    pmc_all = {}
+    try:
+        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_r01.json")))
+    except Exception:
+        pmc_all = {}
+    default_workload = (args.scaffolds, args.samples, R, args.sig_mbp) == (200000, 10, 64, 1000)
+    traffic = pmc_all.get("km_step_kernel", {}).get("hbm_bytes_per_launch") if default_workload else None
     roofline = dict(kernel="km_step_kernel", bound="mfma", achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TFLOPS,
                     unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                     launches=n_launch, ms_per_launch=round(ms_avg, 4), flops_per_unit=flops_per_unit,
@@ -334,7 +336,8 @@ def main():
                                 split=int(sep._res.split), dimension=int(sep._res.dimension), load_s=round(load_s, 2),
                                 roofline=dict(kernel="sep_accum_kernel", bound="hbm", achieved=round(alg_bytes / (msa / na * 1e-3) / 1e9, 1),
                                               peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg_bytes / (msa / na * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                              traffic=None, ms_per_launch=round(msa / na, 4), eval_ms=round(mse / max(ne, 1), 4)))
+                                              traffic=pmc_all.get("sep_accum_kernel", {}).get("hbm_bytes_per_launch_raw") if default_workload else None,
+                                              ms_per_launch=round(msa / na, 4), eval_ms=round(mse / max(ne, 1), 4)))
         del store
 
         blob, off = make_assembly_blob(20244, args.sig_mbp)
@@ -370,7 +373,8 @@ def main():
                                 ms_per_pass=sig_s * 1e3, resident="ASCII in HBM; segmentation + counting + fp64 finalisation timed",
                                 roofline=dict(kernel="sig_count_kernel", bound="hbm", achieved=round(alg / (msc / nc * 1e-3) / 1e9, 1),
                                               peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg / (msc / nc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                              traffic=None, ms_per_launch=round(msc / nc, 4), segment_ms=round(mss / max(ns, 1), 4)))
+                                              traffic=pmc_all.get("sig_count_kernel", {}).get("hbm_bytes_per_launch") if default_workload else None,
+                                              ms_per_launch=round(msc / nc, 4), segment_ms=round(mss / max(ns, 1), 4)))
         del t_ascii, t_dims
 
     # ---------------- CPU baselines (rank 0, N = 1 only) -------------------------------------------
