@@ -58,7 +58,7 @@ struct abw_prof {
 
 // k-means run in progress (abw_km_shard_* phase API; abw_km_run_dev drives the same phases itself)
 struct abw_km_state {
-    bool active = false;
+    bool active = false, single = false;    // single: abw_km_run_dev drives the phases itself, no exchange
     const float* x = nullptr;
     int64_t N = 0, first = 0, N_total = 0, nchunks = 0, ngroups = 0, elems = 0;
     int d = 0, R = 0, Rp = 0, W = 0, DT = 0, chunk = 0;

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void km_sum_groups_kernel(const double* __rest
 // Level 2b: one workgroup per restart takes the (all-shard) sums of cluster 1, derives
 // cluster 0 from the totals, then either moves both centroids and rebuilds the discriminant row
 // (update = 1) or contributes the restart's two inertia terms (update = 0).
-__global__ void km_update_kernel(const double* __restrict__ sums, const double* __restrict__ tot,
+__global__ void km_update_kernel(const double* __restrict__ sums, int64_t nparts, const double* __restrict__ tot,
                                  int Rp, int W, int d, float* __restrict__ cent, float* __restrict__ dT, int update,
                                  double* __restrict__ col_term)
 {
@@ -434,7 +434,8 @@ __global__ void km_update_kernel(const double* __restrict__ sums, const double* 
     double* s0 = sh; double* s1 = sh + W;
     float* c0 = (float*)(sh + 2 * W); float* c1 = c0 + W;
     for (int j = threadIdx.x; j < W; j += blockDim.x) {
-        const double s = sums[(int64_t)r * W + j];
+        double s = 0.0;                       // nparts = 1: combined sums; > 1: this run's own group partials, in order
+        for (int64_t g = 0; g < nparts; g++) s += sums[g * (int64_t)Rp * W + (int64_t)r * W + j];
         s1[j] = s;
         s0[j] = (j <= d) ? tot[j] - s : 0.0;
     }
@@ -462,32 +463,35 @@ __global__ void km_update_kernel(const double* __restrict__ sums, const double* 
 }
 
 // Per dimension j, once per call: T[j] = sum_p x[j][p] and sum_p x[j][p]^2, each as 256 strided fp64
-// partials followed by a fixed butterfly.  tot[d] = N (the count column of the totals).
-__global__ __launch_bounds__(256) void km_moments_kernel(const float* __restrict__ x, int64_t N, int d,
-                                                        double* __restrict__ tot, double* __restrict__ x2_dim)
+// partials followed by a fixed butterfly: xor steps inside each group of 64 partials (one wave per
+// group, so all CUs stream), then (w0 + w1) + (w2 + w3).  tot[d] = N (the count column of the totals).
+__global__ __launch_bounds__(64) void km_moments_kernel(const float* __restrict__ x, int64_t N, double* __restrict__ wpart)
 {
-    __shared__ double w[2][4];
-    const int j = blockIdx.x;
+    const int j = blockIdx.x, g = blockIdx.y;
     const float* row = x + (int64_t)j * N;
     double a1 = 0.0, a2 = 0.0;
-    int64_t p = threadIdx.x;
-    for (; p + 15 * 256 < N; p += 16 * 256) {                // 16 loads in flight; the adds keep their order
-        float v[16];
+    int64_t p = g * 64 + threadIdx.x;
+    for (; p + 31 * 256 < N; p += 32 * 256) {                // 32 loads in flight; the adds keep their order
+        float v[32];
 #pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = row[p + u * 256];
+        for (int u = 0; u < 32; u++) v[u] = row[p + u * 256];
 #pragma unroll
-        for (int u = 0; u < 16; u++) { const double w2 = (double)v[u]; a1 += w2; a2 += w2 * w2; }
+        for (int u = 0; u < 32; u++) { const double w2 = (double)v[u]; a1 += w2; a2 += w2 * w2; }
     }
     for (; p < N; p += 256) { const double v = (double)row[p]; a1 += v; a2 += v * v; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
-    if ((threadIdx.x & 63) == 0) { w[0][threadIdx.x >> 6] = a1; w[1][threadIdx.x >> 6] = a2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        tot[j] = (w[0][0] + w[0][1]) + (w[0][2] + w[0][3]);
-        x2_dim[j] = (w[1][0] + w[1][1]) + (w[1][2] + w[1][3]);
-        if (j == 0) tot[d] = (double)N;
-    }
+    if (threadIdx.x == 0) { wpart[(j * 4 + g) * 2] = a1; wpart[(j * 4 + g) * 2 + 1] = a2; }
+}
+
+__global__ void km_moments_finish_kernel(const double* __restrict__ wpart, int64_t N, int d, double* __restrict__ tot, double* __restrict__ x2_dim)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) tot[d] = (double)N;
+    if (j >= d) return;
+    const double* w = wpart + (int64_t)j * 8;
+    tot[j] = (w[0] + w[2]) + (w[4] + w[6]);
+    x2_dim[j] = (w[1] + w[3]) + (w[5] + w[7]);
 }
 
 __global__ void km_inertia_kernel(const double* __restrict__ x2_dim, int d, const double* __restrict__ col_term, int R,
@@ -637,12 +641,16 @@ int abw_km_shard_begin(abw_ctx* ctx, const float* d_x, int64_t N_local, int64_t 
     {
         ABW_PROF(ctx, "km_moments");
         ABW_HIP(ctx, hipMemsetAsync(k.moments, 0, mom_bytes, st));
-        hipLaunchKernelGGL(km_moments_kernel, dim3(d), dim3(256), 0, st, d_x, N_local, d, k.moments, k.moments + k.W);
+        double* wpart = k.gsum;                             // 8 doubles per dimension; the group sums are not in use yet
+        hipLaunchKernelGGL(km_moments_kernel, dim3(d, 4), dim3(64), 0, st, d_x, N_local, wpart);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(km_moments_finish_kernel, dim3((d + 63) / 64), dim3(64), 0, st, wpart, N_local, d, k.moments, k.moments + k.W);
         ABW_LAUNCH_CHECK(ctx);
     }
     ex->d_init = k.cent; ex->init_count = (uint64_t)k.Rp * 2 * k.W;
     ex->d_moments = k.moments; ex->moments_count = (uint64_t)(k.W + d);
     ex->d_sums = k.sums; ex->sums_count = (uint64_t)k.elems;
+    k.single = false;
     k.active = true;
     return ABW_OK;
 }
@@ -682,8 +690,10 @@ int abw_km_shard_step(abw_ctx* ctx, uint8_t* d_assign)
     hipLaunchKernelGGL(km_group_kernel, dim3((unsigned)((k.elems + 255) / 256), (unsigned)k.ngroups), dim3(256), 0, ctx->stream,
                        k.slabs, k.nchunks, k.elems, k.gsum);
     ABW_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(km_sum_groups_kernel, dim3((unsigned)((k.elems + 255) / 256)), dim3(256), 0, ctx->stream, k.gsum, k.ngroups, k.elems, k.sums);
-    ABW_LAUNCH_CHECK(ctx);
+    if (!k.single) {                          // a lone shard skips the copy: its update reads the group partials
+        hipLaunchKernelGGL(km_sum_groups_kernel, dim3((unsigned)((k.elems + 255) / 256)), dim3(256), 0, ctx->stream, k.gsum, k.ngroups, k.elems, k.sums);
+        ABW_LAUNCH_CHECK(ctx);
+    }
     return ABW_OK;
 }
 
@@ -695,7 +705,8 @@ int abw_km_shard_update(abw_ctx* ctx, int32_t last)
     abw_km_state& k = ctx->km;
     ABW_PROF(ctx, "km_update");
     const size_t upd_lds = (size_t)k.W * 16 + (size_t)k.W * 8;
-    hipLaunchKernelGGL(km_update_kernel, dim3(k.Rp), dim3(k.W), upd_lds, ctx->stream, k.sums, k.moments, k.Rp, k.W, k.d, k.cent, k.dT,
+    hipLaunchKernelGGL(km_update_kernel, dim3(k.Rp), dim3(k.W), upd_lds, ctx->stream, k.single ? k.gsum : k.sums, k.single ? k.ngroups : (int64_t)1,
+                       k.moments, k.Rp, k.W, k.d, k.cent, k.dT,
                        last ? 0 : 1, k.col_term);
     ABW_LAUNCH_CHECK(ctx);
     return ABW_OK;
@@ -728,6 +739,7 @@ int abw_km_run_dev(abw_ctx* ctx, const float* d_x, int64_t N, int32_t d, int32_t
     abw_km_exchange ex;
     int rc = abw_km_shard_begin(ctx, d_x, N, 0, N, d, R, base_seed, chunk, &ex);     // one shard: nothing to exchange
     if (rc) return rc;
+    ctx->km.single = true;
     if ((rc = abw_km_shard_ready(ctx))) return rc;
     for (int it = 0; it <= iters; it++) {
         const bool last = it == iters;

@@ -11,7 +11,7 @@ for rep in range(2):
     ctx.prof_reset(); ctx.prof_enable(True)
     kmeans.kmeans_restarts_dev(ctx, x, N, d, R, 1234, iters, chunk, asg, cent, inert)
     ctx.synchronize()
-    print("chunk", chunk, {k: ctx.prof_read(k) for k in ("km_step", "km_update", "km_totals")})
+    print("chunk", chunk, {k: ctx.prof_read(k) for k in ("km_step", "km_update", "km_moments")})
     ctx.prof_enable(False)
 s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize(); s.record()
