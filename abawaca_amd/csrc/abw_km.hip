@@ -611,7 +611,7 @@ int abw_km_shard_begin(abw_ctx* ctx, const float* d_x, int64_t N_local, int64_t 
     if (chunk == 0) chunk = abw_km_auto_chunk(ctx, N_local, R);
     if (chunk < 32 || (chunk & 31)) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_shard_begin: chunk must be a positive multiple of 32");
     const int DT = (d + 1 + 31) / 32;                       // dims + the count column, in 32-wide tiles
-    if (DT > 7) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_shard_begin: d = %d not supported (max 222)", d);
+    if (DT > 7) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_shard_begin: d = %d not supported (max 223)", d);
     abw_device_guard g(ctx->device);
     abw_km_state& k = ctx->km;
     k.x = d_x; k.N = N_local; k.first = first_point; k.N_total = N_total; k.d = d; k.R = R; k.seed = base_seed; k.chunk = chunk;

@@ -157,7 +157,7 @@ const int32_t* abw_sep_dev_keys(const abw_ctx* ctx);
  * bit-reproducible output across devices passes an explicit chunk instead.  (No reference counterpart.) */
 int32_t abw_km_auto_chunk(const abw_ctx* ctx, int64_t N, int32_t R);
 
-/* d_x: device [d][N] fp32 dimension-major points, d <= 222.  k = 2.  R restarts are run
+/* d_x: device [d][N] fp32 dimension-major points, d <= 223.  k = 2.  R restarts are run
  * together; restart r seeds TinyMT32 with base_seed + r.  chunk: points per fp32 partial sum
  * (multiple of 32; 0 = abw_km_auto_chunk).  Outputs are device pointers (any may be NULL):
  *   d_assign    [R][N] u8   cluster of every point after the final assign pass

@@ -38,8 +38,8 @@ void km_load(const ScafDpData& scaf_db, const ClusterData& root)
 	const size_t N = scaf_db.ndps(), D = root.ndimensions();
 	if(root.ndps() != N)
 		throw std::invalid_argument("ClusterSeparatorKMeans: the first node must hold every datapoint (root of the recursion)");
-	if(D > 222)
-		throw std::invalid_argument("ClusterSeparatorKMeans: more than 222 dimensions");
+	if(D > 223)
+		throw std::invalid_argument("ClusterSeparatorKMeans: more than 223 dimensions");
 	st.scaf_db = &scaf_db; st.N = N; st.D = D;
 	st.x.assign(D * N, 0.0f);
 	for(size_t d = 0; d < D; d++) {

@@ -55,3 +55,27 @@ def test_kmeans_recovers_planted_clusters(ctx):
     pts = x.T.astype(np.float64)
     direct = ((pts - c[best][a[best]].astype(np.float64)) ** 2).sum()
     assert abs(direct - inert[best]) / direct < 1e-6
+
+
+def test_argument_and_state_errors_are_reported_not_faulted(ctx):
+    import ctypes as C
+    L = _lib.lib()
+    x = np.zeros((4, 16), dtype=np.float32)
+    a = np.zeros((1, 16), dtype=np.uint8)
+    # fewer than 32 points, too many dimensions, bad chunk: error codes, message available, no launch
+    rc = L.abw_km_run(ctx.handle, C.c_void_p(x.ctypes.data), 16, 4, 1, 1, 1, 0, C.c_void_p(a.ctypes.data), None, None)
+    assert rc == _lib.ABW_ERR_ARG and b"32" in L.abw_last_error(ctx.handle)
+    big = np.zeros((224, 64), dtype=np.float32)
+    rc = L.abw_km_run(ctx.handle, C.c_void_p(big.ctypes.data), 64, 224, 1, 1, 1, 0, None, None, None)
+    assert rc == _lib.ABW_ERR_ARG and b"223" in L.abw_last_error(ctx.handle)
+    ok = np.zeros((4, 64), dtype=np.float32)
+    rc = L.abw_km_run(ctx.handle, C.c_void_p(ok.ctypes.data), 64, 4, 1, 1, 1, 48, None, None, None)
+    assert rc == _lib.ABW_ERR_ARG and b"multiple of 32" in L.abw_last_error(ctx.handle)
+    # phase calls without a run in progress
+    assert L.abw_km_shard_step(ctx.handle, None) == _lib.ABW_ERR_STATE
+    assert L.abw_km_shard_update(ctx.handle, 0) == _lib.ABW_ERR_STATE
+    assert L.abw_km_shard_finish(ctx.handle, None, None) == _lib.ABW_ERR_STATE
+    # identical points: every restart collapses to one cluster, nothing divides by zero
+    same = np.ones((3, 96), dtype=np.float32)
+    asg, cen, ine = kmeans.kmeans_restarts(ctx, same, 2, base_seed=3, iters=2, chunk=32)
+    assert np.all(asg == 0) and np.all(ine == 0.0) and np.all(cen == 1.0)
