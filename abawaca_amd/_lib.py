@@ -21,6 +21,7 @@ EXPORTS = [
     "abw_abi_version", "abw_prof_enable", "abw_prof_reset", "abw_prof_read", "abw_sig_dim_names", "abw_sig_segment_host", "abw_sig_segment_dev", "abw_sig_count_dev",
     "abw_sig_build", "abw_sep_load", "abw_sep_node", "abw_sep_dev_keys", "abw_km_run_dev", "abw_km_run",
     "abw_km_features_from_keys", "abw_km_tinymt_selftest", "abw_km_auto_chunk",
+    "abw_cov_accumulate", "abw_cov_accumulate_dev",
     "abw_km_shard_begin", "abw_km_shard_ready", "abw_km_shard_step", "abw_km_shard_update", "abw_km_shard_finish",
 ]
 
@@ -76,6 +77,8 @@ def lib():
     L.abw_km_run.argtypes = [vp, vp, i64, i32, i32, u32, i32, i32, vp, vp, vp]
     L.abw_km_features_from_keys.argtypes = [vp, vp, i32, i64, vp, vp]
     L.abw_km_tinymt_selftest.argtypes = [vp, u32, i32, vp]
+    L.abw_cov_accumulate.argtypes = [vp, vp, vp, vp, u64, u64, vp, vp, vp, u64, vp]
+    L.abw_cov_accumulate_dev.argtypes = [vp, vp, vp, vp, u64, u64, vp, vp, vp, u64, vp]
     L.abw_km_shard_begin.argtypes = [vp, vp, i64, i64, i64, i32, i32, u32, i32, vp]
     L.abw_km_shard_ready.argtypes = [vp]
     L.abw_km_shard_step.argtypes = [vp, vp]

@@ -1,0 +1,42 @@
+"""Row N1 — per-segment read coverage on the GPU (abw_cov_accumulate), host-side glue.
+
+`filter_reads` is the part of reference src/abawaca-build.cpp:546 the caller keeps (unmapped, secondary;
+the > 15 SNPs rule needs the MD tag and stays with the reference's SAM parser) and the 1-based SAM POS ->
+0-based position of reference src/ReadMapping.cpp:41."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import Context, lib
+
+
+def filter_reads(read_scaf, read_pos1, read_len, read_flag):
+    """-> (scaf u32, pos0 u64, len u32) of the mappings the reference accumulates, order kept."""
+    read_flag = np.asarray(read_flag)
+    keep = ((read_flag & 0x4) == 0) & ((read_flag & 0x100) == 0)
+    pos0 = np.asarray(read_pos1, dtype=np.int64)[keep] - 1
+    return (np.ascontiguousarray(np.asarray(read_scaf, dtype=np.uint32)[keep]),
+            np.ascontiguousarray(pos0.astype(np.uint64)),
+            np.ascontiguousarray(np.asarray(read_len, dtype=np.uint32)[keep]))
+
+
+def accumulate(ctx: Context, seg_scaf, seg_start, seg_end, n_scaf: int, read_scaf, read_pos0, read_len, cov=None):
+    """cov[g] += overlap / segment length for every read in order (fp64); returns cov."""
+    seg_scaf = np.ascontiguousarray(seg_scaf, dtype=np.uint32)
+    seg_start = np.ascontiguousarray(seg_start, dtype=np.uint64)
+    seg_end = np.ascontiguousarray(seg_end, dtype=np.uint64)
+    read_scaf = np.ascontiguousarray(read_scaf, dtype=np.uint32)
+    read_pos0 = np.ascontiguousarray(read_pos0, dtype=np.uint64)
+    read_len = np.ascontiguousarray(read_len, dtype=np.uint32)
+    out = np.zeros(len(seg_scaf), dtype=np.float64) if cov is None else np.ascontiguousarray(cov, dtype=np.float64)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    ctx.check(lib().abw_cov_accumulate(ctx.handle, p(seg_scaf), p(seg_start), p(seg_end), len(seg_scaf), int(n_scaf),
+                                       p(read_scaf), p(read_pos0), p(read_len), len(read_scaf), p(out)))
+    return out
+
+
+def milli(cov):
+    """the thousandths abawaca.lrn prints (ref src/abawaca-build.cpp:603: int(1000.0 * x))"""
+    return (1000.0 * np.asarray(cov, dtype=np.float64)).astype(np.int64)

@@ -1,0 +1,170 @@
+// Row N1 — per-segment read coverage of abawaca-build.
+//
+// Reference semantics (src/abawaca-build.cpp:231-244 Scaf::add_mapped_read, :177-185
+// Scaf_segment::add_mapped_read, read parsed by src/ReadMapping.cpp:38-44): a mapping with 0-based
+// position p (= SAM POS - 1) and read length l covers [s, e] = [p, p + l - 1]; it is compared AS IS with
+// the 1-based inclusive segment coordinates (start, end) of its scaffold -- the reference's own
+// off-by-one, kept -- and every segment with s <= end and e >= start receives
+//     double(min(e, end) - max(s, start) + 1) / double(end - start + 1)
+// added to its fp64 accumulator IN THE ORDER OF THE SAM FILE.  fp64 addition does not commute in the
+// last bit and abawaca.lrn prints int(1000 * x), so the order is part of the result: contributions are
+// emitted in read order, brought together per segment by a stable radix sort on the segment index
+// (rocPRIM; a library sort, not a hot kernel), and added by one thread per segment in that order.
+// The filter (unmapped / > 15 SNPs / secondary, ref :546) stays with the caller's SAM parser.
+#include "abw_internal.h"
+#include <string.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace {
+
+// first segment of every scaffold (segments arrive grouped by scaffold, ascending start): seg_first[s] ..
+// seg_first[s + 1]; scaffolds without segments get an empty range
+__global__ void cov_seg_first_kernel(const uint32_t* __restrict__ seg_scaf, uint64_t n_seg, uint64_t n_scaf, uint64_t* __restrict__ seg_first)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_seg) return;
+    const uint64_t prev = (i == 0) ? 0 : (uint64_t)seg_scaf[i - 1] + 1;       // scaffolds up to prev-1 end before segment i
+    const uint64_t next = (i == n_seg) ? n_scaf + 1 : (uint64_t)seg_scaf[i] + 1;
+    for (uint64_t s = prev; s < next && s <= n_scaf; s++) seg_first[s] = i;    // scaffolds prev..next-1 start at segment i
+}
+
+// segments [lo, hi) of the read's scaffold that the read touches: first with end >= s (binary search), then
+// forward while start <= e
+__device__ __forceinline__ void read_span(const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ seg_end,
+                                          uint64_t f0, uint64_t f1, uint64_t s, uint64_t e, uint64_t& lo, uint64_t& hi)
+{
+    uint64_t a = f0, b = f1;
+    while (a < b) { const uint64_t m = (a + b) >> 1; if (seg_end[m] >= s) b = m; else a = m + 1; }
+    lo = a;
+    hi = a;
+    while (hi < f1 && seg_start[hi] <= e) hi++;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void cov_pairs_kernel(const uint32_t* __restrict__ read_scaf, const uint64_t* __restrict__ read_pos,
+                                                       const uint32_t* __restrict__ read_len, uint64_t n_reads, uint64_t n_scaf,
+                                                       const uint64_t* __restrict__ seg_first, const uint64_t* __restrict__ seg_start,
+                                                       const uint64_t* __restrict__ seg_end,
+                                                       uint32_t* __restrict__ count, const uint64_t* __restrict__ offset,
+                                                       uint32_t* __restrict__ key, double* __restrict__ val)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t sc = read_scaf[r];
+    uint64_t lo = 0, hi = 0;
+    const uint64_t s = read_pos[r], l = read_len[r];
+    if (sc < n_scaf && l > 0) read_span(seg_start, seg_end, seg_first[sc], seg_first[sc + 1], s, s + l - 1, lo, hi);
+    if (!EMIT) { count[r] = (uint32_t)(hi - lo); return; }
+    const uint64_t e = s + l - 1;
+    uint64_t o = offset[r];
+    for (uint64_t g = lo; g < hi; g++, o++) {
+        const uint64_t st = seg_start[g], en = seg_end[g];
+        const uint64_t a = (s < st) ? st : s, b = (e > en) ? en : e;           // ref :181-182
+        key[o] = (uint32_t)g;
+        val[o] = (double)(b - a + 1) / (double)(en - st + 1);                  // ref :183
+    }
+}
+
+// one thread per run of equal keys: its contributions in (stable-sorted = read) order
+__global__ __launch_bounds__(256) void cov_sum_kernel(const uint32_t* __restrict__ key, const double* __restrict__ val, uint64_t n_pairs,
+                                                     double* __restrict__ cov)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pairs) return;
+    const uint32_t g = key[i];
+    if (i > 0 && key[i - 1] == g) return;                                      // not the head of a run
+    double acc = cov[g];
+    for (uint64_t j = i; j < n_pairs && key[j] == g; j++) acc += val[j];
+    cov[g] = acc;
+}
+
+}  // namespace
+
+// the scan of abw_sig.hip (two-level, scratch[8])
+int abw_device_scan_u32(abw_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out);
+
+extern "C" int abw_cov_accumulate_dev(abw_ctx* ctx, const uint32_t* d_seg_scaf, const uint64_t* d_seg_start, const uint64_t* d_seg_end,
+                                      uint64_t n_seg, uint64_t n_scaf, const uint32_t* d_read_scaf, const uint64_t* d_read_pos,
+                                      const uint32_t* d_read_len, uint64_t n_reads, double* d_cov)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (n_reads == 0 || n_seg == 0) return ABW_OK;
+    if (!d_seg_scaf || !d_seg_start || !d_seg_end || !d_read_scaf || !d_read_pos || !d_read_len || !d_cov)
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_cov_accumulate_dev: null argument");
+    if (n_seg >= 0xFFFFFFFFull || n_reads >= 0xFFFFFFFFull) return abw_fail(ctx, ABW_ERR_ARG, "abw_cov_accumulate_dev: more than 2^32-2 segments or reads per call");
+    abw_device_guard g(ctx->device);
+    hipStream_t st = ctx->stream;
+    int rc;
+    // scratch[10]: seg_first (n_scaf+2) u64 | count u32[n_reads] | offset u64[n_reads+1]
+    const size_t b_first = (n_scaf + 2) * 8, b_count = ((n_reads * 4 + 7) & ~(size_t)7), b_off = (n_reads + 1) * 8;
+    if ((rc = abw_reserve(ctx, ctx->scratch[10], b_first + b_count + b_off))) return rc;
+    uint64_t* seg_first = (uint64_t*)ctx->scratch[10].p;
+    uint32_t* count = (uint32_t*)((uint8_t*)seg_first + b_first);
+    uint64_t* offset = (uint64_t*)((uint8_t*)count + b_count);
+    ABW_PROF(ctx, "cov_accumulate");
+    hipLaunchKernelGGL(cov_seg_first_kernel, dim3((unsigned)((n_seg + 256) / 256)), dim3(256), 0, st, d_seg_scaf, n_seg, n_scaf, seg_first);
+    ABW_LAUNCH_CHECK(ctx);
+    const unsigned gr = (unsigned)((n_reads + 255) / 256);
+    hipLaunchKernelGGL((cov_pairs_kernel<false>), dim3(gr), dim3(256), 0, st, d_read_scaf, d_read_pos, d_read_len, n_reads, n_scaf, seg_first,
+                       d_seg_start, d_seg_end, count, (const uint64_t*)nullptr, (uint32_t*)nullptr, (double*)nullptr);
+    ABW_LAUNCH_CHECK(ctx);
+    if ((rc = abw_device_scan_u32(ctx, count, n_reads, offset))) return rc;
+    uint64_t n_pairs = 0;
+    ABW_HIP(ctx, hipMemcpyAsync(&n_pairs, offset + n_reads, 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    if (n_pairs == 0) return ABW_OK;
+    // scratch[11]: key_in | key_out (u32) | val_in | val_out (f64) | rocPRIM temporary storage
+    int bits = 1;
+    while (((uint64_t)1 << bits) < n_seg) bits++;
+    size_t tmp_bytes = 0;
+    ABW_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (double*)nullptr, (double*)nullptr,
+                                           (size_t)n_pairs, 0u, (unsigned)bits, st));
+    const size_t b_key = (n_pairs * 4 + 7) & ~(size_t)7, b_val = n_pairs * 8;
+    if ((rc = abw_reserve(ctx, ctx->scratch[11], 2 * b_key + 2 * b_val + tmp_bytes + 256))) return rc;
+    uint8_t* base = (uint8_t*)ctx->scratch[11].p;
+    uint32_t* key_in = (uint32_t*)base; uint32_t* key_out = (uint32_t*)(base + b_key);
+    double* val_in = (double*)(base + 2 * b_key); double* val_out = (double*)(base + 2 * b_key + b_val);
+    void* tmp = base + 2 * b_key + 2 * b_val;
+    hipLaunchKernelGGL((cov_pairs_kernel<true>), dim3(gr), dim3(256), 0, st, d_read_scaf, d_read_pos, d_read_len, n_reads, n_scaf, seg_first,
+                       d_seg_start, d_seg_end, (uint32_t*)nullptr, offset, key_in, val_in);
+    ABW_LAUNCH_CHECK(ctx);
+    ABW_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, key_in, key_out, val_in, val_out, (size_t)n_pairs, 0u, (unsigned)bits, st));
+    hipLaunchKernelGGL(cov_sum_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, key_out, val_out, n_pairs, d_cov);
+    ABW_LAUNCH_CHECK(ctx);
+    return ABW_OK;
+}
+
+extern "C" int abw_cov_accumulate(abw_ctx* ctx, const uint32_t* seg_scaf, const uint64_t* seg_start, const uint64_t* seg_end,
+                                  uint64_t n_seg, uint64_t n_scaf, const uint32_t* read_scaf, const uint64_t* read_pos,
+                                  const uint32_t* read_len, uint64_t n_reads, double* cov)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (n_seg == 0 || n_reads == 0) return ABW_OK;
+    if (!seg_scaf || !seg_start || !seg_end || !read_scaf || !read_pos || !read_len || !cov)
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_cov_accumulate: null argument");
+    abw_device_guard g(ctx->device);
+    hipStream_t st = ctx->stream;
+    int rc;
+    const size_t bs = n_seg * (4 + 8 + 8 + 8) + 64, br = n_reads * (4 + 8 + 4) + 64;
+    if ((rc = abw_reserve(ctx, ctx->scratch[3], bs + br))) return rc;
+    uint8_t* p = (uint8_t*)ctx->scratch[3].p;
+    uint64_t* d_start = (uint64_t*)p;              p += n_seg * 8;
+    uint64_t* d_end = (uint64_t*)p;                p += n_seg * 8;
+    double* d_cov = (double*)p;                    p += n_seg * 8;
+    uint64_t* d_rpos = (uint64_t*)p;               p += n_reads * 8;
+    uint32_t* d_sscaf = (uint32_t*)p;              p += n_seg * 4;
+    uint32_t* d_rscaf = (uint32_t*)p;              p += n_reads * 4;
+    uint32_t* d_rlen = (uint32_t*)p;
+    ABW_HIP(ctx, hipMemcpyAsync(d_start, seg_start, n_seg * 8, hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemcpyAsync(d_end, seg_end, n_seg * 8, hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemcpyAsync(d_cov, cov, n_seg * 8, hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemcpyAsync(d_sscaf, seg_scaf, n_seg * 4, hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemcpyAsync(d_rpos, read_pos, n_reads * 8, hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemcpyAsync(d_rscaf, read_scaf, n_reads * 4, hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemcpyAsync(d_rlen, read_len, n_reads * 4, hipMemcpyHostToDevice, st));
+    if ((rc = abw_cov_accumulate_dev(ctx, d_sscaf, d_start, d_end, n_seg, n_scaf, d_rscaf, d_rpos, d_rlen, n_reads, d_cov))) return rc;
+    ABW_HIP(ctx, hipMemcpyAsync(cov, d_cov, n_seg * 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    return ABW_OK;
+}

@@ -597,6 +597,9 @@ int upload_tables(abw_ctx* ctx)
 
 }  // namespace
 
+// shared with abw_cov.hip
+int abw_device_scan_u32(abw_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out) { return device_scan<uint32_t>(ctx, in, n, out); }
+
 extern "C" {
 
 int abw_sig_dim_names(char* buf, uint64_t buf_len)

@@ -148,6 +148,23 @@ int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t 
 /* Device pointer to the resident column store [D][N] int32 (for abw_km_features_from_keys). */
 const int32_t* abw_sep_dev_keys(const abw_ctx* ctx);
 
+/* ---- next row N1: per-segment read coverage (ref: src/abawaca-build.cpp:231-244 Scaf::add_mapped_read,
+ *      :177-185 Scaf_segment::add_mapped_read; the SAM filter of :546 and the parser stay with the caller) ----
+ * Segments as produced by abw_sig_segment_* (grouped by scaffold, ascending start; 1-based inclusive
+ * coordinates).  Read i maps to scaffold read_scaf[i] (an id >= n_scaf is ignored, like a reference name
+ * the reference does not know, ref :550-552) at the 0-based position read_pos[i] (= SAM POS - 1, ref
+ * src/ReadMapping.cpp:41) with read_len[i] bases, in SAM order.  cov[g] += the read's overlap with
+ * segment g divided by the segment's length, added in read order, exactly as the reference's fp64
+ * accumulator; call once per chunk of a SAM file (in order) with the same cov to continue the sums, and
+ * with a zeroed cov for the next sample.  At most 2^32-2 segments and reads per call. */
+int abw_cov_accumulate(abw_ctx* ctx, const uint32_t* seg_scaf, const uint64_t* seg_start, const uint64_t* seg_end,
+                       uint64_t n_seg, uint64_t n_scaf, const uint32_t* read_scaf, const uint64_t* read_pos,
+                       const uint32_t* read_len, uint64_t n_reads, double* cov);
+/* Same with every pointer on the device; asynchronous except for one internal size read-back. */
+int abw_cov_accumulate_dev(abw_ctx* ctx, const uint32_t* d_seg_scaf, const uint64_t* d_seg_start, const uint64_t* d_seg_end,
+                           uint64_t n_seg, uint64_t n_scaf, const uint32_t* d_read_scaf, const uint64_t* d_read_pos,
+                           const uint32_t* d_read_len, uint64_t n_reads, double* d_cov);
+
 /* ---- extension: k-means restarts (NO counterpart in the reference, see DESIGN.md "K-means";
  *      RNG = TinyMT32, ref: src/misc.cpp:24-36, src/TinyMT-src-1.0.1/tinymt/tinymt32.{c,h}) -------- */
 

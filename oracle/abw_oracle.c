@@ -399,6 +399,41 @@ uint32_t abw_or_tinymt_next(abw_or_tinymt* t)
 }
 
 /* ---------------------------------------------------------------------------------------- */
+/* Row N1: per-segment read coverage                                                         */
+/* ---------------------------------------------------------------------------------------- */
+/* ref: Scaf::add_mapped_read src/abawaca-build.cpp:231-244 (walk the scaffold's segments in order: skip
+ * while s > end, stop when e < start) and Scaf_segment::add_mapped_read :177-185 (clip, divide, add).
+ * s = read_pos (0-based, ref src/ReadMapping.cpp:41) and e = s + len - 1 are compared with the 1-based
+ * segment coordinates as they are -- the reference's own off-by-one. */
+int abw_or_coverage(const uint32_t* seg_scaf, const uint64_t* seg_start, const uint64_t* seg_end, uint64_t n_seg,
+                    uint64_t n_scaf, const uint32_t* read_scaf, const uint64_t* read_pos, const uint32_t* read_len,
+                    uint64_t n_reads, double* cov)
+{
+    uint64_t* first = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n_scaf + 2));
+    if (!first) return -2;
+    uint64_t g = 0;
+    for (uint64_t sc = 0; sc <= n_scaf; sc++) {
+        while (g < n_seg && seg_scaf[g] < sc) g++;
+        first[sc] = g;
+    }
+    first[n_scaf + 1] = n_seg;
+    for (uint64_t r = 0; r < n_reads; r++) {
+        const uint64_t sc = read_scaf[r];
+        if (sc >= n_scaf || read_len[r] == 0) continue;                 /* ref :550-552: unknown reference name */
+        const uint64_t s = read_pos[r], e = read_pos[r] + read_len[r] - 1;
+        for (uint64_t q = first[sc]; q < first[sc + 1]; q++) {
+            if (s > seg_end[q]) continue;                               /* ref :235-236 */
+            if (e < seg_start[q]) break;                                /* ref :237-238 */
+            const uint64_t a = (s < seg_start[q]) ? seg_start[q] : s;   /* ref :181 */
+            const uint64_t b = (e > seg_end[q]) ? seg_end[q] : e;       /* ref :182 */
+            cov[q] += (double)(b - a + 1) / (double)(seg_end[q] - seg_start[q] + 1);   /* ref :183 */
+        }
+    }
+    free(first);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------- */
 /* K-means restarts (extension; semantics fixed in DESIGN.md "K-means")                      */
 /* ---------------------------------------------------------------------------------------- */
 #define KM_GROUP 32   /* chunk partials are first added in groups of 32 consecutive chunks, then the groups */

@@ -98,6 +98,15 @@ void     abw_or_tinymt_init(abw_or_tinymt* t, uint32_t seed);
 uint32_t abw_or_tinymt_next(abw_or_tinymt* t);
 
 /* ------------------------------------------------------------------------------------------
+ * Row N1: per-segment read coverage (reference src/abawaca-build.cpp:231-244, :177-185).
+ * cov[g] += overlap/length for every read, in read order (fp64, the reference's accumulator).
+ * Segments grouped by scaffold, ascending; read_pos 0-based (SAM POS - 1).
+ * ------------------------------------------------------------------------------------------ */
+int abw_or_coverage(const uint32_t* seg_scaf, const uint64_t* seg_start, const uint64_t* seg_end, uint64_t n_seg,
+                    uint64_t n_scaf, const uint32_t* read_scaf, const uint64_t* read_pos, const uint32_t* read_len,
+                    uint64_t n_reads, double* cov);
+
+/* ------------------------------------------------------------------------------------------
  * K-means restarts (EXTENSION, parity unpinned — see DESIGN.md "K-means").
  * x: [d][N] fp32 dimension-major points; k = 2; R restarts.  Restart r seeds TinyMT32 with
  * base_seed + r and takes as initial centroids the points  u0 % N  and  u1 % N  (u1 redrawn, at

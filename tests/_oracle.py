@@ -193,3 +193,20 @@ def kmeans_sharded(x, R, base_seed, iters, chunk, bounds, nthreads=0):
     if rc != 0:
         raise RuntimeError("abw_or_kmeans_sharded failed: %d" % rc)
     return assign, cent, inertia
+
+
+def coverage(seg_scaf, seg_start, seg_end, n_scaf, read_scaf, read_pos, read_len, cov=None):
+    """abw_or_coverage: returns cov (fp64 [n_seg]), continuing `cov` when given."""
+    seg_scaf = np.ascontiguousarray(seg_scaf, dtype=np.uint32)
+    seg_start = np.ascontiguousarray(seg_start, dtype=np.uint64)
+    seg_end = np.ascontiguousarray(seg_end, dtype=np.uint64)
+    read_scaf = np.ascontiguousarray(read_scaf, dtype=np.uint32)
+    read_pos = np.ascontiguousarray(read_pos, dtype=np.uint64)
+    read_len = np.ascontiguousarray(read_len, dtype=np.uint32)
+    out = np.zeros(len(seg_scaf), dtype=np.float64) if cov is None else np.ascontiguousarray(cov, dtype=np.float64).copy()
+    rc = lib().abw_or_coverage(_p(seg_scaf, C.c_uint32), _p(seg_start, C.c_uint64), _p(seg_end, C.c_uint64), C.c_uint64(len(seg_scaf)),
+                               C.c_uint64(n_scaf), _p(read_scaf, C.c_uint32), _p(read_pos, C.c_uint64), _p(read_len, C.c_uint32),
+                               C.c_uint64(len(read_scaf)), _p(out, C.c_double))
+    if rc != 0:
+        raise RuntimeError("abw_or_coverage failed: %d" % rc)
+    return out

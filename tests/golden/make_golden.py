@@ -176,8 +176,64 @@ def tinymt_case():
     print("tinymt32_kat:", len(kat), "seeds")
 
 
+def cov_case(tag, seed, n_scaf, n_samples=3, read_len=150):
+    """Row N1: the coverage columns abawaca-build prints for SAM files we wrote, with the reads as arrays."""
+    asm = synth.make_assembly(seed, n_scaf, 3, n_samples, frac_n_run=0.2)
+    asm.cov[:] = np.exp(synth.rng_for(seed + 1).normal(np.log(5.0), 0.5, size=asm.cov.shape))
+    with tempfile.TemporaryDirectory(prefix="abwgold_") as wd:
+        fasta = os.path.join(wd, "asm.fa")
+        synth.write_fasta(fasta, asm)
+        for smp in range(n_samples):
+            p = os.path.join(wd, f"s{smp}.sam")
+            synth.write_sam(p, asm, smp, seed + 10 + smp, read_len=read_len)
+            # lines the reference drops (unmapped, secondary, unknown reference) and reads hanging over both
+            # scaffold ends; appended after the regular ones, order in the file = order of accumulation
+            L0 = len(asm.seqs[0])
+            seq = "A" * read_len
+            with open(p, "a") as f:
+                f.write(f"x0\t4\t*\t0\t0\t*\t*\t0\t0\t{seq}\t{'I' * read_len}\n")
+                f.write(f"x1\t256\t{asm.names[0]}\t10\t255\t{read_len}M\t*\t0\t0\t{seq}\t{'I' * read_len}\n")
+                f.write(f"x2\t0\tnot_a_scaffold\t10\t255\t{read_len}M\t*\t0\t0\t{seq}\t{'I' * read_len}\n")
+                f.write(f"x3\t0\t{asm.names[0]}\t1\t255\t{read_len}M\t*\t0\t0\t{seq}\t{'I' * read_len}\n")
+                f.write(f"x4\t0\t{asm.names[0]}\t{L0 - 20}\t255\t{read_len}M\t*\t0\t0\t{seq}\t{'I' * read_len}\n")
+                f.write(f"x5\t16\t{asm.names[1]}\t2\t255\t{read_len}M\t*\t0\t0\t{seq}\t{'I' * read_len}\n")
+        out = os.path.join(wd, "build")
+        os.makedirs(out, exist_ok=True)
+        subprocess.run([os.path.join(REF, "abawaca-build"), "-f", fasta, "-o", out, "-s", os.path.join(wd, "s*.sam"),
+                        "-c", os.path.join(wd, "s0.sam")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dp, header, milli = synth.read_lrn(os.path.join(out, "abawaca.lrn"))
+        rows = synth.read_names(os.path.join(out, "abawaca.names"))
+        name2idx = {n: i for i, n in enumerate(asm.names)}
+        rs, rp, rl, rf, roff = [], [], [], [], [0]
+        for smp in range(n_samples):
+            for ln in open(os.path.join(wd, f"s{smp}.sam")):
+                if ln.startswith("@"):
+                    continue
+                fs = ln.rstrip("\n").split("\t")
+                rs.append(name2idx.get(fs[2], 0xFFFFFFFF))
+                rp.append(int(fs[3]))                       # SAM POS as written (1-based; 0 for unmapped)
+                rl.append(len(fs[9]))
+                rf.append(int(fs[1]))
+            roff.append(len(rs))
+    seg_scaf = np.array([asm.names.index(r[2]) for r in rows], dtype=np.int32)
+    seg_start = np.array([r[3] for r in rows], dtype=np.int64)
+    seg_end = np.array([r[4] for r in rows], dtype=np.int64)
+    # rows of the .lrn come in scaffold-NAME order; the library wants them grouped by scaffold index
+    order = np.lexsort((seg_start, seg_scaf))
+    cov = milli[:, 179:179 + n_samples]
+    np.savez_compressed(os.path.join(OUT, f"cov_{tag}.npz"), n_scaf=len(asm.names),
+                        seg_scaf=seg_scaf[order], seg_start=seg_start[order], seg_end=seg_end[order],
+                        cov_milli=cov[order].astype(np.int32),
+                        read_scaf=np.array(rs, dtype=np.uint32), read_pos1=np.array(rp, dtype=np.int64),
+                        read_len=np.array(rl, dtype=np.uint32), read_flag=np.array(rf, dtype=np.uint32),
+                        read_off=np.array(roff, dtype=np.int64), header=np.array(header[179:179 + n_samples]))
+    print(f"cov_{tag}: {len(asm.names)} scaffolds, {len(rows)} segments, {len(rs)} SAM lines")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sig", "sep", "tinymt"]
+    which = sys.argv[1:] or ["sig", "sep", "tinymt", "cov"]
+    if "cov" in which:
+        cov_case("a", 31, 24)
     if "sig" in which:
         sig_case("edge", edge_assembly())
         sig_case("rand", synth.make_assembly(11, 40, 4, 1, frac_n_run=0.25))

@@ -1,0 +1,68 @@
+"""Row N1 on the GPU: abw_cov_accumulate against the reference's printed coverage columns (golden) and,
+bit for bit in fp64, against the CPU restatement -- whole files, chunked calls, random read sets with
+reads over segment boundaries, scaffold ends, unknown scaffolds and scaffolds without segments."""
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+from abawaca_amd import _lib, coverage
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def test_reference_coverage_columns(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "cov_a.npz"))
+    for s in range(len(g["read_off"]) - 1):
+        a, b = int(g["read_off"][s]), int(g["read_off"][s + 1])
+        rs, rp, rl = coverage.filter_reads(g["read_scaf"][a:b], g["read_pos1"][a:b], g["read_len"][a:b], g["read_flag"][a:b])
+        cov = coverage.accumulate(ctx, g["seg_scaf"], g["seg_start"], g["seg_end"], int(g["n_scaf"]), rs, rp, rl)
+        assert np.array_equal(coverage.milli(cov), g["cov_milli"][:, s])
+        ref = orc.coverage(g["seg_scaf"], g["seg_start"], g["seg_end"], int(g["n_scaf"]), rs, rp, rl)
+        assert np.array_equal(cov.view(np.uint64), ref.view(np.uint64))        # same fp64 bits: same order of addition
+        # three chunks continue the same sums
+        cut1, cut2 = len(rs) // 4, len(rs) // 2
+        part = None
+        for lo, hi in ((0, cut1), (cut1, cut2), (cut2, len(rs))):
+            part = coverage.accumulate(ctx, g["seg_scaf"], g["seg_start"], g["seg_end"], int(g["n_scaf"]), rs[lo:hi], rp[lo:hi], rl[lo:hi], cov=part)
+        assert np.array_equal(part.view(np.uint64), ref.view(np.uint64))
+
+
+@pytest.mark.parametrize("seed,n_scaf,n_reads", [(1, 50, 20000), (2, 3, 5000), (3, 400, 300000)])
+def test_random_reads_bit_exact_vs_oracle(ctx, seed, n_scaf, n_reads):
+    rng = np.random.default_rng(seed)
+    seg_scaf, seg_start, seg_end, lens = [], [], [], []
+    for s in range(n_scaf):
+        L = int(rng.integers(500, 12000))
+        lens.append(L)
+        if rng.random() < 0.1:
+            continue                                           # a scaffold without segments
+        pos = 1 + int(rng.integers(0, 50))
+        while pos + 300 < L:
+            ln = int(rng.integers(300, 4000))
+            end = min(L, pos + ln - 1)
+            seg_scaf.append(s); seg_start.append(pos); seg_end.append(end)
+            pos = end + 1 + int(rng.integers(0, 3)) * int(rng.integers(0, 40))   # sometimes a gap (N run cut out)
+    lens = np.array(lens)
+    rs = rng.integers(0, n_scaf + 2, size=n_reads).astype(np.uint32)            # ids n_scaf, n_scaf+1: unknown names
+    rl = rng.integers(1, 300, size=n_reads).astype(np.uint32)
+    rp = (rng.random(n_reads) * (lens[np.minimum(rs, n_scaf - 1)] + 100)).astype(np.uint64)   # some hang over the end
+    cov = coverage.accumulate(ctx, seg_scaf, seg_start, seg_end, n_scaf, rs, rp, rl)
+    ref = orc.coverage(seg_scaf, seg_start, seg_end, n_scaf, rs, rp, rl)
+    assert np.array_equal(cov.view(np.uint64), ref.view(np.uint64))
+    assert ref.max() > 0
+
+
+def test_empty_inputs(ctx):
+    z = np.zeros(0)
+    assert coverage.accumulate(ctx, z, z, z, 0, z, z, z).shape == (0,)
+    cov = coverage.accumulate(ctx, [0], [1], [100], 1, z, z, z)
+    assert cov.tolist() == [0.0]
