@@ -37,7 +37,11 @@ struct abw_sep_state {
     std::vector<int64_t> h_binval_off;
     std::vector<int32_t> h_binval;
     std::vector<int32_t> h_scaf_first, h_scaf_ndps;
+    std::vector<int32_t> h_node_ids, h_node_dpoff;   // host copies of the current node's lists (sources of async copies)
     int64_t   TB = 0;                 // total bins
+    bool      node_open = false, node_all = false;   // a node accumulated and not yet evaluated
+    int32_t   node_m = 0;             // its scaffolds held here
+    int64_t   node_n = 0;             // and their dps
     // per-node scratch
     abw_devbuf hist;                  // 3 x int32[TB] + int64[TB]
     abw_devbuf scg_lohi;              // 2 x int32[D][n_scg]

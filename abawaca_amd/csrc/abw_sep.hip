@@ -39,7 +39,7 @@ constexpr int SCAN_CH = 2048;       // bins per scan chunk
 constexpr int ACC_SPB = ABW_ACC_SPB;       // scaffolds per workgroup in sep_accum
 constexpr int MAX_SCG = 4096;
 
-struct DimBestDev { int32_t found; int32_t bin; double sens; double spec; double prod; };
+struct DimBestDev { int32_t found; int32_t bin; double sens; double spec; double prod; long long size1; long long n; };
 
 struct ChunkDesc { int32_t dim; int32_t start; int32_t len; int32_t first_chunk_of_dim; };
 
@@ -246,7 +246,7 @@ __global__ void sep_chunk_scan_kernel(const int32_t* __restrict__ dim_first_chun
     dim_total[d] = run;
 }
 
-struct Cand { double prod; int32_t bin; int32_t found; double sens; double spec; };
+struct Cand { double prod; int32_t bin; int32_t found; double sens; double spec; long long size1; };
 
 __device__ __forceinline__ bool cand_better(const Cand& a, const Cand& b)   // is a better than b
 {
@@ -260,7 +260,7 @@ __device__ __forceinline__ Cand cand_shfl_xor(const Cand& c, int o)
 {
     Cand r;
     r.prod = __shfl_xor(c.prod, o, 64); r.bin = __shfl_xor(c.bin, o, 64); r.found = __shfl_xor(c.found, o, 64);
-    r.sens = __shfl_xor(c.sens, o, 64); r.spec = __shfl_xor(c.spec, o, 64);
+    r.sens = __shfl_xor(c.sens, o, 64); r.spec = __shfl_xor(c.spec, o, 64); r.size1 = __shfl_xor(c.size1, o, 64);
     return r;
 }
 
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void sep_eval_kernel(SepDev P, const ChunkDesc
     }
     __syncthreads();
     const int ng = s_ng;
-    Cand best = {0.0, 0, 0, 0.0, 0.0};
+    Cand best = {0.0, 0, 0, 0.0, 0.0, 0};
     for (int t0 = 0; t0 < c.len; t0 += 256) {
         const int t = t0 + threadIdx.x;
         Sums v = {0, 0, 0, 0};
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void sep_eval_kernel(SepDev P, const ChunkDesc
                 const double spec = (double)(int)TP / (double)(int)SZ;    // ref .h:74
                 const double prod = sens * spec;
                 if (prod == prod) {                                    // NaN is never better (ref .h:28)
-                    Cand cnd = {prod, c.start + t, 1, sens, spec};
+                    Cand cnd = {prod, c.start + t, 1, sens, spec, size1};
                     if (cand_better(cnd, best)) {
                         // gate, ref ClusterQuality.cpp:96-136
                         const int tt = c.start + t;
@@ -351,54 +351,48 @@ __global__ __launch_bounds__(256) void sep_eval_kernel(SepDev P, const ChunkDesc
 
 // phase D: best chunk of each dimension
 __global__ void sep_dimbest_kernel(const int32_t* __restrict__ dim_first_chunk, const int32_t* __restrict__ dim_nchunks,
-                                   int32_t D, const Cand* __restrict__ chunk_best, DimBestDev* __restrict__ out)
+                                   int32_t D, const Cand* __restrict__ chunk_best, const Sums* __restrict__ dim_total,
+                                   DimBestDev* __restrict__ out)
 {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
-    Cand b = {0.0, 0, 0, 0.0, 0.0};
+    Cand b = {0.0, 0, 0, 0.0, 0.0, 0};
     const int f = dim_first_chunk[d], n = dim_nchunks[d];
     for (int i = 0; i < n; i++) if (cand_better(chunk_best[f + i], b)) b = chunk_best[f + i];
     out[d].found = b.found; out[d].bin = b.bin; out[d].sens = b.sens; out[d].spec = b.spec; out[d].prod = b.prod;
+    out[d].size1 = b.size1; out[d].n = (long long)dim_total[d].size;
 }
 
-// per-scaffold count of dps with bin <= t in the winning dimension, the raw flag of each dp, and the
-// node's total of the counts (totals[0])
+// per-scaffold count of dps with bin <= t in the winning dimension and the raw flag of each dp
 __global__ __launch_bounds__(256) void sep_final_kernel(SepDev P, int32_t d, int32_t tbin, const int32_t* __restrict__ node_scaf,
                                                        const int32_t* __restrict__ node_dpoff, int32_t m,
-                                                       int32_t* __restrict__ nle, uint8_t* __restrict__ raw,
-                                                       unsigned long long* __restrict__ totals)
+                                                       int32_t* __restrict__ nle, uint8_t* __restrict__ raw)
 {
-    __shared__ unsigned long long blk;
-    if (threadIdx.x == 0) blk = 0;
-    __syncthreads();
     const int ls = blockIdx.x * 256 + threadIdx.x;
+    if (ls >= m) return;
+    const int s = node_scaf ? node_scaf[ls] : ls;
+    const int f = P.scaf_first[s], n = P.scaf_ndps[s];
+    const int64_t o = node_dpoff ? node_dpoff[ls] : f;
+    const int32_t* col = P.bins + (int64_t)d * P.N;
     int c = 0;
-    if (ls < m) {
-        const int s = node_scaf ? node_scaf[ls] : ls;
-        const int f = P.scaf_first[s], n = P.scaf_ndps[s];
-        const int64_t o = node_dpoff ? node_dpoff[ls] : f;
-        const int32_t* col = P.bins + (int64_t)d * P.N;
-        for (int i = 0; i < n; i++) { const int le = col[f + i] <= tbin; c += le; raw[o + i] = (uint8_t)le; }
-        nle[ls] = c;
-    }
-    if (c) atomicAdd(&blk, (unsigned long long)c);
-    __syncthreads();
-    if (threadIdx.x == 0 && blk) atomicAdd(&totals[0], blk);
+    for (int i = 0; i < n; i++) { const int le = col[f + i] <= tbin; c += le; raw[o + i] = (uint8_t)le; }
+    nle[ls] = c;
 }
 
 // ref ClusterSeparator.cpp:35-53,87-122 on the device: cluster1 is the raw side with fewer dps (tie: the
 // "<=" side); a scaffold goes to cluster1 iff at least half of its dps are there; raw flags become 1 / 2.
-// totals: [0] = dps on the "<=" side (in), [1], [2] = dps of the scaffolds assigned to cluster1 / cluster2 (out)
+// n = dps of the whole node and le = those on the "<=" side (size1 of the winning threshold, known from
+// the histogram scan; both are totals over ALL shards when the node is sharded).
+// totals: [0], [1] = dps of this shard's scaffolds assigned to cluster1 / cluster2 (out)
 __global__ __launch_bounds__(256) void sep_assign_kernel(SepDev P, const int32_t* __restrict__ node_scaf,
-                                                        const int32_t* __restrict__ node_dpoff, int32_t m, int64_t n,
+                                                        const int32_t* __restrict__ node_dpoff, int32_t m, long long n, long long le,
                                                         const int32_t* __restrict__ nle, uint8_t* __restrict__ raw,
                                                         uint8_t* __restrict__ side, unsigned long long* __restrict__ totals)
 {
     __shared__ unsigned long long b1, b2;
     if (threadIdx.x == 0) { b1 = 0; b2 = 0; }
     __syncthreads();
-    const long long le = (long long)totals[0];
-    const bool swap = (long long)n - le < le;
+    const bool swap = n - le < le;
     const int ls = blockIdx.x * 256 + threadIdx.x;
     if (ls < m) {
         const int s = node_scaf ? node_scaf[ls] : ls;
@@ -411,7 +405,7 @@ __global__ __launch_bounds__(256) void sep_assign_kernel(SepDev P, const int32_t
         for (int i = 0; i < tot; i++) raw[o + i] = ((raw[o + i] != 0) != swap) ? 1 : 2;      // ref :87-90
     }
     __syncthreads();
-    if (threadIdx.x == 0) { if (b1) atomicAdd(&totals[1], b1); if (b2) atomicAdd(&totals[2], b2); }
+    if (threadIdx.x == 0) { if (b1) atomicAdd(&totals[0], b1); if (b2) atomicAdd(&totals[1], b2); }
 }
 
 __global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v)
@@ -485,17 +479,29 @@ static int upload(abw_ctx* ctx, T** dst, const T* src, size_t n)
     return ABW_OK;
 }
 
-extern "C" {
-
-int abw_sep_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const int32_t* dp2scaf,
-                 const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
-                 int32_t n_scg)
+// dict_off == NULL: the table is the whole problem, the bin layout follows from it (narrow dimension:
+// T = max key + 1; wide: the column's own distinct keys).  dict_off != NULL: the table is ONE SHARD of a
+// scaffold-sharded problem and every shard must lay its histograms out identically: a dimension with an
+// empty dictionary is narrow with T = NARROW_T, one with a dictionary (the sorted distinct keys of the
+// column over ALL shards) is wide with T = its length.
+static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int32_t D, int64_t N, const int32_t* dp2scaf,
+                         const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
+                         int32_t n_scg, const int32_t* dict_vals, const int64_t* dict_off)
 {
     if (!ctx) return ABW_ERR_ARG;
     if (!keys || !dp2scaf || !scaf_len || D <= 0 || N <= 0 || S <= 0 || N > INT_MAX - 16)
-        return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: bad argument");
-    if (n_scg < 0 || n_scg > MAX_SCG) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: n_scg must be in [0,%d]", MAX_SCG);
-    if (n_scg > 0 && (!scg_off || !scg_ids)) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: null SCG table");
+        return abw_fail(ctx, ABW_ERR_ARG, "%s: bad argument", who);
+    if (n_scg < 0 || n_scg > MAX_SCG) return abw_fail(ctx, ABW_ERR_ARG, "%s: n_scg must be in [0,%d]", who, MAX_SCG);
+    if (n_scg > 0 && (!scg_off || !scg_ids)) return abw_fail(ctx, ABW_ERR_ARG, "%s: null SCG table", who);
+    if (dict_off) {
+        if (dict_off[0] != 0) return abw_fail(ctx, ABW_ERR_ARG, "%s: dict_off[0] != 0", who);
+        for (int32_t d = 0; d < D; d++) {
+            if (dict_off[d + 1] < dict_off[d] || dict_off[d + 1] - dict_off[d] > INT_MAX - 16) return abw_fail(ctx, ABW_ERR_ARG, "%s: dict_off not monotone", who);
+            if (dict_off[d + 1] > dict_off[d] && !dict_vals) return abw_fail(ctx, ABW_ERR_ARG, "%s: null dictionary", who);
+            for (int64_t i = dict_off[d] + 1; i < dict_off[d + 1]; i++)
+                if (dict_vals[i] <= dict_vals[i - 1]) return abw_fail(ctx, ABW_ERR_ARG, "%s: dictionary of dimension %d is not strictly ascending", who, d);
+        }
+    }
     abw_device_guard g(ctx->device);
     ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     abw_sep_free(ctx);
@@ -510,20 +516,20 @@ int abw_sep_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const 
         for (int64_t p = 0; p < N; p++) {
             const int32_t sc = dp2scaf[p];
             if (sc < 0 || sc >= S || (sc != prev && sc != prev + 1))
-                return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: dp2scaf must list scaffolds 0..S-1 contiguously and ascending (dp %lld)", (long long)p);
+                return abw_fail(ctx, ABW_ERR_ARG, "%s: dp2scaf must list scaffolds 0..S-1 contiguously and ascending (dp %lld)", who, (long long)p);
             if (sc != prev) s.h_scaf_first[sc] = (int32_t)p;
             s.h_scaf_ndps[sc]++;
             prev = sc;
         }
-        if (prev != S - 1) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: dp2scaf covers %d scaffolds, S = %d", prev + 1, S);
+        if (prev != S - 1) return abw_fail(ctx, ABW_ERR_ARG, "%s: dp2scaf covers %d scaffolds, S = %d", who, prev + 1, S);
         for (int32_t sc = 0; sc < S; sc++)
             if (s.h_scaf_ndps[sc] < 2)
-                return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: scaffold %d has %d dp(s); the reference drops such scaffolds (ScafDpData.cpp:92-93)", sc, s.h_scaf_ndps[sc]);
+                return abw_fail(ctx, ABW_ERR_ARG, "%s: scaffold %d has %d dp(s); the reference drops such scaffolds (ScafDpData.cpp:92-93)", who, sc, s.h_scaf_ndps[sc]);
     }
     if (n_scg > 0) {
-        if (scg_off[0] != 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: scg_off[0] != 0");
-        for (int32_t sc = 0; sc < S; sc++) if (scg_off[sc + 1] < scg_off[sc]) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: scg_off not monotone");
-        for (int32_t e = 0; e < scg_off[S]; e++) if (scg_ids[e] < 0 || scg_ids[e] >= n_scg) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_load: scg id out of range");
+        if (scg_off[0] != 0) return abw_fail(ctx, ABW_ERR_ARG, "%s: scg_off[0] != 0", who);
+        for (int32_t sc = 0; sc < S; sc++) if (scg_off[sc + 1] < scg_off[sc]) return abw_fail(ctx, ABW_ERR_ARG, "%s: scg_off not monotone", who);
+        for (int32_t e = 0; e < scg_off[S]; e++) if (scg_ids[e] < 0 || scg_ids[e] >= n_scg) return abw_fail(ctx, ABW_ERR_ARG, "%s: scg id out of range", who);
     }
 
     // bins: narrow dimensions use the key as bin; wide ones the rank among the column's distinct keys
@@ -533,6 +539,7 @@ int abw_sep_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const 
     std::vector<std::vector<int32_t>> uniq(D);
     std::vector<int32_t> bins;
     std::vector<char> is_wide(D, 0);
+    std::vector<int32_t> bad_dim(D, 0);
     {
         unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
         auto classify_dim = [&](unsigned t) {
@@ -540,6 +547,17 @@ int abw_sep_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const 
                 const int32_t* col = keys + (int64_t)d * N;
                 int32_t mn = INT_MAX, mx = INT_MIN;
                 for (int64_t p = 0; p < N; p++) { mn = std::min(mn, col[p]); mx = std::max(mx, col[p]); }
+                if (dict_off) {
+                    if (dict_off[d + 1] == dict_off[d]) {
+                        if (mn < 0 || mx >= NARROW_T) bad_dim[d] = 1;
+                        s.h_T[d] = NARROW_T;
+                    } else {
+                        is_wide[d] = 1;
+                        uniq[d].assign(dict_vals + dict_off[d], dict_vals + dict_off[d + 1]);
+                        s.h_T[d] = (int32_t)uniq[d].size();
+                    }
+                    continue;
+                }
                 if (mn >= 0 && mx < NARROW_T) { s.h_T[d] = mx + 1; continue; }
                 is_wide[d] = 1;
                 std::vector<int32_t>& u = uniq[d];
@@ -561,12 +579,20 @@ int abw_sep_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const 
                     if (!is_wide[d]) continue;
                     const std::vector<int32_t>& u = uniq[d];
                     int32_t* col = bins.data() + (int64_t)d * N;
-                    for (int64_t p = 0; p < N; p++) col[p] = (int32_t)(std::lower_bound(u.begin(), u.end(), col[p]) - u.begin());
+                    for (int64_t p = 0; p < N; p++) {
+                        const auto it = std::lower_bound(u.begin(), u.end(), col[p]);
+                        if (it == u.end() || *it != col[p]) { bad_dim[d] = 2; break; }
+                        col[p] = (int32_t)(it - u.begin());
+                    }
                 }
             };
             std::vector<std::thread> th2;
             for (unsigned t = 0; t < nt; t++) th2.emplace_back(rank_dim, t);
             for (auto& x : th2) x.join();
+        }
+        for (int32_t d = 0; d < D; d++) {
+            if (bad_dim[d] == 1) return abw_fail(ctx, ABW_ERR_ARG, "%s: dimension %d has no dictionary but keys outside [0,%d)", who, d, NARROW_T);
+            if (bad_dim[d] == 2) return abw_fail(ctx, ABW_ERR_ARG, "%s: a key of dimension %d is missing from its dictionary", who, d);
         }
     }
     s.h_binval.clear();
@@ -616,55 +642,12 @@ int abw_sep_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const 
     if ((rc = abw_reserve(ctx, s.scg_lohi, (size_t)std::max<int64_t>(1, (int64_t)D * n_scg) * 8))) return rc;
     if ((rc = abw_reserve(ctx, s.dimbest, (size_t)D * sizeof(DimBestDev)))) return rc;
     s.loaded = true;
+    s.node_open = false;
     return ABW_OK;
 }
 
-const int32_t* abw_sep_dev_keys(const abw_ctx* ctx) { return (ctx && ctx->sep.loaded) ? ctx->sep.d_keys : nullptr; }
-
-int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t min_ndps,
-                 abw_split* out, abw_dimbest* per_dim, uint8_t* scaf_side, uint8_t* dp_raw_side)
+static SepDev sep_params(abw_sep_state& s)
 {
-    if (!ctx) return ABW_ERR_ARG;
-    abw_sep_state& s = ctx->sep;
-    if (!s.loaded) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_node: call abw_sep_load first");
-    if (!out) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_node: null out");
-    abw_device_guard g(ctx->device);
-    SepHost& H = g_extra_of(ctx)->h;
-    hipStream_t st = ctx->stream;
-    const int32_t m = scaf_ids ? n_scaf : s.S;
-    if (m <= 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_node: empty node");
-    memset(out, 0, sizeof(*out));
-    out->dimension = -1; out->key = -1;
-
-    // node description
-    std::vector<int32_t> dpoff;
-    int64_t n = 0;
-    const int32_t* d_node_scaf = nullptr;
-    const int32_t* d_node_dpoff = nullptr;
-    int rc;
-    if (scaf_ids) {
-        dpoff.resize((size_t)m + 1);
-        std::vector<char> seen;                                     // duplicate check without O(S) work for small nodes
-        for (int32_t i = 0; i < m; i++) {
-            const int32_t sc = scaf_ids[i];
-            if (sc < 0 || sc >= s.S) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_node: scaffold id %d out of range", sc);
-            dpoff[i] = (int32_t)n;
-            n += s.h_scaf_ndps[sc];
-        }
-        dpoff[m] = (int32_t)n;
-        {
-            std::vector<int32_t> tmp(scaf_ids, scaf_ids + m);
-            std::sort(tmp.begin(), tmp.end());
-            if (std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end()) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_node: duplicate scaffold id");
-        }
-        if ((rc = abw_reserve(ctx, s.node_scaf, (size_t)m * 4))) return rc;
-        if ((rc = abw_reserve(ctx, s.node_dpoff, ((size_t)m + 1) * 4))) return rc;
-        ABW_HIP(ctx, hipMemcpyAsync(s.node_scaf.p, scaf_ids, (size_t)m * 4, hipMemcpyHostToDevice, st));
-        ABW_HIP(ctx, hipMemcpyAsync(s.node_dpoff.p, dpoff.data(), ((size_t)m + 1) * 4, hipMemcpyHostToDevice, st));
-        d_node_scaf = (const int32_t*)s.node_scaf.p;
-        d_node_dpoff = (const int32_t*)s.node_dpoff.p;
-    } else n = s.N;
-
     SepDev P;
     P.bins = s.d_bins ? s.d_bins : s.d_keys; P.N = s.N;
     P.scaf_first = s.d_scaf_first; P.scaf_ndps = s.d_scaf_ndps; P.scaf_len = s.d_scaf_len;
@@ -672,7 +655,45 @@ int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t 
     P.T = s.d_T; P.Toff = s.d_Toff;
     P.h_st = (unsigned long long*)s.hist.p; P.h_bp = P.h_st + s.TB; P.h_tot = (uint32_t*)(P.h_bp + s.TB);
     P.scg_lo = (int32_t*)s.scg_lohi.p; P.scg_hi = P.scg_lo + (int64_t)s.D * s.n_scg;
+    return P;
+}
 
+// Phase 1: the node's scaffolds held by this context -> histograms and SCG lo/hi lists.
+// all = every scaffold of the table (scaf_ids ignored); otherwise m >= 0 ids (an empty shard of a node is fine).
+static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_t* scaf_ids, int32_t m)
+{
+    abw_sep_state& s = ctx->sep;
+    SepHost& H = g_extra_of(ctx)->h;
+    hipStream_t st = ctx->stream;
+    s.node_open = false;
+    if (all) m = s.S;
+    if (m < 0 || (!all && m > 0 && !scaf_ids)) return abw_fail(ctx, ABW_ERR_ARG, "%s: bad scaffold list", who);
+    int64_t n = 0;
+    int rc;
+    if (!all && m > 0) {
+        std::vector<int32_t>& dpoff = s.h_node_dpoff;                // both outlive the asynchronous copies below
+        dpoff.resize((size_t)m + 1);
+        s.h_node_ids.assign(scaf_ids, scaf_ids + m);
+        for (int32_t i = 0; i < m; i++) {
+            const int32_t sc = scaf_ids[i];
+            if (sc < 0 || sc >= s.S) return abw_fail(ctx, ABW_ERR_ARG, "%s: scaffold id %d out of range", who, sc);
+            dpoff[i] = (int32_t)n;
+            n += s.h_scaf_ndps[sc];
+        }
+        dpoff[m] = (int32_t)n;
+        {
+            std::vector<int32_t> tmp(scaf_ids, scaf_ids + m);
+            std::sort(tmp.begin(), tmp.end());
+            if (std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end()) return abw_fail(ctx, ABW_ERR_ARG, "%s: duplicate scaffold id", who);
+        }
+        if ((rc = abw_reserve(ctx, s.node_scaf, (size_t)m * 4))) return rc;
+        if ((rc = abw_reserve(ctx, s.node_dpoff, ((size_t)m + 1) * 4))) return rc;
+        ABW_HIP(ctx, hipMemcpyAsync(s.node_scaf.p, s.h_node_ids.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+        ABW_HIP(ctx, hipMemcpyAsync(s.node_dpoff.p, dpoff.data(), ((size_t)m + 1) * 4, hipMemcpyHostToDevice, st));
+    } else if (all) n = s.N;
+    const int32_t* d_node_scaf = all ? nullptr : (const int32_t*)s.node_scaf.p;
+
+    SepDev P = sep_params(s);
     ABW_HIP(ctx, hipMemsetAsync(s.hist.p, 0, (size_t)s.TB * (4 * 3 + 8) + 8, st));
     if (s.n_scg > 0) {
         const int64_t cnt = (int64_t)s.D * s.n_scg;
@@ -681,18 +702,42 @@ int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t 
         hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)std::min<int64_t>(1024, (cnt + 255) / 256)), dim3(256), 0, st, P.scg_hi, cnt, -1);
         ABW_LAUNCH_CHECK(ctx);
     }
-    const unsigned gx = (unsigned)((m + ACC_SPB - 1) / ACC_SPB);
-    {
-    ABW_PROF(ctx, "sep_accum");
-    if (!H.narrow_dims.empty()) {
-        hipLaunchKernelGGL(sep_accum_kernel<true>, dim3(gx, (unsigned)H.narrow_dims.size()), dim3(256), 0, st, P, H.d_narrow, d_node_scaf, m);
-        ABW_LAUNCH_CHECK(ctx);
+    if (m > 0) {
+        const unsigned gx = (unsigned)((m + ACC_SPB - 1) / ACC_SPB);
+        ABW_PROF(ctx, "sep_accum");
+        if (!H.narrow_dims.empty()) {
+            hipLaunchKernelGGL(sep_accum_kernel<true>, dim3(gx, (unsigned)H.narrow_dims.size()), dim3(256), 0, st, P, H.d_narrow, d_node_scaf, m);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        if (!H.wide_dims.empty()) {
+            hipLaunchKernelGGL(sep_accum_kernel<false>, dim3(gx, (unsigned)H.wide_dims.size()), dim3(256), 0, st, P, H.d_wide, d_node_scaf, m);
+            ABW_LAUNCH_CHECK(ctx);
+        }
     }
-    if (!H.wide_dims.empty()) {
-        hipLaunchKernelGGL(sep_accum_kernel<false>, dim3(gx, (unsigned)H.wide_dims.size()), dim3(256), 0, st, P, H.d_wide, d_node_scaf, m);
-        ABW_LAUNCH_CHECK(ctx);
-    }
-    }
+    s.node_open = true; s.node_all = all; s.node_m = m; s.node_n = n;
+    return ABW_OK;
+}
+
+// Phase 2: scan + evaluation of the (combined) histograms, the global winner, and this context's part of
+// the finalisation.  out->ndps1/2 = dps of THIS context's scaffolds that went to cluster1/2; out->split is
+// left 0: the size check needs the totals over all shards (sep_decide).
+static int sep_eval_phase(abw_ctx* ctx, const char* who, int32_t min_ndps, abw_split* out, abw_dimbest* per_dim,
+                          uint8_t* scaf_side, uint8_t* dp_raw_side)
+{
+    abw_sep_state& s = ctx->sep;
+    SepHost& H = g_extra_of(ctx)->h;
+    hipStream_t st = ctx->stream;
+    if (!s.node_open) return abw_fail(ctx, ABW_ERR_STATE, "%s: no node accumulated", who);
+    s.node_open = false;
+    const int32_t m = s.node_m;
+    const int64_t n = s.node_n;
+    const int32_t* d_node_scaf = s.node_all ? nullptr : (const int32_t*)s.node_scaf.p;
+    const int32_t* d_node_dpoff = s.node_all ? nullptr : (const int32_t*)s.node_dpoff.p;
+    memset(out, 0, sizeof(*out));
+    out->dimension = -1; out->key = -1;
+    SepDev P = sep_params(s);
+    int rc;
+
     const unsigned nch = (unsigned)H.chunks.size();
     DimBestDev* d_dimbest = (DimBestDev*)s.dimbest.p;
     {
@@ -703,7 +748,7 @@ int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t 
     ABW_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(sep_eval_kernel, dim3(nch), dim3(256), 0, st, P, H.d_chunks, H.d_chunk_sums, H.d_dim_total, min_ndps, H.d_chunk_best);
     ABW_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(sep_dimbest_kernel, dim3((s.D + 63) / 64), dim3(64), 0, st, H.d_dim_first_chunk, H.d_dim_nchunks, s.D, H.d_chunk_best, d_dimbest);
+    hipLaunchKernelGGL(sep_dimbest_kernel, dim3((s.D + 63) / 64), dim3(64), 0, st, H.d_dim_first_chunk, H.d_dim_nchunks, s.D, H.d_chunk_best, H.d_dim_total, d_dimbest);
     ABW_LAUNCH_CHECK(ctx);
     }
     std::vector<DimBestDev> db((size_t)s.D);
@@ -731,8 +776,8 @@ int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t 
         else better = value < gvalue;
         if (better) { gsens = sens; gspec = spec; gdim = dim; gvalue = value; gbin = db[d].bin; }
     }
-    if (scaf_side) memset(scaf_side, 0, (size_t)m);
-    if (dp_raw_side) memset(dp_raw_side, 0, (size_t)n);
+    if (scaf_side && m > 0) memset(scaf_side, 0, (size_t)m);
+    if (dp_raw_side && n > 0) memset(dp_raw_side, 0, (size_t)n);
     if (gdim == (uint64_t)-1) return ABW_OK;
     const int32_t gd = (int32_t)gdim - 1;
     out->dimension = (int32_t)gdim;
@@ -741,32 +786,107 @@ int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t 
     // is_legal, ref ...Specificity.h:31-35
     out->legal = (gsens >= 0.8) && (gspec >= 0.8) && (gsens + gspec >= 1.6) && (gsens * gspec >= 0.8);
     if (!out->legal) return ABW_OK;                                   // reconstruct_best_clusters returns early (ref ClusterSeparator.cpp:27-28)
+    if (m == 0) return ABW_OK;                                        // this shard holds nothing of the node
 
     if ((rc = abw_reserve(ctx, s.nle, (size_t)m * 4))) return rc;
     if ((rc = abw_reserve(ctx, s.raw, (size_t)n))) return rc;
     if ((rc = abw_reserve(ctx, ctx->scratch[9], (size_t)m + 64))) return rc;
-    unsigned long long* d_tot = (unsigned long long*)ctx->scratch[9].p;       // 3 totals, then the scaffold sides
+    unsigned long long* d_tot = (unsigned long long*)ctx->scratch[9].p;       // 2 totals, then the scaffold sides
     uint8_t* d_side = (uint8_t*)ctx->scratch[9].p + 32;
-    ABW_HIP(ctx, hipMemsetAsync(d_tot, 0, 24, st));
+    ABW_HIP(ctx, hipMemsetAsync(d_tot, 0, 16, st));
     hipLaunchKernelGGL(sep_final_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, gd, gbin, d_node_scaf, d_node_dpoff, m,
-                       (int32_t*)s.nle.p, (uint8_t*)s.raw.p, d_tot);
+                       (int32_t*)s.nle.p, (uint8_t*)s.raw.p);
     ABW_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(sep_assign_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, d_node_scaf, d_node_dpoff, m, n,
-                       (const int32_t*)s.nle.p, (uint8_t*)s.raw.p, d_side, d_tot);
+    hipLaunchKernelGGL(sep_assign_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, d_node_scaf, d_node_dpoff, m,
+                       db[gd].n, db[gd].size1, (const int32_t*)s.nle.p, (uint8_t*)s.raw.p, d_side, d_tot);
     ABW_LAUNCH_CHECK(ctx);
-    unsigned long long tot3[3] = {0, 0, 0};
-    ABW_HIP(ctx, hipMemcpyAsync(tot3, d_tot, 24, hipMemcpyDeviceToHost, st));
+    unsigned long long tot2[2] = {0, 0};
+    ABW_HIP(ctx, hipMemcpyAsync(tot2, d_tot, 16, hipMemcpyDeviceToHost, st));
     if (scaf_side) ABW_HIP(ctx, hipMemcpyAsync(scaf_side, d_side, (size_t)m, hipMemcpyDeviceToHost, st));
     if (dp_raw_side) ABW_HIP(ctx, hipMemcpyAsync(dp_raw_side, s.raw.p, (size_t)n, hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));
-    const int64_t nd1 = (int64_t)tot3[1], nd2 = (int64_t)tot3[2];
-    if (nd1 >= min_ndps && nd2 >= min_ndps) {                          // ref :125-132
-        out->split = 1; out->ndps1 = nd1; out->ndps2 = nd2;
+    out->ndps1 = (int64_t)tot2[0]; out->ndps2 = (int64_t)tot2[1];
+    return ABW_OK;
+}
+
+extern "C" {
+
+int abw_sep_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const int32_t* dp2scaf,
+                 const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
+                 int32_t n_scg)
+{
+    return sep_load_impl(ctx, "abw_sep_load", keys, D, N, dp2scaf, scaf_len, S, scg_off, scg_ids, n_scg, nullptr, nullptr);
+}
+
+int abw_sep_shard_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const int32_t* dp2scaf,
+                       const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
+                       int32_t n_scg, const int32_t* dict_vals, const int64_t* dict_off)
+{
+    if (ctx && !dict_off) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_shard_load: null dict_off");
+    return sep_load_impl(ctx, "abw_sep_shard_load", keys, D, N, dp2scaf, scaf_len, S, scg_off, scg_ids, n_scg, dict_vals, dict_off);
+}
+
+const int32_t* abw_sep_dev_keys(const abw_ctx* ctx) { return (ctx && ctx->sep.loaded) ? ctx->sep.d_keys : nullptr; }
+
+// ref ClusterSeparator.cpp:125-132: both clusters need cluster_ndps_threshold dps, else everything is reset
+int abw_sep_shard_decide(abw_split* out, int64_t ndps1_total, int64_t ndps2_total, int32_t min_ndps)
+{
+    if (!out) return ABW_ERR_ARG;
+    if (out->dimension < 0 || !out->legal) { out->split = 0; out->ndps1 = out->ndps2 = 0; return ABW_OK; }
+    if (ndps1_total >= min_ndps && ndps2_total >= min_ndps) {
+        out->split = 1; out->ndps1 = ndps1_total; out->ndps2 = ndps2_total;
     } else {
+        out->split = 0; out->ndps1 = out->ndps2 = 0;
         out->dimension = -1; out->key = -1; out->sensitivity = 0; out->specificity = 0;   // best_separation->reset(), ref :130
-        if (scaf_side) memset(scaf_side, 0, (size_t)m);
     }
     return ABW_OK;
+}
+
+int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t min_ndps,
+                 abw_split* out, abw_dimbest* per_dim, uint8_t* scaf_side, uint8_t* dp_raw_side)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    abw_sep_state& s = ctx->sep;
+    if (!s.loaded) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_node: call abw_sep_load first");
+    if (!out) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_node: null out");
+    if (scaf_ids && n_scaf <= 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_node: empty node");
+    abw_device_guard g(ctx->device);
+    int rc;
+    if ((rc = sep_accum_phase(ctx, "abw_sep_node", scaf_ids == nullptr, scaf_ids, n_scaf))) return rc;
+    const int32_t m = s.node_m;
+    if ((rc = sep_eval_phase(ctx, "abw_sep_node", min_ndps, out, per_dim, scaf_side, dp_raw_side))) return rc;
+    const int32_t legal = out->legal;
+    abw_sep_shard_decide(out, out->ndps1, out->ndps2, min_ndps);
+    if (legal && !out->split && scaf_side) memset(scaf_side, 0, (size_t)m);
+    return ABW_OK;
+}
+
+int abw_sep_shard_accum(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, abw_sep_exchange* ex)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    abw_sep_state& s = ctx->sep;
+    if (!s.loaded) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_shard_accum: call abw_sep_shard_load first");
+    if (!ex) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_shard_accum: null exchange");
+    abw_device_guard g(ctx->device);
+    int rc;
+    if ((rc = sep_accum_phase(ctx, "abw_sep_shard_accum", n_scaf < 0, scaf_ids, n_scaf))) return rc;
+    ex->d_hist = (int64_t*)s.hist.p;
+    ex->hist_count = ((uint64_t)s.TB * 20 + 7) / 8;
+    ex->d_scg_lo = (int32_t*)s.scg_lohi.p;
+    ex->d_scg_hi = ex->d_scg_lo + (int64_t)s.D * s.n_scg;
+    ex->scg_count = (uint64_t)s.D * (uint64_t)s.n_scg;
+    return ABW_OK;
+}
+
+int abw_sep_shard_eval(abw_ctx* ctx, int32_t min_ndps, abw_split* out, abw_dimbest* per_dim,
+                       uint8_t* scaf_side, uint8_t* dp_raw_side)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    abw_sep_state& s = ctx->sep;
+    if (!s.loaded) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_shard_eval: call abw_sep_shard_load first");
+    if (!out) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_shard_eval: null out");
+    abw_device_guard g(ctx->device);
+    return sep_eval_phase(ctx, "abw_sep_shard_eval", min_ndps, out, per_dim, scaf_side, dp_raw_side);
 }
 
 }  // extern "C"

@@ -101,3 +101,102 @@ def combine_ordered_sum(t, dist=None):
     for p in parts[1:]:
         t.add_(p)
     return t
+
+
+# ---- scaffold-sharded separator (SURVEY §8 row e): shard layout, shared bin layout, the exchange ----
+
+NARROW_T = 1024      # abw_sep.hip: a dimension whose keys all lie in [0, NARROW_T) uses the key itself as bin
+
+
+def scaffold_bounds(scaf_ndps, world: int) -> list[int]:
+    """Contiguous scaffold ranges with about the same number of dps each (whole scaffolds per shard)."""
+    import numpy as np
+    cum = np.concatenate([[0], np.cumsum(np.asarray(scaf_ndps, dtype=np.int64))])
+    S, N = len(cum) - 1, int(cum[-1])
+    b = [0]
+    for k in range(1, world):
+        b.append(max(b[-1], int(np.searchsorted(cum, k * N / world, side="left"))))
+    b.append(S)
+    if any(b[k + 1] <= b[k] for k in range(world)):
+        raise ValueError("every shard needs at least one scaffold")
+    return b
+
+
+def global_dictionary(keys_local, dist=None):
+    """Bin layout shared by all shards, from each shard's own [D, N_local] int32 keys: dimension d is wide when
+    any shard holds a key outside [0, NARROW_T); its dictionary is the sorted union of the shards' distinct
+    keys.  -> (dict_vals int32[...], dict_off int64[D+1]) for abw_sep_shard_load.  One MIN/MAX all-reduce of D
+    values and one all-gather of the local distinct keys of the wide columns, once per run."""
+    import numpy as np
+    keys_local = np.asarray(keys_local)
+    D = keys_local.shape[0]
+    mn = keys_local.min(axis=1).astype(np.int64)
+    mx = keys_local.max(axis=1).astype(np.int64)
+    multi_rank = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    if multi_rank:
+        import torch
+        tmn, tmx = torch.from_numpy(mn), torch.from_numpy(mx)
+        dist.all_reduce(tmn, op=dist.ReduceOp.MIN)
+        dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+        mn, mx = tmn.numpy(), tmx.numpy()
+    wide = (mn < 0) | (mx >= NARROW_T)
+    uniq = [np.unique(keys_local[d]).astype(np.int32) if wide[d] else np.empty(0, np.int32) for d in range(D)]
+    if multi_rank:
+        import torch
+        world = dist.get_world_size()
+        flat = np.concatenate(uniq) if wide.any() else np.empty(0, np.int32)
+        sizes = torch.tensor([len(u) for u in uniq], dtype=torch.int64)
+        all_sizes = [torch.empty_like(sizes) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes)
+        nmax = max(int(s.sum()) for s in all_sizes)
+        pad = torch.zeros(max(nmax, 1), dtype=torch.int32)
+        pad[:len(flat)] = torch.from_numpy(flat)
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+        merged = []
+        offs = [np.concatenate([[0], np.cumsum(s.numpy())]) for s in all_sizes]
+        for d in range(D):
+            if not wide[d]:
+                merged.append(np.empty(0, np.int32))
+                continue
+            merged.append(np.unique(np.concatenate([parts[r].numpy()[offs[r][d]:offs[r][d + 1]] for r in range(world)])).astype(np.int32))
+        uniq = merged
+    dict_off = np.concatenate([[0], np.cumsum([len(u) for u in uniq])]).astype(np.int64)
+    dict_vals = np.concatenate(uniq).astype(np.int32) if wide.any() else np.empty(0, np.int32)
+    return dict_vals, dict_off
+
+
+def merge_dictionaries(keys_per_shard):
+    """global_dictionary for shards that live in one process (tests, single-node multi-context drivers)."""
+    import numpy as np
+    D = keys_per_shard[0].shape[0]
+    mn = np.min([k.min(axis=1) for k in keys_per_shard], axis=0)
+    mx = np.max([k.max(axis=1) for k in keys_per_shard], axis=0)
+    wide = (mn < 0) | (mx >= NARROW_T)
+    uniq = [np.unique(np.concatenate([k[d] for k in keys_per_shard])).astype(np.int32) if wide[d] else np.empty(0, np.int32)
+            for d in range(D)]
+    dict_off = np.concatenate([[0], np.cumsum([len(u) for u in uniq])]).astype(np.int64)
+    dict_vals = np.concatenate(uniq).astype(np.int32) if wide.any() else np.empty(0, np.int32)
+    return dict_vals, dict_off
+
+
+def combine_sep(hist, scg_lo, scg_hi, dist=None):
+    """The separator's exchange, in place: integer SUM of the histograms (int64 words; per node
+    20 B x total bins: 3.7 MB for 179 narrow dimensions + 20 B per distinct coverage key), MIN / MAX of the
+    per-SCG flip values.  All exact and order-free."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+    if scg_lo is not None:
+        dist.all_reduce(scg_lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(scg_hi, op=dist.ReduceOp.MAX)
+
+
+def sum_counts(counts, dist=None, device=None):
+    """Integer sum over the shards of a short list of counts (the dps each shard sent to cluster1 / cluster2)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [int(c) for c in counts]
+    import torch
+    t = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.tolist()]

@@ -146,3 +146,189 @@ def binning(store: ColumnStore, max_nodes: int = 1 << 30):
                 dp2cluster[store.scaf_first[s]:store.scaf_first[s] + store.scaf_ndps[s]] = nid
         nodes.append(row)
     return nodes, scaf2cluster, dp2cluster
+
+
+# ---- scaffold-sharded separator (SURVEY §8 row e; abw_sep_shard_*) ------------------------------------
+
+class SepExchange(C.Structure):
+    _fields_ = [("d_hist", C.c_void_p), ("hist_count", C.c_uint64), ("d_scg_lo", C.c_void_p), ("d_scg_hi", C.c_void_p),
+                ("scg_count", C.c_uint64)]
+
+
+class ShardedColumnStore(ColumnStore):
+    """One shard's scaffolds (local ids 0..S-1) with the bin layout all shards share (multi.global_dictionary)."""
+
+    def __init__(self, ctx: Context, keys, dp2scaf, scaf_len, dict_vals, dict_off, scg_off=None, scg_ids=None, n_scg=0):
+        self.ctx = ctx
+        self.keys = np.ascontiguousarray(keys, dtype=np.int32)
+        self.D, self.N = self.keys.shape
+        self.dp2scaf = np.ascontiguousarray(dp2scaf, dtype=np.int32)
+        self.scaf_len = np.ascontiguousarray(scaf_len, dtype=np.int64)
+        self.S = len(self.scaf_len)
+        self.scaf_ndps = np.bincount(self.dp2scaf, minlength=self.S).astype(np.int32)
+        self.scaf_first = np.concatenate([[0], np.cumsum(self.scaf_ndps)[:-1]]).astype(np.int64)
+        self.n_scg = int(n_scg)
+        so = np.ascontiguousarray(scg_off, dtype=np.int32) if self.n_scg else None
+        si = np.ascontiguousarray(scg_ids, dtype=np.int32) if self.n_scg else None
+        dv = np.ascontiguousarray(dict_vals, dtype=np.int32)
+        do = np.ascontiguousarray(dict_off, dtype=np.int64)
+        p = lambda a: C.c_void_p(a.ctypes.data) if a is not None and a.size else None
+        ctx.check(lib().abw_sep_shard_load(ctx.handle, p(self.keys), self.D, self.N, p(self.dp2scaf), p(self.scaf_len), self.S,
+                                           p(so), p(si), self.n_scg, p(dv), C.c_void_p(do.ctypes.data)))
+
+
+class ShardNode:
+    """One node of the recursion on one shard: accum -> (caller combines hist / scg_lo / scg_hi) -> eval -> decide."""
+    cluster_ndps_threshold = ClusterSeparatorHip.cluster_ndps_threshold
+
+    def __init__(self, store: ShardedColumnStore, local_ids=None, device=None):
+        import torch
+        from .kmeans import _DevView
+        self.store = store
+        self.ids = np.arange(store.S, dtype=np.int32) if local_ids is None else np.ascontiguousarray(local_ids, dtype=np.int32)
+        self.m = len(self.ids)
+        self.n = int(store.scaf_ndps[self.ids].sum()) if self.m else 0
+        ex = SepExchange()
+        ptr = C.c_void_p(self.ids.ctypes.data) if self.m else None
+        store.ctx.check(lib().abw_sep_shard_accum(store.ctx.handle, ptr, -1 if local_ids is None else self.m, C.byref(ex)))
+        dev = device if device is not None else torch.device("cuda", store.ctx.device)
+        self.hist = torch.as_tensor(_DevView(ex.d_hist, ex.hist_count, "<i8"), device=dev)
+        if ex.scg_count:
+            self.scg_lo = torch.as_tensor(_DevView(ex.d_scg_lo, ex.scg_count, "<i4"), device=dev)
+            self.scg_hi = torch.as_tensor(_DevView(ex.d_scg_hi, ex.scg_count, "<i4"), device=dev)
+        else:
+            self.scg_lo = self.scg_hi = None
+
+    def eval(self):
+        st = self.store
+        self.out = Split()
+        per = (DimBest * st.D)()
+        self.side = np.zeros(max(self.m, 1), dtype=np.uint8)
+        self.raw = np.zeros(max(self.n, 1), dtype=np.uint8)
+        st.ctx.check(lib().abw_sep_shard_eval(st.ctx.handle, self.cluster_ndps_threshold, C.byref(self.out), per,
+                                              C.c_void_p(self.side.ctypes.data), C.c_void_p(self.raw.ctypes.data)))
+        self.side, self.raw = self.side[:self.m], self.raw[:self.n]
+        self.per = np.array([(p.found, p.key, p.sensitivity, p.specificity) for p in per],
+                            dtype=[("found", "i4"), ("key", "i4"), ("sens", "f8"), ("spec", "f8")])
+        return int(self.out.ndps1), int(self.out.ndps2)
+
+    def decide(self, ndps1_total, ndps2_total) -> bool:
+        legal = self.out.legal
+        lib().abw_sep_shard_decide(C.byref(self.out), int(ndps1_total), int(ndps2_total), self.cluster_ndps_threshold)
+        if legal and not self.out.split:
+            self.side[:] = 0
+        return bool(self.out.split)
+
+
+def separate_sharded(store: ShardedColumnStore, local_ids, dist=None, device=None) -> ShardNode:
+    """One node over torch.distributed (RCCL on GPUs): every rank passes its own part of the node."""
+    import torch
+    from . import multi
+    node = ShardNode(store, local_ids, device)
+    store.ctx.synchronize()
+    multi.combine_sep(node.hist, node.scg_lo, node.scg_hi, dist)
+    torch.cuda.synchronize(node.hist.device)
+    n1, n2 = node.eval()
+    n1, n2 = multi.sum_counts([n1, n2], dist, node.hist.device)
+    node.decide(n1, n2)
+    return node
+
+
+def separate_shards_local(stores, ids_list):
+    """The same node played by several shards of ONE process (tests; stores may share a GPU): the
+    combination is done with plain tensor arithmetic."""
+    import torch
+    nodes = [ShardNode(st, ids) for st, ids in zip(stores, ids_list)]
+    for nd in nodes:
+        nd.store.ctx.synchronize()
+    hist = torch.stack([nd.hist for nd in nodes]).sum(0)
+    for nd in nodes:
+        nd.hist.copy_(hist)
+    if nodes[0].scg_lo is not None:
+        lo = torch.stack([nd.scg_lo for nd in nodes]).amin(0)
+        hi = torch.stack([nd.scg_hi for nd in nodes]).amax(0)
+        for nd in nodes:
+            nd.scg_lo.copy_(lo)
+            nd.scg_hi.copy_(hi)
+    torch.cuda.synchronize()
+    parts = [nd.eval() for nd in nodes]
+    n1, n2 = sum(p[0] for p in parts), sum(p[1] for p in parts)
+    for nd in nodes:
+        nd.decide(n1, n2)
+    return nodes
+
+
+def binning_sharded(store: ShardedColumnStore, separate, max_nodes: int = 1 << 30):
+    """reference src/abawaca.cpp:95-197 with every node's scaffolds spread over the shards.  `separate(local_ids)`
+    -> ShardNode (e.g. lambda ids: separate_sharded(store, ids, dist)).  The split decisions are identical on every
+    shard, so all shards walk the same tree.  -> (nodes, scaf2cluster of the LOCAL scaffolds)"""
+    work = {1: None}
+    next_id = 2
+    nodes = []
+    scaf2cluster = np.zeros(store.S, dtype=np.int32)
+    while work and len(nodes) < max_nodes:
+        nid = min(work)
+        ids = work.pop(nid)
+        nd = separate(ids)
+        o = nd.out
+        row = dict(id=nid, split=int(o.split), dim=int(o.dimension), key=int(o.key), spec=float(o.specificity),
+                   sens=float(o.sensitivity), c1=0, n1=0, c2=0, n2=0)
+        if o.split:
+            c1, c2 = next_id, next_id + 1
+            next_id += 2
+            work[c1], work[c2] = np.sort(nd.ids[nd.side == 1]), np.sort(nd.ids[nd.side == 2])
+            row.update(c1=c1, n1=int(o.ndps1), c2=c2, n2=int(o.ndps2))
+        else:
+            scaf2cluster[nd.ids] = nid
+        nodes.append(row)
+    return nodes, scaf2cluster
+
+
+def carve_shard(keys, dp2scaf, scaf_len, scaf_ids, scg_scaf=(), scg_id=()):
+    """The table of one shard: the given (global) scaffolds in the given order, renumbered 0..len-1.
+    -> dict(keys, dp2scaf, scaf_len, scg_scaf, scg_id, dps) with dps = the global dp index of every local dp."""
+    keys = np.asarray(keys)
+    dp2scaf = np.asarray(dp2scaf)
+    scaf_ids = np.asarray(scaf_ids, dtype=np.int64)
+    S = len(scaf_len)
+    ndps = np.bincount(dp2scaf, minlength=S)
+    first = np.concatenate([[0], np.cumsum(ndps)[:-1]])
+    dps = np.concatenate([np.arange(first[s], first[s] + ndps[s]) for s in scaf_ids]).astype(np.int64)
+    local_of = np.full(S, -1, dtype=np.int64)
+    local_of[scaf_ids] = np.arange(len(scaf_ids))
+    scg_scaf = np.asarray(scg_scaf, dtype=np.int64)
+    keep = local_of[scg_scaf] >= 0 if len(scg_scaf) else np.zeros(0, bool)
+    return dict(keys=np.ascontiguousarray(keys[:, dps]), dp2scaf=np.repeat(np.arange(len(scaf_ids)), ndps[scaf_ids]).astype(np.int32),
+                scaf_len=np.asarray(scaf_len)[scaf_ids], scg_scaf=local_of[scg_scaf[keep]] if len(scg_scaf) else scg_scaf,
+                scg_id=np.asarray(scg_id)[keep] if len(scg_scaf) else np.asarray(scg_id), dps=dps)
+
+
+def binning_shards_local(stores, max_nodes: int = 1 << 30):
+    """binning_sharded for several shards driven in lock-step from one process (tests)."""
+    k = len(stores)
+    work = {1: [None] * k}
+    next_id = 2
+    rows = []
+    s2c = [np.zeros(st.S, dtype=np.int32) for st in stores]
+    while work and len(rows) < max_nodes:
+        nid = min(work)
+        ids = work.pop(nid)
+        nodes = separate_shards_local(stores, ids)
+        o = nodes[0].out
+        for nd in nodes[1:]:                                   # every shard reached the same verdict
+            p = nd.out
+            assert (p.split, p.dimension, p.key, p.legal, p.sensitivity, p.specificity, p.ndps1, p.ndps2) == \
+                   (o.split, o.dimension, o.key, o.legal, o.sensitivity, o.specificity, o.ndps1, o.ndps2)
+        row = dict(id=nid, ndps=sum(nd.n for nd in nodes), split=int(o.split), dim=int(o.dimension), key=int(o.key),
+                   spec=float(o.specificity), sens=float(o.sensitivity), c1=0, n1=0, c2=0, n2=0, empty_shards=sum(nd.m == 0 for nd in nodes))
+        if o.split:
+            c1, c2 = next_id, next_id + 1
+            next_id += 2
+            work[c1] = [np.sort(nd.ids[nd.side == 1]) for nd in nodes]
+            work[c2] = [np.sort(nd.ids[nd.side == 2]) for nd in nodes]
+            row.update(c1=c1, n1=int(o.ndps1), c2=c2, n2=int(o.ndps2))
+        else:
+            for nd, a in zip(nodes, s2c):
+                a[nd.ids] = nid
+        rows.append(row)
+    return rows, s2c

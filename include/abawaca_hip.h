@@ -145,6 +145,43 @@ int abw_sep_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const 
 int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t min_ndps,
                  abw_split* out, abw_dimbest* per_dim, uint8_t* scaf_side, uint8_t* dp_raw_side);
 
+/* ---- the separator with the SCAFFOLDS sharded over several contexts / processes / GPUs (SURVEY §8(e):
+ *      "scaffold-sharded" full recursive binning; the reference itself is one process with a thread per
+ *      dimension, ref: src/ClusterSeparator.cpp:72-78).  A shard holds whole scaffolds (a node of the
+ *      recursion always does, ref: src/ClusterSeparator.cpp:104-122).  Every flip value t_s is local to the
+ *      shard that owns scaffold s and every quantity the sweep looks at is a count, so the histograms of the
+ *      shards simply add; the SCG gate needs min / max of the per-SCG flip values.  The library runs each
+ *      shard's local part, the CALLER combines three device buffers in between (abawaca_amd/multi.py: RCCL /
+ *      gloo all-reduce).  All counts are integers: the result is bit-identical to abw_sep_node on the
+ *      unsharded table for any number of shards.
+ *
+ *   load   : as abw_sep_load for the shard's own scaffolds (local ids 0..S-1), plus the bin layout every shard
+ *            must share: dict_off [D+1] / dict_vals — for dimension d an EMPTY range means "narrow": all keys
+ *            of all shards lie in [0,1024) (every signature column: thousandths in [0,1000]); otherwise the
+ *            strictly ascending distinct keys of column d over ALL shards (coverage columns).
+ *   accum  : the node's scaffolds on this shard (local ids; n_scaf < 0 = all of them; n_scaf = 0 = none, the
+ *            shard still takes part in the exchange) -> ex: d_hist (hist_count int64 words: integer SUM over
+ *            shards), d_scg_lo (MIN) and d_scg_hi (MAX), scg_count int32 each.  Asynchronous.
+ *   eval   : on the combined buffers: every shard finds the same per-dimension winners and global winner
+ *            (out->dimension/key/sensitivity/specificity/legal as abw_sep_node), then assigns ITS scaffolds
+ *            (scaf_side, dp_raw_side as abw_sep_node, local order).  out->ndps1/ndps2 = dps of this shard's
+ *            scaffolds sent to cluster1/cluster2; out->split stays 0.
+ *   decide : host only.  The caller sums ndps1/ndps2 over the shards; this applies the final size check
+ *            (ref: src/ClusterSeparator.cpp:125-132) and sets out->split / resets out as separate() would.
+ *            When it resets (legal winner, a side too small) the caller discards scaf_side.
+ * Needs the node's dps over all shards to stay below 2^31. */
+typedef struct abw_sep_exchange {
+    int64_t* d_hist;    uint64_t hist_count;
+    int32_t* d_scg_lo;  int32_t* d_scg_hi;  uint64_t scg_count;
+} abw_sep_exchange;
+int abw_sep_shard_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const int32_t* dp2scaf,
+                       const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
+                       int32_t n_scg, const int32_t* dict_vals, const int64_t* dict_off);
+int abw_sep_shard_accum(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, abw_sep_exchange* ex);
+int abw_sep_shard_eval(abw_ctx* ctx, int32_t min_ndps, abw_split* out, abw_dimbest* per_dim,
+                       uint8_t* scaf_side, uint8_t* dp_raw_side);
+int abw_sep_shard_decide(abw_split* out, int64_t ndps1_total, int64_t ndps2_total, int32_t min_ndps);
+
 /* Device pointer to the resident column store [D][N] int32 (for abw_km_features_from_keys). */
 const int32_t* abw_sep_dev_keys(const abw_ctx* ctx);
 

@@ -118,3 +118,130 @@ def test_sharded_oracle_reduces_to_the_plain_one_and_stays_close():
     a3, c3, i3 = orc.kmeans_sharded(x, 4, 77, 3, 64, b)
     assert (a3 != a1).mean() < 0.01                            # same algorithm, another summation order
     assert np.allclose(c3, c1, rtol=1e-4, atol=1e-4) and np.allclose(i3, i1, rtol=1e-6)
+
+
+# ---- scaffold-sharded separator: shared bin layout + the exchange, with a numpy model of the histograms ----
+
+def _np_local_hist(keys, dp2scaf, scaf_len, scg_scaf, scg_id, n_scg, dict_vals, dict_off):
+    """What a shard contributes: per dimension size / tp1 / tot / bp histograms over the shared
+    bins and per-SCG min / max flip value.  Plain loops: test model of abw_sep_shard_accum's output."""
+    D, N = keys.shape
+    S = len(scaf_len)
+    T = [int(dict_off[d + 1] - dict_off[d]) or multi.NARROW_T for d in range(D)]
+    Tmax = max(T)
+    hist = np.zeros((D, 4, Tmax), dtype=np.int64)
+    lo = np.full((D, max(n_scg, 1)), np.iinfo(np.int32).max, dtype=np.int32)
+    hi = np.full((D, max(n_scg, 1)), -1, dtype=np.int32)
+    ndps = np.bincount(dp2scaf, minlength=S)
+    first = np.concatenate([[0], np.cumsum(ndps)[:-1]])
+    genes = [[] for _ in range(S)]
+    for s, g in zip(scg_scaf, scg_id):
+        genes[int(s)].append(int(g))
+    for d in range(D):
+        col = keys[d]
+        if dict_off[d + 1] > dict_off[d]:
+            col = np.searchsorted(dict_vals[dict_off[d]:dict_off[d + 1]], col)
+        for s in range(S):
+            v = np.sort(col[first[s]:first[s] + ndps[s]])
+            ts = v[ndps[s] // 2]
+            np.add.at(hist[d, 0], v, 1)
+            np.add.at(hist[d, 1], np.maximum(v, ts), 1)
+            hist[d, 2, ts] += ndps[s]
+            hist[d, 3, ts] += scaf_len[s]
+            for g in genes[s]:
+                lo[d, g] = min(lo[d, g], ts)
+                hi[d, g] = max(hi[d, g], ts)
+    return hist, lo, hi, T
+
+
+def _np_eval(hist, lo, hi, T, n_scg, min_ndps=100):
+    """Per-dimension winner from the combined histograms (reference rules: ...Specificity.cpp:146-161, .h:25-30,
+    ClusterQuality.cpp:96-136) -> list of (found, bin, sens, spec)."""
+    out = []
+    for d in range(hist.shape[0]):
+        size1, tp1, tot1, bp1 = (np.cumsum(hist[d, k, :T[d]]) for k in range(4))
+        n, bp = int(size1[-1]), int(bp1[-1])
+        l, h = lo[d][lo[d] != np.iinfo(np.int32).max], hi[d][lo[d] != np.iinfo(np.int32).max]
+        best = (0, -1, 0.0, 0.0)
+        bp_ = -1.0
+        for t in np.flatnonzero(hist[d, 0, :T[d]]):
+            s1, s2 = int(size1[t]), n - int(size1[t])
+            if s1 < min_ndps or s2 < min_ndps:
+                continue
+            small1 = s1 < s2
+            TP = int(tp1[t]) if small1 else n - (s1 + int(tot1[t]) - int(tp1[t]))
+            TOT = int(tot1[t]) if small1 else n - int(tot1[t])
+            SZ = s1 if small1 else s2
+            if TOT == 0:
+                continue
+            sens, spec = TP / TOT, TP / SZ
+            if not sens * spec > bp_:
+                continue
+            G1, G2, both = int((l <= t).sum()), int((h > t).sum()), int(((l <= t) & (h > t)).sum())
+            if G1 == 0 or G2 == 0:
+                ok = bp1[t] >= 500000 and bp - bp1[t] >= 500000
+            else:
+                ok = not (both / min(G1, G2) < 0.2)
+            if ok:
+                best, bp_ = (1, int(t), sens, spec), sens * spec
+        out.append(best)
+    return out
+
+
+def _sep_tables():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sep_g3.npz"))
+    dims = np.r_[0:6, 40:44, 179:182]                         # a few signature columns + the coverage columns
+    return np.ascontiguousarray(g["milli"][dims]), g["dp2scaf"], g["scaf_len"], g["scg_scaf"], g["scg_id"], int(g["n_scg"])
+
+
+def _sep_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from abawaca_amd import separator
+        keys, dp2scaf, scaf_len, scg_scaf, scg_id, n_scg = _sep_tables()
+        S = len(scaf_len)
+        mine = np.arange(rank, S, world)                      # scaffolds dealt round-robin
+        p = separator.carve_shard(keys, dp2scaf, scaf_len, mine, scg_scaf, scg_id)
+        dv, do = multi.global_dictionary(p["keys"], dist)
+        hist, lo, hi, T = _np_local_hist(p["keys"], p["dp2scaf"], p["scaf_len"], p["scg_scaf"], p["scg_id"], n_scg, dv, do)
+        th, tl, thi = torch.from_numpy(hist), torch.from_numpy(lo), torch.from_numpy(hi)
+        multi.combine_sep(th, tl, thi, dist)
+        tot = multi.sum_counts([len(mine), int(p["keys"].shape[1])], dist)
+        per = _np_eval(th.numpy(), tl.numpy(), thi.numpy(), T, n_scg)
+        keyof = [(int(dv[do[d] + b]) if do[d + 1] > do[d] else b) if f else -1 for d, (f, b, _, _) in enumerate(per)]
+        np.savez(os.path.join(out_dir, f"s{rank}.npz"), dv=dv, do=do, found=[x[0] for x in per], key=keyof,
+                 sens=[x[2] for x in per], spec=[x[3] for x in per], tot=tot)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_separator_histograms_add_up_to_the_reference_sweep(tmp_path, world):
+    mp.spawn(_sep_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    keys, dp2scaf, scaf_len, scg_scaf, scg_id, n_scg = _sep_tables()
+    S = len(scaf_len)
+    off, ids = orc.scg_csr(scg_scaf, scg_id, S)
+    ndps = np.bincount(dp2scaf, minlength=S).astype(np.int32)
+    res, per, raw, side = orc.separate(keys, dp2scaf, ndps, scaf_len, off, ids, n_scg, np.arange(keys.shape[1], dtype=np.int32), 100)
+    dv1, do1 = multi.merge_dictionaries([keys])
+    assert per["found"].sum() > 0
+    for rank in range(world):
+        z = np.load(tmp_path / f"s{rank}.npz")
+        assert np.array_equal(z["dv"], dv1) and np.array_equal(z["do"], do1)        # every rank built the same layout
+        assert list(z["tot"]) == [S, keys.shape[1]]
+        assert np.array_equal(z["found"], per["found"])
+        f = per["found"] == 1
+        assert np.array_equal(z["key"][f], per["key"][f])
+        assert np.array_equal(z["sens"][f], per["sens"][f]) and np.array_equal(z["spec"][f], per["spec"][f])
+
+
+def test_scaffold_bounds_balance_dps():
+    rng = np.random.default_rng(0)
+    ndps = rng.integers(2, 9, size=1000)
+    for world in (1, 2, 3, 8):
+        b = multi.scaffold_bounds(ndps, world)
+        assert b[0] == 0 and b[-1] == 1000 and all(b[k] < b[k + 1] for k in range(world))
+        per = [ndps[b[k]:b[k + 1]].sum() for k in range(world)]
+        assert max(per) - min(per) <= 16
