@@ -9,6 +9,30 @@ harness's barrier / MAX of the elapsed time.  The same code runs over RCCL ("ncc
 from __future__ import annotations
 
 
+def _active(dist) -> bool:
+    return dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _coll_device(dist, device=None):
+    """Where a tensor must live for a collective of the current backend: RCCL ("nccl") needs it on this
+    rank's GPU, gloo takes host memory."""
+    import torch
+    if dist.get_backend() == "nccl":
+        return device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def _all_reduce(t, op, dist):
+    """In-place all-reduce of a tensor wherever it lives: over gloo a device tensor is staged through the host."""
+    if t.is_cuda and dist.get_backend() != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def restart_range(R_total: int, rank: int, world: int) -> tuple[int, int]:
     """(first restart id, number of restarts) of `rank` when R_total restarts are dealt out as evenly
     as possible, lower ranks taking the remainder."""
@@ -36,7 +60,7 @@ def best_restart(inertia_local, first_restart: int, dist=None, device=None):
         i = int(torch.argmin(loc))          # first minimum
         return first_restart + i, float(loc[i]), 0
     world = dist.get_world_size()
-    dev = device if device is not None else loc.device
+    dev = _coll_device(dist, device if device is not None else (loc.device if loc.is_cuda else None))
     # ragged ranges: exchange (count, first id), then inertia padded with +inf
     meta = torch.tensor([loc.numel(), first_restart], dtype=torch.int64, device=dev)
     metas = [torch.empty_like(meta) for _ in range(world)]
@@ -63,7 +87,7 @@ def max_elapsed(elapsed: float, dist=None, device=None) -> float:
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return float(elapsed)
     import torch
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=_coll_device(dist, device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -83,8 +107,8 @@ def shard_bounds(N: int, world: int) -> list[int]:
 def combine_int_sum(t, dist=None):
     """In-place integer sum over the shards of an int32 tensor (initial centroids: bit patterns of the
     owner, zero elsewhere).  Exact and order-free."""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if _active(dist):
+        _all_reduce(t, dist.ReduceOp.SUM, dist)
     return t
 
 
@@ -95,11 +119,13 @@ def combine_ordered_sum(t, dist=None):
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return t
     import torch
-    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(parts, t)
-    t.copy_(parts[0])
+    src = t.cpu() if (t.is_cuda and dist.get_backend() != "nccl") else t
+    parts = [torch.empty_like(src) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, src)
+    acc = parts[0].clone()
     for p in parts[1:]:
-        t.add_(p)
+        acc.add_(p)
+    t.copy_(acc)
     return t
 
 
@@ -122,7 +148,7 @@ def scaffold_bounds(scaf_ndps, world: int) -> list[int]:
     return b
 
 
-def global_dictionary(keys_local, dist=None):
+def global_dictionary(keys_local, dist=None, device=None):
     """Bin layout shared by all shards, from each shard's own [D, N_local] int32 keys: dimension d is wide when
     any shard holds a key outside [0, NARROW_T); its dictionary is the sorted union of the shards' distinct
     keys.  -> (dict_vals int32[...], dict_off int64[D+1]) for abw_sep_shard_load.  One MIN/MAX all-reduce of D
@@ -132,27 +158,31 @@ def global_dictionary(keys_local, dist=None):
     D = keys_local.shape[0]
     mn = keys_local.min(axis=1).astype(np.int64)
     mx = keys_local.max(axis=1).astype(np.int64)
-    multi_rank = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    multi_rank = _active(dist)
     if multi_rank:
         import torch
-        tmn, tmx = torch.from_numpy(mn), torch.from_numpy(mx)
+        cdev = _coll_device(dist, device)
+        tmn, tmx = torch.from_numpy(mn).to(cdev), torch.from_numpy(mx).to(cdev)
         dist.all_reduce(tmn, op=dist.ReduceOp.MIN)
         dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
-        mn, mx = tmn.numpy(), tmx.numpy()
+        mn, mx = tmn.cpu().numpy(), tmx.cpu().numpy()
     wide = (mn < 0) | (mx >= NARROW_T)
     uniq = [np.unique(keys_local[d]).astype(np.int32) if wide[d] else np.empty(0, np.int32) for d in range(D)]
     if multi_rank:
         import torch
         world = dist.get_world_size()
         flat = np.concatenate(uniq) if wide.any() else np.empty(0, np.int32)
-        sizes = torch.tensor([len(u) for u in uniq], dtype=torch.int64)
+        sizes = torch.tensor([len(u) for u in uniq], dtype=torch.int64, device=cdev)
         all_sizes = [torch.empty_like(sizes) for _ in range(world)]
         dist.all_gather(all_sizes, sizes)
+        all_sizes = [s.cpu() for s in all_sizes]
         nmax = max(int(s.sum()) for s in all_sizes)
         pad = torch.zeros(max(nmax, 1), dtype=torch.int32)
         pad[:len(flat)] = torch.from_numpy(flat)
+        pad = pad.to(cdev)
         parts = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(parts, pad)
+        parts = [p.cpu() for p in parts]
         merged = []
         offs = [np.concatenate([[0], np.cumsum(s.numpy())]) for s in all_sizes]
         for d in range(D):
@@ -184,12 +214,12 @@ def combine_sep(hist, scg_lo, scg_hi, dist=None):
     """The separator's exchange, in place: integer SUM of the histograms (int64 words; per node
     20 B x total bins: 3.7 MB for 179 narrow dimensions + 20 B per distinct coverage key), MIN / MAX of the
     per-SCG flip values.  All exact and order-free."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active(dist):
         return
-    dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+    _all_reduce(hist, dist.ReduceOp.SUM, dist)
     if scg_lo is not None:
-        dist.all_reduce(scg_lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(scg_hi, op=dist.ReduceOp.MAX)
+        _all_reduce(scg_lo, dist.ReduceOp.MIN, dist)
+        _all_reduce(scg_hi, dist.ReduceOp.MAX, dist)
 
 
 def sum_counts(counts, dist=None, device=None):
@@ -197,6 +227,6 @@ def sum_counts(counts, dist=None, device=None):
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return [int(c) for c in counts]
     import torch
-    t = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=device if device is not None else "cpu")
+    t = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=_coll_device(dist, device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [int(v) for v in t.tolist()]

@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--sig-mbp", type=int, default=1000, help="signature side bench: assembly size in Mbp")
     ap.add_argument("--cov-mreads", type=int, default=20, help="coverage side bench: million reads of 150 bp")
     ap.add_argument("--no-extras", action="store_true", help="only the k-means headline")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1: nccl (= RCCL over xGMI); "
+                    "gloo lets several ranks share one GPU for rehearsals (collectives staged through the host)")
+    ap.add_argument("--no-sep-sharded", action="store_true", help="skip the scaffold-sharded separator leg of a multi-rank run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines")
     return ap.parse_args()
 
@@ -216,16 +219,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if args.backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from abawaca_amd import _lib, kmeans, multi, separator, signature
-    ctx = _lib.Context(local_rank)
+    ctx = _lib.Context(dev_index)
 
     # ---------------- workload: configs[1] -------------------------------------------------------
     keys_t, dp2scaf, scaf_len, genome, G = make_points(20241, args.scaffolds, args.samples, dev)
@@ -273,6 +280,36 @@ def main():
     units_per_step = N * R * iters
     value = world * units_per_step * args.steps / elapsed
 
+    # ---------------- multi-rank only: the real separator with the SCAFFOLDS sharded over the ranks -----------
+    # (SURVEY §8(e), configs[4] shape: every rank holds its own scaffolds; per node one integer all-reduce of the
+    # histograms + min/max of the SCG flip values.)  Weak scaling: rank k holds a table of the configs[1] size
+    # generated from its own seed; the node timed is the root of the union.
+    sep_sharded = None
+    if dist is not None and not args.no_sep_sharded:
+        keys_k, dp2scaf_k, scaf_len_k, _g, _G = make_points(20241 + 1000 * rank, args.scaffolds, args.samples, dev)
+        keys_k_host = keys_k.cpu().numpy()
+        t0 = time.perf_counter()
+        dv, do = multi.global_dictionary(keys_k_host, dist, dev)
+        dict_s = time.perf_counter() - t0
+        sctx = _lib.Context(dev_index)
+        sstore = separator.ShardedColumnStore(sctx, keys_k_host, dp2scaf_k, scaf_len_k, dv, do)
+        nd = separator.separate_sharded(sstore, None, dist, dev)          # warm-up (RCCL channels, buffers)
+        barrier()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            nd = separator.separate_sharded(sstore, None, dist, dev)
+        torch.cuda.synchronize()
+        sh_s = multi.max_elapsed((time.perf_counter() - t0) / reps, dist, dev)
+        n_all = multi.sum_counts([keys_k.shape[1]], dist, dev)[0]
+        sep_sharded = dict(value=D * n_all / sh_s, unit="dimension*points/s", ms_per_node=sh_s * 1e3, node="root of the union of the ranks' tables",
+                           dps_total=int(n_all), split=int(nd.out.split), dimension=int(nd.out.dimension), key=int(nd.out.key),
+                           exchange_bytes_per_node=int(nd.hist.numel() * 8), dictionary_s=round(dict_s, 2),
+                           collective=f"all-reduce SUM int64 x{nd.hist.numel()} per node over {args.backend}")
+        del sstore, nd
+        sctx.close()
+        dist.barrier()
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -311,6 +348,8 @@ def main():
                                     f"(z-scored), k=2, {R} restarts x {iters} Lloyd iterations per GPU, chunk {args.chunk}",
                            parallelism=f"restarts x{world}" if world > 1 else "single GPU"),
                roofline=roofline, best_restart=dict(id=int(winner[0]), inertia=float(winner[1]), rank=int(winner[2])))
+    if sep_sharded is not None:
+        out["separator_sharded"] = sep_sharded
 
     # ---------------- extras: real separator + signature build on this GPU -----------------------
     keys_host = None
