@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
 //   pass 2: exclusive scan of the block counts (single workgroup, decoupled chunks)
 //   pass 3: per scaffold: nonN, nseg, nbps, number of segments produced
 //   pass 4: exclusive scan over scaffolds -> segment offsets
-//   pass 5: one wave per segment: locate the position of its last non-N base by rank
+//   pass 5: one thread per segment: locate its last non-N base by rank (block prefix sums)
 // ---------------------------------------------------------------------------------------------
 constexpr int SEGBLK = 1024;
 
@@ -395,10 +395,13 @@ __device__ __forceinline__ uint64_t prefix_nonN(const uint8_t* __restrict__ asci
                                                 uint64_t pos, int lane)
 {
     const uint64_t b = pos / SEGBLK;
+    const uint64_t before = blk_prefix[b];
+    if (pos == b * SEGBLK) return before;
+    if (blk_prefix[b + 1] - before == SEGBLK) return before + (pos - b * SEGBLK);   // a block without 'N': nothing to read
     const uint64_t A = b * SEGBLK + (uint64_t)lane * 16;
     uint32_t c = 0;
     for (uint64_t i = A; i < A + 16 && i < pos; i++) c += ascii[i] != 'N';
-    return blk_prefix[b] + wave_sum(c);
+    return before + wave_sum(c);
 }
 
 struct ScafSeg { uint64_t rank0; uint64_t nbps; uint64_t nseg; };
@@ -422,17 +425,6 @@ __global__ __launch_bounds__(256) void seg_scaf_kernel(const uint8_t* __restrict
         const uint64_t produced = (nbps == 0) ? (e - b) : nonN / nbps;
         if (lane == 0) { info[s].rank0 = r0; info[s].nbps = nbps; info[s].nseg = produced; nseg_out[s] = produced; }
     }
-}
-
-// One wave per 1 KiB block of the blob: every non-N byte knows its rank inside its scaffold
-// (block prefix + wave prefix + position in the lane's 16 bytes), and the byte whose 1-based rank k
-// is a multiple of nbps closes segment k/nbps (ref :212-224).  No search per segment.
-struct ScafCursor { uint64_t s, sb, se, g0; ScafSeg si; };
-
-__device__ __forceinline__ void cursor_load(ScafCursor& c, uint64_t s, const uint64_t* __restrict__ scaf_off,
-                                            const ScafSeg* __restrict__ info, const uint64_t* __restrict__ seg_off)
-{
-    c.s = s; c.sb = scaf_off[s]; c.se = scaf_off[s + 1]; c.si = info[s]; c.g0 = seg_off[s];
 }
 
 // inclusive prefix sum over the 64 lanes, DPP only (row shifts, then the two row broadcasts of gfx9)
@@ -469,100 +461,76 @@ __device__ __forceinline__ int nth_set_bit16(uint32_t m, uint32_t j)
     return pos;
 }
 
+// One thread per segment.  Segment j (0-based) of scaffold s is closed by the base whose 1-based rank among
+// the scaffold's non-N bases is (j+1)*nbps (ref :212-224), i.e. by the byte at which the count of non-N bytes
+// of the whole blob reaches R = rank0 + (j+1)*nbps.  Its 1 KiB block b is the one with
+// blk_prefix[b] < R <= blk_prefix[b+1]: the block the byte would sit in if the scaffold had no N so far is a
+// lower bound and almost always the answer, otherwise a binary search over the scaffold's blocks.  Inside a
+// block without N the position is arithmetic; a block with N is read once, by the whole wave, for each
+// segment that ends in it (ballot loop).  Nothing else of the sequence is read again.
 __global__ __launch_bounds__(256) void seg_emit_kernel(const uint8_t* __restrict__ ascii, uint64_t total_len,
                                                       const uint64_t* __restrict__ scaf_off, uint64_t n_scaf,
-                                                      const uint64_t* __restrict__ blk_prefix, uint64_t nblk,
+                                                      const uint64_t* __restrict__ blk_prefix,
                                                       const ScafSeg* __restrict__ info, const uint64_t* __restrict__ seg_off,
-                                                      uint32_t* __restrict__ seg_scaf,
+                                                      uint64_t n_seg, uint32_t* __restrict__ seg_scaf,
                                                       uint64_t* __restrict__ seg_start, uint64_t* __restrict__ seg_end)
 {
     const int lane = threadIdx.x & 63;
-    // wave-uniform on purpose (readfirstlane): the block walk and the scaffold cursor stay in scalar registers
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint64_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    // every wave walks a CONTIGUOUS run of blocks, so the scaffold cursor only moves forward
-    const uint64_t per = (nblk + nwaves - 1) / nwaves;
-    const uint64_t b_first = wave * per;
-    const uint64_t b_last = (b_first + per < nblk) ? b_first + per : nblk;
-    if (b_first >= b_last || n_scaf == 0) return;
-    ScafCursor cur;
-    {
-        // first scaffold that reaches into the first block: smallest s with scaf_off[s+1] > b_first*SEGBLK
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool active = g < n_seg;
+    uint64_t s = 0, j = 0, sb = 0, nseg = 0, pos = 0;     // pos: blob offset of the closing byte
+    bool need = false;
+    uint64_t need_b = 0; uint32_t need_k = 0;
+    if (active) {
+        // scaffold of segment g: the s with seg_off[s] <= g < seg_off[s+1] (scaffolds without segments are skipped)
         uint64_t lo = 0, hi = n_scaf;
-        const uint64_t at = b_first * SEGBLK;
-        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (scaf_off[mid + 1] > at) hi = mid; else lo = mid + 1; }
-        if (lo >= n_scaf) return;
-        cursor_load(cur, lo, scaf_off, info, seg_off);
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (seg_off[mid] <= g) lo = mid; else hi = mid; }
+        s = lo; j = g - seg_off[s];
+        const ScafSeg si = info[s];
+        sb = scaf_off[s]; nseg = si.nseg;
+        if (si.nbps == 0) pos = sb + j;                    // all-N scaffold: every base is a segment (ref :206 nbps = 0)
+        else {
+            const uint64_t k = (j + 1) * si.nbps;          // rank of the closing base inside the scaffold
+            const uint64_t R = si.rank0 + k;
+            uint64_t b = (sb + k - 1) / SEGBLK;
+            if (blk_prefix[b + 1] < R) {
+                uint64_t l = b + 1, h = (scaf_off[s + 1] - 1) / SEGBLK;          // answer in [l, h]
+                while (l < h) { const uint64_t mid = (l + h) >> 1; if (blk_prefix[mid + 1] >= R) h = mid; else l = mid + 1; }
+                b = l;
+            }
+            const uint64_t before = blk_prefix[b];
+            if (blk_prefix[b + 1] - before == SEGBLK) pos = b * SEGBLK + (R - before) - 1;
+            else { need = true; need_b = b; need_k = (uint32_t)(R - before); }
+        }
     }
-    for (uint64_t b = b_first; b < b_last; b++) {
-        const uint64_t b_begin = b * SEGBLK;
-        const uint64_t b_end = (b_begin + SEGBLK < total_len) ? b_begin + SEGBLK : total_len;
-        if (b_begin >= b_end) break;
-        const uint64_t A = b_begin + (uint64_t)lane * 16;
-        // bit i of nmask: byte i of this lane's piece exists and is a non-N base
+    unsigned long long todo = __ballot(need);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const uint64_t bb = __shfl(need_b, src, 64);
+        const uint32_t kk = __shfl(need_k, src, 64);       // 1-based rank inside block bb
+        const uint64_t A = bb * SEGBLK + (uint64_t)lane * 16;
         uint32_t nmask = 0;
-        int len = 0;
-        if (b_begin + SEGBLK <= total_len) {
+        if (A + 16 <= total_len) {
             const uint4 v = *reinterpret_cast<const uint4*>(ascii + A);
             nmask = nonN4(v.x) | (nonN4(v.y) << 4) | (nonN4(v.z) << 8) | (nonN4(v.w) << 12);
-            len = 16;
         } else {
-            for (uint64_t i = A; i < total_len && i < A + 16; i++) { nmask |= (uint32_t)(ascii[i] != 'N') << (i - A); len++; }
+            for (uint64_t i = A; i < total_len && i < A + 16; i++) nmask |= (uint32_t)(ascii[i] != 'N') << (i - A);
         }
         const uint32_t c = __popc(nmask);
         const uint32_t x = wave_scan(c);
-        const uint64_t blk_rank = blk_prefix[b];                    // non-N bytes of the blob before this block
-        const uint32_t lane_before = x - c;                         // ... and inside the block before this lane's piece
-        while (cur.se <= b_begin && cur.s + 1 < n_scaf) cursor_load(cur, cur.s + 1, scaf_off, info, seg_off);
-        for (;;) {
-            if (cur.sb >= b_end) break;
-            if (cur.se > cur.sb && cur.si.nseg != 0) {
-                const uint64_t sb = cur.sb, se = cur.se, g0 = cur.g0, nbps = cur.si.nbps;
-                if (sb >= b_begin && lane == 0) seg_start[g0] = 1;   // ref :209 sit = seq.begin()
-                const uint64_t p0 = (A > sb) ? A : sb;               // this lane's bytes of the scaffold: [p0, p1)
-                const uint64_t p1 = (A + (uint64_t)len < se) ? A + (uint64_t)len : se;
-                if (nbps == 0) {                                     // all-N scaffold: every base is a segment
-                    for (uint64_t p = p0; p < p1; p++) {
-                        const uint64_t j = p - sb;
-                        seg_scaf[g0 + j] = (uint32_t)cur.s; seg_start[g0 + j] = j + 1; seg_end[g0 + j] = j + 1;
-                    }
-                } else {
-                    // (uniform) 1-based rank inside the scaffold of the first of its non-N bytes that lies in
-                    // this block, as quotient and remainder by nbps: one division per (block, scaffold)
-                    const uint64_t kb = ((blk_rank > cur.si.rank0) ? blk_rank - cur.si.rank0 : 0) + 1;
-                    uint64_t qb, rb;
-                    if (((kb | nbps) >> 32) == 0) { qb = (uint32_t)kb / (uint32_t)nbps; rb = (uint32_t)kb % (uint32_t)nbps; }
-                    else { qb = kb / nbps; rb = kb % nbps; }
-                    if (p0 < p1) {
-                        const int i0 = (int)(p0 - A), i1 = (int)(p1 - A);
-                        const uint32_t todo = nmask & ~((1u << i0) - 1u) & ((1u << i1) - 1u);
-                        const uint32_t cnt = __popc(todo);
-                        // rank of this lane's first such byte = kb + delta; bytes of the block in front of the
-                        // scaffold (when it starts inside the block) are not counted in kb
-                        const uint64_t first_rank = blk_rank + lane_before + __popc(nmask & ((1u << i0) - 1u)) - cur.si.rank0 + 1;
-                        const uint64_t delta = first_rank - kb;                    // < 1024
-                        uint64_t r = rb + delta, q = qb;
-                        if (nbps >= 2048) { if (r >= nbps) { r -= nbps; q++; } }
-                        else { q += r / nbps; r = r % nbps; }
-                        // first cut at or after this byte: the byte whose rank is a multiple of nbps
-                        uint64_t j = (r == 0) ? 0 : nbps - r;                       // 0-based among this lane's bytes
-                        uint64_t qc = (r == 0) ? q : q + 1;
-                        while (j < cnt) {
-                            if (qc >= 1 && qc <= cur.si.nseg) {                     // this base closes segment qc-1
-                                const int i = nth_set_bit16(todo, (uint32_t)j);
-                                const uint64_t g = g0 + qc - 1, rel = A + i - sb;
-                                seg_scaf[g] = (uint32_t)cur.s;
-                                seg_end[g] = rel + 1;
-                                if (qc < cur.si.nseg) seg_start[g + 1] = rel + 2;   // ref :221-222 sit = it + 1
-                            }
-                            j += nbps; qc++;
-                        }
-                    }
-                }
-            }
-            if (cur.se >= b_end || cur.s + 1 >= n_scaf) break;       // the scaffold continues past this block
-            cursor_load(cur, cur.s + 1, scaf_off, info, seg_off);
-        }
+        const bool mine = (x - c < kk) && (kk <= x);
+        const uint64_t found = mine ? A + (uint64_t)nth_set_bit16(nmask, kk - (x - c) - 1) : 0;
+        const unsigned long long who = __ballot(mine);
+        const uint64_t p = __shfl(found, who ? __ffsll((long long)who) - 1 : 0, 64);
+        if (lane == src) pos = p;
+    }
+    if (active) {
+        const uint64_t rel = pos - sb;                     // 0-based inside the scaffold
+        seg_scaf[g] = (uint32_t)s;
+        seg_end[g] = rel + 1;
+        if (j == 0) seg_start[g] = 1;                      // ref :209 sit = seq.begin()
+        if (j + 1 < nseg) seg_start[g + 1] = rel + 2;      // ref :221-222 sit = it + 1
     }
 }
 
@@ -717,8 +685,8 @@ int abw_sig_segment_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len
     if (total > seg_cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "segment capacity %llu < %llu", (unsigned long long)seg_cap, (unsigned long long)total);
     if (total == 0) return ABW_OK;
     if (!d_seg_scaf || !d_seg_start || !d_seg_end) return abw_fail(ctx, ABW_ERR_ARG, "null segment output");
-    hipLaunchKernelGGL(seg_emit_kernel, dim3(grid), dim3(256), 0, st, d_ascii, total_len, d_scaf_off, n_scaf, blk_prefix, nblk,
-                       info, seg_off, d_seg_scaf, d_seg_start, d_seg_end);
+    hipLaunchKernelGGL(seg_emit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_ascii, total_len, d_scaf_off, n_scaf,
+                       blk_prefix, info, seg_off, total, d_seg_scaf, d_seg_start, d_seg_end);
     ABW_LAUNCH_CHECK(ctx);
     return ABW_OK;
 }

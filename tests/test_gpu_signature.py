@@ -121,3 +121,42 @@ def test_counts_and_device_entry_points(ctx):
             assert counts[s, o:o + w].sum() == tot[k]
     live = np.array([[(counts[s, o:o + w].sum() > 0) for (o, w) in [(0, 4), (4, 16), (20, 64), (84, 256)]] for s in range(n)])
     assert np.allclose(dims.sum(axis=1), live.sum(axis=1), atol=1e-12)
+
+
+def test_segmentation_with_many_N(ctx):
+    """Rank lookup of the segment ends when N is everywhere: sprinkled N (every block has some), long N runs
+    (the closing base lies many blocks behind its N-free position), all-N, empty and tiny scaffolds."""
+    import torch
+    rng = np.random.default_rng(77)
+    seqs = []
+    for i in range(60):
+        L = int(rng.choice([0, 1, 3, 900, 5000, 40000, 150000]))
+        s = synth.ACGT[rng.integers(0, 4, size=L)].copy()
+        mode = i % 4
+        if mode == 0 and L:
+            s[rng.random(L) < 0.5] = ord("N")
+        elif mode == 1 and L > 100:
+            for _ in range(6):
+                a = int(rng.integers(0, L - 1)); s[a:a + int(rng.integers(1, 9000))] = ord("N")
+        elif mode == 2 and L:
+            s[:] = ord("N")
+        seqs.append(s)
+    blob = np.concatenate(seqs)
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    dev = torch.device("cuda:0")
+    t_ascii = torch.from_numpy(np.concatenate([blob, np.zeros((-len(blob)) % 16 + 16, np.uint8)])).to(dev)
+    t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    for window in (2000, 700):
+        exp = []
+        for i in range(len(seqs)):
+            a, b = orc.segments(seqs[i], window)
+            exp += [(i, int(x), int(y)) for x, y in zip(a, b)]
+        cap = len(exp) + 8
+        t_scaf = torch.empty(cap, dtype=torch.int32, device=dev)
+        t_st = torch.empty(cap, dtype=torch.int64, device=dev)
+        t_en = torch.empty(cap, dtype=torch.int64, device=dev)
+        n = signature.segment_dev(ctx, t_ascii, len(blob), t_off, window, t_scaf, t_st, t_en)
+        assert n == len(exp)
+        got = list(zip(t_scaf[:n].cpu().tolist(), t_st[:n].cpu().tolist(), t_en[:n].cpu().tolist()))
+        assert got == exp
