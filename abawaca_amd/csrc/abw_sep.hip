@@ -17,9 +17,11 @@
 //   gate     : per SCG g, lo_g/hi_g = min/max t_s over the node's scaffolds carrying g;
 //              |G1| = #{lo_g <= t}, |G2| = #{hi_g > t}, |G1 n G2| = #{lo_g <= t < hi_g};
 //              bp1(t) = sum of len_s over t_s <= t.
-// Kernels: (1) sep_accum — one thread per (scaffold, dimension): order statistic + histogram
-// updates, LDS-privatised per workgroup for narrow dimensions; (2) chunked scan of the histograms
-// and evaluation of every threshold; (3) per-scaffold counts for the final assignment.
+// Kernels: (1) histograms -- narrow dimensions: sep_accum, one thread per (scaffold, dimension), order
+// statistic + updates of a workgroup-private LDS histogram; wide dimensions: sep_wide_ts + sep_wide_hist, a
+// walk over the dps in (static) bin order with run-length reduction in registers, no scatter;
+// (2) chunked scan of the histograms and evaluation of every threshold; (3) per-scaffold counts for the
+// final assignment.
 #include "abw_internal.h"
 #include <string.h>
 #include <algorithm>
@@ -69,39 +71,36 @@ __device__ inline int32_t select_kth_mem(const int32_t* __restrict__ col, int n,
     return lo;
 }
 
-// Histogram updates of one (scaffold, dimension): per dp ONE 64-bit add of (size += 1, tp1 += [v >= t_s])
-// at bin v, where the dps below the flip value are credited to tp1 at bin t_s together with the dps
-// that sit on it (tp1 counts max(v, t_s) <= t); per scaffold tot[t_s] += n and bp[t_s] += len.
+// Narrow dimensions (keys in [0, NARROW_T): every signature column).  One thread per (scaffold, dimension):
+// the flip value by a sorting network, then per dp size[v] += 1 and tp1[max(v, t_s)] += 1 (the dps at or below
+// the flip value are credited to bin t_s in one add), per scaffold tot[t_s] += n and bp[t_s] += len -- all
+// in a histogram private to the workgroup (LDS, 32-bit atomics), flushed to the node's histogram at the end.
 constexpr int ACC_COPIES = ABW_ACC_COPIES;       // LDS copies of the (size, tp1) histograms, by lane.  Measured (r01): 1 copy 0.25 ms,
                                     // 4 copies 0.40 ms for the 179 narrow dimensions -- zeroing and flushing cost more than
                                     // the same-bin contention they remove
 
-template <bool USE_LDS>
 __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t* __restrict__ dimlist,
                                                        const int32_t* __restrict__ node_scaf, int32_t m)
 {
-    __shared__ uint32_t s_size[USE_LDS ? ACC_COPIES * NARROW_T : 1];    // LDS atomics: 32-bit ones are the fast ones
-    __shared__ uint32_t s_tp1[USE_LDS ? ACC_COPIES * NARROW_T : 1];
-    __shared__ uint32_t s_tot[USE_LDS ? NARROW_T : 1];
-    __shared__ unsigned long long s_bp[USE_LDS ? NARROW_T : 1];
+    __shared__ uint32_t s_size[ACC_COPIES * NARROW_T];    // LDS atomics: 32-bit ones are the fast ones
+    __shared__ uint32_t s_tp1[ACC_COPIES * NARROW_T];
+    __shared__ uint32_t s_tot[NARROW_T];
+    __shared__ unsigned long long s_bp[NARROW_T];
     const int d = dimlist[blockIdx.y];
     const int T = P.T[d];
     const int64_t toff = P.Toff[d];
     const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
-    if (USE_LDS) {
-        for (int t = threadIdx.x; t < T; t += 256) {
+    for (int t = threadIdx.x; t < T; t += 256) {
 #pragma unroll
-            for (int c = 0; c < ACC_COPIES; c++) { s_size[c * NARROW_T + t] = 0; s_tp1[c * NARROW_T + t] = 0; }
-            s_tot[t] = 0; s_bp[t] = 0;
-        }
-        __syncthreads();
+        for (int c = 0; c < ACC_COPIES; c++) { s_size[c * NARROW_T + t] = 0; s_tp1[c * NARROW_T + t] = 0; }
+        s_tot[t] = 0; s_bp[t] = 0;
     }
+    __syncthreads();
     unsigned long long* g_st = P.h_st + toff;
     uint32_t* g_tot = P.h_tot + toff;
     unsigned long long* g_bp = P.h_bp + toff;
     uint32_t* my_size = s_size + (threadIdx.x & (ACC_COPIES - 1)) * NARROW_T;
     uint32_t* my_tp1 = s_tp1 + (threadIdx.x & (ACC_COPIES - 1)) * NARROW_T;
-    constexpr unsigned long long BOTH = 1ull | (1ull << 32);
 
     const int ls_end = min(m, (int)(blockIdx.x + 1) * ACC_SPB);
     for (int ls = blockIdx.x * ACC_SPB + threadIdx.x; ls < ls_end; ls += 256) {
@@ -110,6 +109,7 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t*
         const int n = P.scaf_ndps[s];
         const int k = n >> 1;                              // 0-based index of the flip value
         int ts;
+        uint32_t tp_ts = 0;                                // dps at or below the flip value: tp1 credits bin t_s
         if (n <= 8) {
             int v[8];
 #pragma unroll
@@ -130,51 +130,24 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t*
 #undef ABW_CX
                 ts = (k == 1) ? w[1] : (k == 2) ? w[2] : (k == 3) ? w[3] : w[4];
             }
-            if (USE_LDS) {
-                uint32_t tp_ts = 0;                        // dps at or below the flip value: tp1 credits bin t_s
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    if (i < n) {
-                        atomicAdd(&my_size[v[i]], 1u);
-                        if (v[i] > ts) atomicAdd(&my_tp1[v[i]], 1u); else tp_ts++;
-                    }
+            for (int i = 0; i < 8; i++) {
+                if (i < n) {
+                    atomicAdd(&my_size[v[i]], 1u);
+                    if (v[i] > ts) atomicAdd(&my_tp1[v[i]], 1u); else tp_ts++;
                 }
-                atomicAdd(&my_tp1[ts], tp_ts);
-            } else {
-                unsigned long long at_ts = 0;              // everything that lands on bin t_s, in one add
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    if (i < n) {
-                        if (v[i] > ts) atomicAdd(&g_st[v[i]], BOTH);
-                        else if (v[i] < ts) { atomicAdd(&g_st[v[i]], 1ull); at_ts += 1ull << 32; }
-                        else at_ts += BOTH;
-                    }
-                }
-                atomicAdd(&g_st[ts], at_ts);
             }
         } else {
             ts = select_kth_mem(col + f, n, k, T);
-            if (USE_LDS) {
-                uint32_t tp_ts = 0;
-                for (int i = 0; i < n; i++) {
-                    const int v = col[f + i];
-                    atomicAdd(&my_size[v], 1u);
-                    if (v > ts) atomicAdd(&my_tp1[v], 1u); else tp_ts++;
-                }
-                atomicAdd(&my_tp1[ts], tp_ts);
-            } else {
-                unsigned long long at_ts = 0;
-                for (int i = 0; i < n; i++) {
-                    const int v = col[f + i];
-                    if (v > ts) atomicAdd(&g_st[v], BOTH);
-                    else if (v < ts) { atomicAdd(&g_st[v], 1ull); at_ts += 1ull << 32; }
-                    else at_ts += BOTH;
-                }
-                atomicAdd(&g_st[ts], at_ts);
+            for (int i = 0; i < n; i++) {
+                const int v = col[f + i];
+                atomicAdd(&my_size[v], 1u);
+                if (v > ts) atomicAdd(&my_tp1[v], 1u); else tp_ts++;
             }
         }
-        if (USE_LDS) { atomicAdd(&s_tot[ts], (uint32_t)n); atomicAdd(&s_bp[ts], (unsigned long long)P.scaf_len[s]); }
-        else { atomicAdd(&g_tot[ts], (uint32_t)n); atomicAdd(&g_bp[ts], (unsigned long long)P.scaf_len[s]); }
+        atomicAdd(&my_tp1[ts], tp_ts);
+        atomicAdd(&s_tot[ts], (uint32_t)n);
+        atomicAdd(&s_bp[ts], (unsigned long long)P.scaf_len[s]);
         if (P.n_scg > 0) {
             for (int e = P.scg_off[s]; e < P.scg_off[s + 1]; e++) {
                 const int g = P.scg_ids[e];
@@ -183,17 +156,171 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t*
             }
         }
     }
-    if (USE_LDS) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < T; t += 256) {
-            unsigned long long a = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+        unsigned long long a = 0;
 #pragma unroll
-            for (int c = 0; c < ACC_COPIES; c++) a += (unsigned long long)s_size[c * NARROW_T + t] | ((unsigned long long)s_tp1[c * NARROW_T + t] << 32);
-            const uint32_t c3 = s_tot[t];
-            const unsigned long long e = s_bp[t];
-            if (a) atomicAdd(&g_st[t], a);
-            if (c3) atomicAdd(&g_tot[t], c3);
-            if (e) atomicAdd(&g_bp[t], e);
+        for (int c = 0; c < ACC_COPIES; c++) a += (unsigned long long)s_size[c * NARROW_T + t] | ((unsigned long long)s_tp1[c * NARROW_T + t] << 32);
+        const uint32_t c3 = s_tot[t];
+        const unsigned long long e = s_bp[t];
+        if (a) atomicAdd(&g_st[t], a);
+        if (c3) atomicAdd(&g_tot[t], c3);
+        if (e) atomicAdd(&g_bp[t], e);
+    }
+}
+
+// ---- wide dimensions (coverage: about as many distinct keys as dps) -----------------------------------
+// Scattering N dps into ~N bins costs one device-scope atomic per dp (measured r01: ~23 G atomics/s, 0.52 ms
+// for 10 columns of 0.8 M dps, twice the time of the 179 narrow columns).  Instead the table keeps, per wide
+// dimension, the dps SORTED by bin (perm / sbin, built once at load): walking the node in that order makes
+// every histogram update land on the walker's own bin, so a wave reduces runs of equal bins in registers and
+// writes each bin once with a plain store -- no atomics except for runs cut by a wave boundary.
+//   pass A (sep_wide_ts):   per (scaffold, dimension) the flip value t_s and the number of dps below it; SCG lo/hi.
+//   pass B (sep_wide_hist): per sorted position: size += 1, tp1 += [v >= t_s]; the scaffold's "owner" also carries
+//                           what the scaffold puts on bin t_s: tp1 credits of the dps below it, tot += n_s,
+//                           bp += len_s.  Owner = first dp of the scaffold that sits on t_s; the dps of a scaffold
+//                           are consecutive dp ids, so those on one bin are ADJACENT in (bin, dp) order and the
+//                           owner is the position whose predecessor is another scaffold or another bin.
+// The only random access left is the 4-byte gather of t_s by scaffold (S x 4 B per dimension: L2-resident).
+struct WideDev {
+    const int32_t* sscaf;     // [Dw][N] scaffold of the dp at each sorted position (ascending (bin, dp))
+    const int32_t* sbin;      // [Dw][N] its bin
+    int32_t* ts;              // [Dw][S] flip value of scaffold s in the current node, -1 = not in the node
+    int32_t* below;           // [Dw][S] dps of s below t_s
+    int32_t S;
+};
+
+__global__ __launch_bounds__(256) void sep_wide_ts_kernel(SepDev P, WideDev W, const int32_t* __restrict__ dimlist,
+                                                         const int32_t* __restrict__ node_scaf, int32_t m)
+{
+    const int ls = blockIdx.x * 256 + threadIdx.x;
+    if (ls >= m) return;
+    const int w = blockIdx.y;
+    const int d = dimlist[w];
+    const int T = P.T[d];
+    const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
+    const int s = node_scaf ? node_scaf[ls] : ls;
+    const int f = P.scaf_first[s];
+    const int n = P.scaf_ndps[s];
+    const int k = n >> 1;
+    int ts, below = 0;
+    if (n <= 8) {
+        int v[8], x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { v[i] = (i < n) ? col[f + i] : INT_MAX; x[i] = v[i]; }
+#define ABW_CX(a, b) { const int lo_ = min(x[a], x[b]), hi_ = max(x[a], x[b]); x[a] = lo_; x[b] = hi_; }
+        ABW_CX(0, 1) ABW_CX(2, 3) ABW_CX(4, 5) ABW_CX(6, 7)
+        ABW_CX(0, 2) ABW_CX(1, 3) ABW_CX(4, 6) ABW_CX(5, 7)
+        ABW_CX(1, 2) ABW_CX(5, 6)
+        ABW_CX(0, 4) ABW_CX(1, 5) ABW_CX(2, 6) ABW_CX(3, 7)
+        ABW_CX(2, 4) ABW_CX(3, 5)
+        ABW_CX(1, 2) ABW_CX(3, 4) ABW_CX(5, 6)
+#undef ABW_CX
+        ts = (k == 1) ? x[1] : (k == 2) ? x[2] : (k == 3) ? x[3] : x[4];
+#pragma unroll
+        for (int i = 0; i < 8; i++) below += v[i] < ts;
+    } else {
+        ts = select_kth_mem(col + f, n, k, T);
+        for (int i = 0; i < n; i++) below += col[f + i] < ts;
+    }
+    W.ts[(int64_t)w * W.S + s] = ts;
+    W.below[(int64_t)w * W.S + s] = below;
+    if (P.n_scg > 0) {
+        for (int e = P.scg_off[s]; e < P.scg_off[s + 1]; e++) {
+            const int g = P.scg_ids[e];
+            atomicMin(&P.scg_lo[(int64_t)d * P.n_scg + g], ts);
+            atomicMax(&P.scg_hi[(int64_t)d * P.n_scg + g], ts);
+        }
+    }
+}
+
+constexpr int WIDE_TILES = 4;        // 64-position tiles per wave: their loads are issued together (the kernel is
+                                     // a chain of dependent loads; one tile per wave left it latency-bound)
+
+__global__ __launch_bounds__(256) void sep_wide_hist_kernel(SepDev P, WideDev W, const int32_t* __restrict__ dimlist)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.y;
+    const int d = dimlist[w];
+    const int64_t N = P.N;
+    const int64_t wave0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * WIDE_TILES);
+    const int32_t* __restrict__ sbin = W.sbin + (int64_t)w * N;
+    const int32_t* __restrict__ sscaf = W.sscaf + (int64_t)w * N;
+    const int32_t* __restrict__ tsd = W.ts + (int64_t)w * W.S;
+    const int32_t* __restrict__ belowd = W.below + (int64_t)w * W.S;
+    if (wave0 >= N) return;
+    int v[WIDE_TILES], sc[WIDE_TILES], vprev[WIDE_TILES], scprev[WIDE_TILES], vnext[WIDE_TILES], t[WIDE_TILES];
+    // predecessor / successor in sorted order: neighbours inside the wave's span come by shuffle, the two
+    // positions outside it are read by lane 0 / lane 63
+#pragma unroll
+    for (int k = 0; k < WIDE_TILES; k++) {
+        const int64_t i = wave0 + 64 * k + lane;
+        v[k] = -1; sc[k] = -1;
+        if (i < N) { v[k] = sbin[i]; sc[k] = sscaf[i]; }
+    }
+    int v_before = -2, sc_before = -2, v_after = -2;
+    if (lane == 0 && wave0 > 0) { v_before = sbin[wave0 - 1]; sc_before = sscaf[wave0 - 1]; }
+    if (lane == 63 && wave0 + 64 * WIDE_TILES < N) v_after = sbin[wave0 + 64 * WIDE_TILES];
+#pragma unroll
+    for (int k = 0; k < WIDE_TILES; k++) t[k] = (sc[k] >= 0) ? tsd[sc[k]] : -1;
+#pragma unroll
+    for (int k = 0; k < WIDE_TILES; k++) {
+        const int up_v = __shfl_up(v[k], 1, 64), up_s = __shfl_up(sc[k], 1, 64);
+        const int last_v = (k > 0) ? __shfl(v[k > 0 ? k - 1 : 0], 63, 64) : v_before;      // lane 0's predecessor
+        const int last_s = (k > 0) ? __shfl(sc[k > 0 ? k - 1 : 0], 63, 64) : sc_before;
+        vprev[k] = lane == 0 ? last_v : up_v;
+        scprev[k] = lane == 0 ? last_s : up_s;
+        const int dn_v = __shfl_down(v[k], 1, 64);
+        const int first_v = (k + 1 < WIDE_TILES) ? __shfl(v[k + 1 < WIDE_TILES ? k + 1 : k], 0, 64) : v_after;
+        vnext[k] = lane == 63 ? first_v : dn_v;
+    }
+    unsigned long long st[WIDE_TILES], bp[WIDE_TILES];
+    uint32_t tot[WIDE_TILES];
+#pragma unroll
+    for (int k = 0; k < WIDE_TILES; k++) {
+        st[k] = 0; bp[k] = 0; tot[k] = 0;
+        if (t[k] >= 0) {
+            st[k] = 1ull | ((unsigned long long)(v[k] >= t[k]) << 32);
+            if (v[k] == t[k] && (sc[k] != scprev[k] || v[k] != vprev[k])) {          // the scaffold's owner
+                st[k] += (unsigned long long)(uint32_t)belowd[sc[k]] << 32;
+                tot[k] = (uint32_t)P.scaf_ndps[sc[k]]; bp[k] = (unsigned long long)P.scaf_len[sc[k]];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < WIDE_TILES; k++) {
+        // runs of equal bins inside the tile
+        const bool head = lane == 0 || v[k] != vprev[k];
+        const bool tail = lane == 63 || v[k] != vnext[k];
+        bool f = head;
+        unsigned long long a = st[k], c = bp[k];
+        uint32_t b3 = tot[k];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long ya = __shfl_up(a, o, 64), yc = __shfl_up(c, o, 64);
+            const uint32_t yb = __shfl_up(b3, o, 64);
+            const int yf = __shfl_up((int)f, o, 64);
+            if (lane >= o && !f) { a += ya; c += yc; b3 += yb; f = yf != 0; }
+        }
+        const unsigned long long heads = __ballot(head);
+        const int headlane = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));
+        // does the tile's first / last run go on in the neighbouring tile?
+        const int first_open = __shfl((int)(v[k] == vprev[k]), 0, 64);
+        const bool open_tail = (lane == 63) && (v[k] == vnext[k]);
+        if (v[k] >= 0 && tail) {
+            const int64_t bin = P.Toff[d] + v[k];
+            if ((headlane > 0 || !first_open) && !open_tail) {
+                // write-through stores (system scope).  Measured r01: with ordinary stores the dirty histogram
+                // lines push the t_s table out of L2 and the gathers above go to HBM: 0.246 ms vs 0.140 ms
+                // (no stores at all: 0.089 ms; "nt" stores: 0.276 ms)
+                __hip_atomic_store(&P.h_st[bin], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&P.h_tot[bin], b3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&P.h_bp[bin], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                if (a) atomicAdd(&P.h_st[bin], a);
+                if (b3) atomicAdd(&P.h_tot[bin], b3);
+                if (c) atomicAdd(&P.h_bp[bin], c);
+            }
         }
     }
 }
@@ -421,6 +548,8 @@ struct SepHost {
     ChunkDesc* d_chunks = nullptr;
     Sums *d_chunk_sums = nullptr, *d_dim_total = nullptr;
     Cand* d_chunk_best = nullptr;
+    // wide dimensions: dps sorted by bin (static) and the per-node flip-value records
+    int32_t *d_sscaf = nullptr, *d_sbin = nullptr, *d_wts = nullptr, *d_wbelow = nullptr;
 };
 
 }  // namespace
@@ -463,7 +592,8 @@ extern "C" void abw_sep_free(abw_ctx* ctx)
     }
     if (e) {
         void* q[] = {e->h.d_narrow, e->h.d_wide, e->h.d_dim_first_chunk, e->h.d_dim_nchunks, e->h.d_chunks,
-                     e->h.d_chunk_sums, e->h.d_dim_total, e->h.d_chunk_best};
+                     e->h.d_chunk_sums, e->h.d_dim_total, e->h.d_chunk_best, e->h.d_sscaf, e->h.d_sbin,
+                     e->h.d_wts, e->h.d_wbelow};
         for (void* p : q) if (p) (void)hipFree(p);
         delete e;
     }
@@ -638,6 +768,32 @@ static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int
     if ((rc = upload<Sums>(ctx, &H.d_chunk_sums, nullptr, H.chunks.size()))) return rc;
     if ((rc = upload<Sums>(ctx, &H.d_dim_total, nullptr, (size_t)D))) return rc;
     if ((rc = upload<Cand>(ctx, &H.d_chunk_best, nullptr, H.chunks.size()))) return rc;
+    if (!H.wide_dims.empty()) {
+        // dps of every wide dimension in ascending (bin, dp) order: counting sort on the dense ranks
+        const size_t Dw = H.wide_dims.size();
+        std::vector<int32_t> sscaf(Dw * (size_t)N), sbin(Dw * (size_t)N);
+        unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        auto sort_dim = [&](unsigned t) {
+            std::vector<int64_t> start;
+            for (size_t w = t; w < Dw; w += nt) {
+                const int32_t d = H.wide_dims[w];
+                const int32_t* col = bins.data() + (int64_t)d * N;
+                start.assign((size_t)s.h_T[d] + 1, 0);
+                for (int64_t p = 0; p < N; p++) start[(size_t)col[p] + 1]++;
+                for (int32_t b = 0; b < s.h_T[d]; b++) start[(size_t)b + 1] += start[b];
+                int32_t* pw = sscaf.data() + w * (size_t)N;
+                int32_t* sw = sbin.data() + w * (size_t)N;
+                for (int64_t p = 0; p < N; p++) { const int64_t at = start[col[p]]++; pw[at] = dp2scaf[p]; sw[at] = col[p]; }
+            }
+        };
+        std::vector<std::thread> th3;
+        for (unsigned t = 0; t < nt; t++) th3.emplace_back(sort_dim, t);
+        for (auto& x : th3) x.join();
+        if ((rc = upload(ctx, &H.d_sscaf, sscaf.data(), sscaf.size()))) return rc;
+        if ((rc = upload(ctx, &H.d_sbin, sbin.data(), sbin.size()))) return rc;
+        if ((rc = upload<int32_t>(ctx, &H.d_wts, nullptr, Dw * (size_t)S))) return rc;
+        if ((rc = upload<int32_t>(ctx, &H.d_wbelow, nullptr, Dw * (size_t)S))) return rc;
+    }
     if ((rc = abw_reserve(ctx, s.hist, (size_t)tb * (4 * 3 + 8) + 64))) return rc;
     if ((rc = abw_reserve(ctx, s.scg_lohi, (size_t)std::max<int64_t>(1, (int64_t)D * n_scg) * 8))) return rc;
     if ((rc = abw_reserve(ctx, s.dimbest, (size_t)D * sizeof(DimBestDev)))) return rc;
@@ -706,11 +862,16 @@ static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_
         const unsigned gx = (unsigned)((m + ACC_SPB - 1) / ACC_SPB);
         ABW_PROF(ctx, "sep_accum");
         if (!H.narrow_dims.empty()) {
-            hipLaunchKernelGGL(sep_accum_kernel<true>, dim3(gx, (unsigned)H.narrow_dims.size()), dim3(256), 0, st, P, H.d_narrow, d_node_scaf, m);
+            hipLaunchKernelGGL(sep_accum_kernel, dim3(gx, (unsigned)H.narrow_dims.size()), dim3(256), 0, st, P, H.d_narrow, d_node_scaf, m);
             ABW_LAUNCH_CHECK(ctx);
         }
         if (!H.wide_dims.empty()) {
-            hipLaunchKernelGGL(sep_accum_kernel<false>, dim3(gx, (unsigned)H.wide_dims.size()), dim3(256), 0, st, P, H.d_wide, d_node_scaf, m);
+            const unsigned Dw = (unsigned)H.wide_dims.size();
+            WideDev W = {H.d_sscaf, H.d_sbin, H.d_wts, H.d_wbelow, s.S};
+            ABW_HIP(ctx, hipMemsetAsync(H.d_wts, 0xFF, (size_t)Dw * (size_t)s.S * 4, st));      // -1: not in the node
+            hipLaunchKernelGGL(sep_wide_ts_kernel, dim3((unsigned)((m + 255) / 256), Dw), dim3(256), 0, st, P, W, H.d_wide, d_node_scaf, m);
+            ABW_LAUNCH_CHECK(ctx);
+            hipLaunchKernelGGL(sep_wide_hist_kernel, dim3((unsigned)((s.N + 256 * WIDE_TILES - 1) / (256 * WIDE_TILES)), Dw), dim3(256), 0, st, P, W, H.d_wide);
             ABW_LAUNCH_CHECK(ctx);
         }
     }
