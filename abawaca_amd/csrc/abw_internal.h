@@ -37,6 +37,7 @@ struct abw_sep_state {
     std::vector<int64_t> h_binval_off;
     std::vector<int32_t> h_binval;
     std::vector<int32_t> h_scaf_first, h_scaf_ndps;
+    std::vector<uint32_t> h_stamp; uint32_t stamp = 0;   // duplicate check of a node's scaffold list
     std::vector<int32_t> h_node_ids, h_node_dpoff;   // host copies of the current node's lists (sources of async copies)
     int64_t   TB = 0;                 // total bins
     bool      node_open = false, node_all = false;   // a node accumulated and not yet evaluated

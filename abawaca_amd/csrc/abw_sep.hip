@@ -830,18 +830,18 @@ static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_
         std::vector<int32_t>& dpoff = s.h_node_dpoff;                // both outlive the asynchronous copies below
         dpoff.resize((size_t)m + 1);
         s.h_node_ids.assign(scaf_ids, scaf_ids + m);
+        // duplicate check in O(m): a stamp per scaffold, a new stamp value per call
+        if (s.h_stamp.size() != (size_t)s.S) { s.h_stamp.assign((size_t)s.S, 0); s.stamp = 0; }
+        if (++s.stamp == 0) { std::fill(s.h_stamp.begin(), s.h_stamp.end(), 0u); s.stamp = 1; }
         for (int32_t i = 0; i < m; i++) {
             const int32_t sc = scaf_ids[i];
             if (sc < 0 || sc >= s.S) return abw_fail(ctx, ABW_ERR_ARG, "%s: scaffold id %d out of range", who, sc);
+            if (s.h_stamp[sc] == s.stamp) return abw_fail(ctx, ABW_ERR_ARG, "%s: duplicate scaffold id", who);
+            s.h_stamp[sc] = s.stamp;
             dpoff[i] = (int32_t)n;
             n += s.h_scaf_ndps[sc];
         }
         dpoff[m] = (int32_t)n;
-        {
-            std::vector<int32_t> tmp(scaf_ids, scaf_ids + m);
-            std::sort(tmp.begin(), tmp.end());
-            if (std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end()) return abw_fail(ctx, ABW_ERR_ARG, "%s: duplicate scaffold id", who);
-        }
         if ((rc = abw_reserve(ctx, s.node_scaf, (size_t)m * 4))) return rc;
         if ((rc = abw_reserve(ctx, s.node_dpoff, ((size_t)m + 1) * 4))) return rc;
         ABW_HIP(ctx, hipMemcpyAsync(s.node_scaf.p, s.h_node_ids.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));

@@ -64,15 +64,20 @@ class ClusterSeparatorHip:
         n = int(st.scaf_ndps[ids].sum())
         out = Split()
         per = (DimBest * st.D)()
-        side = np.zeros(m, dtype=np.uint8)
-        raw = np.zeros(n, dtype=np.uint8)
+        # output buffers are kept on the store and re-used (fresh numpy pages would be faulted in by the copy)
+        buf = st.__dict__.setdefault("_outbuf", {})
+        if "side" not in buf or len(buf["side"]) < m:
+            buf["side"] = np.zeros(max(m, 1), dtype=np.uint8)
+        if "raw" not in buf or len(buf["raw"]) < n:
+            buf["raw"] = np.zeros(max(n, 1), dtype=np.uint8)
+        side, raw = buf["side"][:m], buf["raw"][:n]
         t0 = time.perf_counter()
         st.ctx.check(lib().abw_sep_node(st.ctx.handle,
                                         C.c_void_p(self.scaf_ids.ctypes.data) if self.scaf_ids is not None else None,
                                         m, self.cluster_ndps_threshold, C.byref(out), per,
                                         C.c_void_p(side.ctypes.data), C.c_void_p(raw.ctypes.data)))
         self.last_call_s = time.perf_counter() - t0          # the C-ABI call alone (host buffers in and out)
-        self._res, self._side, self._raw, self._ids = out, side, raw, ids
+        self._res, self._side, self._raw, self._ids = out, side.copy(), raw.copy(), ids
         self._per = np.array([(p.found, p.key, p.sensitivity, p.specificity) for p in per],
                              dtype=[("found", "i4"), ("key", "i4"), ("sens", "f8"), ("spec", "f8")])
         return bool(out.split)

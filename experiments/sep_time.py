@@ -19,3 +19,26 @@ for _ in range(5):
     sep.separate()
     t += sep.last_call_s
 print("ms per node", t / 5 * 1e3, "split", sep._res.split, "dim", sep._res.dimension)
+
+# where the rest of the call goes: the same node without the host outputs
+import ctypes as C
+import numpy as np
+L = _lib.lib()
+out = _lib.Split()
+per = (_lib.DimBest * store.D)()
+side = np.zeros(store.S, np.uint8); raw = np.zeros(store.N, np.uint8)
+def run(per_, side_, raw_, reps=5):
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.check(L.abw_sep_node(ctx.handle, None, store.S, 100, C.byref(out), per_, side_, raw_))
+    return (time.perf_counter() - t0) / reps * 1e3
+pv = lambda a: C.c_void_p(a.ctypes.data)
+print("full        ", run(per, pv(side), pv(raw)))
+print("no raw      ", run(per, pv(side), None))
+print("no raw/side ", run(per, None, None))
+print("no outputs  ", run(None, None, None))
+ids = np.arange(store.S, dtype=np.int32)
+t0 = time.perf_counter()
+for _ in range(5):
+    ctx.check(L.abw_sep_node(ctx.handle, pv(ids), store.S, 100, C.byref(out), per, pv(side), pv(raw)))
+print("explicit ids", (time.perf_counter() - t0) / 5 * 1e3)
