@@ -21,7 +21,7 @@ EXPORTS = [
     "abw_abi_version", "abw_prof_enable", "abw_prof_reset", "abw_prof_read", "abw_sig_dim_names", "abw_sig_segment_host", "abw_sig_segment_dev", "abw_sig_count_dev",
     "abw_sig_build", "abw_sep_load", "abw_sep_node", "abw_sep_dev_keys", "abw_km_run_dev", "abw_km_run",
     "abw_km_features_from_keys", "abw_km_tinymt_selftest", "abw_km_auto_chunk",
-    "abw_cov_accumulate", "abw_cov_accumulate_dev",
+    "abw_cov_accumulate", "abw_cov_accumulate_dev", "abw_km_load", "abw_km_node",
     "abw_sep_shard_load", "abw_sep_shard_accum", "abw_sep_shard_eval", "abw_sep_shard_decide",
     "abw_km_shard_begin", "abw_km_shard_ready", "abw_km_shard_step", "abw_km_shard_update", "abw_km_shard_finish",
 ]
@@ -35,6 +35,11 @@ class AbwError(RuntimeError):
 
 class DimBest(C.Structure):
     _fields_ = [("found", C.c_int32), ("key", C.c_int32), ("sensitivity", C.c_double), ("specificity", C.c_double)]
+
+
+class KmSplit(C.Structure):
+    _fields_ = [("split", C.c_int32), ("best_restart", C.c_int32), ("inertia", C.c_double), ("agreement", C.c_double),
+                ("ndps", C.c_int64), ("raw1", C.c_int64), ("ndps1", C.c_int64), ("ndps2", C.c_int64)]
 
 
 class Split(C.Structure):
@@ -89,6 +94,8 @@ def lib():
     L.abw_km_shard_step.argtypes = [vp, vp]
     L.abw_km_shard_update.argtypes = [vp, i32]
     L.abw_km_shard_finish.argtypes = [vp, vp, vp]
+    L.abw_km_load.argtypes = [vp, vp, i32, i64, vp, i32]
+    L.abw_km_node.argtypes = [vp, vp, i32, i32, u32, i32, i32, C.POINTER(KmSplit), vp, vp]
     L.abw_km_auto_chunk.argtypes = [vp, i64, i32]
     L.abw_km_auto_chunk.restype = i32
     _LIB = L

@@ -124,6 +124,7 @@ int abw_ctx_create(int device, abw_ctx** out)
 }
 
 void abw_sep_free(abw_ctx* ctx);   // abw_sep.hip
+void abw_kmstore_free(abw_ctx* ctx);   // abw_kmnode.hip
 
 void abw_ctx_destroy(abw_ctx* ctx)
 {
@@ -131,6 +132,7 @@ void abw_ctx_destroy(abw_ctx* ctx)
     abw_device_guard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     abw_sep_free(ctx);
+    abw_kmstore_free(ctx);
     for (auto& r : ctx->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto& e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (auto& b : ctx->scratch) abw_release(b);

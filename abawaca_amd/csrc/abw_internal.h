@@ -72,9 +72,20 @@ struct abw_km_state {
     float *cent = nullptr, *dT = nullptr, *slabs = nullptr;
 };
 
+// resident feature table of the k-means separator (abw_km_load / abw_km_node)
+struct abw_km_store {
+    bool loaded = false;
+    int32_t D = 0, S = 0;
+    int64_t N = 0;
+    float* d_x = nullptr;                 // [D][N]
+    int32_t *d_scaf_first = nullptr, *d_scaf_ndps = nullptr;
+    std::vector<int32_t> h_scaf_first, h_scaf_ndps, h_node_ids, h_node_dpoff;
+};
+
 struct abw_ctx {
     int         device = 0;
     abw_km_state km;
+    abw_km_store kmst;
     abw_prof    prof;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;

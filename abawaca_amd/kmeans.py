@@ -107,3 +107,35 @@ def kmeans_sharded_dev(ctx: Context, t_x_local, first_point: int, N_total: int, 
         run.update(last)
     run.finish(t_centroids, t_inertia)
     return run
+
+
+# ---- the k-means separator on a resident feature table (abw_km_load / abw_km_node) --------------------
+
+class KmColumnStore:
+    """fp32 features of every datapoint, resident on the GPU for the whole recursion."""
+
+    def __init__(self, ctx: Context, x_dn: np.ndarray, dp2scaf):
+        self.ctx = ctx
+        self.x = np.ascontiguousarray(x_dn, dtype=np.float32)
+        self.D, self.N = self.x.shape
+        self.dp2scaf = np.ascontiguousarray(dp2scaf, dtype=np.int32)
+        self.S = int(self.dp2scaf.max()) + 1
+        self.scaf_ndps = np.bincount(self.dp2scaf, minlength=self.S).astype(np.int32)
+        self.scaf_first = np.concatenate([[0], np.cumsum(self.scaf_ndps)[:-1]]).astype(np.int64)
+        ctx.check(lib().abw_km_load(ctx.handle, C.c_void_p(self.x.ctypes.data), self.D, self.N,
+                                    C.c_void_p(self.dp2scaf.ctypes.data), self.S))
+
+
+def km_node(store: KmColumnStore, scaf_ids, R: int, base_seed: int, iters: int, min_ndps: int = 100):
+    """One node (scaf_ids ascending, None = all).  -> (KmSplit, scaf_side u8[m], dp_raw_side u8[n])"""
+    from ._lib import KmSplit
+    ids = None if scaf_ids is None else np.ascontiguousarray(scaf_ids, dtype=np.int32)
+    m = store.S if ids is None else len(ids)
+    n = store.N if ids is None else int(store.scaf_ndps[ids].sum())
+    out = KmSplit()
+    side = np.zeros(max(m, 1), dtype=np.uint8)
+    raw = np.zeros(max(n, 1), dtype=np.uint8)
+    store.ctx.check(lib().abw_km_node(store.ctx.handle, C.c_void_p(ids.ctypes.data) if ids is not None else None, m, int(R),
+                                      int(base_seed) & 0xFFFFFFFF, int(iters), int(min_ndps), C.byref(out),
+                                      C.c_void_p(side.ctypes.data), C.c_void_p(raw.ctypes.data)))
+    return out, side[:m], raw[:n]

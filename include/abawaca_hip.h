@@ -254,6 +254,30 @@ int abw_km_shard_step(abw_ctx* ctx, uint8_t* d_assign);
 int abw_km_shard_update(abw_ctx* ctx, int32_t last);
 int abw_km_shard_finish(abw_ctx* ctx, float* d_centroids, double* d_inertia);
 
+/* ---- the k-means separator on a RESIDENT feature table (SURVEY §8(f) row N2 applied to the extension; no
+ *      reference counterpart for the k-means itself).  abw_km_load: x host [D][N] fp32 (the caller's scaling,
+ *      e.g. z-scores over the root), dp2scaf as abw_sep_load.  abw_km_node = one node of the recursion given its
+ *      scaffolds (strictly ascending ids; NULL = all): R restarts x iters Lloyd iterations over the node's dps in
+ *      ascending dp order, the restart of smallest inertia (ties: the earlier), then what every separator of the
+ *      reference does with a raw split (ref: src/ClusterSeparator.cpp:49-53 the smaller raw side is cluster1,
+ *      tie: the library's side 0; :94-101 a scaffold goes to cluster1 iff at least half of its dps are there;
+ *      :103-122 dps follow their scaffold; :125-132 both children need min_ndps dps).  Outputs as abw_sep_node:
+ *      scaf_side [n_scaf] 1/2, dp_raw_side [node dps] 1/2, zero when there is no split candidate.
+ *      out->split = 1 says the sizes allow a split; ACCEPTING it (agreement level, the SCG gate
+ *      ClusterQuality::is_split_better, ref: src/ClusterQuality.cpp:96-136) stays with the caller. */
+typedef struct {
+    int32_t split;          /* raw side and both children reach min_ndps */
+    int32_t best_restart;   /* -1 when the node is too small to try (n < 2*min_ndps or n < 32) */
+    double  inertia;        /* of the best restart */
+    double  agreement;      /* share of the node's dps that lie on their scaffold's side */
+    int64_t ndps;           /* dps of the node */
+    int64_t raw1;           /* dps on the smaller raw side */
+    int64_t ndps1, ndps2;   /* children sizes after dps followed their scaffolds */
+} abw_km_split;
+int abw_km_load(abw_ctx* ctx, const float* x, int32_t D, int64_t N, const int32_t* dp2scaf, int32_t S);
+int abw_km_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t R, uint32_t base_seed, int32_t iters,
+                int32_t min_ndps, abw_km_split* out, uint8_t* scaf_side, uint8_t* dp_raw_side);
+
 /* Host-buffer convenience: x is host [d][N]; outputs host. */
 int abw_km_run(abw_ctx* ctx, const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed,
                int32_t iters, int32_t chunk, uint8_t* assign, float* centroids, double* inertia);

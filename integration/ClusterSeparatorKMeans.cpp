@@ -1,5 +1,6 @@
 // See ClusterSeparatorKMeans.h.  Host-side adapter between the reference's data model and
-// abw_km_run (include/abawaca_hip.h).
+// abw_km_load / abw_km_node (include/abawaca_hip.h): the feature table goes to the GPU once, at the root;
+// every node of the recursion then sends only its scaffold list.
 #include "ClusterSeparatorKMeans.h"
 #include "abawaca_hip.h"
 #include <algorithm>
@@ -15,7 +16,7 @@ struct KmStore {
 	abw_ctx*		ctx = NULL;
 	const ScafDpData*	scaf_db = NULL;
 	size_t			N = 0, D = 0;
-	std::vector<float>	x;		// [D][N] z-scored over the root, dp id - 1 is the column
+	std::vector<float>	x;		// [D][N] z-scored over the root, dp id - 1 is the column (staging for abw_km_load)
 	int			restarts = 16, iterations = 20;
 	unsigned		base_seed = 20240;
 };
@@ -52,6 +53,11 @@ void km_load(const ScafDpData& scaf_db, const ClusterData& root)
 		for(auto it = dim.begin(); it != dim.end(); it++)
 			st.x[d * N + (it->dp - 1)] = (float)((it->value - mean) * inv);
 	}
+	std::vector<int32_t> dp2scaf(N);
+	for(size_t dp = 1; dp <= N; dp++) dp2scaf[dp - 1] = (int32_t)scaf_db.dp2scaf(dp) - 1;
+	if(abw_km_load(st.ctx, st.x.data(), (int32_t)D, (int64_t)N, dp2scaf.data(), (int32_t)scaf_db.nscafs()) != ABW_OK)
+		km_fail("ClusterSeparatorKMeans: abw_km_load failed");
+	std::vector<float>().swap(st.x);						// resident now
 }
 
 }	// namespace
@@ -94,63 +100,43 @@ bool ClusterSeparatorKMeans::separate()
 		km_load(scaf_db, clustering_db);
 	KmStore& st = g_km;
 
-	// the node's datapoints in ascending id order = the columns handed to the library
-	std::vector<size_t> dps(clustering_db.datapoints().begin(), clustering_db.datapoints().end());
-	std::sort(dps.begin(), dps.end());
-	const size_t n = dps.size();
-	if(n < 2 * this->cluster_ndps_threshold || n < 32)
-		return false;								// two children of cluster_ndps_threshold datapoints cannot exist
-	std::vector<float> x(st.D * n);
-	for(size_t d = 0; d < st.D; d++)
-		for(size_t i = 0; i < n; i++)
-			x[d * n + i] = st.x[d * st.N + (dps[i] - 1)];
-
-	const int R = st.restarts;
-	std::vector<uint8_t> assign((size_t)R * n);
-	std::vector<double> inertia(R);
-	if(abw_km_run(st.ctx, x.data(), (int64_t)n, (int32_t)st.D, R, st.base_seed, st.iterations, 0, assign.data(), NULL, inertia.data()) != ABW_OK)
-		km_fail("ClusterSeparatorKMeans: abw_km_run failed");
-	size_t best = 0;
-	for(int r = 1; r < R; r++) if(inertia[r] < inertia[best]) best = r;		// ties: the earlier restart
-	const uint8_t* side = assign.data() + best * n;
-
-	// raw split; the smaller side is cluster1 (reference :49-53; every datapoint is "useful": ScafDpData keeps
-	// no single-datapoint scaffolds, reference src/ScafDpData.cpp:92-93)
-	size_t n_side1 = 0;
-	for(size_t i = 0; i < n; i++) n_side1 += side[i];
-	const uint8_t first = (n_side1 < n - n_side1) ? 1 : 0;				// library side that becomes cluster1
-	for(size_t i = 0; i < n; i++)
-		(side[i] == first ? raw_dps_cluster1 : raw_dps_cluster2).insert(dps[i]);
-	if(raw_dps_cluster1.size() < this->cluster_ndps_threshold) {
-		raw_dps_cluster1.clear(); raw_dps_cluster2.clear();
-		return false;								// no significant separation (reference :83-84)
+	// the node as a list of whole scaffolds in ascending id order, which is ascending datapoint order too
+	// (separate() always hands whole scaffolds to its children, reference src/ClusterSeparator.cpp:94-122)
+	const unordered_set<size_t>& node_dps = clustering_db.datapoints();
+	std::map<size_t, std::vector<size_t> > per_scaf;
+	for(auto it = node_dps.begin(); it != node_dps.end(); it++) per_scaf[scaf_db.dp2scaf(*it)].push_back(*it);
+	std::vector<int32_t> scaf_ids;
+	for(auto it = per_scaf.begin(); it != per_scaf.end(); it++) {
+		if(it->second.size() != scaf_db.ndps(it->first))
+			throw std::invalid_argument("ClusterSeparatorKMeans: node holds only part of scaffold " + scaf_db.scaf_id2name(it->first));
+		std::sort(it->second.begin(), it->second.end());
+		scaf_ids.push_back((int32_t)it->first - 1);
 	}
+	const int32_t m = (int32_t)scaf_ids.size();
+	const size_t n = node_dps.size();
+	abw_km_split out;
+	std::vector<uint8_t> side(m), raw(n);
+	if(abw_km_node(st.ctx, scaf_ids.data(), m, st.restarts, st.base_seed, st.iterations, (int32_t)this->cluster_ndps_threshold,
+			&out, side.data(), raw.data()) != ABW_OK)
+		km_fail("ClusterSeparatorKMeans: abw_km_node failed");
+	if(out.best_restart < 0 || out.raw1 < (int64_t)this->cluster_ndps_threshold)
+		return false;								// too small, or no significant separation (reference :83-84)
 
-	// scaffold assignment (reference :94-101): cluster1 takes a scaffold with at least half of its datapoints there
-	std::map<size_t, size_t> in1, total;
-	for(size_t i = 0; i < n; i++) {
-		const size_t s = scaf_db.dp2scaf(dps[i]);
-		total[s]++;
-		if(side[i] == first) in1[s]++;
-	}
+	// raw sets (reference :87-90) and the two children (reference :94-122), as the library assigned them
 	this->cluster1 = new Cluster(scaf_db);
 	this->cluster2 = new Cluster(scaf_db);
-	std::map<size_t, bool> to1;
-	size_t agree = 0;
-	for(auto it = total.begin(); it != total.end(); it++) {
-		const size_t k = in1.count(it->first) ? in1[it->first] : 0;
-		const bool c1 = 2 * k >= scaf_db.ndps(it->first);
-		to1[it->first] = c1;
-		agree += c1 ? k : it->second - k;
-		(c1 ? this->cluster1 : this->cluster2)->add_assigned_scaf(it->first);
+	size_t k = 0;
+	int32_t i = 0;
+	for(auto it = per_scaf.begin(); it != per_scaf.end(); it++, i++) {
+		Cluster* c = (side[i] == 1) ? this->cluster1 : this->cluster2;
+		c->add_assigned_scaf(it->first);
+		for(size_t j = 0; j < it->second.size(); j++, k++) {
+			(raw[k] == 1 ? raw_dps_cluster1 : raw_dps_cluster2).insert(it->second[j]);
+			*c += it->second[j];
+		}
 	}
-	for(size_t i = 0; i < n; i++)							// datapoints follow their scaffold (reference :103-122)
-		*(to1[scaf_db.dp2scaf(dps[i])] ? this->cluster1 : this->cluster2) += dps[i];
-
-	const double agreement = (double)agree / (double)n;
-	const bool big_enough = this->cluster1->ndps() >= this->cluster_ndps_threshold && this->cluster2->ndps() >= this->cluster_ndps_threshold;
-	const bool legal = big_enough && agreement >= 0.8 && cq.is_split_better(*this->cluster1, *this->cluster2);
-	static_cast<Result*>(best_separation)->set(best, agreement, inertia[best], legal);
+	const bool legal = out.split && out.agreement >= 0.8 && cq.is_split_better(*this->cluster1, *this->cluster2);
+	static_cast<Result*>(best_separation)->set((size_t)out.best_restart, out.agreement, out.inertia, legal);
 	if(!legal) {									// reference :125-132
 		delete(this->cluster1); delete(this->cluster2);
 		this->cluster1 = this->cluster2 = NULL;
