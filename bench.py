@@ -56,6 +56,8 @@ def parse():
                     "gloo lets several ranks share one GPU for rehearsals (collectives staged through the host)")
     ap.add_argument("--no-sep-sharded", action="store_true", help="skip the scaffold-sharded separator leg of a multi-rank run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines")
+    ap.add_argument("--c1", action="store_true", help="also run configs[0] end to end: the whole recursive binning of a 10k-scaffold "
+                    "table, reference driver (its own separator, all host cores; takes about a minute) beside the GPU separator")
     return ap.parse_args()
 
 
@@ -209,6 +211,49 @@ def cpu_separator_baseline(keys_host, dp2scaf, scaf_len, n_scaf_sample=12000):
     return dict(value=D * n / (usec * 1e-6), unit="dimension*points/s", cores=cores, kind="reference",
                 sample=f"reference ClusterSeparatorBySensitivitySpecificity::separate() (-O2 build of its own sources, "
                        f"-p {cores}) on the root node of the first {S} scaffolds ({n} dps x {D} dims), {usec / 1e6:.2f} s")
+
+
+def recursion_c1(ctx):
+    """configs[0]: 10 000 scaffolds, 179 signature + 3 coverage columns, the whole recursion (reference
+    src/abawaca.cpp:95-197) -- reference objects + reference separator (oracle/_ref/ref_sep_driver, -O2) beside
+    abawaca_amd.separator.binning on the GPU; the two must give the same tree and the same bins."""
+    from abawaca_amd import separator, synth
+    f = synth.make_features(20240, 10000, 25, 3)
+    S = len(f["scaf_len"])
+    off, ids = separator.scg_csr(f["scg_scaf"], f["scg_id"], S)
+    t0 = time.perf_counter()
+    store = separator.ColumnStore(ctx, f["milli"], f["dp2scaf"], f["scaf_len"], off, ids, f["n_scg"])
+    load_s = time.perf_counter() - t0
+    separator.binning(store, max_nodes=3)                     # warm-up
+    t0 = time.perf_counter()
+    nodes, s2c, d2c = separator.binning(store)
+    gpu_s = time.perf_counter() - t0
+    res = dict(workload=f"configs[0]: {S} scaffolds -> {f['milli'].shape[1]} dps x {f['milli'].shape[0]} dims, {f['n_scg']} SCGs, whole recursion",
+               nodes=len(nodes), bins=int(sum(1 for r in nodes if not r["split"])), gpu_s=round(gpu_s, 4), gpu_load_s=round(load_s, 3),
+               gpu_ms_per_node=round(gpu_s / len(nodes) * 1e3, 3))
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_sep_driver")
+    if os.path.exists(exe):
+        cores = min(40, os.cpu_count() or 1)
+        with tempfile.TemporaryDirectory(prefix="abwc1_") as wd:
+            files = synth.write_build_dir(wd, f["milli"], f["dp2scaf"], f["scaf_len"], f["scg_scaf"], f["scg_id"], f["n_scg"])
+            t0 = time.perf_counter()
+            subprocess.run([exe, files["names"], files["fasta"], files["info"], files["lrn"], files["scg"], files["scg_list"],
+                            str(cores), os.path.join(wd, "ref")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            wall = time.perf_counter() - t0
+            rows = np.loadtxt(os.path.join(wd, "ref.nodes.tsv"), ndmin=2)
+            ref_s2c = np.array([int(ln.split("\t")[1]) for ln in open(os.path.join(wd, "ref.scaf2cluster.tsv"))], dtype=np.int32)
+        same_tree = len(rows) == len(nodes) and all(
+            (int(r[0]), int(r[1]), int(r[2]), int(r[3])) == (a["id"], a["ndps"], a["split"], a["dim"]) and
+            (a["dim"] <= 0 or a["key"] / 1000.0 == r[4]) and a["spec"] == r[5] and a["sens"] == r[6] and
+            (int(r[7]), int(r[8]), int(r[9]), int(r[10])) == (a["c1"], a["n1"], a["c2"], a["n2"]) for r, a in zip(rows, nodes))
+        res["reference"] = dict(separate_s=round(float(rows[:, 11].sum()) / 1e6, 2), wall_s=round(wall, 2), cores=cores,
+                                note="reference ClusterSeparatorBySensitivitySpecificity (-O2 build of its own sources) inside our driver of "
+                                     "its main loop; separate_s = sum of its separate() calls, wall_s also has file loading and the "
+                                     "per-node ClusterData subsets")
+        res["identical_tree"] = bool(same_tree)
+        res["identical_bins"] = bool(np.array_equal(ref_s2c, s2c))
+        res["speedup_vs_separate_s"] = round(float(rows[:, 11].sum()) / 1e6 / gpu_s, 1)
+    return res
 
 
 def main():
@@ -459,6 +504,10 @@ def main():
                                                    sample=f"oracle abw_or_coverage (the reference's loops, its SAM text parsing not included), "
                                                           f"first {ns} reads, {dt:.1f} s")
         del t_ascii, t_dims
+
+    # ---------------- optional: configs[0], the reference's own CPU-runnable case, end to end -----------------
+    if args.c1 and world == 1:
+        out["recursion_c1"] = recursion_c1(ctx)
 
     # ---------------- CPU baselines (rank 0, N = 1 only) -------------------------------------------
     if world == 1 and not args.no_cpu:
