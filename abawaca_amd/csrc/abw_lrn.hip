@@ -1,0 +1,330 @@
+// SURVEY §8(f) row N4, loader side: the data rows of an ESOM .lrn feature table, text -> integer keys.
+//
+// Reference behaviour restated here (reference = CK7/abawaca, src/ClusterData.cpp):
+//   :36-111   four header lines, read with fgets into an 8 KiB buffer: "% <ndps>", "% <ncols>" (ncols counts the key
+//             column), the weights line (only its field count is checked), "% Key<TAB>name<TAB>name..."
+//   :117-152  every further line: chomp trailing white space; skip it when empty or starting with '%'; it must have
+//             ncols tab-separated fields; field 0 is the datapoint name (atoi), the rest the values
+//   :154-163  values = atof(field)
+//   :127-130,164-167  the number of data lines must equal ndps
+// abawaca-build prints every value as "%.3lf" of a 3-decimal truncation (src/abawaca-build.cpp:603), so a value is an
+// integer number of thousandths; that integer is the key the separator works on (abw_sep_load).  This parser accepts
+// exactly such fixed-point text -- [-]digits[.digits], more than 3 decimals only when the extra ones are zeros -- and
+// reports anything else (exponents, inf/nan, blanks inside a field) as ABW_ERR_FORMAT with its line, so that a caller
+// can fall back to the reference's loader for tables that did not come from abawaca-build.
+//
+// Kernels (byte work, HBM-bound: the text is read twice, 16 B per lane):
+//   lrn_nlcount   newlines per 1 KiB block                          -> scan -> line numbers
+//   lrn_lines     start offset of every line
+//   lrn_classify  one thread per line: chomp, data line or not      -> scan -> row numbers
+//   lrn_rows      one wave per data line: the line goes through LDS in 1 KiB pieces; a lane owns 16 bytes, knows the
+//                 field number of its first byte from a wave prefix sum of tab counts, and converts every field that
+//                 STARTS in its bytes (a field may run on into the next lanes' bytes; the LDS copy has a 32-byte halo)
+#include "abw_internal.h"
+#include <string.h>
+#include <stdlib.h>
+#include <ctype.h>
+
+int abw_device_scan_u32(abw_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out);   // abw_sig.hip
+
+namespace {
+
+constexpr int LBLK = 1024;
+constexpr int MAX_FIELD = 24;          // longest field converted (a 3-decimal int32 key has at most 12 characters)
+constexpr int REF_LINE = 8191;         // the reference reads lines in pieces of this many bytes (char line[8192])
+
+__device__ __forceinline__ uint32_t eq_mask4(uint32_t x, uint32_t pat)     // bit i set iff byte i of x equals the pattern byte
+{
+    const uint32_t t = x ^ pat;
+    const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+    return __builtin_amdgcn_udot4(z, 0x08040201u, 0u, false) >> 7;
+}
+
+__device__ __forceinline__ uint32_t eq_mask16(const uint8_t* __restrict__ p, uint64_t at, uint64_t len, uint32_t pat)
+{
+    if (at + 16 <= len) {
+        uint4 v;
+        memcpy(&v, p + at, 16);
+        return eq_mask4(v.x, pat) | (eq_mask4(v.y, pat) << 4) | (eq_mask4(v.z, pat) << 8) | (eq_mask4(v.w, pat) << 12);
+    }
+    uint32_t m = 0;
+    for (uint64_t i = at; i < len && i < at + 16; i++) m |= (uint32_t)(p[i] == (uint8_t)pat) << (i - at);
+    return m;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    return x;
+}
+
+__global__ __launch_bounds__(256) void lrn_nlcount_kernel(const uint8_t* __restrict__ text, uint64_t len, uint32_t* __restrict__ blk_nl, uint64_t nblk)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
+    for (uint64_t b = wave; b < nblk; b += nwaves) {
+        const uint32_t c = __popc(eq_mask16(text, b * LBLK + (uint64_t)lane * 16, len, 0x0A0A0A0Au));
+        const uint32_t x = wave_incl_scan_u32(c, lane);
+        if (lane == 63) blk_nl[b] = x;
+    }
+}
+
+// line_start[k + 1] = offset after the k-th newline (0-based)
+__global__ __launch_bounds__(256) void lrn_lines_kernel(const uint8_t* __restrict__ text, uint64_t len, const uint64_t* __restrict__ blk_prefix,
+                                                       uint64_t nblk, uint64_t* __restrict__ line_start)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
+    for (uint64_t b = wave; b < nblk; b += nwaves) {
+        const uint64_t A = b * LBLK + (uint64_t)lane * 16;
+        uint32_t m = eq_mask16(text, A, len, 0x0A0A0A0Au);
+        const uint32_t c = __popc(m);
+        uint64_t k = blk_prefix[b] + wave_incl_scan_u32(c, lane) - c;
+        while (m) { const int i = __ffs(m) - 1; m &= m - 1; line_start[++k] = A + i + 1; }
+    }
+}
+
+struct LineInfo { uint64_t begin, end; };     // [begin, end) after the chomp
+
+__global__ __launch_bounds__(256) void lrn_classify_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ line_start,
+                                                          uint64_t n_lines, LineInfo* __restrict__ info, uint32_t* __restrict__ is_row,
+                                                          unsigned long long* __restrict__ err)
+{
+    const uint64_t l = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= n_lines) return;
+    const uint64_t b = line_start[l];
+    uint64_t e = line_start[l + 1] - 1;                                  // the newline (or one past the end of the text)
+    if (e - b > (uint64_t)REF_LINE - 1 && l >= 4) atomicMin(err, (unsigned long long)(l + 1) << 8 | 1);   // ref fgets would split it
+    while (e > b) {                                                      // ref :119-120 chomp (isspace in the C locale)
+        const uint8_t c = text[e - 1];
+        if (c == ' ' || (c >= 9 && c <= 13)) e--; else break;
+    }
+    info[l].begin = b; info[l].end = e;
+    is_row[l] = (l >= 4 && e > b && text[b] != '%') ? 1u : 0u;           // ref :123; the first four lines are the header
+}
+
+// error codes in the low byte of err (smallest line wins): 1 line too long, 2 field count, 3 number format, 4 key overflow
+__global__ __launch_bounds__(256) void lrn_rows_kernel(const uint8_t* __restrict__ text, const LineInfo* __restrict__ info,
+                                                      const uint32_t* __restrict__ is_row, const uint64_t* __restrict__ row_of,
+                                                      uint64_t n_lines, int32_t ncols, int64_t stride,
+                                                      int32_t* __restrict__ dp_names, int32_t* __restrict__ keys,
+                                                      unsigned long long* __restrict__ err)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t buf[4][LBLK + 48];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint8_t* lb = buf[wid];
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t l = (uint64_t)blockIdx.x * 4 + wid; l < n_lines; l += nwaves) {
+        if (!is_row[l]) continue;                                        // wave-uniform
+        const uint64_t row = row_of[l];
+        const uint64_t b = info[l].begin, e = info[l].end;
+        uint32_t carry = 0;                                              // tabs of the line before this piece
+        for (uint64_t base = b; base < e; base += LBLK) {
+            // piece [base, base + 1024) + 32 bytes of halo into LDS; bytes past the end of the line read as tab
+            for (int o = lane * 16; o < LBLK + 32; o += 1024) {
+                const uint64_t at = base + o;
+                uint4 v;
+                if (at + 16 <= e) memcpy(&v, text + at, 16);
+                else {
+                    uint8_t t[16];
+                    for (int i = 0; i < 16; i++) t[i] = (at + i < e) ? text[at + i] : (uint8_t)'\t';
+                    memcpy(&v, t, 16);
+                }
+                *reinterpret_cast<uint4*>(lb + o) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint4 mine = *reinterpret_cast<const uint4*>(lb + lane * 16);
+            uint32_t tabs = eq_mask4(mine.x, 0x09090909u) | (eq_mask4(mine.y, 0x09090909u) << 4) | (eq_mask4(mine.z, 0x09090909u) << 8) |
+                            (eq_mask4(mine.w, 0x09090909u) << 12);
+            const uint64_t A = base + (uint64_t)lane * 16;
+            const int live = (A >= e) ? 0 : (e - A >= 16 ? 16 : (int)(e - A));     // bytes of the line among this lane's 16
+            tabs &= (1u << live) - 1u;
+            const uint32_t c = __popc(tabs);
+            const uint32_t incl = wave_incl_scan_u32(c, lane);
+            uint32_t field = carry + incl - c;                           // field number of this lane's first byte
+            // a field starts at the first byte of the line and after every tab; the byte before this lane's first one
+            // is the last byte of the previous lane (or of the previous piece)
+            const uint32_t prev_tab = (A == b) ? 1u : (A > b && A <= e ? (uint32_t)(text[A - 1] == '\t') : 0u);
+            uint32_t starts = ((tabs << 1) | prev_tab) & ((1u << live) - 1u);
+            // a tab that is the very last byte of the line opens one more (empty) field at e: handled by the lane that owns e - 1
+            while (starts) {
+                const int i = __ffs(starts) - 1;
+                starts &= starts - 1;
+                const uint32_t f = field + __popc(tabs & ((1u << i) - 1u));
+                const uint8_t* p = lb + lane * 16 + i;
+                // [-]digits[.digits]
+                int j = 0;
+                bool neg = false, bad = false;
+                long long ip = 0;
+                int frac = 0, nd = 0, nfr = 0;
+                if (p[0] == '-') { neg = true; j = 1; }
+                for (; j < MAX_FIELD && p[j] >= '0' && p[j] <= '9'; j++) { ip = ip * 10 + (p[j] - '0'); nd++; if (ip > 4000000000ll) bad = true; }
+                if (f > 0 && p[j] == '.') {
+                    j++;
+                    for (; j < MAX_FIELD && p[j] >= '0' && p[j] <= '9'; j++) {
+                        if (nfr < 3) frac = frac * 10 + (p[j] - '0'); else if (p[j] != '0') bad = true;
+                        nfr++;
+                    }
+                }
+                if (p[j] != '\t') bad = true;                            // anything else inside the field (or a field too long)
+                if (nd + nfr == 0 && !(j == 0 || (j == 1 && neg))) bad = true;
+                if (nd + nfr == 0 && j > 0) bad = true;                  // "-" or "." alone
+                for (; nfr < 3; nfr++) frac *= 10;
+                const long long key = (neg ? -1 : 1) * (ip * 1000 + frac);
+                if (bad) atomicMin(err, (unsigned long long)(l + 1) << 8 | 3);
+                else if (key > 2147483647ll || key < -2147483647ll || (f == 0 && (ip > 2147483647ll || neg))) atomicMin(err, (unsigned long long)(l + 1) << 8 | 4);
+                else if (f == 0) dp_names[row] = (int32_t)ip;            // ref :146 atoi
+                else if (f < (uint32_t)ncols) keys[(int64_t)(f - 1) * stride + (int64_t)row] = (int32_t)key;
+            }
+            carry += __shfl(incl, 63, 64);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0 && carry + 1 != (uint32_t)ncols) atomicMin(err, (unsigned long long)(l + 1) << 8 | 2);   // ref :135-140
+    }
+}
+
+// header: the first four lines, on the host (ref :36-111)
+struct LrnHeader { int64_t ndps; int32_t ncols; uint64_t names_begin, names_end; };
+
+int parse_header(const uint8_t* text, uint64_t len, LrnHeader& h, std::string& why)
+{
+    uint64_t ls[5], n = 0, p = 0;
+    ls[0] = 0;
+    while (n < 4 && p < len) { if (text[p] == '\n') ls[++n] = p + 1; p++; }
+    if (n < 4) { why = "fewer than four header lines"; return ABW_ERR_FORMAT; }
+    auto num_after_percent = [&](uint64_t b, uint64_t e, long long& v) {
+        if (b >= e || text[b] != '%') return false;                       // ref :48 "%c %u", c == '%'
+        uint64_t q = b + 1;
+        while (q < e && isspace(text[q])) q++;
+        if (q >= e || !isdigit(text[q])) return false;
+        v = 0;
+        while (q < e && isdigit(text[q])) { v = v * 10 + (text[q] - '0'); if (v > (1ll << 40)) return false; q++; }
+        return true;
+    };
+    long long a = 0, c = 0;
+    if (!num_after_percent(ls[0], ls[1], a)) { why = "unexpected line 1"; return ABW_ERR_FORMAT; }
+    if (!num_after_percent(ls[1], ls[2], c) || c < 2 || c > 100000) { why = "unexpected line 2"; return ABW_ERR_FORMAT; }
+    uint32_t t = 1;
+    for (uint64_t q = ls[2]; q < ls[3]; q++) t += text[q] == '\t';       // ref :74-82 the weights line has ncols fields
+    if (t != (uint32_t)c) { why = "line 3 does not have as many fields as line 2 says"; return ABW_ERR_FORMAT; }
+    uint64_t e = ls[4] - 1;
+    while (e > ls[3] && isspace(text[e - 1])) e--;                       // ref :92-93
+    t = 1;
+    for (uint64_t q = ls[3]; q < e; q++) t += text[q] == '\t';
+    if (t != (uint32_t)c) { why = "line 4 does not name as many dimensions as line 2 says"; return ABW_ERR_FORMAT; }   // ref :108-111
+    h.ndps = a; h.ncols = (int32_t)c;
+    uint64_t q = ls[3];
+    while (q < e && text[q] != '\t') q++;
+    h.names_begin = q + 1; h.names_end = e;                              // ref :97 the first column is the key's title
+    return ABW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int abw_lrn_header(const uint8_t* text, uint64_t len, int64_t* ndps, int32_t* ndims, char* names_buf, uint64_t names_len)
+{
+    if (!text || !ndps || !ndims) return ABW_ERR_ARG;
+    LrnHeader h;
+    std::string why;
+    const int rc = parse_header(text, len, h, why);
+    if (rc) return rc;
+    *ndps = h.ndps; *ndims = h.ncols - 1;
+    if (names_buf) {                                                     // dimension names, NUL-separated
+        const uint64_t need = h.names_end - h.names_begin + 1;
+        if (names_len < need) return ABW_ERR_CAPACITY;
+        for (uint64_t q = h.names_begin; q < h.names_end; q++) names_buf[q - h.names_begin] = text[q] == '\t' ? '\0' : (char)text[q];
+        names_buf[need - 1] = '\0';
+    }
+    return ABW_OK;
+}
+
+int abw_lrn_parse(abw_ctx* ctx, const uint8_t* text, uint64_t len, int64_t ndps, int32_t ndims, int32_t* dp_names, int32_t* keys)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!text || !dp_names || !keys || ndps < 0 || ndims < 1) return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_parse: bad argument");
+    LrnHeader h;
+    std::string why;
+    int rc = parse_header(text, len, h, why);
+    if (rc) return abw_fail(ctx, rc, "abw_lrn_parse: %s", why.c_str());
+    if (h.ndps != ndps || h.ncols - 1 != ndims)
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_parse: the file declares %lld datapoints x %d dimensions, the caller expects %lld x %d",
+                        (long long)h.ndps, h.ncols - 1, (long long)ndps, ndims);
+    abw_device_guard g(ctx->device);
+    hipStream_t st = ctx->stream;
+    const uint64_t nblk = len / LBLK + 1;
+    // scratch[0]: text | scratch[1]: blk_nl u32 + blk_prefix u64 | scratch[2]: line_start u64 | scratch[3]: LineInfo
+    // scratch[4]: is_row u32 + row_of u64 | scratch[6]: keys + dp_names + err
+    if ((rc = abw_reserve(ctx, ctx->scratch[0], len + 64))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[1], nblk * 4 + 8 + (nblk + 1) * 8))) return rc;
+    uint8_t* d_text = (uint8_t*)ctx->scratch[0].p;
+    uint32_t* blk_nl = (uint32_t*)ctx->scratch[1].p;
+    uint64_t* blk_prefix = (uint64_t*)((uint8_t*)blk_nl + ((nblk * 4 + 7) & ~(uint64_t)7));
+    ABW_HIP(ctx, hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, st));
+    const int grid = ctx->num_cu * 8;
+    {
+        ABW_PROF(ctx, "lrn_parse");                                      // kernels only; the copies are the caller's PCIe cost
+        hipLaunchKernelGGL(lrn_nlcount_kernel, dim3(grid), dim3(256), 0, st, d_text, len, blk_nl, nblk);
+        ABW_LAUNCH_CHECK(ctx);
+        if ((rc = abw_device_scan_u32(ctx, blk_nl, nblk, blk_prefix))) return rc;
+    }
+    uint64_t n_nl = 0;
+    ABW_HIP(ctx, hipMemcpyAsync(&n_nl, blk_prefix + nblk, 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    const uint64_t n_lines = n_nl + ((len > 0 && text[len - 1] != '\n') ? 1 : 0);
+    if ((rc = abw_reserve(ctx, ctx->scratch[2], (n_lines + 2) * 8))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[3], (n_lines + 1) * sizeof(LineInfo)))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[4], ((n_lines * 4 + 15) & ~(uint64_t)7) + (n_lines + 2) * 8))) return rc;
+    const size_t kb = (size_t)ndims * (size_t)std::max<int64_t>(ndps, 1) * 4, nb = (size_t)std::max<int64_t>(ndps, 1) * 4;
+    if ((rc = abw_reserve(ctx, ctx->scratch[6], kb + nb + 64))) return rc;
+    uint64_t* line_start = (uint64_t*)ctx->scratch[2].p;
+    LineInfo* info = (LineInfo*)ctx->scratch[3].p;
+    uint32_t* is_row = (uint32_t*)ctx->scratch[4].p;
+    uint64_t* row_of = (uint64_t*)((uint8_t*)is_row + ((n_lines * 4 + 15) & ~(uint64_t)7));
+    int32_t* d_keys = (int32_t*)ctx->scratch[6].p;
+    int32_t* d_names = (int32_t*)((uint8_t*)d_keys + kb);
+    unsigned long long* d_err = (unsigned long long*)((uint8_t*)d_names + ((nb + 7) & ~(size_t)7));
+    const uint64_t zero = 0, endmark = len + 1;
+    ABW_HIP(ctx, hipMemsetAsync(d_err, 0xFF, 8, st));
+    ABW_HIP(ctx, hipMemcpyAsync(line_start, &zero, 8, hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemcpyAsync(line_start + n_lines, &endmark, 8, hipMemcpyHostToDevice, st));   // overwritten by the last newline's entry when the text ends with one
+    {
+        ABW_PROF(ctx, "lrn_parse");
+        hipLaunchKernelGGL(lrn_lines_kernel, dim3(grid), dim3(256), 0, st, d_text, len, blk_prefix, nblk, line_start);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(lrn_classify_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, d_text, line_start, n_lines, info, is_row, d_err);
+        ABW_LAUNCH_CHECK(ctx);
+        if ((rc = abw_device_scan_u32(ctx, is_row, n_lines, row_of))) return rc;
+    }
+    uint64_t n_rows = 0;
+    ABW_HIP(ctx, hipMemcpyAsync(&n_rows, row_of + n_lines, 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    if ((int64_t)n_rows != ndps)                                         // ref :127-130, :164-167
+        return abw_fail(ctx, ABW_ERR_FORMAT, "abw_lrn_parse: %llu datapoint lines, the header says %lld", (unsigned long long)n_rows, (long long)ndps);
+    if (n_rows > 0) {
+        ABW_PROF(ctx, "lrn_parse");
+        hipLaunchKernelGGL(lrn_rows_kernel, dim3(grid), dim3(256), 0, st, d_text, info, is_row, row_of, n_lines, h.ncols, (int64_t)ndps, d_names, d_keys, d_err);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    unsigned long long err = 0;
+    ABW_HIP(ctx, hipMemcpyAsync(&err, d_err, 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    if (err != ~0ull) {
+        static const char* what[] = {"", "longer than the 8191 bytes the reference reads at once", "wrong number of fields",
+                                     "a field is not [-]digits[.digits] with at most 3 decimals", "a key does not fit 32 bits"};
+        const unsigned code = (unsigned)(err & 0xFF);
+        return abw_fail(ctx, ABW_ERR_FORMAT, "abw_lrn_parse: line %llu: %s", (unsigned long long)(err >> 8), what[code < 5 ? code : 0]);
+    }
+    if (n_rows > 0) {
+        ABW_HIP(ctx, hipMemcpyAsync(keys, d_keys, kb, hipMemcpyDeviceToHost, st));
+        ABW_HIP(ctx, hipMemcpyAsync(dp_names, d_names, nb, hipMemcpyDeviceToHost, st));
+        ABW_HIP(ctx, hipStreamSynchronize(st));
+    }
+    return ABW_OK;
+}
+
+}  // extern "C"

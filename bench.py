@@ -213,6 +213,65 @@ def cpu_separator_baseline(keys_host, dp2scaf, scaf_len, n_scaf_sample=12000):
                        f"-p {cores}) on the root node of the first {S} scaffolds ({n} dps x {D} dims), {usec / 1e6:.2f} s")
 
 
+def lrn_bench(ctx, with_cpu):
+    """row N4 (next), loader side: the .lrn text of a configs[1]-shaped table (200 000 rows x 189 columns of the
+    bench table's widths, fixed-width so that numpy can write it quickly) -> int32 keys."""
+    from abawaca_amd import lrn
+    rng = np.random.default_rng(20248)
+    N, Ds, Dc = 200_000, 179, 10
+    sig = rng.integers(0, 1001, size=(N, Ds), dtype=np.int64)
+    cov = rng.integers(0, 10_000_000, size=(N, Dc), dtype=np.int64)
+    row_len = 7 + Ds * 6 + Dc * 9 + 1
+    buf = np.empty((N, row_len), dtype=np.uint8)
+    names = np.arange(1, N + 1)
+    for k in range(7):
+        buf[:, 6 - k] = 48 + (names // 10 ** k) % 10
+    o = 7
+    s3 = buf[:, o:o + Ds * 6].reshape(N, Ds, 6)
+    s3[:, :, 0] = 9; s3[:, :, 1] = 48 + sig // 1000; s3[:, :, 2] = 46
+    for k in range(3):
+        s3[:, :, 5 - k] = 48 + (sig // 10 ** k) % 10
+    o += Ds * 6
+    c3 = buf[:, o:o + Dc * 9].reshape(N, Dc, 9)
+    c3[:, :, 0] = 9; c3[:, :, 5] = 46
+    for k in range(3):
+        c3[:, :, 8 - k] = 48 + (cov // 10 ** k) % 10
+    for k in range(4):
+        c3[:, :, 4 - k] = 48 + (cov // 10 ** (3 + k)) % 10
+    buf[:, -1] = 10
+    D = Ds + Dc
+    head = (f"% {N}\n% {D + 1}\n% 9" + "\t1" * D + "\n% Key" + "".join(f"\tc{j}" for j in range(D)) + "\n").encode()
+    text = np.concatenate([np.frombuffer(head, np.uint8), buf.reshape(-1)])
+    dp, keys, _ = lrn.lrn_parse(ctx, text)                       # warm-up + check
+    assert np.array_equal(dp, names) and np.array_equal(keys[:Ds], sig.T) and np.array_equal(keys[Ds:], cov.T)
+    ctx.prof_reset(); ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        lrn.lrn_parse(ctx, text)
+    wall = (time.perf_counter() - t0) / reps
+    n, ms = ctx.prof_read("lrn_parse")
+    ctx.prof_enable(False)
+    k_s = ms / reps * 1e-3
+    alg = 2.0 * len(text) + 4.0 * D * N                          # the text twice (lines, then fields) + the keys
+    res = dict(value=len(text) / k_s / 1e9, unit="GB/s of text (kernels, text resident)", rows=N, columns=D, text_mb=round(len(text) / 1e6, 1),
+               ms_kernels=round(k_s * 1e3, 3), ms_with_pcie_both_ways=round(wall * 1e3, 2), fields_per_s=round(N * (D + 1) / k_s / 1e9, 2),
+               note="row N4 (next), loader side; fields_per_s in G fields/s; wall includes H2D of the text and D2H of the keys from pageable memory",
+               roofline=dict(kernel="lrn_rows_kernel (+ line scan)", bound="hbm", achieved=round(alg / k_s / 1e9, 1), peak=HBM_PEAK_GBS,
+                             unit="GB/s", frac=round(alg / k_s / 1e9 / HBM_PEAK_GBS, 4), traffic=None))
+    if with_cpu:
+        import _oracle as orc
+        ns = 20_000
+        sample = np.concatenate([np.frombuffer(head.replace(f"% {N}".encode(), f"% {ns}".encode(), 1), np.uint8), buf[:ns].reshape(-1)])
+        t0 = time.perf_counter()
+        orc.lrn_parse(sample, ns + 1, D)
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = dict(value=len(sample) / dt / 1e9, unit="GB/s of text", cores=1, kind="port",
+                                   sample=f"oracle abw_or_lrn_parse (the reference's fgets/strchr/atof loop, without its std::map and "
+                                          f"Dimension inserts), first {ns} rows, {dt:.2f} s")
+    return res
+
+
 def recursion_c1(ctx):
     """configs[0]: 10 000 scaffolds, 179 signature + 3 coverage columns, the whole recursion (reference
     src/abawaca.cpp:95-197) -- reference objects + reference separator (oracle/_ref/ref_sep_driver, -O2) beside
@@ -504,6 +563,7 @@ def main():
                                                    sample=f"oracle abw_or_coverage (the reference's loops, its SAM text parsing not included), "
                                                           f"first {ns} reads, {dt:.1f} s")
         del t_ascii, t_dims
+        out["lrn"] = lrn_bench(ctx, world == 1 and not args.no_cpu)
 
     # ---------------- optional: configs[0], the reference's own CPU-runnable case, end to end -----------------
     if args.c1 and world == 1:

@@ -28,6 +28,7 @@ extern "C" {
 #define ABW_ERR_LOWER_N     -4   /* lower-case 'n' in a sequence (ref: src/String.cpp:45-49 throws) */
 #define ABW_ERR_STATE       -5   /* call order (e.g. abw_sep_node before abw_sep_load) */
 #define ABW_ERR_NOMEM       -6
+#define ABW_ERR_FORMAT      -7   /* text input the parser does not take (abw_lrn_parse) */
 
 #define ABW_SIG_NDIMS  180       /* canonical 1..4-mers incl. "A" (ref: src/abawaca-build.cpp:75-100) */
 #define ABW_SIG_NCOLS  179       /* columns written to abawaca.lrn: all but "A" (ref: :585,591,602) */
@@ -201,6 +202,21 @@ int abw_cov_accumulate(abw_ctx* ctx, const uint32_t* seg_scaf, const uint64_t* s
 int abw_cov_accumulate_dev(abw_ctx* ctx, const uint32_t* d_seg_scaf, const uint64_t* d_seg_start, const uint64_t* d_seg_end,
                            uint64_t n_seg, uint64_t n_scaf, const uint32_t* d_read_scaf, const uint64_t* d_read_pos,
                            const uint32_t* d_read_len, uint64_t n_reads, double* d_cov);
+
+/* ---- next row N4 (loader side): the .lrn feature table, text -> integer keys
+ *      (ref: ClusterData::ClusterData(esom_lrn_file, scaf_db), src/ClusterData.cpp:27-168; the file is written by
+ *      src/abawaca-build.cpp:578-607 with every value printed "%.3lf").
+ * abw_lrn_header (host only): the four header lines (ref :36-111) -> number of datapoints, number of dimensions
+ * (without the key column) and, when names_buf is given, the dimension names NUL-separated.
+ * abw_lrn_parse: the data rows (ref :117-163) on the GPU.  keys [ndims][ndps] int32 (dimension-major, rows in file
+ * order) = thousandths of every value, i.e. exactly atof(field) * 1000 for 3-decimal text; dp_names [ndps] = the key
+ * column (ref :146 atoi; mapping names to ScafDpData ids, ref :146-150, stays with the caller).  Lines are chomped,
+ * empty lines and lines starting with '%' are skipped (ref :118-124); a wrong field count (ref :135-140) or row
+ * count (ref :127-130,164-167) is ABW_ERR_FORMAT where the reference exits.  Fields must be [-]digits[.digits] with
+ * at most 3 significant decimals -- what abawaca-build writes; anything else (exponents, inf, nan) is ABW_ERR_FORMAT
+ * with the line number, and the caller falls back to the reference's loader.  Host memory in, host memory out. */
+int abw_lrn_header(const uint8_t* text, uint64_t len, int64_t* ndps, int32_t* ndims, char* names_buf, uint64_t names_len);
+int abw_lrn_parse(abw_ctx* ctx, const uint8_t* text, uint64_t len, int64_t ndps, int32_t ndims, int32_t* dp_names, int32_t* keys);
 
 /* ---- extension: k-means restarts (NO counterpart in the reference, see DESIGN.md "K-means";
  *      RNG = TinyMT32, ref: src/misc.cpp:24-36, src/TinyMT-src-1.0.1/tinymt/tinymt32.{c,h}) -------- */

@@ -591,3 +591,51 @@ int abw_or_kmeans_sharded(const float* x, int64_t N, int32_t d, int32_t R, uint3
     free(T);
     return err ? -2 : 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * .lrn loader, reference src/ClusterData.cpp:27-168 (see abw_oracle.h)
+ * ------------------------------------------------------------------------------------------ */
+#include <ctype.h>
+#include <stdio.h>
+int64_t abw_or_lrn_parse(const uint8_t* text, uint64_t len, int64_t row_cap, int32_t* ndps_declared, int32_t* ndims,
+                         int32_t* dp_names, double* values)
+{
+    uint64_t pos = 0;
+    int lineno = 0;
+    unsigned ndps = 0, ncols = 0;
+    int64_t entry = 0;
+    char* line = (char*)malloc(8192);
+    if (!line) return -1;
+    while (pos < len) {
+        /* fgets(line, 8192, fp): up to 8191 bytes, through the newline (ref :36,40,117) */
+        uint64_t n = 0;
+        while (pos < len && n < 8191) { line[n++] = (char)text[pos++]; if (line[n - 1] == '\n') break; }
+        line[n] = 0;
+        lineno++;
+        if (lineno == 1) { char c; if (sscanf(line, "%c %u", &c, &ndps) != 2 || c != '%') { free(line); return -1; } continue; }   /* ref :48 */
+        if (lineno == 2) { char c; if (sscanf(line, "%c %u", &c, &ncols) != 2 || c != '%' || ncols < 2) { free(line); return -1; } continue; }   /* ref :61 */
+        if (lineno == 3) { unsigned t = 1; for (char* p = line; *p; p++) t += *p == '\t'; if (t != ncols) { free(line); return -1; } continue; }  /* ref :74-82 */
+        while (strlen(line) > 0 && isspace((unsigned char)line[strlen(line) - 1])) line[strlen(line) - 1] = 0;   /* ref :92-93, :119-120 */
+        if (lineno == 4) { unsigned t = 1; for (char* p = line; *p; p++) t += *p == '\t'; if (t != ncols) { free(line); return -1; } continue; }  /* ref :97-111 */
+        if (line[0] == '%' || strlen(line) == 0) continue;                                  /* ref :123 */
+        unsigned t = 1;
+        for (char* p = line; *p; p++) t += *p == '\t';
+        if (t != ncols) { free(line); return -2; }                                          /* ref :135-140 */
+        if (entry >= row_cap) { free(line); return -3; }
+        char* p1 = line;
+        char* p2 = strchr(p1, '\t');
+        *p2 = 0;
+        dp_names[entry] = atoi(p1);                                                          /* ref :146 */
+        p1 = p2 + 1;
+        for (unsigned d = 0; d + 1 < ncols; d++) {
+            p2 = strchr(p1, '\t');
+            if (p2) *p2 = 0;
+            values[(int64_t)d * row_cap + entry] = atof(p1);                                 /* ref :159,162 */
+            p1 = p2 ? p2 + 1 : p1 + strlen(p1);
+        }
+        entry++;
+    }
+    free(line);
+    *ndps_declared = (int32_t)ndps; *ndims = (int32_t)ncols - 1;
+    return entry;
+}

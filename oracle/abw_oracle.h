@@ -141,3 +141,15 @@ int abw_or_kmeans_sharded(const float* x, int64_t N, int32_t d, int32_t R, uint3
 }
 #endif
 #endif
+
+/* ------------------------------------------------------------------------------------------
+ * .lrn loader, the reference's way: ClusterData::ClusterData(esom_lrn_file, scaf_db),
+ * reference src/ClusterData.cpp:27-168.  Four header lines ("% ndps", "% ncols", weights, names), then per
+ * line: chomp trailing white space (:119-120), skip empty and '%' lines (:123), ncols tab-separated fields
+ * (:135-140), field 0 = atoi -> dp name (:146), the others atof (:159,162).  The name -> internal id mapping
+ * of ScafDpData (:146-150) is not part of this function.
+ * values: [ndims][row_cap] doubles in file row order; dp_names [row_cap].  Returns the number of data rows,
+ * -1 on a malformed header, -2 on a wrong field count, -3 when there are more rows than row_cap.
+ * ------------------------------------------------------------------------------------------ */
+int64_t abw_or_lrn_parse(const uint8_t* text, uint64_t len, int64_t row_cap, int32_t* ndps_declared, int32_t* ndims,
+                         int32_t* dp_names, double* values);

@@ -210,3 +210,19 @@ def coverage(seg_scaf, seg_start, seg_end, n_scaf, read_scaf, read_pos, read_len
     if rc != 0:
         raise RuntimeError("abw_or_coverage failed: %d" % rc)
     return out
+
+
+def lrn_parse(text: np.ndarray, row_cap: int, ndims_cap: int = 4096):
+    """-> (n_rows, ndps_declared, ndims, dp_names int32[n_rows], values f64[ndims, n_rows]); negative n_rows = error"""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    names = np.zeros(max(row_cap, 1), dtype=np.int32)
+    vals = np.zeros((ndims_cap, max(row_cap, 1)), dtype=np.float64)
+    a, b = C.c_int32(0), C.c_int32(0)
+    L = lib()
+    L.abw_or_lrn_parse.restype = C.c_int64
+    L.abw_or_lrn_parse.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]
+    n = L.abw_or_lrn_parse(C.c_void_p(text.ctypes.data), len(text), row_cap, C.byref(a), C.byref(b), C.c_void_p(names.ctypes.data),
+                           C.c_void_p(vals.ctypes.data))
+    if n < 0:
+        return int(n), 0, 0, None, None
+    return int(n), a.value, b.value, names[:n], vals[:b.value, :n].copy()

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Golden vectors of the .lrn loader (row N4): a small feature table with every oddity the reference's loader
+tolerates, read by the REFERENCE's own ClusterData constructor (oracle/_ref/lrn_dump, built by oracle/Makefile from
+the sources under /root/reference; nothing of the reference is copied).  Output tests/golden/lrn_a.npz: the text of
+the file we wrote (input) and the values the reference holds after loading it (expected output).
+
+usage: python tests/golden/make_golden_lrn.py            (from the repo root)
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from abawaca_amd import synth  # noqa: E402
+
+rng = np.random.default_rng(11)
+S, D = 6, 7
+ndps_of = [2, 3, 2, 4, 2, 3]
+dp2scaf = np.repeat(np.arange(S), ndps_of)
+N = len(dp2scaf)
+milli = rng.integers(0, 1001, size=(D, N))
+milli[5] = rng.integers(0, 3_000_000, size=N)          # a coverage-like column
+milli[6] = -rng.integers(0, 5000, size=N)              # negative values parse too (atof)
+with tempfile.TemporaryDirectory(prefix="abwlrn_") as wd:
+    files = synth.write_build_dir(wd, milli, dp2scaf, np.full(S, 9000))
+
+    def fmt(v, style):
+        sign = "-" if v < 0 else ""
+        q, r = divmod(abs(int(v)), 1000)
+        if style == 0:
+            return f"{sign}{q}.{r:03d}"                 # what abawaca-build writes
+        if style == 1:
+            s = f"{sign}{q}.{r:03d}".rstrip("0")         # fewer decimals, possibly a bare "5."
+            return s
+        if style == 2:
+            return f"{sign}{q}.{r:03d}000"               # more decimals, all zero
+        return f"{sign}.{r:03d}" if q == 0 else f"{sign}{q}.{r:03d}"    # ".125"
+    lines = [f"% {N + 1}", f"% {D + 1}", "% 9" + "\t1" * D, "% Key" + "".join(f"\tdim{j}" for j in range(D))]
+    order = rng.permutation(N)                            # rows in any order
+    for k, p in enumerate(order):
+        row = str(p + 1) + "".join("\t" + fmt(milli[j, p], (k + j) % 4) for j in range(D))
+        if k % 5 == 1:
+            row += "  \t "                                # trailing blanks are chomped (ref :119-120)
+        if k % 5 == 2:
+            row += "\r"                                   # CRLF
+        lines.append(row)
+        if k == 3:
+            lines.append("% a comment line")              # skipped (ref :123)
+        if k == 6:
+            lines.append("")                              # empty lines too
+            lines.append("   ")
+    lines.append("777" + "".join("\t1.000" for _ in range(D)))     # a datapoint the .names file does not know (ref :146-150)
+    text = ("\n".join(lines)).encode()                    # no newline after the last row
+    path = os.path.join(wd, "tricky.lrn")
+    open(path, "wb").write(text)
+    out = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "lrn_dump"), files["names"], files["fasta"], files["info"], path, "1000"],
+                         check=True, capture_output=True, text=True).stdout.strip().split("\n")
+head = [int(x) for x in out[0].split("\t")]
+rows = [ln.split("\t") for ln in out[1:]]
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "lrn_a.npz"),
+                    text=np.frombuffer(text, dtype=np.uint8), ndps_loaded=head[0], ndims=head[1],
+                    names=np.array([int(r[0]) for r in rows]), iids=np.array([int(r[1]) for r in rows]),
+                    values=np.array([[float(x) for x in r[2:]] for r in rows]))
+print("reference loaded", head, "rows dumped", len(rows))

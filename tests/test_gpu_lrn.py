@@ -1,0 +1,67 @@
+"""GPU .lrn loader (abw_lrn_parse, row N4) against the golden vectors of the reference's own loader, against the
+oracle on a large table, and its error behaviour."""
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+from abawaca_amd import _lib, lrn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def test_matches_reference_loader(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "lrn_a.npz"))
+    names, keys, dims = lrn.lrn_parse(ctx, g["text"])
+    assert dims == [f"dim{j}" for j in range(7)] and len(names) == 17
+    by_name = {int(nm): k for k, nm in enumerate(names)}
+    for nm, row in zip(g["names"], g["values"]):
+        assert np.array_equal(keys[:, by_name[int(nm)]] / 1000.0, row)     # key/1000.0 is the double atof gives
+    assert np.array_equal(keys[:, by_name[777]], np.full(7, 1000))
+
+
+def _table_text(rng, N, D, wide_cols=3, crlf=False):
+    milli = rng.integers(0, 1001, size=(N, D))
+    wide_cols = min(wide_cols, D)
+    milli[:, D - wide_cols:] = rng.integers(0, 2_000_000_000, size=(N, wide_cols))
+    names = rng.permutation(N) + 1
+    import io
+    f = io.StringIO()
+    f.write(f"% {N}\n% {D + 1}\n% 9" + "\t1" * D + "\n% Key" + "".join(f"\tc{j}" for j in range(D)) + "\n")
+    eol = "\r\n" if crlf else "\n"
+    for p in range(N):
+        f.write(str(names[p]) + "".join("\t%d.%03d" % divmod(int(v), 1000) for v in milli[p]) + eol)
+    return np.frombuffer(f.getvalue().encode(), dtype=np.uint8), names, milli
+
+
+@pytest.mark.parametrize("N,D,crlf", [(5000, 189, False), (300, 1100, True), (1, 2, False)])
+def test_matches_oracle_on_tables(ctx, N, D, crlf):
+    """rows of ~1.5 kB and of ~7.7 kB (several 1 KiB pieces per line), 10-digit coverage keys"""
+    text, names, milli = _table_text(np.random.default_rng(N), N, D, crlf=crlf)
+    got_names, keys, dims = lrn.lrn_parse(ctx, text)
+    assert np.array_equal(got_names, names) and np.array_equal(keys, milli.T)
+    n, ndps, ndims, onames, vals = orc.lrn_parse(text, N + 1)
+    assert (n, ndps, ndims) == (N, N, D) and np.array_equal(onames, got_names)
+    assert np.array_equal(keys / 1000.0, vals)                              # bit-exact doubles
+
+
+def test_errors(ctx):
+    head = b"% 2\n% 3\n% 9\t1\t1\n% Key\ta\tb\n"
+    ok = head + b"1\t0.5\t2\n2\t3.25\t0.001\n"
+    names, keys, _ = lrn.lrn_parse(ctx, np.frombuffer(ok, np.uint8))
+    assert keys.tolist() == [[500, 3250], [2000, 1]]
+    for bad, what in [(head + b"1\t0.5\n2\t3.25\t0.001\n", "fields"), (head + b"1\t0.5\t2\n", "datapoint lines"),
+                      (head + b"1\t1e-3\t2\n2\t3.25\t0.001\n", "digits"), (head + b"1\t0.1234\t2\n2\t3.25\t0.001\n", "digits"),
+                      (head + b"1\t0.5\t2\n2\t3.25\t0.001\n3\t1\t1\n", "datapoint lines"),
+                      (head + b"1\t9999999.999\t2\n2\t3.25\t0.001\n", "32 bits"), (b"% 2\n% 3\n% 9\t1\n% Key\ta\tb\n", "header")]:
+        with pytest.raises(_lib.AbwError) as e:
+            lrn.lrn_parse(ctx, np.frombuffer(bad, np.uint8))
+        assert e.value.code == _lib.ABW_ERR_FORMAT and what in str(e.value)

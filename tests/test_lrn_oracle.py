@@ -1,0 +1,25 @@
+"""The oracle's .lrn loader against the golden vectors the reference's own ClusterData constructor produced
+(tests/golden/make_golden_lrn.py -> lrn_a.npz): comment / empty / CRLF / blank-padded lines, 0-6 decimals,
+".125", "5.", negative values, rows in any order, a datapoint the .names file does not know."""
+import os
+
+import numpy as np
+
+import _oracle as orc
+
+
+def test_oracle_lrn_matches_reference_loader(golden_dir):
+    g = np.load(os.path.join(golden_dir, "lrn_a.npz"))
+    n, ndps, ndims, names, vals = orc.lrn_parse(g["text"], 64)
+    assert ndps == 17 and n == 17 and ndims == int(g["ndims"])             # the unknown datapoint is a row too (ref :151)
+    assert int(g["ndps_loaded"]) == 16
+    by_name = {int(nm): k for k, nm in enumerate(names)}
+    assert 777 in by_name and 777 not in set(g["names"].tolist())
+    for nm, row in zip(g["names"], g["values"]):
+        assert np.array_equal(vals[:, by_name[int(nm)]], row)              # bit-exact doubles
+
+
+def test_oracle_lrn_rejects_wrong_field_count():
+    text = b"% 1\n% 3\n% 9\t1\t1\n% Key\ta\tb\n1\t0.5\n"
+    assert orc.lrn_parse(np.frombuffer(text, np.uint8), 4)[0] == -2
+    assert orc.lrn_parse(np.frombuffer(b"% 1\n% 3\n% 9\t1\n% Key\ta\tb\n", np.uint8), 4)[0] == -1
