@@ -9,7 +9,8 @@
 // added to its fp64 accumulator IN THE ORDER OF THE SAM FILE.  fp64 addition does not commute in the
 // last bit and abawaca.lrn prints int(1000 * x), so the order is part of the result: contributions are
 // emitted in read order, brought together per segment by a stable radix sort on the segment index
-// (rocPRIM; a library sort, not a hot kernel), and added by one thread per segment in that order.
+// (rocPRIM; a library sort, not a hot kernel), and added by one thread per segment in that order
+// (cov_runs marks where every segment's run begins and ends).
 // The filter (unmapped / > 15 SNPs / secondary, ref :546) stays with the caller's SAM parser.
 #include "abw_internal.h"
 #include <string.h>
@@ -41,13 +42,12 @@ __device__ __forceinline__ void read_span(const uint64_t* __restrict__ seg_start
     while (hi < f1 && seg_start[hi] <= e) hi++;
 }
 
-template <bool EMIT>
-__global__ __launch_bounds__(256) void cov_pairs_kernel(const uint32_t* __restrict__ read_scaf, const uint64_t* __restrict__ read_pos,
-                                                       const uint32_t* __restrict__ read_len, uint64_t n_reads, uint64_t n_scaf,
-                                                       const uint64_t* __restrict__ seg_first, const uint64_t* __restrict__ seg_start,
-                                                       const uint64_t* __restrict__ seg_end,
-                                                       uint32_t* __restrict__ count, const uint64_t* __restrict__ offset,
-                                                       uint32_t* __restrict__ key, double* __restrict__ val)
+// pass 1: the segments [lo, lo + count) every read touches
+__global__ __launch_bounds__(256) void cov_span_kernel(const uint32_t* __restrict__ read_scaf, const uint64_t* __restrict__ read_pos,
+                                                      const uint32_t* __restrict__ read_len, uint64_t n_reads, uint64_t n_scaf,
+                                                      const uint64_t* __restrict__ seg_first, const uint64_t* __restrict__ seg_start,
+                                                      const uint64_t* __restrict__ seg_end,
+                                                      uint32_t* __restrict__ count, uint32_t* __restrict__ first)
 {
     const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n_reads) return;
@@ -55,10 +55,25 @@ __global__ __launch_bounds__(256) void cov_pairs_kernel(const uint32_t* __restri
     uint64_t lo = 0, hi = 0;
     const uint64_t s = read_pos[r], l = read_len[r];
     if (sc < n_scaf && l > 0) read_span(seg_start, seg_end, seg_first[sc], seg_first[sc + 1], s, s + l - 1, lo, hi);
-    if (!EMIT) { count[r] = (uint32_t)(hi - lo); return; }
-    const uint64_t e = s + l - 1;
+    count[r] = (uint32_t)(hi - lo);
+    first[r] = (uint32_t)lo;
+}
+
+// pass 2: (segment, contribution) pairs in read order
+__global__ __launch_bounds__(256) void cov_pairs_kernel(const uint64_t* __restrict__ read_pos, const uint32_t* __restrict__ read_len,
+                                                       uint64_t n_reads, const uint64_t* __restrict__ seg_start,
+                                                       const uint64_t* __restrict__ seg_end, const uint32_t* __restrict__ count,
+                                                       const uint32_t* __restrict__ first, const uint64_t* __restrict__ offset,
+                                                       uint32_t* __restrict__ key, double* __restrict__ val)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t c = count[r];
+    if (c == 0) return;
+    const uint64_t s = read_pos[r], e = s + read_len[r] - 1;
     uint64_t o = offset[r];
-    for (uint64_t g = lo; g < hi; g++, o++) {
+    const uint64_t lo = first[r];
+    for (uint64_t g = lo; g < lo + c; g++, o++) {
         const uint64_t st = seg_start[g], en = seg_end[g];
         const uint64_t a = (s < st) ? st : s, b = (e > en) ? en : e;           // ref :181-182
         key[o] = (uint32_t)g;
@@ -66,16 +81,27 @@ __global__ __launch_bounds__(256) void cov_pairs_kernel(const uint32_t* __restri
     }
 }
 
-// one thread per run of equal keys: its contributions in (stable-sorted = read) order
-__global__ __launch_bounds__(256) void cov_sum_kernel(const uint32_t* __restrict__ key, const double* __restrict__ val, uint64_t n_pairs,
-                                                     double* __restrict__ cov)
+// after the stable sort: where the run of every segment begins and ends
+__global__ __launch_bounds__(256) void cov_runs_kernel(const uint32_t* __restrict__ key, uint64_t n_pairs, uint64_t* __restrict__ run_start,
+                                                      uint64_t* __restrict__ run_end)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pairs) return;
     const uint32_t g = key[i];
-    if (i > 0 && key[i - 1] == g) return;                                      // not the head of a run
+    if (i == 0 || key[i - 1] != g) run_start[g] = i;
+    if (i + 1 == n_pairs || key[i + 1] != g) run_end[g] = i + 1;
+}
+
+// one thread per segment: its contributions in (stable-sorted = read) order, onto the caller's accumulator
+__global__ __launch_bounds__(256) void cov_sum_kernel(const double* __restrict__ val, const uint64_t* __restrict__ run_start,
+                                                     const uint64_t* __restrict__ run_end, uint64_t n_seg, double* __restrict__ cov)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_seg) return;
+    const uint64_t a = run_start[g], b = run_end[g];
+    if (a >= b) return;
     double acc = cov[g];
-    for (uint64_t j = i; j < n_pairs && key[j] == g; j++) acc += val[j];
+    for (uint64_t j = a; j < b; j++) acc += val[j];
     cov[g] = acc;
 }
 
@@ -96,18 +122,21 @@ extern "C" int abw_cov_accumulate_dev(abw_ctx* ctx, const uint32_t* d_seg_scaf, 
     abw_device_guard g(ctx->device);
     hipStream_t st = ctx->stream;
     int rc;
-    // scratch[10]: seg_first (n_scaf+2) u64 | count u32[n_reads] | offset u64[n_reads+1]
-    const size_t b_first = (n_scaf + 2) * 8, b_count = ((n_reads * 4 + 7) & ~(size_t)7), b_off = (n_reads + 1) * 8;
-    if ((rc = abw_reserve(ctx, ctx->scratch[10], b_first + b_count + b_off))) return rc;
+    // scratch[10]: seg_first (n_scaf+2) u64 | offset u64[n_reads+1] | run_start, run_end u64[n_seg] | count, first u32[n_reads]
+    const size_t b_first = (n_scaf + 2) * 8, b_off = (n_reads + 1) * 8, b_run = n_seg * 8, b_count = ((n_reads * 4 + 7) & ~(size_t)7);
+    if ((rc = abw_reserve(ctx, ctx->scratch[10], b_first + b_off + 2 * b_run + 2 * b_count))) return rc;
     uint64_t* seg_first = (uint64_t*)ctx->scratch[10].p;
-    uint32_t* count = (uint32_t*)((uint8_t*)seg_first + b_first);
-    uint64_t* offset = (uint64_t*)((uint8_t*)count + b_count);
+    uint64_t* offset = (uint64_t*)((uint8_t*)seg_first + b_first);
+    uint64_t* run_start = (uint64_t*)((uint8_t*)offset + b_off);
+    uint64_t* run_end = (uint64_t*)((uint8_t*)run_start + b_run);
+    uint32_t* count = (uint32_t*)((uint8_t*)run_end + b_run);
+    uint32_t* first = (uint32_t*)((uint8_t*)count + b_count);
     ABW_PROF(ctx, "cov_accumulate");
     hipLaunchKernelGGL(cov_seg_first_kernel, dim3((unsigned)((n_seg + 256) / 256)), dim3(256), 0, st, d_seg_scaf, n_seg, n_scaf, seg_first);
     ABW_LAUNCH_CHECK(ctx);
     const unsigned gr = (unsigned)((n_reads + 255) / 256);
-    hipLaunchKernelGGL((cov_pairs_kernel<false>), dim3(gr), dim3(256), 0, st, d_read_scaf, d_read_pos, d_read_len, n_reads, n_scaf, seg_first,
-                       d_seg_start, d_seg_end, count, (const uint64_t*)nullptr, (uint32_t*)nullptr, (double*)nullptr);
+    hipLaunchKernelGGL(cov_span_kernel, dim3(gr), dim3(256), 0, st, d_read_scaf, d_read_pos, d_read_len, n_reads, n_scaf, seg_first,
+                       d_seg_start, d_seg_end, count, first);
     ABW_LAUNCH_CHECK(ctx);
     if ((rc = abw_device_scan_u32(ctx, count, n_reads, offset))) return rc;
     uint64_t n_pairs = 0;
@@ -126,11 +155,14 @@ extern "C" int abw_cov_accumulate_dev(abw_ctx* ctx, const uint32_t* d_seg_scaf, 
     uint32_t* key_in = (uint32_t*)base; uint32_t* key_out = (uint32_t*)(base + b_key);
     double* val_in = (double*)(base + 2 * b_key); double* val_out = (double*)(base + 2 * b_key + b_val);
     void* tmp = base + 2 * b_key + 2 * b_val;
-    hipLaunchKernelGGL((cov_pairs_kernel<true>), dim3(gr), dim3(256), 0, st, d_read_scaf, d_read_pos, d_read_len, n_reads, n_scaf, seg_first,
-                       d_seg_start, d_seg_end, (uint32_t*)nullptr, offset, key_in, val_in);
+    hipLaunchKernelGGL(cov_pairs_kernel, dim3(gr), dim3(256), 0, st, d_read_pos, d_read_len, n_reads, d_seg_start, d_seg_end, count, first,
+                       offset, key_in, val_in);
     ABW_LAUNCH_CHECK(ctx);
     ABW_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, key_in, key_out, val_in, val_out, (size_t)n_pairs, 0u, (unsigned)bits, st));
-    hipLaunchKernelGGL(cov_sum_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, key_out, val_out, n_pairs, d_cov);
+    ABW_HIP(ctx, hipMemsetAsync(run_start, 0, 2 * b_run, st));                      // start = end = 0: no contributions
+    hipLaunchKernelGGL(cov_runs_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, key_out, n_pairs, run_start, run_end);
+    ABW_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(cov_sum_kernel, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, st, val_out, run_start, run_end, n_seg, d_cov);
     ABW_LAUNCH_CHECK(ctx);
     return ABW_OK;
 }
