@@ -414,6 +414,33 @@ def main():
         sctx.close()
         dist.barrier()
 
+    # ---------------- multi-rank only: k-means with the POINTS sharded over the ranks ---------------------------
+    # (SURVEY §8(e) second way, configs[2] shape: every rank holds its own points, the same R restarts run over
+    # the union; per pass one exchange of the cluster-1 partial sums [Rp][W] fp64, added in rank order.)
+    km_sharded = None
+    if dist is not None and not args.no_sep_sharded:
+        n_loc = (N // 32) * 32                                              # whole MFMA tiles per shard
+        x_loc = x_t[:, :n_loc].contiguous()
+        n_tot = n_loc * world
+        t_a = torch.empty((R, n_loc), dtype=torch.uint8, device=dev)
+        t_c2 = torch.empty((R, 2, D), dtype=torch.float32, device=dev)
+        t_i2 = torch.empty(R, dtype=torch.float64, device=dev)
+        it_sh = max(2, iters // 4)
+        kmeans.kmeans_sharded_dev(ctx, x_loc, rank * n_loc, n_tot, R, 20240, 1, args.chunk, dist, t_a, t_c2, t_i2)   # warm-up
+        barrier()
+        t0 = time.perf_counter()
+        kmeans.kmeans_sharded_dev(ctx, x_loc, rank * n_loc, n_tot, R, 20240, it_sh, args.chunk, dist, t_a, t_c2, t_i2)
+        ctx.synchronize(); torch.cuda.synchronize()
+        ks = multi.max_elapsed(time.perf_counter() - t0, dist, dev)
+        chk = t_i2.clone()
+        multi._all_reduce(chk, dist.ReduceOp.MAX, dist)                      # every rank must hold the same inertia bits
+        km_sharded = dict(value=n_tot * R * it_sh / ks, unit="point*iterations/s", points_total=int(n_tot), restarts=R, iterations=it_sh,
+                          ms_per_iteration=round(ks / (it_sh + 1) * 1e3, 3), identical_on_all_ranks=bool(torch.equal(chk, t_i2)),
+                          exchange_bytes_per_pass=int(8 * ((R + 31) // 32 * 32) * ((D + 1 + 31) // 32 * 32)),
+                          collective=f"all-gather + rank-ordered fp64 adds per pass over {args.backend}")
+        del x_loc, t_a
+        dist.barrier()
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -454,6 +481,8 @@ def main():
                roofline=roofline, best_restart=dict(id=int(winner[0]), inertia=float(winner[1]), rank=int(winner[2])))
     if sep_sharded is not None:
         out["separator_sharded"] = sep_sharded
+    if km_sharded is not None:
+        out["kmeans_point_sharded"] = km_sharded
 
     # ---------------- extras: real separator + signature build on this GPU -----------------------
     keys_host = None
