@@ -230,3 +230,18 @@ def sum_counts(counts, dist=None, device=None):
     t = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=_coll_device(dist, device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [int(v) for v in t.tolist()]
+
+
+# ---- signature build: scaffolds dealt to the ranks by length, no exchange (SURVEY §8 row e) ----
+
+def scaffold_ranges_by_length(scaf_off, world: int) -> list[int]:
+    """Contiguous scaffold ranges with about the same number of bases each: rank k builds the signatures of
+    scaffolds [b[k], b[k+1]); segments are independent, so the ranks' rows simply concatenate in scaffold order."""
+    import numpy as np
+    off = np.asarray(scaf_off, dtype=np.int64)
+    n, total = len(off) - 1, int(off[-1]) - int(off[0])
+    b = [0]
+    for k in range(1, world):
+        b.append(min(n, max(b[-1], int(np.searchsorted(off, off[0] + k * total / world, side="left")))))
+    b.append(n)
+    return b

@@ -441,6 +441,36 @@ def main():
         del x_loc, t_a
         dist.barrier()
 
+    # ---------------- multi-rank only: signature build, scaffolds dealt to the ranks (no exchange) ---------------
+    sig_sharded = None
+    if dist is not None and not args.no_sep_sharded:
+        mbp_k = max(100, args.sig_mbp // 2)                                 # weak scaling: every rank its own assembly
+        blob_k, off_k = make_assembly_blob(20244 + 7 * rank, mbp_k)
+        tot_k = len(blob_k)
+        ta = torch.from_numpy(np.concatenate([blob_k, np.zeros((-tot_k) % 16 + 16, np.uint8)])).to(dev)
+        to = torch.from_numpy(off_k.astype(np.int64)).to(dev)
+        cap_k = tot_k // 2000 + len(off_k) + 16
+        ts_, tst, ten = (torch.empty(cap_k, dtype=torch.int32, device=dev), torch.empty(cap_k, dtype=torch.int64, device=dev),
+                         torch.empty(cap_k, dtype=torch.int64, device=dev))
+        td = torch.empty((cap_k, 180), dtype=torch.float64, device=dev)
+
+        def sig_k():
+            nk = signature.segment_dev(ctx, ta, tot_k, to, 2000, ts_, tst, ten)
+            signature.count_dev(ctx, ta, tot_k, to, ts_, tst, ten, nk, t_dims=td)
+            return nk
+        n_k = sig_k()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sig_k()
+        ctx.synchronize()
+        sk = multi.max_elapsed((time.perf_counter() - t0) / 3, dist, dev)
+        segs = multi.sum_counts([n_k], dist, dev)[0]
+        sig_sharded = dict(value=world * tot_k / sk / 1e9, unit="Gbp/s", mbp_per_rank=mbp_k, segments_total=int(segs),
+                           ms_per_pass=round(sk * 1e3, 3), collective="none (rows concatenate in scaffold order)")
+        del ta, td
+        dist.barrier()
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -483,6 +513,8 @@ def main():
         out["separator_sharded"] = sep_sharded
     if km_sharded is not None:
         out["kmeans_point_sharded"] = km_sharded
+    if sig_sharded is not None:
+        out["signature_sharded"] = sig_sharded
 
     # ---------------- extras: real separator + signature build on this GPU -----------------------
     keys_host = None

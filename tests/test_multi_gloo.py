@@ -245,3 +245,29 @@ def test_scaffold_bounds_balance_dps():
         assert b[0] == 0 and b[-1] == 1000 and all(b[k] < b[k + 1] for k in range(world))
         per = [ndps[b[k]:b[k + 1]].sum() for k in range(world)]
         assert max(per) - min(per) <= 16
+
+
+def test_signature_ranges_cover_every_scaffold_once_and_rows_concatenate():
+    """Signature sharding has no exchange: the oracle on each rank's scaffold range, concatenated, is the oracle on
+    the whole assembly."""
+    from abawaca_amd import synth
+    asm = synth.make_assembly(31, 40, 3, 1, frac_n_run=0.3)
+    blob = np.concatenate(asm.seqs)
+    off = np.zeros(len(asm.seqs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(s) for s in asm.seqs])
+    whole = orc.build_signatures(blob, off)
+    for world in (1, 2, 3, 8):
+        b = multi.scaffold_ranges_by_length(off, world)
+        assert b[0] == 0 and b[-1] == len(asm.seqs) and all(b[k] <= b[k + 1] for k in range(world))
+        parts = []
+        for k in range(world):
+            if b[k] == b[k + 1]:
+                continue
+            lo, hi = int(off[b[k]]), int(off[b[k + 1]])
+            seg_scaf, st, en, dims = orc.build_signatures(blob[lo:hi], off[b[k]:b[k + 1] + 1] - off[b[k]])
+            parts.append((seg_scaf + b[k], st, en, dims))
+        assert np.array_equal(np.concatenate([p[0] for p in parts]), whole[0])
+        assert np.array_equal(np.concatenate([p[1] for p in parts]), whole[1]) and np.array_equal(np.concatenate([p[2] for p in parts]), whole[2])
+        assert np.array_equal(np.concatenate([p[3] for p in parts]).view(np.uint64), whole[3].view(np.uint64))
+        sizes = [int(off[b[k + 1]] - off[b[k]]) for k in range(world)]
+        assert max(sizes) - min(sizes) <= 2 * max(len(s) for s in asm.seqs)
