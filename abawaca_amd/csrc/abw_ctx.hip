@@ -28,6 +28,17 @@ int abw_reserve(abw_ctx* ctx, abw_devbuf& b, size_t bytes)
     return ABW_OK;
 }
 
+int abw_reserve_pinned(abw_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->pinned_cap) return ABW_OK;
+    if (ctx->pinned) { ABW_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault);
+    if (e != hipSuccess) { ctx->pinned = nullptr; return abw_fail(ctx, ABW_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+    ctx->pinned_cap = want;
+    return ABW_OK;
+}
+
 void abw_release(abw_devbuf& b)
 {
     if (b.p) (void)hipFree(b.p);
@@ -136,6 +147,7 @@ void abw_ctx_destroy(abw_ctx* ctx)
     for (auto& r : ctx->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto& e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (auto& b : ctx->scratch) abw_release(b);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -93,11 +93,14 @@ struct abw_ctx {
     abw_sep_state sep;
     abw_devbuf  scratch[12];           // general-purpose grow-only scratch
     int         num_cu = 256;
+    void*       pinned = nullptr;      // grow-only pinned host staging (results of a call leave the GPU in one batch)
+    size_t      pinned_cap = 0;
 };
 
 int abw_fail(abw_ctx* ctx, int code, const char* fmt, ...);
 int abw_reserve(abw_ctx* ctx, abw_devbuf& b, size_t bytes);
 void abw_release(abw_devbuf& b);
+int abw_reserve_pinned(abw_ctx* ctx, size_t bytes);
 
 #define ABW_HIP(ctx, call)                                                                      \
     do {                                                                                        \

@@ -490,13 +490,39 @@ __global__ void sep_dimbest_kernel(const int32_t* __restrict__ dim_first_chunk, 
     out[d].size1 = b.size1; out[d].n = (long long)dim_total[d].size;
 }
 
+// The global winner over the dimensions: ClusteringResult::is_better (ref ...Specificity.h:25-30 +
+// ClusterSeparator.cpp:11-16) applied in dimension order from the reset best_separation (dimension = (size_t)-1,
+// value = -1, sens = spec = 0): a larger product wins, equal products keep the smaller dimension -- and a
+// dimension whose winner has product 0 still replaces the reset state.  Then is_legal (ref .h:31-35).
+struct GlobalRes { int32_t found; int32_t dim; int32_t bin; int32_t legal; double sens; double spec; long long size1; long long n; };
+
+__global__ void sep_global_kernel(const DimBestDev* __restrict__ db, int32_t D, GlobalRes* __restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double gsens = 0, gspec = 0;
+    int gd = -1;
+    for (int d = 0; d < D; d++) {
+        if (!db[d].found) continue;
+        const double a = db[d].sens * db[d].spec, b = gsens * gspec;
+        const bool better = (a != b) ? (a >= b) : (gd < 0);
+        if (better) { gsens = db[d].sens; gspec = db[d].spec; gd = d; }
+    }
+    GlobalRes r;
+    r.found = gd >= 0; r.dim = gd; r.bin = gd >= 0 ? db[gd].bin : -1;
+    r.sens = gsens; r.spec = gspec;
+    r.legal = (gd >= 0) && (gsens >= 0.8) && (gspec >= 0.8) && (gsens + gspec >= 1.6) && (gsens * gspec >= 0.8);
+    r.size1 = gd >= 0 ? db[gd].size1 : 0; r.n = gd >= 0 ? db[gd].n : 0;
+    *out = r;
+}
+
 // per-scaffold count of dps with bin <= t in the winning dimension and the raw flag of each dp
-__global__ __launch_bounds__(256) void sep_final_kernel(SepDev P, int32_t d, int32_t tbin, const int32_t* __restrict__ node_scaf,
+__global__ __launch_bounds__(256) void sep_final_kernel(SepDev P, const GlobalRes* __restrict__ win, const int32_t* __restrict__ node_scaf,
                                                        const int32_t* __restrict__ node_dpoff, int32_t m,
                                                        int32_t* __restrict__ nle, uint8_t* __restrict__ raw)
 {
     const int ls = blockIdx.x * 256 + threadIdx.x;
-    if (ls >= m) return;
+    if (ls >= m || !win->legal) return;                   // no legal winner: nothing to reconstruct (ref ClusterSeparator.cpp:27-28)
+    const int d = win->dim, tbin = win->bin;
     const int s = node_scaf ? node_scaf[ls] : ls;
     const int f = P.scaf_first[s], n = P.scaf_ndps[s];
     const int64_t o = node_dpoff ? node_dpoff[ls] : f;
@@ -512,11 +538,13 @@ __global__ __launch_bounds__(256) void sep_final_kernel(SepDev P, int32_t d, int
 // the histogram scan; both are totals over ALL shards when the node is sharded).
 // totals: [0], [1] = dps of this shard's scaffolds assigned to cluster1 / cluster2 (out)
 __global__ __launch_bounds__(256) void sep_assign_kernel(SepDev P, const int32_t* __restrict__ node_scaf,
-                                                        const int32_t* __restrict__ node_dpoff, int32_t m, long long n, long long le,
+                                                        const int32_t* __restrict__ node_dpoff, int32_t m, const GlobalRes* __restrict__ win,
                                                         const int32_t* __restrict__ nle, uint8_t* __restrict__ raw,
                                                         uint8_t* __restrict__ side, unsigned long long* __restrict__ totals)
 {
     __shared__ unsigned long long b1, b2;
+    if (!win->legal) return;                              // uniform
+    const long long n = win->n, le = win->size1;
     if (threadIdx.x == 0) { b1 = 0; b2 = 0; }
     __syncthreads();
     const bool swap = n - le < le;
@@ -796,7 +824,7 @@ static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int
     }
     if ((rc = abw_reserve(ctx, s.hist, (size_t)tb * (4 * 3 + 8) + 64))) return rc;
     if ((rc = abw_reserve(ctx, s.scg_lohi, (size_t)std::max<int64_t>(1, (int64_t)D * n_scg) * 8))) return rc;
-    if ((rc = abw_reserve(ctx, s.dimbest, (size_t)D * sizeof(DimBestDev)))) return rc;
+    if ((rc = abw_reserve(ctx, s.dimbest, (size_t)D * sizeof(DimBestDev) + sizeof(GlobalRes)))) return rc;
     s.loaded = true;
     s.node_open = false;
     return ABW_OK;
@@ -912,60 +940,64 @@ static int sep_eval_phase(abw_ctx* ctx, const char* who, int32_t min_ndps, abw_s
     hipLaunchKernelGGL(sep_dimbest_kernel, dim3((s.D + 63) / 64), dim3(64), 0, st, H.d_dim_first_chunk, H.d_dim_nchunks, s.D, H.d_chunk_best, H.d_dim_total, d_dimbest);
     ABW_LAUNCH_CHECK(ctx);
     }
-    std::vector<DimBestDev> db((size_t)s.D);
-    ABW_HIP(ctx, hipMemcpyAsync(db.data(), d_dimbest, (size_t)s.D * sizeof(DimBestDev), hipMemcpyDeviceToHost, st));
+    // the global winner and this context's part of the finalisation follow on the device without a host round trip
+    GlobalRes* d_win = (GlobalRes*)(d_dimbest + s.D);
+    hipLaunchKernelGGL(sep_global_kernel, dim3(1), dim3(64), 0, st, d_dimbest, s.D, d_win);
+    ABW_LAUNCH_CHECK(ctx);
+    unsigned long long* d_tot = nullptr;
+    uint8_t* d_side = nullptr;
+    if (m > 0) {
+        if ((rc = abw_reserve(ctx, s.nle, (size_t)m * 4))) return rc;
+        if ((rc = abw_reserve(ctx, s.raw, (size_t)n))) return rc;
+        if ((rc = abw_reserve(ctx, ctx->scratch[9], (size_t)m + 64))) return rc;
+        d_tot = (unsigned long long*)ctx->scratch[9].p;                       // 2 totals, then the scaffold sides
+        d_side = (uint8_t*)ctx->scratch[9].p + 32;
+        ABW_HIP(ctx, hipMemsetAsync(d_tot, 0, 16, st));
+        hipLaunchKernelGGL(sep_final_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, d_win, d_node_scaf, d_node_dpoff, m,
+                           (int32_t*)s.nle.p, (uint8_t*)s.raw.p);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(sep_assign_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, d_node_scaf, d_node_dpoff, m, d_win,
+                           (const int32_t*)s.nle.p, (uint8_t*)s.raw.p, d_side, d_tot);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    // one copy batch through pinned memory, one synchronisation: winners | global winner | totals | sides | raw flags
+    const size_t b_db = (size_t)s.D * sizeof(DimBestDev) + sizeof(GlobalRes);
+    const size_t o_tot = (b_db + 15) & ~(size_t)15, o_side = o_tot + 16, o_raw = o_side + (((size_t)m + 15) & ~(size_t)15);
+    const bool want_side = scaf_side && m > 0, want_raw = dp_raw_side && n > 0;
+    if ((rc = abw_reserve_pinned(ctx, o_raw + (size_t)n + 16))) return rc;
+    uint8_t* hp = (uint8_t*)ctx->pinned;
+    ABW_HIP(ctx, hipMemcpyAsync(hp, d_dimbest, b_db, hipMemcpyDeviceToHost, st));
+    if (m > 0) {
+        ABW_HIP(ctx, hipMemcpyAsync(hp + o_tot, d_tot, 16, hipMemcpyDeviceToHost, st));
+        if (want_side) ABW_HIP(ctx, hipMemcpyAsync(hp + o_side, d_side, (size_t)m, hipMemcpyDeviceToHost, st));
+        if (want_raw) ABW_HIP(ctx, hipMemcpyAsync(hp + o_raw, s.raw.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    }
     ABW_HIP(ctx, hipStreamSynchronize(st));
+    const DimBestDev* db = (const DimBestDev*)hp;
+    const GlobalRes win = *(const GlobalRes*)(hp + (size_t)s.D * sizeof(DimBestDev));
 
     auto key_of = [&](int32_t d, int32_t bin) -> int32_t {
         return s.h_binval_off[d] < 0 ? bin : s.h_binval[(size_t)s.h_binval_off[d] + bin];
     };
-    // global winner: ClusteringResult::is_better (ref ...Specificity.h:25-30 + ClusterSeparator.cpp:11-16),
-    // starting from the reset best_separation (dimension = (size_t)-1, value = -1, sens = spec = 0)
-    double gsens = 0, gspec = 0, gvalue = -1;
-    uint64_t gdim = (uint64_t)-1;
-    int32_t gbin = -1;
-    for (int32_t d = 0; d < s.D; d++) {
-        const bool f = db[d].found != 0;
-        const double sens = f ? db[d].sens : 0.0, spec = f ? db[d].spec : 0.0;
-        const uint64_t dim = f ? (uint64_t)(d + 1) : (uint64_t)-1;
-        const double value = f ? (double)key_of(d, db[d].bin) : -1.0;
-        if (per_dim) { per_dim[d].found = f; per_dim[d].key = f ? key_of(d, db[d].bin) : -1; per_dim[d].sensitivity = sens; per_dim[d].specificity = spec; }
-        const double a = sens * spec, b = gsens * gspec;
-        bool better;
-        if (a != b) better = a >= b;
-        else if (dim != gdim) better = dim < gdim;
-        else better = value < gvalue;
-        if (better) { gsens = sens; gspec = spec; gdim = dim; gvalue = value; gbin = db[d].bin; }
+    if (per_dim) {
+        for (int32_t d = 0; d < s.D; d++) {
+            const bool f = db[d].found != 0;
+            per_dim[d].found = f; per_dim[d].key = f ? key_of(d, db[d].bin) : -1;
+            per_dim[d].sensitivity = f ? db[d].sens : 0.0; per_dim[d].specificity = f ? db[d].spec : 0.0;
+        }
     }
     if (scaf_side && m > 0) memset(scaf_side, 0, (size_t)m);
     if (dp_raw_side && n > 0) memset(dp_raw_side, 0, (size_t)n);
-    if (gdim == (uint64_t)-1) return ABW_OK;
-    const int32_t gd = (int32_t)gdim - 1;
-    out->dimension = (int32_t)gdim;
-    out->key = key_of(gd, gbin);
-    out->sensitivity = gsens; out->specificity = gspec;
-    // is_legal, ref ...Specificity.h:31-35
-    out->legal = (gsens >= 0.8) && (gspec >= 0.8) && (gsens + gspec >= 1.6) && (gsens * gspec >= 0.8);
+    if (!win.found) return ABW_OK;
+    out->dimension = win.dim + 1;
+    out->key = key_of(win.dim, win.bin);
+    out->sensitivity = win.sens; out->specificity = win.spec;
+    out->legal = win.legal;                                           // is_legal, ref ...Specificity.h:31-35
     if (!out->legal) return ABW_OK;                                   // reconstruct_best_clusters returns early (ref ClusterSeparator.cpp:27-28)
     if (m == 0) return ABW_OK;                                        // this shard holds nothing of the node
-
-    if ((rc = abw_reserve(ctx, s.nle, (size_t)m * 4))) return rc;
-    if ((rc = abw_reserve(ctx, s.raw, (size_t)n))) return rc;
-    if ((rc = abw_reserve(ctx, ctx->scratch[9], (size_t)m + 64))) return rc;
-    unsigned long long* d_tot = (unsigned long long*)ctx->scratch[9].p;       // 2 totals, then the scaffold sides
-    uint8_t* d_side = (uint8_t*)ctx->scratch[9].p + 32;
-    ABW_HIP(ctx, hipMemsetAsync(d_tot, 0, 16, st));
-    hipLaunchKernelGGL(sep_final_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, gd, gbin, d_node_scaf, d_node_dpoff, m,
-                       (int32_t*)s.nle.p, (uint8_t*)s.raw.p);
-    ABW_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(sep_assign_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, d_node_scaf, d_node_dpoff, m,
-                       db[gd].n, db[gd].size1, (const int32_t*)s.nle.p, (uint8_t*)s.raw.p, d_side, d_tot);
-    ABW_LAUNCH_CHECK(ctx);
-    unsigned long long tot2[2] = {0, 0};
-    ABW_HIP(ctx, hipMemcpyAsync(tot2, d_tot, 16, hipMemcpyDeviceToHost, st));
-    if (scaf_side) ABW_HIP(ctx, hipMemcpyAsync(scaf_side, d_side, (size_t)m, hipMemcpyDeviceToHost, st));
-    if (dp_raw_side) ABW_HIP(ctx, hipMemcpyAsync(dp_raw_side, s.raw.p, (size_t)n, hipMemcpyDeviceToHost, st));
-    ABW_HIP(ctx, hipStreamSynchronize(st));
+    if (want_side) memcpy(scaf_side, hp + o_side, (size_t)m);
+    if (want_raw) memcpy(dp_raw_side, hp + o_raw, (size_t)n);
+    const unsigned long long* tot2 = (const unsigned long long*)(hp + o_tot);
     out->ndps1 = (int64_t)tot2[0]; out->ndps2 = (int64_t)tot2[1];
     return ABW_OK;
 }
