@@ -186,6 +186,84 @@ __global__ __launch_bounds__(256) void lrn_rows_kernel(const uint8_t* __restrict
     }
 }
 
+// ---- writer side (ref src/abawaca-build.cpp:595-607): rows "<key>\t%.3lf\t%.3lf...\n" ------------------------------
+// A value is printed as "%.3lf" of int(1000.0*x)/1000.0 (ref :603); with k = int(1000.0*x) that text is
+// [-]<|k| / 1000>.<|k| % 1000, three digits> (k/1000.0 is the double nearest to the 3-decimal number, which "%.3lf"
+// prints back).  One wave per row, a lane takes every 64th column: field lengths -> wave prefix sum -> characters
+// into an LDS copy of the row -> coalesced bytes out.
+__device__ __forceinline__ int dec_digits(uint32_t v)
+{
+    return v < 10u ? 1 : v < 100u ? 2 : v < 1000u ? 3 : v < 10000u ? 4 : v < 100000u ? 5 : v < 1000000u ? 6 : v < 10000000u ? 7 :
+           v < 100000000u ? 8 : v < 1000000000u ? 9 : 10;
+}
+__device__ __forceinline__ int field_len(int32_t k)          // "\t" + [-] + integer digits + "." + 3 decimals
+{
+    const uint32_t a = k < 0 ? 0u - (uint32_t)k : (uint32_t)k;
+    return 1 + (k < 0) + dec_digits(a / 1000u) + 4;
+}
+__device__ __forceinline__ int key_len(unsigned long long key)
+{
+    int n = 1;
+    while (key >= 10ull) { key /= 10ull; n++; }
+    return n;
+}
+
+constexpr int EMIT_COLS_PER_LANE = 16;                        // up to 1024 columns
+constexpr int EMIT_ROW_MAX = 16384;                           // bytes of one row staged in LDS
+
+__global__ __launch_bounds__(256) void lrn_rowlen_kernel(const int32_t* __restrict__ milli, int64_t n_rows, int32_t n_cols, uint64_t first_key,
+                                                        uint32_t* __restrict__ row_len)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int32_t* r = milli + row * n_cols;
+    uint32_t len = 0;
+    for (int c = lane; c < n_cols; c += 64) len += (uint32_t)field_len(r[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
+    if (lane == 0) row_len[row] = len + (uint32_t)key_len(first_key + (uint64_t)row) + 1u;       // + key + "\n"
+}
+
+__global__ __launch_bounds__(256) void lrn_emit_kernel(const int32_t* __restrict__ milli, int64_t n_rows, int32_t n_cols, uint64_t first_key,
+                                                      const uint64_t* __restrict__ row_off, uint8_t* __restrict__ text)
+{
+    __shared__ uint8_t buf[4][EMIT_ROW_MAX];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+    if (row >= n_rows) return;
+    uint8_t* lb = buf[wid];
+    const int32_t* r = milli + row * n_cols;
+    const uint64_t key = first_key + (uint64_t)row;
+    const int klen = key_len(key);
+    if (lane == 0) { unsigned long long k = key; for (int i = klen - 1; i >= 0; i--) { lb[i] = (uint8_t)('0' + k % 10ull); k /= 10ull; } }
+    uint32_t carry = (uint32_t)klen;
+    for (int c0 = 0; c0 < n_cols; c0 += 64) {                // columns c0 .. c0+63, one per lane, in order
+        const int c = c0 + lane;
+        const int32_t k = (c < n_cols) ? r[c] : 0;
+        const uint32_t len = (c < n_cols) ? (uint32_t)field_len(k) : 0u;
+        const uint32_t incl = wave_incl_scan_u32(len, lane);
+        if (c < n_cols) {
+            uint8_t* p = lb + carry + incl - len;
+            const uint32_t a = k < 0 ? 0u - (uint32_t)k : (uint32_t)k;
+            uint32_t q = a / 1000u, f = a % 1000u;
+            *p++ = '\t';
+            if (k < 0) *p++ = '-';
+            const int nd = dec_digits(q);
+            for (int i = nd - 1; i >= 0; i--) { p[i] = (uint8_t)('0' + q % 10u); q /= 10u; }
+            p += nd;
+            p[0] = '.'; p[1] = (uint8_t)('0' + f / 100u); p[2] = (uint8_t)('0' + (f / 10u) % 10u); p[3] = (uint8_t)('0' + f % 10u);
+        }
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) lb[carry] = '\n';
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t o = row_off[row];
+    const uint32_t total = carry + 1u;
+    for (uint32_t i = lane; i < total; i += 64) text[o + i] = lb[i];
+}
+
 // header: the first four lines, on the host (ref :36-111)
 struct LrnHeader { int64_t ndps; int32_t ncols; uint64_t names_begin, names_end; };
 
@@ -324,6 +402,49 @@ int abw_lrn_parse(abw_ctx* ctx, const uint8_t* text, uint64_t len, int64_t ndps,
         ABW_HIP(ctx, hipMemcpyAsync(dp_names, d_names, nb, hipMemcpyDeviceToHost, st));
         ABW_HIP(ctx, hipStreamSynchronize(st));
     }
+    return ABW_OK;
+}
+
+int abw_lrn_emit(abw_ctx* ctx, const int32_t* milli, int64_t n_rows, int32_t n_cols, uint64_t first_key,
+                 uint8_t* text, uint64_t text_cap, uint64_t* text_len)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!milli || !text_len || n_rows < 0 || n_cols < 1 || n_cols > 64 * EMIT_COLS_PER_LANE)
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_emit: bad argument (1 <= n_cols <= %d)", 64 * EMIT_COLS_PER_LANE);
+    *text_len = 0;
+    if (n_rows == 0) return ABW_OK;
+    if ((uint64_t)n_cols * 17 + 24 > (uint64_t)EMIT_ROW_MAX) return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_emit: rows of %d columns do not fit the staging buffer", n_cols);
+    abw_device_guard g(ctx->device);
+    hipStream_t st = ctx->stream;
+    int rc;
+    // scratch[6]: milli | scratch[4]: row_len u32 + row_off u64 | scratch[0]: text
+    const size_t mb = (size_t)n_rows * n_cols * 4;
+    if ((rc = abw_reserve(ctx, ctx->scratch[6], mb))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[4], (((size_t)n_rows * 4 + 15) & ~(size_t)7) + ((size_t)n_rows + 2) * 8))) return rc;
+    int32_t* d_milli = (int32_t*)ctx->scratch[6].p;
+    uint32_t* row_len = (uint32_t*)ctx->scratch[4].p;
+    uint64_t* row_off = (uint64_t*)((uint8_t*)row_len + (((size_t)n_rows * 4 + 15) & ~(size_t)7));
+    ABW_HIP(ctx, hipMemcpyAsync(d_milli, milli, mb, hipMemcpyHostToDevice, st));
+    const unsigned gr = (unsigned)((n_rows + 3) / 4);
+    {
+        ABW_PROF(ctx, "lrn_emit");
+        hipLaunchKernelGGL(lrn_rowlen_kernel, dim3(gr), dim3(256), 0, st, d_milli, n_rows, n_cols, first_key, row_len);
+        ABW_LAUNCH_CHECK(ctx);
+        if ((rc = abw_device_scan_u32(ctx, row_len, (uint64_t)n_rows, row_off))) return rc;
+    }
+    uint64_t total = 0;
+    ABW_HIP(ctx, hipMemcpyAsync(&total, row_off + n_rows, 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    *text_len = total;
+    if (!text || total > text_cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_lrn_emit: the rows take %llu bytes, capacity %llu", (unsigned long long)total, (unsigned long long)text_cap);
+    if ((rc = abw_reserve(ctx, ctx->scratch[0], total + 64))) return rc;
+    {
+        ABW_PROF(ctx, "lrn_emit");
+        hipLaunchKernelGGL(lrn_emit_kernel, dim3(gr), dim3(256), 0, st, d_milli, n_rows, n_cols, first_key, row_off, (uint8_t*)ctx->scratch[0].p);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    ABW_HIP(ctx, hipMemcpyAsync(text, ctx->scratch[0].p, total, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
     return ABW_OK;
 }
 

@@ -30,3 +30,19 @@ def lrn_parse(ctx: Context, text: np.ndarray):
     ctx.check(lib().abw_lrn_parse(ctx.handle, C.c_void_p(text.ctypes.data), len(text), ndps, ndims,
                                   C.c_void_p(dp_names.ctypes.data), C.c_void_p(keys.ctypes.data)))
     return dp_names[:ndps], keys[:, :ndps], names
+
+
+def lrn_emit(ctx: Context, milli_rows: np.ndarray, first_key: int = 1) -> np.ndarray:
+    """milli_rows int32 [n_rows, n_cols] -> the data rows of the .lrn as bytes (uint8 array)"""
+    m = np.ascontiguousarray(milli_rows, dtype=np.int32)
+    n_rows, n_cols = m.shape
+    cap = n_rows * (n_cols * 8 + 12) + 64
+    n = C.c_uint64(0)
+    while True:
+        text = np.empty(cap, dtype=np.uint8)
+        rc = lib().abw_lrn_emit(ctx.handle, C.c_void_p(m.ctypes.data), n_rows, n_cols, int(first_key), C.c_void_p(text.ctypes.data), cap, C.byref(n))
+        if rc == -3 and n.value > cap:            # ABW_ERR_CAPACITY: now we know the size
+            cap = int(n.value)
+            continue
+        ctx.check(rc)
+        return text[:n.value]

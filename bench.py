@@ -259,6 +259,23 @@ def lrn_bench(ctx, with_cpu):
                note="row N4 (next), loader side; fields_per_s in G fields/s; wall includes H2D of the text and D2H of the keys from pageable memory",
                roofline=dict(kernel="lrn_rows_kernel (+ line scan)", bound="hbm", achieved=round(alg / k_s / 1e9, 1), peak=HBM_PEAK_GBS,
                              unit="GB/s", frac=round(alg / k_s / 1e9 / HBM_PEAK_GBS, 4), traffic=None))
+    # writer side: the same table back to text (reference src/abawaca-build.cpp:595-607), checked by parsing it again
+    rows_m = np.ascontiguousarray(np.concatenate([sig, cov], axis=1).astype(np.int32))
+    out_text = lrn.lrn_emit(ctx, rows_m, 1)
+    dp2, keys2, _ = lrn.lrn_parse(ctx, np.concatenate([np.frombuffer(head, np.uint8), out_text]))
+    assert np.array_equal(dp2, names) and np.array_equal(keys2.T, rows_m)
+    ctx.prof_reset(); ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lrn.lrn_emit(ctx, rows_m, 1)
+    wall_e = (time.perf_counter() - t0) / reps
+    ne, mse = ctx.prof_read("lrn_emit")
+    ctx.prof_enable(False)
+    e_s = mse / reps * 1e-3
+    res["writer"] = dict(value=len(out_text) / e_s / 1e9, unit="GB/s of text (kernels)", text_mb=round(len(out_text) / 1e6, 1),
+                         ms_kernels=round(e_s * 1e3, 3), ms_with_pcie_both_ways=round(wall_e * 1e3, 2),
+                         roofline=dict(kernel="lrn_emit_kernel (+ row lengths)", bound="hbm", achieved=round((8.0 * D * N + len(out_text)) / e_s / 1e9, 1),
+                                       peak=HBM_PEAK_GBS, unit="GB/s", frac=round((8.0 * D * N + len(out_text)) / e_s / 1e9 / HBM_PEAK_GBS, 4), traffic=None))
     if with_cpu:
         import _oracle as orc
         ns = 20_000

@@ -203,7 +203,7 @@ int abw_cov_accumulate_dev(abw_ctx* ctx, const uint32_t* d_seg_scaf, const uint6
                            uint64_t n_seg, uint64_t n_scaf, const uint32_t* d_read_scaf, const uint64_t* d_read_pos,
                            const uint32_t* d_read_len, uint64_t n_reads, double* d_cov);
 
-/* ---- next row N4 (loader side): the .lrn feature table, text -> integer keys
+/* ---- next row N4: the .lrn feature table, text -> integer keys (loader) and integer keys -> text (writer)
  *      (ref: ClusterData::ClusterData(esom_lrn_file, scaf_db), src/ClusterData.cpp:27-168; the file is written by
  *      src/abawaca-build.cpp:578-607 with every value printed "%.3lf").
  * abw_lrn_header (host only): the four header lines (ref :36-111) -> number of datapoints, number of dimensions
@@ -217,6 +217,13 @@ int abw_cov_accumulate_dev(abw_ctx* ctx, const uint32_t* d_seg_scaf, const uint6
  * with the line number, and the caller falls back to the reference's loader.  Host memory in, host memory out. */
 int abw_lrn_header(const uint8_t* text, uint64_t len, int64_t* ndps, int32_t* ndims, char* names_buf, uint64_t names_len);
 int abw_lrn_parse(abw_ctx* ctx, const uint8_t* text, uint64_t len, int64_t ndps, int32_t ndims, int32_t* dp_names, int32_t* keys);
+/* Writer side (ref: src/abawaca-build.cpp:595-607): the data rows of abawaca.lrn.  milli: host [n_rows][n_cols] int32,
+ * row-major, = int(1000.0*x) of every printed column (abw_sig_count_dev's d_milli for the signature columns, the
+ * truncated coverage sums behind them); row r is printed as "<first_key + r>\t%.3lf\t...\n" with every value
+ * int(1000.0*x)/1000.0 -- byte for byte what fprintf writes (ref :600-605).  The four header lines (ref :579-593) are
+ * the caller's.  *text_len receives the size even when it exceeds text_cap (then ABW_ERR_CAPACITY).  n_cols <= 960. */
+int abw_lrn_emit(abw_ctx* ctx, const int32_t* milli, int64_t n_rows, int32_t n_cols, uint64_t first_key,
+                 uint8_t* text, uint64_t text_cap, uint64_t* text_len);
 
 /* ---- extension: k-means restarts (NO counterpart in the reference, see DESIGN.md "K-means";
  *      RNG = TinyMT32, ref: src/misc.cpp:24-36, src/TinyMT-src-1.0.1/tinymt/tinymt32.{c,h}) -------- */

@@ -66,3 +66,25 @@ np.savez_compressed(os.path.join(ROOT, "tests", "golden", "lrn_a.npz"),
                     names=np.array([int(r[0]) for r in rows]), iids=np.array([int(r[1]) for r in rows]),
                     values=np.array([[float(x) for x in r[2:]] for r in rows]))
 print("reference loaded", head, "rows dumped", len(rows))
+
+
+# ---- writer side: the abawaca.lrn the REFERENCE's abawaca-build printed for a small assembly with two samples ----
+def writer_case():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    asm = synth.make_assembly(41, 12, 3, 2, frac_n_run=0.3)
+    with tempfile.TemporaryDirectory(prefix="abwlrnw_") as wd:
+        fasta, out_dir = mg.run_build(asm, wd, 2, 500)
+        raw = open(os.path.join(out_dir, "abawaca.lrn"), "rb").read()
+    lines = raw.split(b"\n")
+    header, rows = lines[:4], [ln for ln in lines[4:] if ln]
+    milli = np.array([[int(round(float(v) * 1000)) for v in ln.split(b"\t")[1:]] for ln in rows], dtype=np.int64)
+    assert np.abs(milli).max() < 2 ** 31, "a coverage column holds the reference's out-of-bounds garbage; pick another seed"
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "lrn_w.npz"), text=np.frombuffer(raw, dtype=np.uint8),
+                        milli=milli.astype(np.int32), n_header_bytes=len(b"\n".join(header)) + 1)
+    print("writer case:", len(rows), "rows x", milli.shape[1], "columns; coverage max", milli[:, 179:].max())
+
+
+writer_case()
