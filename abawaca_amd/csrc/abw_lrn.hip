@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void lrn_rows_kernel(const uint8_t* __restrict
                 for (; nfr < 3; nfr++) frac *= 10;
                 const long long key = (neg ? -1 : 1) * (ip * 1000 + frac);
                 if (bad) atomicMin(err, (unsigned long long)(l + 1) << 8 | 3);
-                else if (key > 2147483647ll || key < -2147483647ll || (f == 0 && (ip > 2147483647ll || neg))) atomicMin(err, (unsigned long long)(l + 1) << 8 | 4);
+                else if (f == 0 ? (ip > 2147483647ll || neg) : (key > 2147483647ll || key < -2147483647ll)) atomicMin(err, (unsigned long long)(l + 1) << 8 | 4);
                 else if (f == 0) dp_names[row] = (int32_t)ip;            // ref :146 atoi
                 else if (f < (uint32_t)ncols) keys[(int64_t)(f - 1) * stride + (int64_t)row] = (int32_t)key;
             }

@@ -87,7 +87,7 @@ def test_writer_round_trip_and_format(ctx, N, D, first):
     m[:, -1] = rng.integers(-2_000_000_000, 2_000_000_000, size=N)             # wide and negative values
     m[0, 0] = 0
     text = bytes(lrn.lrn_emit(ctx, m.astype(np.int32), first))
-    want = "".join(str(first + r) + "".join("\t%s%d.%03d" % (("-" if v < 0 else ""),) + divmod(abs(int(v)), 1000) for v in m[r]) + "\n"
+    want = "".join(str(first + r) + "".join("\t%s%d.%03d" % ((("-" if v < 0 else ""),) + divmod(abs(int(v)), 1000)) for v in m[r]) + "\n"
                    for r in range(N)).encode()
     assert text == want
     if first + N < 2 ** 31:
