@@ -561,6 +561,22 @@ def main():
                                               peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg_bytes / (msa / na * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                               traffic=pmc_all.get("sep_accum_kernel", {}).get("hbm_bytes_per_launch_raw") if default_workload else None,
                                               ms_per_launch=round(msa / na, 4), eval_ms=round(mse / max(ne, 1), 4)))
+        # the whole recursion on this table (reference src/abawaca.cpp:95-197 with the GPU separator): every node is one
+        # abw_sep_node call on the resident column store, given its scaffold list
+        t0 = time.perf_counter()
+        nodes_all, s2c_all, _d2c = separator.binning(store)
+        rec_s = time.perf_counter() - t0
+        bins = [r for r in nodes_all if not r["split"]]
+        # planted genomes vs bins: share of scaffolds whose bin's majority genome is their own
+        lab = np.asarray(genome)
+        agree = 0
+        for r in bins:
+            mem = lab[s2c_all == r["id"]]
+            if len(mem):
+                agree += int(np.bincount(mem).max())
+        out["separator"]["recursion"] = dict(s=round(rec_s, 3), nodes=len(nodes_all), bins=len(bins), ms_per_node=round(rec_s / len(nodes_all) * 1e3, 3),
+                                             planted_genomes=int(G), scaffolds_in_their_bins_majority_genome=round(agree / len(lab), 4),
+                                             note="whole recursive binning of the configs[1] table, GPU separator + Python work-list loop")
         del store
 
         blob, off = make_assembly_blob(20244, args.sig_mbp)
