@@ -234,6 +234,42 @@ __global__ __launch_bounds__(256) void sep_wide_ts_kernel(SepDev P, WideDev W, c
     }
 }
 
+// Small nodes: the sorted walk costs the whole table whatever the node holds, so a node with few dps scatters them
+// instead -- one thread per (scaffold, wide dimension), one device-scope atomic per dp (size and tp1 share a 64-bit
+// word) plus what lands on bin t_s.  Cost proportional to the node (~23 G atomics/s).
+__global__ __launch_bounds__(256) void sep_wide_scatter_kernel(SepDev P, const int32_t* __restrict__ dimlist,
+                                                              const int32_t* __restrict__ node_scaf, int32_t m)
+{
+    const int ls = blockIdx.x * 256 + threadIdx.x;
+    if (ls >= m) return;
+    const int d = dimlist[blockIdx.y];
+    const int T = P.T[d];
+    const int64_t toff = P.Toff[d];
+    const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
+    const int s = node_scaf ? node_scaf[ls] : ls;
+    const int f = P.scaf_first[s];
+    const int n = P.scaf_ndps[s];
+    const int ts = select_kth_mem(col + f, n, n >> 1, T);
+    constexpr unsigned long long BOTH = 1ull | (1ull << 32);
+    unsigned long long at_ts = 0;                          // everything that lands on bin t_s, in one add
+    for (int i = 0; i < n; i++) {
+        const int v = col[f + i];
+        if (v > ts) atomicAdd(&P.h_st[toff + v], BOTH);
+        else if (v < ts) { atomicAdd(&P.h_st[toff + v], 1ull); at_ts += 1ull << 32; }
+        else at_ts += BOTH;
+    }
+    atomicAdd(&P.h_st[toff + ts], at_ts);
+    atomicAdd(&P.h_tot[toff + ts], (uint32_t)n);
+    atomicAdd(&P.h_bp[toff + ts], (unsigned long long)P.scaf_len[s]);
+    if (P.n_scg > 0) {
+        for (int e = P.scg_off[s]; e < P.scg_off[s + 1]; e++) {
+            const int g = P.scg_ids[e];
+            atomicMin(&P.scg_lo[(int64_t)d * P.n_scg + g], ts);
+            atomicMax(&P.scg_hi[(int64_t)d * P.n_scg + g], ts);
+        }
+    }
+}
+
 constexpr int WIDE_TILES = 4;        // 64-position tiles per wave: their loads are issued together (the kernel is
                                      // a chain of dependent loads; one tile per wave left it latency-bound)
 
@@ -895,12 +931,17 @@ static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_
         }
         if (!H.wide_dims.empty()) {
             const unsigned Dw = (unsigned)H.wide_dims.size();
+            if (n * 6 < s.N) {                                 // small node: scatter (cost ~ node), else the sorted walk (cost ~ table)
+                hipLaunchKernelGGL(sep_wide_scatter_kernel, dim3((unsigned)((m + 255) / 256), Dw), dim3(256), 0, st, P, H.d_wide, d_node_scaf, m);
+                ABW_LAUNCH_CHECK(ctx);
+            } else {
             WideDev W = {H.d_sscaf, H.d_sbin, H.d_wts, H.d_wbelow, s.S};
             ABW_HIP(ctx, hipMemsetAsync(H.d_wts, 0xFF, (size_t)Dw * (size_t)s.S * 4, st));      // -1: not in the node
             hipLaunchKernelGGL(sep_wide_ts_kernel, dim3((unsigned)((m + 255) / 256), Dw), dim3(256), 0, st, P, W, H.d_wide, d_node_scaf, m);
             ABW_LAUNCH_CHECK(ctx);
             hipLaunchKernelGGL(sep_wide_hist_kernel, dim3((unsigned)((s.N + 256 * WIDE_TILES - 1) / (256 * WIDE_TILES)), Dw), dim3(256), 0, st, P, W, H.d_wide);
             ABW_LAUNCH_CHECK(ctx);
+            }
         }
     }
     s.node_open = true; s.node_all = all; s.node_m = m; s.node_n = n;

@@ -25,6 +25,9 @@ def scg_csr(scg_scaf, scg_id, S):
     return np.cumsum(off).astype(np.int32), np.ascontiguousarray(np.asarray(scg_id, dtype=np.int32)[order])
 
 
+_PER_DTYPE = np.dtype([("found", "i4"), ("key", "i4"), ("sens", "f8"), ("spec", "f8")])     # = struct abw_dimbest
+
+
 class ColumnStore:
     """The resident feature table (ClusterData + ScafDpData + SCGdb as the separator sees them)."""
 
@@ -78,8 +81,7 @@ class ClusterSeparatorHip:
                                         C.c_void_p(side.ctypes.data), C.c_void_p(raw.ctypes.data)))
         self.last_call_s = time.perf_counter() - t0          # the C-ABI call alone (host buffers in and out)
         self._res, self._side, self._raw, self._ids = out, side.copy(), raw.copy(), ids
-        self._per = np.array([(p.found, p.key, p.sensitivity, p.specificity) for p in per],
-                             dtype=[("found", "i4"), ("key", "i4"), ("sens", "f8"), ("spec", "f8")])
+        self._per = np.frombuffer(per, dtype=_PER_DTYPE).copy()
         return bool(out.split)
 
     # -- accessors named after the reference's (ClusterSeparator.h:45-52, ...Specificity.h:51-52) --
@@ -138,7 +140,7 @@ def binning(store: ColumnStore, max_nodes: int = 1 << 30):
         all_ids = np.arange(store.S, dtype=np.int32) if ids is None else ids
         n = int(store.scaf_ndps[all_ids].sum())
         row = dict(id=nid, ndps=n, split=int(split), dim=sep.get_separating_dimension(), key=sep.get_separating_value(),
-                   spec=sep.get_best_specificity(), sens=sep.get_best_sensitivity(), c1=0, n1=0, c2=0, n2=0)
+                   spec=sep.get_best_specificity(), sens=sep.get_best_sensitivity(), c1=0, n1=0, c2=0, n2=0, call_s=sep.last_call_s)
         if split:
             c1, c2 = next_id, next_id + 1
             next_id += 2
@@ -147,8 +149,9 @@ def binning(store: ColumnStore, max_nodes: int = 1 << 30):
             row.update(c1=c1, n1=n1, c2=c2, n2=n2)
         else:
             scaf2cluster[all_ids] = nid
-            for s in all_ids:
-                dp2cluster[store.scaf_first[s]:store.scaf_first[s] + store.scaf_ndps[s]] = nid
+            cnt = store.scaf_ndps[all_ids].astype(np.int64)
+            within = np.arange(int(cnt.sum()), dtype=np.int64) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+            dp2cluster[np.repeat(store.scaf_first[all_ids], cnt) + within] = nid
         nodes.append(row)
     return nodes, scaf2cluster, dp2cluster
 
@@ -213,8 +216,7 @@ class ShardNode:
         st.ctx.check(lib().abw_sep_shard_eval(st.ctx.handle, self.cluster_ndps_threshold, C.byref(self.out), per,
                                               C.c_void_p(self.side.ctypes.data), C.c_void_p(self.raw.ctypes.data)))
         self.side, self.raw = self.side[:self.m], self.raw[:self.n]
-        self.per = np.array([(p.found, p.key, p.sensitivity, p.specificity) for p in per],
-                            dtype=[("found", "i4"), ("key", "i4"), ("sens", "f8"), ("spec", "f8")])
+        self.per = np.frombuffer(per, dtype=_PER_DTYPE).copy()
         return int(self.out.ndps1), int(self.out.ndps2)
 
     def decide(self, ndps1_total, ndps2_total) -> bool:

@@ -574,7 +574,7 @@ def main():
             mem = lab[s2c_all == r["id"]]
             if len(mem):
                 agree += int(np.bincount(mem).max())
-        out["separator"]["recursion"] = dict(s=round(rec_s, 3), nodes=len(nodes_all), bins=len(bins), ms_per_node=round(rec_s / len(nodes_all) * 1e3, 3),
+        out["separator"]["recursion"] = dict(s=round(rec_s, 3), c_abi_s=round(sum(r["call_s"] for r in nodes_all), 3), nodes=len(nodes_all), bins=len(bins), ms_per_node=round(rec_s / len(nodes_all) * 1e3, 3),
                                              planted_genomes=int(G), scaffolds_in_their_bins_majority_genome=round(agree / len(lab), 4),
                                              note="whole recursive binning of the configs[1] table, GPU separator + Python work-list loop")
         del store
