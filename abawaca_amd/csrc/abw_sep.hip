@@ -396,17 +396,31 @@ __global__ __launch_bounds__(256) void sep_chunk_sums_kernel(SepDev P, const Chu
     if (threadIdx.x == 0) chunk_sums[blockIdx.x] = sums_add(sums_add(wsum[0], wsum[1]), sums_add(wsum[2], wsum[3]));
 }
 
-// phase B: exclusive scan of the chunk totals within each dimension (chunks of a dimension are
-// consecutive); one thread per dimension is plenty (<= N/2048 chunks for the widest column).
-__global__ void sep_chunk_scan_kernel(const int32_t* __restrict__ dim_first_chunk, const int32_t* __restrict__ dim_nchunks,
-                                      int32_t D, Sums* __restrict__ chunk_sums, Sums* __restrict__ dim_total)
+// phase B: exclusive scan of the chunk totals within each dimension (chunks of a dimension are consecutive);
+// one wave per dimension, 64 chunks at a time
+__global__ __launch_bounds__(64) void sep_chunk_scan_kernel(const int32_t* __restrict__ dim_first_chunk, const int32_t* __restrict__ dim_nchunks,
+                                                           int32_t D, Sums* __restrict__ chunk_sums, Sums* __restrict__ dim_total)
 {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.x;
+    const int lane = threadIdx.x;
     if (d >= D) return;
-    Sums run = {0, 0, 0, 0};
     const int f = dim_first_chunk[d], n = dim_nchunks[d];
-    for (int i = 0; i < n; i++) { Sums v = chunk_sums[f + i]; chunk_sums[f + i] = run; run = sums_add(run, v); }
-    dim_total[d] = run;
+    Sums run = {0, 0, 0, 0};
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        Sums v = {0, 0, 0, 0};
+        if (i < n) v = chunk_sums[f + i];
+        const Sums x = wave_incl_scan(v, lane);
+        if (i < n) {
+            Sums e = sums_add(run, x);
+            e.size -= v.size; e.tp1 -= v.tp1; e.tot -= v.tot; e.bp -= v.bp;        // exclusive
+            chunk_sums[f + i] = e;
+        }
+        Sums last;
+        last.size = __shfl(x.size, 63, 64); last.tp1 = __shfl(x.tp1, 63, 64); last.tot = __shfl(x.tot, 63, 64); last.bp = __shfl(x.bp, 63, 64);
+        run = sums_add(run, last);
+    }
+    if (lane == 0) dim_total[d] = run;
 }
 
 struct Cand { double prod; int32_t bin; int32_t found; double sens; double spec; long long size1; };
@@ -512,18 +526,23 @@ __global__ __launch_bounds__(256) void sep_eval_kernel(SepDev P, const ChunkDesc
     }
 }
 
-// phase D: best chunk of each dimension
-__global__ void sep_dimbest_kernel(const int32_t* __restrict__ dim_first_chunk, const int32_t* __restrict__ dim_nchunks,
-                                   int32_t D, const Cand* __restrict__ chunk_best, const Sums* __restrict__ dim_total,
-                                   DimBestDev* __restrict__ out)
+// phase D: best chunk of each dimension; one wave per dimension
+__global__ __launch_bounds__(64) void sep_dimbest_kernel(const int32_t* __restrict__ dim_first_chunk, const int32_t* __restrict__ dim_nchunks,
+                                                        int32_t D, const Cand* __restrict__ chunk_best, const Sums* __restrict__ dim_total,
+                                                        DimBestDev* __restrict__ out)
 {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.x;
+    const int lane = threadIdx.x;
     if (d >= D) return;
     Cand b = {0.0, 0, 0, 0.0, 0.0, 0};
     const int f = dim_first_chunk[d], n = dim_nchunks[d];
-    for (int i = 0; i < n; i++) if (cand_better(chunk_best[f + i], b)) b = chunk_best[f + i];
-    out[d].found = b.found; out[d].bin = b.bin; out[d].sens = b.sens; out[d].spec = b.spec; out[d].prod = b.prod;
-    out[d].size1 = b.size1; out[d].n = (long long)dim_total[d].size;
+    for (int i = lane; i < n; i += 64) if (cand_better(chunk_best[f + i], b)) b = chunk_best[f + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { Cand other = cand_shfl_xor(b, o); if (cand_better(other, b)) b = other; }
+    if (lane == 0) {
+        out[d].found = b.found; out[d].bin = b.bin; out[d].sens = b.sens; out[d].spec = b.spec; out[d].prod = b.prod;
+        out[d].size1 = b.size1; out[d].n = (long long)dim_total[d].size;
+    }
 }
 
 // The global winner over the dimensions: ClusteringResult::is_better (ref ...Specificity.h:25-30 +
@@ -974,11 +993,11 @@ static int sep_eval_phase(abw_ctx* ctx, const char* who, int32_t min_ndps, abw_s
     ABW_PROF(ctx, "sep_eval");
     hipLaunchKernelGGL(sep_chunk_sums_kernel, dim3(nch), dim3(256), 0, st, P, H.d_chunks, H.d_chunk_sums);
     ABW_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(sep_chunk_scan_kernel, dim3((s.D + 63) / 64), dim3(64), 0, st, H.d_dim_first_chunk, H.d_dim_nchunks, s.D, H.d_chunk_sums, H.d_dim_total);
+    hipLaunchKernelGGL(sep_chunk_scan_kernel, dim3(s.D), dim3(64), 0, st, H.d_dim_first_chunk, H.d_dim_nchunks, s.D, H.d_chunk_sums, H.d_dim_total);
     ABW_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(sep_eval_kernel, dim3(nch), dim3(256), 0, st, P, H.d_chunks, H.d_chunk_sums, H.d_dim_total, min_ndps, H.d_chunk_best);
     ABW_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(sep_dimbest_kernel, dim3((s.D + 63) / 64), dim3(64), 0, st, H.d_dim_first_chunk, H.d_dim_nchunks, s.D, H.d_chunk_best, H.d_dim_total, d_dimbest);
+    hipLaunchKernelGGL(sep_dimbest_kernel, dim3(s.D), dim3(64), 0, st, H.d_dim_first_chunk, H.d_dim_nchunks, s.D, H.d_chunk_best, H.d_dim_total, d_dimbest);
     ABW_LAUNCH_CHECK(ctx);
     }
     // the global winner and this context's part of the finalisation follow on the device without a host round trip
