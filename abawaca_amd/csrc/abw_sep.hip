@@ -551,17 +551,27 @@ __global__ __launch_bounds__(64) void sep_dimbest_kernel(const int32_t* __restri
 // dimension whose winner has product 0 still replaces the reset state.  Then is_legal (ref .h:31-35).
 struct GlobalRes { int32_t found; int32_t dim; int32_t bin; int32_t legal; double sens; double spec; long long size1; long long n; };
 
-__global__ void sep_global_kernel(const DimBestDev* __restrict__ db, int32_t D, GlobalRes* __restrict__ out)
+// In dimension order that rule picks, among the dimensions that found a winner, the largest product and on equal
+// products the smallest dimension: a strict order, so one wave reduces it (lanes stride over the dimensions).
+__global__ __launch_bounds__(64) void sep_global_kernel(const DimBestDev* __restrict__ db, int32_t D, GlobalRes* __restrict__ out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double gsens = 0, gspec = 0;
-    int gd = -1;
-    for (int d = 0; d < D; d++) {
+    const int lane = threadIdx.x;
+    double bp = -1.0;                                      // products are >= 0: -1 = nothing found yet
+    int bd = -1;
+    for (int d = lane; d < D; d += 64) {
         if (!db[d].found) continue;
-        const double a = db[d].sens * db[d].spec, b = gsens * gspec;
-        const bool better = (a != b) ? (a >= b) : (gd < 0);
-        if (better) { gsens = db[d].sens; gspec = db[d].spec; gd = d; }
+        const double a = db[d].sens * db[d].spec;
+        if (a > bp) { bp = a; bd = d; }                    // d ascends within a lane: equal products keep the smaller d
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double op = __shfl_xor(bp, o, 64);
+        const int od = __shfl_xor(bd, o, 64);
+        if (od >= 0 && (bd < 0 || op > bp || (op == bp && od < bd))) { bp = op; bd = od; }
+    }
+    if (lane != 0) return;
+    const int gd = bd;
+    const double gsens = gd >= 0 ? db[gd].sens : 0.0, gspec = gd >= 0 ? db[gd].spec : 0.0;
     GlobalRes r;
     r.found = gd >= 0; r.dim = gd; r.bin = gd >= 0 ? db[gd].bin : -1;
     r.sens = gsens; r.spec = gspec;
