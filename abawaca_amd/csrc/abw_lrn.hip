@@ -169,8 +169,7 @@ __global__ __launch_bounds__(256) void lrn_rows_kernel(const uint8_t* __restrict
                     }
                 }
                 if (p[j] != '\t') bad = true;                            // anything else inside the field (or a field too long)
-                if (nd + nfr == 0 && !(j == 0 || (j == 1 && neg))) bad = true;
-                if (nd + nfr == 0 && j > 0) bad = true;                  // "-" or "." alone
+                if (nd + nfr == 0 && j > 0) bad = true;                  // "-" or "." alone; an empty field is atof("") = 0
                 for (; nfr < 3; nfr++) frac *= 10;
                 const long long key = (neg ? -1 : 1) * (ip * 1000 + frac);
                 if (bad) atomicMin(err, (unsigned long long)(l + 1) << 8 | 3);

@@ -76,3 +76,40 @@ def test_segment_host_rejects_lowercase_n():
     with pytest.raises(_lib.AbwError) as e:
         signature.segment_host(blob, np.array([0, 9], dtype=np.uint64))
     assert e.value.code == _lib.ABW_ERR_LOWER_N
+
+
+def test_lrn_header_host_only(golden_dir):
+    """abw_lrn_header needs no GPU: the four header lines of the reference's own abawaca.lrn and of the tricky file."""
+    from abawaca_amd import lrn
+    g = np.load(os.path.join(golden_dir, "lrn_w.npz"))
+    ndps, ndims, names = lrn.lrn_header(g["text"])
+    assert (ndps, ndims) == g["milli"].shape and names[:4] == ["C", "AA", "AC", "AG"] and len(names) == ndims
+    assert names[:179] == signature.dim_names()[1:]                       # the reference's column order
+    t = np.load(os.path.join(golden_dir, "lrn_a.npz"))["text"]
+    assert lrn.lrn_header(t)[:2] == (17, 7)
+    for bad in (b"", b"% 3\n% 2\n", b"x 3\n% 3\n% 9\t1\t1\n% Key\ta\tb\n", b"% 3\n% 3\n% 9\t1\n% Key\ta\tb\n", b"% 3\n% 3\n% 9\t1\t1\n% Key\ta\n"):
+        with pytest.raises(_lib.AbwError) as e:
+            lrn.lrn_header(np.frombuffer(bad, dtype=np.uint8))
+        assert e.value.code == _lib.ABW_ERR_FORMAT
+
+
+def test_shard_decide_is_the_final_size_check():
+    """abw_sep_shard_decide (host only): reference src/ClusterSeparator.cpp:125-132 on the summed child sizes."""
+    L = _lib.lib()
+
+    def mk(dim=5, key=123, legal=1):
+        o = _lib.Split()
+        o.dimension, o.key, o.legal, o.sensitivity, o.specificity, o.ndps1, o.ndps2 = dim, key, legal, 0.9, 0.95, 7, 9
+        return o
+    o = mk()
+    assert L.abw_sep_shard_decide(C.byref(o), 150, 4000, 100) == 0
+    assert (o.split, o.ndps1, o.ndps2, o.dimension, o.key) == (1, 150, 4000, 5, 123)
+    o = mk()
+    L.abw_sep_shard_decide(C.byref(o), 99, 4000, 100)                      # a child too small: everything is reset
+    assert (o.split, o.ndps1, o.ndps2, o.dimension, o.key, o.sensitivity, o.specificity) == (0, 0, 0, -1, -1, 0.0, 0.0)
+    o = mk(legal=0)
+    L.abw_sep_shard_decide(C.byref(o), 500, 500, 100)                      # an illegal winner stays reported, no split
+    assert (o.split, o.dimension, o.key, o.ndps1, o.ndps2) == (0, 5, 123, 0, 0)
+    o = mk(dim=-1, key=-1, legal=0)
+    L.abw_sep_shard_decide(C.byref(o), 500, 500, 100)
+    assert o.split == 0
