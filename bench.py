@@ -614,6 +614,18 @@ def main():
                                               peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg / (msc / nc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                               traffic=pmc_all.get("sig_count_kernel", {}).get("hbm_bytes_per_launch") if default_workload else None,
                                               ms_per_launch=round(msc / nc, 4), segment_ms=round(mss / max(ns, 1), 4)))
+        # the boundary with HOST buffers (abw_sig_build: H2D of the ASCII, segmentation + counting, D2H of the rows):
+        # PCIe-inclusive, never the headline
+        sub = min(total, 200_000_000)
+        n_sub = int(np.searchsorted(off, sub, side="right")) - 1
+        hb, ho = blob[:int(off[n_sub])], off[:n_sub + 1]
+        signature.build_signatures(ctx, hb[:10_000_000], off[:1001], want_dims=False)      # warm-up (buffers)
+        t0 = time.perf_counter()
+        r_host = signature.build_signatures(ctx, hb, ho, want_dims=False)
+        host_s = time.perf_counter() - t0
+        out["signature"]["host_buffers"] = dict(value=round(len(hb) / host_s / 1e9, 2), unit="Gbp/s", mbp=len(hb) // 1_000_000, segments=int(len(r_host["seg_scaf"])),
+                                                note="abw_sig_build on pageable host memory, milli rows back (716 B per segment): PCIe both ways + allocation of the outputs")
+        del r_host
         # ---- row N1: coverage accumulation on the same segments (20 M reads of 150 bp ~ depth 3 of this assembly)
         n_scaf_sig = len(off) - 1
         n_reads = args.cov_mreads * 1_000_000
