@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
                         } else if (u < DT) {
                             bb[0][u] = sop[32 * XS * u];                 // first operands of the sums product
                         }
-                        if (NBUF == 2 && (m * PT) % 16 == 0) load_k(m * PT / 16);
+                        if ((m * PT) % 16 == 0) load_k(m * PT / 16);      // next tiles -> registers, also with one buffer
                         __builtin_amdgcn_sched_barrier(0);
                         if (bt == 0 && u < 2) mfma_v_first((u & 1) ? acc1b : acc1, a[0][u], b[0][u]);
                         else                  mfma_v((u & 1) ? acc1b : acc1, a[bt & 1][u], b[bt & 1][u]);
@@ -351,9 +351,9 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
                 __syncthreads();                             // next tiles stored by all; these read by all
                 cur ^= 1;
             } else if (have_next) {
+                // one buffer per point lane: the next tiles were fetched into registers behind the discriminant
+                // MFMAs; only their LDS stores wait for the readers of the current ones
                 __syncthreads();                             // everyone done reading the only buffers
-#pragma unroll
-                for (int k = 0; k < NL; k++) load_k(k);
 #pragma unroll
                 for (int k = 0; k < NL; k++) store_k(k);
                 __syncthreads();

@@ -35,7 +35,8 @@ def _blobs(seed, N, d, sep=4.0):
 
 
 @pytest.mark.parametrize("N,d,R,iters,chunk", [(1000, 7, 5, 4, 64), (4097, 33, 16, 6, 256), (6000, 189, 64, 3, 512),
-                                                  (333, 31, 3, 2, 32), (2500, 64, 20, 3, 128)])
+                                                  (333, 31, 3, 2, 32), (2500, 64, 20, 3, 128),
+                                                  (3000, 150, 8, 3, 256), (2100, 199, 32, 2, 160)])   # one LDS buffer per point lane
 def test_kmeans_bit_exact_vs_oracle(ctx, N, d, R, iters, chunk):
     x, _ = _blobs(N + d, N, d)
     a, c, inert = kmeans.kmeans_restarts(ctx, x, R, base_seed=20240, iters=iters, chunk=chunk)
