@@ -107,3 +107,24 @@ def test_load_rejects_bad_layout(ctx):
         separator.ColumnStore(ctx, keys, np.array([0, 0, 1, 2, 2, 2]), np.ones(3, np.int64))
     with pytest.raises(_lib.AbwError):      # not contiguous
         separator.ColumnStore(ctx, keys, np.array([0, 1, 0, 1, 2, 2]), np.ones(3, np.int64))
+
+
+def test_degenerate_columns_match_oracle(ctx):
+    """Columns that stress the run handling of the sorted walk and the LDS histograms: a constant wide column (one bin:
+    every tile's run is open on both sides), a two-valued wide column, a wide column of all-distinct keys, a constant
+    narrow column; scaffolds of 2..40 dps so that both order-statistic paths run."""
+    f = synth.make_features(9, 2500, 5, 2, n_lo=2, n_hi=40)
+    keys = f["milli"].copy()
+    N = keys.shape[1]
+    rng = np.random.default_rng(3)
+    keys[170] = 5000                                                   # constant, wide
+    keys[171] = np.where(rng.random(N) < 0.5, 2000, 70000)             # two values, wide
+    keys[172] = 1024 + rng.permutation(N)                              # all distinct, wide
+    keys[173] = 7                                                      # constant, narrow
+    S = 2500
+    off, ids = separator.scg_csr(f["scg_scaf"], f["scg_id"], S)
+    store = separator.ColumnStore(ctx, keys, f["dp2scaf"], f["scaf_len"], off, ids, f["n_scg"])
+    arrays = (keys, f["dp2scaf"], f["scaf_ndps"], f["scaf_len"], off, ids, f["n_scg"])
+    _compare_node(store, None, arrays)
+    sub = np.sort(rng.choice(S, size=S // 10, replace=False)).astype(np.int32)      # small node: the scatter path
+    _compare_node(store, sub, arrays, min_ndps=20)
