@@ -53,6 +53,7 @@ struct SepDev {
     unsigned long long* h_st;          // per bin: size (low 32 bits) and tp1 (high 32 bits), updated by one 64-bit atomic
     uint32_t* h_tot; unsigned long long* h_bp;
     int32_t* scg_lo; int32_t* scg_hi;
+    int32_t* range;                    // [D][2] bins the current node touched in each dimension (lo, hi inclusive; hi < lo: none)
 };
 
 // k-th smallest (0-based) of the n values at col[0..n), n > 8: binary search on the answer.
@@ -241,33 +242,89 @@ __global__ __launch_bounds__(256) void sep_wide_scatter_kernel(SepDev P, const i
                                                               const int32_t* __restrict__ node_scaf, int32_t m)
 {
     const int ls = blockIdx.x * 256 + threadIdx.x;
-    if (ls >= m) return;
     const int d = dimlist[blockIdx.y];
-    const int T = P.T[d];
-    const int64_t toff = P.Toff[d];
-    const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
-    const int s = node_scaf ? node_scaf[ls] : ls;
-    const int f = P.scaf_first[s];
-    const int n = P.scaf_ndps[s];
-    const int ts = select_kth_mem(col + f, n, n >> 1, T);
-    constexpr unsigned long long BOTH = 1ull | (1ull << 32);
-    unsigned long long at_ts = 0;                          // everything that lands on bin t_s, in one add
-    for (int i = 0; i < n; i++) {
-        const int v = col[f + i];
-        if (v > ts) atomicAdd(&P.h_st[toff + v], BOTH);
-        else if (v < ts) { atomicAdd(&P.h_st[toff + v], 1ull); at_ts += 1ull << 32; }
-        else at_ts += BOTH;
-    }
-    atomicAdd(&P.h_st[toff + ts], at_ts);
-    atomicAdd(&P.h_tot[toff + ts], (uint32_t)n);
-    atomicAdd(&P.h_bp[toff + ts], (unsigned long long)P.scaf_len[s]);
-    if (P.n_scg > 0) {
-        for (int e = P.scg_off[s]; e < P.scg_off[s + 1]; e++) {
-            const int g = P.scg_ids[e];
-            atomicMin(&P.scg_lo[(int64_t)d * P.n_scg + g], ts);
-            atomicMax(&P.scg_hi[(int64_t)d * P.n_scg + g], ts);
+    int vmin = INT_MAX, vmax = -1;
+    if (ls < m) {
+        const int T = P.T[d];
+        const int64_t toff = P.Toff[d];
+        const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
+        const int s = node_scaf ? node_scaf[ls] : ls;
+        const int f = P.scaf_first[s];
+        const int n = P.scaf_ndps[s];
+        constexpr unsigned long long BOTH = 1ull | (1ull << 32);
+        unsigned long long at_ts = 0;                          // everything that lands on bin t_s, in one add
+        int ts;
+        if (n <= 8) {                                          // values in registers, flip value by the sorting network
+            int v[8], x[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { v[i] = (i < n) ? col[f + i] : INT_MAX; x[i] = v[i]; }
+#define ABW_CX(a, b) { const int lo_ = min(x[a], x[b]), hi_ = max(x[a], x[b]); x[a] = lo_; x[b] = hi_; }
+            ABW_CX(0, 1) ABW_CX(2, 3) ABW_CX(4, 5) ABW_CX(6, 7)
+            ABW_CX(0, 2) ABW_CX(1, 3) ABW_CX(4, 6) ABW_CX(5, 7)
+            ABW_CX(1, 2) ABW_CX(5, 6)
+            ABW_CX(0, 4) ABW_CX(1, 5) ABW_CX(2, 6) ABW_CX(3, 7)
+            ABW_CX(2, 4) ABW_CX(3, 5)
+            ABW_CX(1, 2) ABW_CX(3, 4) ABW_CX(5, 6)
+#undef ABW_CX
+            const int k = n >> 1;
+            ts = (k == 1) ? x[1] : (k == 2) ? x[2] : (k == 3) ? x[3] : x[4];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (i < n) {
+                    vmin = min(vmin, v[i]); vmax = max(vmax, v[i]);
+                    if (v[i] > ts) atomicAdd(&P.h_st[toff + v[i]], BOTH);
+                    else if (v[i] < ts) { atomicAdd(&P.h_st[toff + v[i]], 1ull); at_ts += 1ull << 32; }
+                    else at_ts += BOTH;
+                }
+            }
+        } else {
+            ts = select_kth_mem(col + f, n, n >> 1, T);
+            for (int i = 0; i < n; i++) {
+                const int v = col[f + i];
+                vmin = min(vmin, v); vmax = max(vmax, v);
+                if (v > ts) atomicAdd(&P.h_st[toff + v], BOTH);
+                else if (v < ts) { atomicAdd(&P.h_st[toff + v], 1ull); at_ts += 1ull << 32; }
+                else at_ts += BOTH;
+            }
+        }
+        atomicAdd(&P.h_st[toff + ts], at_ts);
+        atomicAdd(&P.h_tot[toff + ts], (uint32_t)n);
+        atomicAdd(&P.h_bp[toff + ts], (unsigned long long)P.scaf_len[s]);
+        if (P.n_scg > 0) {
+            for (int e = P.scg_off[s]; e < P.scg_off[s + 1]; e++) {
+                const int g = P.scg_ids[e];
+                atomicMin(&P.scg_lo[(int64_t)d * P.n_scg + g], ts);
+                atomicMax(&P.scg_hi[(int64_t)d * P.n_scg + g], ts);
+            }
         }
     }
+    // the bins this node touches in dimension d: only they are evaluated and cleared afterwards
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { vmin = min(vmin, __shfl_xor(vmin, o, 64)); vmax = max(vmax, __shfl_xor(vmax, o, 64)); }
+    if ((threadIdx.x & 63) == 0 && vmax >= 0) { atomicMin(&P.range[2 * d], vmin); atomicMax(&P.range[2 * d + 1], vmax); }
+}
+
+// Between nodes the histograms are all zero: a node clears what the node before it touched (its recorded ranges)
+// instead of the whole block, then the ranges start over -- full for the dimensions in `full` mode (narrow dimensions,
+// the sorted walk, sharded tables: every bin may receive something), empty for dimensions that scatter.
+__global__ __launch_bounds__(256) void sep_clear_kernel(SepDev P, const ChunkDesc* __restrict__ chunks)
+{
+    const ChunkDesc c = chunks[blockIdx.x];
+    const int lo = P.range[2 * c.dim], hi = P.range[2 * c.dim + 1];
+    if (hi < lo || c.start + c.len - 1 < lo || c.start > hi) return;
+    const int64_t base = P.Toff[c.dim] + c.start;
+    for (int t = threadIdx.x; t < c.len; t += 256) { P.h_st[base + t] = 0; P.h_tot[base + t] = 0; P.h_bp[base + t] = 0; }
+}
+
+__global__ void sep_range_reset_kernel(SepDev P, int32_t D, const int32_t* __restrict__ widelist, int32_t n_wide, int wide_full)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    bool wide = false;
+    for (int w = 0; w < n_wide; w++) wide |= widelist[w] == d;
+    const bool full = !wide || wide_full;
+    P.range[2 * d] = full ? 0 : INT_MAX;
+    P.range[2 * d + 1] = full ? P.T[d] - 1 : -1;
 }
 
 constexpr int WIDE_TILES = 4;        // 64-position tiles per wave: their loads are issued together (the kernel is
@@ -383,6 +440,10 @@ __global__ __launch_bounds__(256) void sep_chunk_sums_kernel(SepDev P, const Chu
 {
     __shared__ Sums wsum[4];
     const ChunkDesc c = chunks[blockIdx.x];
+    if (c.start + c.len - 1 < P.range[2 * c.dim] || c.start > P.range[2 * c.dim + 1]) {      // untouched by this node: all zero
+        if (threadIdx.x == 0) chunk_sums[blockIdx.x] = Sums{0, 0, 0, 0};
+        return;
+    }
     const int64_t base = P.Toff[c.dim] + c.start;
     Sums acc = {0, 0, 0, 0};
     for (int t = threadIdx.x; t < c.len; t += 256) {
@@ -453,6 +514,10 @@ __global__ __launch_bounds__(256) void sep_eval_kernel(SepDev P, const ChunkDesc
     __shared__ Cand wbest[4];
     const ChunkDesc c = chunks[blockIdx.x];
     const int d = c.dim;
+    if (c.start + c.len - 1 < P.range[2 * d] || c.start > P.range[2 * d + 1]) {             // no value of the node here: no threshold
+        if (threadIdx.x == 0) chunk_best[blockIdx.x] = Cand{0.0, 0, 0, 0.0, 0.0, 0};
+        return;
+    }
     const int64_t base = P.Toff[d] + c.start;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const Sums total = dim_total[d];
@@ -643,6 +708,8 @@ struct SepHost {
     Cand* d_chunk_best = nullptr;
     // wide dimensions: dps sorted by bin (static) and the per-node flip-value records
     int32_t *d_sscaf = nullptr, *d_sbin = nullptr, *d_wts = nullptr, *d_wbelow = nullptr;
+    int32_t* d_range = nullptr;        // [D][2] bins touched by the current node
+    bool sharded = false;              // table loaded with a shared bin layout (abw_sep_shard_load)
 };
 
 }  // namespace
@@ -686,7 +753,7 @@ extern "C" void abw_sep_free(abw_ctx* ctx)
     if (e) {
         void* q[] = {e->h.d_narrow, e->h.d_wide, e->h.d_dim_first_chunk, e->h.d_dim_nchunks, e->h.d_chunks,
                      e->h.d_chunk_sums, e->h.d_dim_total, e->h.d_chunk_best, e->h.d_sscaf, e->h.d_sbin,
-                     e->h.d_wts, e->h.d_wbelow};
+                     e->h.d_wts, e->h.d_wbelow, e->h.d_range};
         for (void* p : q) if (p) (void)hipFree(p);
         delete e;
     }
@@ -888,6 +955,13 @@ static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int
         if ((rc = upload<int32_t>(ctx, &H.d_wbelow, nullptr, Dw * (size_t)S))) return rc;
     }
     if ((rc = abw_reserve(ctx, s.hist, (size_t)tb * (4 * 3 + 8) + 64))) return rc;
+    ABW_HIP(ctx, hipMemset(s.hist.p, 0, (size_t)tb * (4 * 3 + 8) + 64));          // all zero between nodes from here on
+    {
+        std::vector<int32_t> none((size_t)2 * D);
+        for (int32_t d = 0; d < D; d++) { none[2 * d] = INT_MAX; none[2 * d + 1] = -1; }   // nothing touched yet
+        if ((rc = upload(ctx, &H.d_range, none.data(), none.size()))) return rc;
+    }
+    H.sharded = dict_off != nullptr;
     if ((rc = abw_reserve(ctx, s.scg_lohi, (size_t)std::max<int64_t>(1, (int64_t)D * n_scg) * 8))) return rc;
     if ((rc = abw_reserve(ctx, s.dimbest, (size_t)D * sizeof(DimBestDev) + sizeof(GlobalRes)))) return rc;
     s.loaded = true;
@@ -895,7 +969,7 @@ static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int
     return ABW_OK;
 }
 
-static SepDev sep_params(abw_sep_state& s)
+static SepDev sep_params(abw_sep_state& s, SepHost& H)
 {
     SepDev P;
     P.bins = s.d_bins ? s.d_bins : s.d_keys; P.N = s.N;
@@ -904,6 +978,7 @@ static SepDev sep_params(abw_sep_state& s)
     P.T = s.d_T; P.Toff = s.d_Toff;
     P.h_st = (unsigned long long*)s.hist.p; P.h_bp = P.h_st + s.TB; P.h_tot = (uint32_t*)(P.h_bp + s.TB);
     P.scg_lo = (int32_t*)s.scg_lohi.p; P.scg_hi = P.scg_lo + (int64_t)s.D * s.n_scg;
+    P.range = H.d_range;
     return P;
 }
 
@@ -942,8 +1017,13 @@ static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_
     } else if (all) n = s.N;
     const int32_t* d_node_scaf = all ? nullptr : (const int32_t*)s.node_scaf.p;
 
-    SepDev P = sep_params(s);
-    ABW_HIP(ctx, hipMemsetAsync(s.hist.p, 0, (size_t)s.TB * (4 * 3 + 8) + 8, st));
+    SepDev P = sep_params(s, H);
+    // small nodes scatter their wide-dimension dps (cost ~ node); big ones and sharded tables take the sorted walk
+    const bool scatter = !H.sharded && n * 6 < s.N;
+    hipLaunchKernelGGL(sep_clear_kernel, dim3((unsigned)H.chunks.size()), dim3(256), 0, st, P, H.d_chunks);      // what the node before touched
+    ABW_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(sep_range_reset_kernel, dim3((s.D + 63) / 64), dim3(64), 0, st, P, s.D, H.d_wide, (int32_t)H.wide_dims.size(), scatter ? 0 : 1);
+    ABW_LAUNCH_CHECK(ctx);
     if (s.n_scg > 0) {
         const int64_t cnt = (int64_t)s.D * s.n_scg;
         hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)std::min<int64_t>(1024, (cnt + 255) / 256)), dim3(256), 0, st, P.scg_lo, cnt, INT_MAX);
@@ -960,7 +1040,7 @@ static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_
         }
         if (!H.wide_dims.empty()) {
             const unsigned Dw = (unsigned)H.wide_dims.size();
-            if (n * 6 < s.N) {                                 // small node: scatter (cost ~ node), else the sorted walk (cost ~ table)
+            if (scatter) {
                 hipLaunchKernelGGL(sep_wide_scatter_kernel, dim3((unsigned)((m + 255) / 256), Dw), dim3(256), 0, st, P, H.d_wide, d_node_scaf, m);
                 ABW_LAUNCH_CHECK(ctx);
             } else {
@@ -994,7 +1074,7 @@ static int sep_eval_phase(abw_ctx* ctx, const char* who, int32_t min_ndps, abw_s
     const int32_t* d_node_dpoff = s.node_all ? nullptr : (const int32_t*)s.node_dpoff.p;
     memset(out, 0, sizeof(*out));
     out->dimension = -1; out->key = -1;
-    SepDev P = sep_params(s);
+    SepDev P = sep_params(s, H);
     int rc;
 
     const unsigned nch = (unsigned)H.chunks.size();
