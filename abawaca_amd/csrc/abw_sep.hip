@@ -103,18 +103,32 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t*
     uint32_t* my_size = s_size + (threadIdx.x & (ACC_COPIES - 1)) * NARROW_T;
     uint32_t* my_tp1 = s_tp1 + (threadIdx.x & (ACC_COPIES - 1)) * NARROW_T;
 
+    // The loads of a scaffold are a dependent chain (list -> scaffold table -> column values); the next scaffold's are
+    // issued before this one is processed.
+    struct Item { int s, f, n; long long len; int v[8]; };
+    auto fetch = [&](int ls, Item& it) {
+        it.s = node_scaf ? node_scaf[ls] : ls;
+        it.f = P.scaf_first[it.s];
+        it.n = P.scaf_ndps[it.s];
+        it.len = P.scaf_len[it.s];
+#pragma unroll
+        for (int i = 0; i < 8; i++) it.v[i] = (i < it.n) ? col[it.f + i] : INT_MAX;      // the first 8 values (all, for n <= 8)
+    };
     const int ls_end = min(m, (int)(blockIdx.x + 1) * ACC_SPB);
-    for (int ls = blockIdx.x * ACC_SPB + threadIdx.x; ls < ls_end; ls += 256) {
-        const int s = node_scaf ? node_scaf[ls] : ls;
-        const int f = P.scaf_first[s];
-        const int n = P.scaf_ndps[s];
+    Item cur, nxt;
+    int ls = blockIdx.x * ACC_SPB + threadIdx.x;
+    if (ls < ls_end) fetch(ls, cur);
+    for (; ls < ls_end; ls += 256) {
+        if (ls + 256 < ls_end) fetch(ls + 256, nxt);
+        const int s = cur.s, f = cur.f, n = cur.n;
+        const long long slen = cur.len;
         const int k = n >> 1;                              // 0-based index of the flip value
         int ts;
         uint32_t tp_ts = 0;                                // dps at or below the flip value: tp1 credits bin t_s
         if (n <= 8) {
             int v[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = (i < n) ? col[f + i] : INT_MAX;
+            for (int i = 0; i < 8; i++) v[i] = cur.v[i];
             {
                 // k-th smallest of the n values (the tail is padded with INT_MAX): Batcher's 19-comparator
                 // network on a copy, then the element at k = n/2 (1..4)
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t*
         }
         atomicAdd(&my_tp1[ts], tp_ts);
         atomicAdd(&s_tot[ts], (uint32_t)n);
-        atomicAdd(&s_bp[ts], (unsigned long long)P.scaf_len[s]);
+        atomicAdd(&s_bp[ts], (unsigned long long)slen);
         if (P.n_scg > 0) {
             for (int e = P.scg_off[s]; e < P.scg_off[s + 1]; e++) {
                 const int g = P.scg_ids[e];
@@ -156,6 +170,7 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t*
                 atomicMax(&P.scg_hi[(int64_t)d * P.n_scg + g], ts);
             }
         }
+        cur = nxt;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += 256) {
