@@ -316,6 +316,21 @@ def recursion_c1(ctx):
             subprocess.run([exe, files["names"], files["fasta"], files["info"], files["lrn"], files["scg"], files["scg_list"],
                             str(cores), os.path.join(wd, "ref")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             wall = time.perf_counter() - t0
+            # the same driver and reference objects with integration/ClusterSeparatorHip in place of the reference's separator:
+            # what a user of the reference sees after the one-line change (adapter work on the reference's containers included)
+            hip_exe = os.path.join(ROOT, "oracle", "_ref", "hip_sep_driver")
+            if os.path.exists(hip_exe):
+                t0 = time.perf_counter()
+                subprocess.run([hip_exe, files["names"], files["fasta"], files["info"], files["lrn"], files["scg"], files["scg_list"],
+                                str(cores), os.path.join(wd, "hip")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                hip_wall = time.perf_counter() - t0
+                hrows = np.loadtxt(os.path.join(wd, "hip.nodes.tsv"), ndmin=2)
+                res["dropin"] = dict(separate_s=round(float(hrows[:, 11].sum()) / 1e6, 3), first_node_s=round(float(hrows[0, 11]) / 1e6, 3),
+                                     wall_s=round(hip_wall, 2), identical_output=bool(
+                                         open(os.path.join(wd, "hip.scaf2cluster.tsv")).read() == open(os.path.join(wd, "ref.scaf2cluster.tsv")).read()
+                                         and np.array_equal(hrows[:, :11], np.loadtxt(os.path.join(wd, "ref.nodes.tsv"), ndmin=2)[:, :11])),
+                                     note="reference main loop + reference containers + ClusterSeparatorHip (C++ adapter over the C ABI); "
+                                          "first_node_s includes building the column store from the reference's Dimension objects and abw_sep_load")
             rows = np.loadtxt(os.path.join(wd, "ref.nodes.tsv"), ndmin=2)
             ref_s2c = np.array([int(ln.split("\t")[1]) for ln in open(os.path.join(wd, "ref.scaf2cluster.tsv"))], dtype=np.int32)
         same_tree = len(rows) == len(nodes) and all(
