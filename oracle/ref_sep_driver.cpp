@@ -35,6 +35,9 @@
 #else
 #define SEPARATOR_CLASS ClusterSeparatorBySensitivitySpecificity
 #endif
+#if defined(ABW_USE_HIP_SEPARATOR) || defined(ABW_USE_KMEANS_SEPARATOR)
+#include "ClusterDataView.h"
+#endif
 #include "Semaphore.h"
 #include "SCGdb.h"
 
@@ -79,7 +82,14 @@ int main(int argc, const char** argv)
 		work.erase(it);
 		visited++;
 
+#if defined(ABW_USE_HIP_SEPARATOR) || defined(ABW_USE_KMEANS_SEPARATOR)
+		// the GPU separators keep the table resident: after the first node a node needs only its datapoint set
+		// (integration/ClusterDataView.h; this driver has no ClusterEsomWriter that would read the node's values)
+		ClusterData* node_db = (visited == 1 || getenv("ABW_FULL_NODE_TABLES")) ? new ClusterData(clustering_db, cur->get_dps())
+		                                                                          : new ClusterDataView(clustering_db, cur->get_dps());
+#else
 		ClusterData* node_db = new ClusterData(clustering_db, cur->get_dps());
+#endif
 		SEPARATOR_CLASS sep(scaf_db, scg_db, *node_db, sem);
 
 		auto t0 = std::chrono::steady_clock::now();
