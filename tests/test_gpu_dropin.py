@@ -18,9 +18,9 @@ REF = os.path.join(ROOT, "oracle", "_ref", "ref_sep_driver")
 HIP = os.path.join(ROOT, "oracle", "_ref", "hip_sep_driver")
 
 
-def _run(exe, files, prefix):
+def _run(exe, files, prefix, env=None):
     subprocess.run([exe, files["names"], files["fasta"], files["info"], files["lrn"], files["scg"], files["scg_list"],
-                    "8", prefix], check=True, timeout=300)
+                    "8", prefix], check=True, timeout=300, env=env)
     nodes = [ln.split("\t")[:11] for ln in open(prefix + ".nodes.tsv").read().strip().split("\n")]
     return nodes, open(prefix + ".scaf2cluster.tsv").read(), open(prefix + ".dp2cluster.tsv").read()
 
@@ -32,7 +32,9 @@ def test_reference_main_loop_with_hip_separator(golden_dir, case):
     with tempfile.TemporaryDirectory(prefix="abwdrop_") as wd:
         files = synth.write_build_dir(wd, g["milli"], g["dp2scaf"], g["scaf_len"], g["scg_scaf"], g["scg_id"], int(g["n_scg"]))
         ref = _run(REF, files, os.path.join(wd, "ref"))
-        hip = _run(HIP, files, os.path.join(wd, "hip"))
+        hip = _run(HIP, files, os.path.join(wd, "hip"))                    # nodes after the first are ClusterDataViews (row N2)
+        hip_full = _run(HIP, files, os.path.join(wd, "hipf"), dict(os.environ, ABW_FULL_NODE_TABLES="1"))   # the reference's subset tables
+    assert hip_full == hip
     assert ref[0] == hip[0]          # per node: id ndps split dim value spec sens children sizes (%.17g text)
     assert ref[1] == hip[1] and ref[2] == hip[2]
     # and the reference run on these regenerated files reproduces the committed golden nodes
