@@ -263,6 +263,122 @@ __global__ __launch_bounds__(256) void lrn_emit_kernel(const int32_t* __restrict
     for (uint32_t i = lane; i < total; i += 64) text[o + i] = lb[i];
 }
 
+// ---- cluster writer (ref src/ClusterWriter.cpp:92-98): rows "<dp>\t%lf\t%lf...\n" ---------------------------------
+// "%lf" prints six decimals of the EXACT binary value, rounded to nearest, ties to even (the C library's conversion,
+// which is what the reference's fprintf does).  |v| = m * 2^e exactly with m < 2^53, so v * 10^6 = (m * 10^6) * 2^e with
+// m * 10^6 < 2^73: a 128-bit integer, shifted; the bits shifted out decide the rounding.  Magnitudes whose millionths pass
+// 2^63 (|v| >= 9.2e12) and inf / nan are reported, not printed.
+struct Fix6 { uint64_t q; uint32_t neg, bad; };
+__device__ __forceinline__ Fix6 fix6_of(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    Fix6 r;
+    r.q = 0; r.neg = (uint32_t)(b >> 63); r.bad = 0;
+    const uint32_t ex = (uint32_t)(b >> 52) & 0x7FFu;
+    uint64_t m = b & ((1ull << 52) - 1ull);
+    if (ex == 0x7FFu) { r.bad = 1; return r; }
+    int s = 1074;                                            // |v| = m * 2^-s
+    if (ex != 0) { m |= 1ull << 52; s = 1075 - (int)ex; }
+    if (m == 0) return r;
+    const uint64_t lo = m * 1000000ull, hi = __umul64hi(m, 1000000ull);
+    if (s <= 0) {                                            // an integer: no rounding
+        const int k = -s;
+        if (k >= 63 || hi != 0 || (lo >> (63 - k)) != 0) { r.bad = 1; return r; }
+        r.q = lo << k;
+        return r;
+    }
+    if (s >= 128) return r;                                  // below 2^73 / 2^128: rounds to zero
+    uint64_t q, q_hi, rem_hi, rem_lo, half_hi, half_lo;
+    if (s < 64) {
+        q = (lo >> s) | (hi << (64 - s)); q_hi = hi >> s;
+        rem_hi = 0; rem_lo = lo & ((1ull << s) - 1ull); half_hi = 0; half_lo = 1ull << (s - 1);
+    } else if (s == 64) {
+        q = hi; q_hi = 0; rem_hi = 0; rem_lo = lo; half_hi = 0; half_lo = 1ull << 63;
+    } else {
+        const int t = s - 64;
+        q = hi >> t; q_hi = 0;
+        rem_hi = hi & ((1ull << t) - 1ull); rem_lo = lo; half_hi = 1ull << (t - 1); half_lo = 0;
+    }
+    if (q_hi != 0 || (q >> 63) != 0) { r.bad = 1; return r; }
+    const bool above = rem_hi > half_hi || (rem_hi == half_hi && rem_lo > half_lo);
+    const bool tie = rem_hi == half_hi && rem_lo == half_lo;
+    if (above || (tie && (q & 1ull))) q++;
+    r.q = q;
+    return r;
+}
+__device__ __forceinline__ int dec_digits64(uint64_t v)
+{
+    int n = 1;
+    while (v >= 10ull) { v /= 10ull; n++; }
+    return n;
+}
+__device__ __forceinline__ uint32_t field6_len(const Fix6& f) { return 1u + f.neg + (uint32_t)dec_digits64(f.q / 1000000ull) + 7u; }
+
+constexpr int EMIT6_FIELD_MAX = 23;                           // "\t-" + 13 digits + "." + 6 decimals, rounded up
+
+__global__ __launch_bounds__(256) void lrn_rowlen6_kernel(const double* __restrict__ values, int64_t ld, int32_t n_cols,
+                                                         const int64_t* __restrict__ dps, int64_t n_rows, uint32_t* __restrict__ row_len,
+                                                         unsigned long long* __restrict__ err)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    int64_t dp = dps[row];
+    if (dp < 1 || dp > ld) { if (lane == 0) atomicMin(err, (unsigned long long)(row + 1) << 8 | 1); dp = 1; }
+    uint32_t len = 0;
+    for (int c = lane; c < n_cols; c += 64) {
+        const Fix6 f = fix6_of(values[(int64_t)c * ld + dp - 1]);
+        if (f.bad) atomicMin(err, (unsigned long long)(row + 1) << 8 | 2);
+        len += field6_len(f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
+    if (lane == 0) row_len[row] = len + (uint32_t)key_len((unsigned long long)dp) + 1u;
+}
+
+__global__ __launch_bounds__(256) void lrn_emit6_kernel(const double* __restrict__ values, int64_t ld, int32_t n_cols,
+                                                       const int64_t* __restrict__ dps, int64_t n_rows,
+                                                       const uint64_t* __restrict__ row_off, uint8_t* __restrict__ text)
+{
+    __shared__ uint8_t buf[4][EMIT_ROW_MAX];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+    if (row >= n_rows) return;
+    uint8_t* lb = buf[wid];
+    int64_t dp = dps[row];
+    if (dp < 1 || dp > ld) dp = 1;                           // reported by the length pass; the text is not handed out
+    const int klen = key_len((unsigned long long)dp);
+    if (lane == 0) { unsigned long long k = (unsigned long long)dp; for (int i = klen - 1; i >= 0; i--) { lb[i] = (uint8_t)('0' + k % 10ull); k /= 10ull; } }
+    uint32_t carry = (uint32_t)klen;
+    for (int c0 = 0; c0 < n_cols; c0 += 64) {
+        const int c = c0 + lane;
+        Fix6 f;
+        f.q = 0; f.neg = 0; f.bad = 0;
+        if (c < n_cols) f = fix6_of(values[(int64_t)c * ld + dp - 1]);
+        const uint32_t len = (c < n_cols) ? field6_len(f) : 0u;
+        const uint32_t incl = wave_incl_scan_u32(len, lane);
+        if (c < n_cols) {
+            uint8_t* p = lb + carry + incl - len;
+            uint64_t ip = f.q / 1000000ull;
+            uint32_t fr = (uint32_t)(f.q - ip * 1000000ull);
+            *p++ = '\t';
+            if (f.neg) *p++ = '-';
+            const int nd = dec_digits64(ip);
+            for (int i = nd - 1; i >= 0; i--) { p[i] = (uint8_t)('0' + ip % 10ull); ip /= 10ull; }
+            p += nd;
+            *p++ = '.';
+            for (int i = 5; i >= 0; i--) { p[i] = (uint8_t)('0' + fr % 10u); fr /= 10u; }
+        }
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) lb[carry] = '\n';
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t o = row_off[row];
+    const uint32_t total = carry + 1u;
+    for (uint32_t i = lane; i < total; i += 64) text[o + i] = lb[i];
+}
+
 // header: the first four lines, on the host (ref :36-111)
 struct LrnHeader { int64_t ndps; int32_t ncols; uint64_t names_begin, names_end; };
 
@@ -443,6 +559,84 @@ int abw_lrn_emit(abw_ctx* ctx, const int32_t* milli, int64_t n_rows, int32_t n_c
         ABW_LAUNCH_CHECK(ctx);
     }
     ABW_HIP(ctx, hipMemcpyAsync(text, ctx->scratch[0].p, total, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    return ABW_OK;
+}
+
+int abw_lrn_emit_rows_dev(abw_ctx* ctx, const double* d_values, int64_t ld, int32_t n_cols, const int64_t* d_dps, int64_t n_rows,
+                          uint8_t* d_text, uint64_t text_cap, uint64_t* text_len)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!d_values || !text_len || n_rows < 0 || ld < 1 || n_cols < 1 || (n_rows > 0 && !d_dps))
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_emit_rows: bad argument");
+    if ((uint64_t)n_cols * EMIT6_FIELD_MAX + 24 > (uint64_t)EMIT_ROW_MAX)
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_emit_rows: rows of %d columns do not fit the staging buffer (at most %d)", n_cols, (EMIT_ROW_MAX - 24) / EMIT6_FIELD_MAX);
+    *text_len = 0;
+    if (n_rows == 0) return ABW_OK;
+    abw_device_guard g(ctx->device);
+    hipStream_t st = ctx->stream;
+    int rc;
+    // scratch[4]: row_len u32 + row_off u64 + err
+    const size_t lb = ((size_t)n_rows * 4 + 15) & ~(size_t)7;
+    if ((rc = abw_reserve(ctx, ctx->scratch[4], lb + ((size_t)n_rows + 2) * 8 + 8))) return rc;
+    uint32_t* row_len = (uint32_t*)ctx->scratch[4].p;
+    uint64_t* row_off = (uint64_t*)((uint8_t*)row_len + lb);
+    unsigned long long* d_err = (unsigned long long*)(row_off + n_rows + 2);
+    ABW_HIP(ctx, hipMemsetAsync(d_err, 0xFF, 8, st));
+    const unsigned gr = (unsigned)((n_rows + 3) / 4);
+    {
+        ABW_PROF(ctx, "lrn_emit_rows");
+        hipLaunchKernelGGL(lrn_rowlen6_kernel, dim3(gr), dim3(256), 0, st, d_values, ld, n_cols, d_dps, n_rows, row_len, d_err);
+        ABW_LAUNCH_CHECK(ctx);
+        if ((rc = abw_device_scan_u32(ctx, row_len, (uint64_t)n_rows, row_off))) return rc;
+    }
+    uint64_t total = 0;
+    unsigned long long err = 0;
+    ABW_HIP(ctx, hipMemcpyAsync(&total, row_off + n_rows, 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipMemcpyAsync(&err, d_err, 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    if (err != ~0ull) {
+        if ((err & 0xFF) == 1) return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_emit_rows: row %llu names a datapoint outside [1, %lld]", (unsigned long long)(err >> 8), (long long)ld);
+        return abw_fail(ctx, ABW_ERR_FORMAT, "abw_lrn_emit_rows: row %llu holds a value that is not finite or not below 9.2e12", (unsigned long long)(err >> 8));
+    }
+    *text_len = total;
+    if (!d_text || total > text_cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_lrn_emit_rows: the rows take %llu bytes, capacity %llu", (unsigned long long)total, (unsigned long long)text_cap);
+    {
+        ABW_PROF(ctx, "lrn_emit_rows");
+        hipLaunchKernelGGL(lrn_emit6_kernel, dim3(gr), dim3(256), 0, st, d_values, ld, n_cols, d_dps, n_rows, row_off, d_text);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    return ABW_OK;
+}
+
+int abw_lrn_emit_rows(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_cols, const int64_t* dps, int64_t n_rows,
+                      uint8_t* text, uint64_t text_cap, uint64_t* text_len)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!values || !text_len || n_rows < 0 || ld < 1 || n_cols < 1 || (n_rows > 0 && !dps))
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_emit_rows: bad argument");
+    *text_len = 0;
+    if (n_rows == 0) return ABW_OK;
+    abw_device_guard g(ctx->device);
+    hipStream_t st = ctx->stream;
+    int rc;
+    // scratch[6]: the table | scratch[5]: the datapoint list | scratch[0]: text
+    const size_t vb = (size_t)ld * (size_t)n_cols * 8, db = (size_t)n_rows * 8;
+    if ((rc = abw_reserve(ctx, ctx->scratch[6], vb))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[5], db))) return rc;
+    ABW_HIP(ctx, hipMemcpyAsync(ctx->scratch[6].p, values, vb, hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemcpyAsync(ctx->scratch[5].p, dps, db, hipMemcpyHostToDevice, st));
+    // the length pass sizes the text
+    uint64_t need = 0;
+    rc = abw_lrn_emit_rows_dev(ctx, (const double*)ctx->scratch[6].p, ld, n_cols, (const int64_t*)ctx->scratch[5].p, n_rows, NULL, 0, &need);
+    if (rc != ABW_ERR_CAPACITY) return rc;
+    *text_len = need;
+    if (!text || need > text_cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_lrn_emit_rows: the rows take %llu bytes, capacity %llu", (unsigned long long)need, (unsigned long long)text_cap);
+    if ((rc = abw_reserve(ctx, ctx->scratch[0], need + 64))) return rc;
+    if ((rc = abw_lrn_emit_rows_dev(ctx, (const double*)ctx->scratch[6].p, ld, n_cols, (const int64_t*)ctx->scratch[5].p, n_rows,
+                                    (uint8_t*)ctx->scratch[0].p, need, &need))) return rc;
+    ABW_HIP(ctx, hipMemcpyAsync(text, ctx->scratch[0].p, need, hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));
     return ABW_OK;
 }

@@ -46,3 +46,35 @@ def lrn_emit(ctx: Context, milli_rows: np.ndarray, first_key: int = 1) -> np.nda
             continue
         ctx.check(rc)
         return text[:n.value]
+
+
+def lrn_emit_rows(ctx: Context, values: np.ndarray, dps: np.ndarray) -> np.ndarray:
+    """One cluster's rows the way ClusterEsomWriter prints them (reference src/ClusterWriter.cpp:92-98).
+    values f64 [n_cols, ld] (dimension-major, column dp-1 = datapoint dp), dps int64 (1-based ids in row order)
+    -> the rows as bytes (uint8 array)."""
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    d = np.ascontiguousarray(dps, dtype=np.int64)
+    n_cols, ld = v.shape
+    n = C.c_uint64(0)
+    rc = lib().abw_lrn_emit_rows(ctx.handle, C.c_void_p(v.ctypes.data), ld, n_cols, C.c_void_p(d.ctypes.data), len(d), None, 0, C.byref(n))
+    if len(d) == 0:
+        ctx.check(rc)
+        return np.empty(0, dtype=np.uint8)
+    if rc != -3:                                   # ABW_ERR_CAPACITY carries the size
+        ctx.check(rc)
+    text = np.empty(int(n.value), dtype=np.uint8)
+    ctx.check(lib().abw_lrn_emit_rows(ctx.handle, C.c_void_p(v.ctypes.data), ld, n_cols, C.c_void_p(d.ctypes.data), len(d),
+                                      C.c_void_p(text.ctypes.data), len(text), C.byref(n)))
+    return text[:n.value]
+
+
+def lrn_emit_rows_dev(ctx: Context, t_values, t_dps, t_text=None):
+    """Device-resident form: torch tensors values f64 [n_cols, ld], dps int64 [n_rows], text uint8 (or None: size only).
+    -> number of bytes the rows take."""
+    n_cols, ld = t_values.shape
+    n = C.c_uint64(0)
+    rc = lib().abw_lrn_emit_rows_dev(ctx.handle, C.c_void_p(t_values.data_ptr()), ld, n_cols, C.c_void_p(t_dps.data_ptr()), t_dps.numel(),
+                                     C.c_void_p(t_text.data_ptr()) if t_text is not None else None, t_text.numel() if t_text is not None else 0, C.byref(n))
+    if not (t_text is None and rc == -3):
+        ctx.check(rc)
+    return int(n.value)

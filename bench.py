@@ -276,6 +276,46 @@ def lrn_bench(ctx, with_cpu):
                          ms_kernels=round(e_s * 1e3, 3), ms_with_pcie_both_ways=round(wall_e * 1e3, 2),
                          roofline=dict(kernel="lrn_emit_kernel (+ row lengths)", bound="hbm", achieved=round((8.0 * D * N + len(out_text)) / e_s / 1e9, 1),
                                        peak=HBM_PEAK_GBS, unit="GB/s", frac=round((8.0 * D * N + len(out_text)) / e_s / 1e9 / HBM_PEAK_GBS, 4), traffic=None))
+    # cluster writer (reference src/ClusterWriter.cpp:92-98): the table as resident doubles, 100 clusters of 2 000 datapoints
+    # each written as "<dp>\t%lf..." rows, one call per cluster
+    import torch
+    t_vals = torch.from_numpy(np.ascontiguousarray(rows_m.T.astype(np.float64) / 1000.0)).cuda()     # [D][N]
+    perm = torch.from_numpy(rng.permutation(N).astype(np.int64) + 1).cuda()
+    n_cl = 100
+    per = N // n_cl
+    t_out = torch.empty(per * (D * 14 + 12), dtype=torch.uint8, device="cuda")
+    def clusters():
+        tot = 0
+        for c in range(n_cl):
+            tot += lrn.lrn_emit_rows_dev(ctx, t_vals, perm[c * per:(c + 1) * per], t_out)
+        return tot
+    clusters()
+    ctx.prof_reset(); ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    cbytes = clusters()
+    wall_c = time.perf_counter() - t0
+    nc, msc = ctx.prof_read("lrn_emit_rows")
+    ctx.prof_enable(False)
+    c_s = msc * 1e-3
+    res["cluster_writer"] = dict(value=cbytes / c_s / 1e9, unit="GB/s of text (kernels)", clusters=n_cl, rows_per_cluster=per, text_mb=round(cbytes / 1e6, 1),
+                                 ms_kernels=round(c_s * 1e3, 3), ms_wall_text_left_on_device=round(wall_c * 1e3, 2),
+                                 roofline=dict(kernel="lrn_emit6_kernel (+ row lengths)", bound="hbm", achieved=round((16.0 * D * N + cbytes) / c_s / 1e9, 1),
+                                               peak=HBM_PEAK_GBS, unit="GB/s", frac=round((16.0 * D * N + cbytes) / c_s / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
+                                               note="algorithmic bytes: every value read twice (length pass, print pass) + the text once"))
+    if with_cpu:
+        import _oracle as orc
+        hv = t_vals.cpu().numpy()
+        hd = perm[:per].cpu().numpy()
+        t0 = time.perf_counter()
+        ref_rows = orc.lrn_emit_rows(hv, hd)
+        dt = time.perf_counter() - t0
+        chk = torch.empty(len(ref_rows), dtype=torch.uint8, device="cuda")
+        lrn.lrn_emit_rows_dev(ctx, t_vals, perm[:per], chk)
+        assert np.array_equal(chk.cpu().numpy(), ref_rows)
+        res["cluster_writer"]["cpu_baseline"] = dict(value=len(ref_rows) / dt / 1e9, unit="GB/s of text", cores=1, kind="port",
+                                                     sample=f"oracle abw_or_lrn_emit_rows (the reference's fprintf loop into memory), one cluster of {per} rows, {dt:.2f} s")
+        del chk
+    del t_vals, t_out
     if with_cpu:
         import _oracle as orc
         ns = 20_000

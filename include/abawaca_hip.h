@@ -224,6 +224,19 @@ int abw_lrn_parse(abw_ctx* ctx, const uint8_t* text, uint64_t len, int64_t ndps,
  * the caller's.  *text_len receives the size even when it exceeds text_cap (then ABW_ERR_CAPACITY).  n_cols <= 960. */
 int abw_lrn_emit(abw_ctx* ctx, const int32_t* milli, int64_t n_rows, int32_t n_cols, uint64_t first_key,
                  uint8_t* text, uint64_t text_cap, uint64_t* text_len);
+/* Cluster writer (ref: ClusterEsomWriter::write_clustering_info_file, src/ClusterWriter.cpp:92-98): the data rows of one
+ * cluster's .lrn, "<dp>" then "\t%lf" of the datapoint's value in every dimension, "\n".  "%lf" is reproduced exactly
+ * (six decimals of the binary value, round to nearest, ties to even).  values: [n_cols][ld] doubles, dimension-major, the
+ * value of datapoint dp (1-based internal id) in column c at values[c*ld + dp-1]; dps: the cluster's datapoints in the
+ * order of the rows (the reference walks an unordered_set: the order is the caller's); the four header lines (ref :81-90)
+ * stay with the caller.  *text_len = bytes the rows take, also when they do not fit text_cap (ABW_ERR_CAPACITY, nothing
+ * written; text may then be NULL).  A dp outside [1, ld]: ABW_ERR_ARG; a value that is not finite or not below 9.2e12 in
+ * magnitude: ABW_ERR_FORMAT.  _dev: values, dps and text are device pointers (the table stays resident between clusters);
+ * the other form takes host pointers and copies. */
+int abw_lrn_emit_rows_dev(abw_ctx* ctx, const double* d_values, int64_t ld, int32_t n_cols, const int64_t* d_dps, int64_t n_rows,
+                          uint8_t* d_text, uint64_t text_cap, uint64_t* text_len);
+int abw_lrn_emit_rows(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_cols, const int64_t* dps, int64_t n_rows,
+                      uint8_t* text, uint64_t text_cap, uint64_t* text_len);
 
 /* ---- extension: k-means restarts (NO counterpart in the reference, see DESIGN.md "K-means";
  *      RNG = TinyMT32, ref: src/misc.cpp:24-36, src/TinyMT-src-1.0.1/tinymt/tinymt32.{c,h}) -------- */

@@ -639,3 +639,24 @@ int64_t abw_or_lrn_parse(const uint8_t* text, uint64_t len, int64_t row_cap, int
     *ndps_declared = (int32_t)ndps; *ndims = (int32_t)ncols - 1;
     return entry;
 }
+
+/* reference src/ClusterWriter.cpp:92-98 (the C library's own "%lf": correctly rounded, ties to even) */
+uint64_t abw_or_lrn_emit_rows(const double* values, int64_t ld, int32_t n_cols, const int64_t* dps, int64_t n_rows,
+                              uint8_t* text, uint64_t cap)
+{
+    uint64_t n = 0;
+    char f[400];
+    for (int64_t r = 0; r < n_rows; r++) {
+        int l = snprintf(f, sizeof f, "%lu", (unsigned long)dps[r]);
+        if (n + (uint64_t)l <= cap) memcpy(text + n, f, (size_t)l);
+        n += (uint64_t)l;
+        for (int32_t c = 0; c < n_cols; c++) {
+            l = snprintf(f, sizeof f, "\t%lf", values[(int64_t)c * ld + dps[r] - 1]);
+            if (n + (uint64_t)l <= cap) memcpy(text + n, f, (size_t)l);
+            n += (uint64_t)l;
+        }
+        if (n + 1 <= cap) text[n] = '\n';
+        n += 1;
+    }
+    return n;
+}

@@ -153,3 +153,13 @@ int abw_or_kmeans_sharded(const float* x, int64_t N, int32_t d, int32_t R, uint3
  * ------------------------------------------------------------------------------------------ */
 int64_t abw_or_lrn_parse(const uint8_t* text, uint64_t len, int64_t row_cap, int32_t* ndps_declared, int32_t* ndims,
                          int32_t* dp_names, double* values);
+
+/* ------------------------------------------------------------------------------------------
+ * One cluster's ESOM table, the rows of ClusterEsomWriter::write_clustering_info_file, reference
+ * src/ClusterWriter.cpp:92-98: per datapoint "%lu" of its id, then "\t%lf" of its value in every dimension, "\n".
+ * The reference walks an unordered_set, so the row order is the caller's (dps, 1-based ids).
+ * values: [n_cols][ld] doubles, the value of datapoint dp in column c at values[c*ld + dp-1].
+ * Returns the number of bytes the rows take; writes them when they fit cap.
+ * ------------------------------------------------------------------------------------------ */
+uint64_t abw_or_lrn_emit_rows(const double* values, int64_t ld, int32_t n_cols, const int64_t* dps, int64_t n_rows,
+                              uint8_t* text, uint64_t cap);

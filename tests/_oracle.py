@@ -226,3 +226,17 @@ def lrn_parse(text: np.ndarray, row_cap: int, ndims_cap: int = 4096):
     if n < 0:
         return int(n), 0, 0, None, None
     return int(n), a.value, b.value, names[:n], vals[:b.value, :n].copy()
+
+
+def lrn_emit_rows(values: np.ndarray, dps: np.ndarray) -> np.ndarray:
+    """values f64 [n_cols, ld], dps int64 (1-based ids, row order) -> the rows of the cluster's .lrn as bytes"""
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    dps = np.ascontiguousarray(dps, dtype=np.int64)
+    L = lib()
+    L.abw_or_lrn_emit_rows.restype = C.c_uint64
+    L.abw_or_lrn_emit_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64]
+    n_cols, ld = values.shape
+    need = L.abw_or_lrn_emit_rows(C.c_void_p(values.ctypes.data), ld, n_cols, C.c_void_p(dps.ctypes.data), len(dps), None, 0)
+    text = np.empty(max(int(need), 1), dtype=np.uint8)
+    L.abw_or_lrn_emit_rows(C.c_void_p(values.ctypes.data), ld, n_cols, C.c_void_p(dps.ctypes.data), len(dps), C.c_void_p(text.ctypes.data), need)
+    return text[:need]

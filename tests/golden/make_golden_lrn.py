@@ -88,3 +88,58 @@ def writer_case():
 
 
 writer_case()
+
+
+# ---- cluster writer: one cluster's .lrn as the REFERENCE's ClusterEsomWriter prints it ("%lu" + "\t%lf" per value,
+#      ref src/ClusterWriter.cpp:92-98), for a table whose values need every kind of rounding to six decimals ----
+def cluster_case():
+    rng = np.random.default_rng(23)
+    S, D = 20, 11
+    ndps_of = rng.integers(2, 6, size=S)
+    dp2scaf = np.repeat(np.arange(S), ndps_of)
+    N = len(dp2scaf)
+    special = ["0.0078125", "0.0234375", "-0.0078125", "999999.9999995", "0.9999995", "0.99999949", "1e-7", "-1e-9", "4.9e-324",
+               "123456789.123456", "8999999999999.5", "0.0000005", "0.00000051", "-0", "0", "2.5", "1234.5678915", "0.1", "0.3",
+               "7.0000004999", "99.9999995000001", "5e-7", "1.5e-6", "2.5e-6", "0.000244140625", "33554432.0000305"]
+    cols = []
+    for j in range(D):
+        kind = j % 4
+        if kind == 0:
+            v = [f"{x:.3f}" for x in rng.random(N)]                              # what abawaca-build writes
+        elif kind == 1:
+            v = [repr(float(x)) for x in rng.random(N) * 10.0 ** rng.integers(-8, 9, size=N)]   # 17 significant digits
+        elif kind == 2:
+            v = [repr(float(x)) for x in -rng.random(N) * 1000]
+        else:
+            v = [special[(j * N + i) % len(special)] for i in range(N)]
+        cols.append(v)
+    k = 0
+    for i in range(N):                                                            # every special value appears somewhere
+        cols[3][i] = special[k % len(special)]; k += 1
+    for i in range(N):                                                            # the cluster takes every second row
+        cols[7][i] = special[(i // 2) % len(special)]
+    with tempfile.TemporaryDirectory(prefix="abwlrnc_") as wd:
+        files = synth.write_build_dir(wd, np.zeros((D, N), dtype=np.int64), dp2scaf, np.full(S, 9000))
+        lines = [f"% {N}", f"% {D + 1}", "% 9" + "\t1" * D, "% Key" + "".join(f"\tdim{j}" for j in range(D))]
+        for i in range(N):
+            lines.append(str(i + 1) + "".join("\t" + cols[j][i] for j in range(D)))
+        path = os.path.join(wd, "wild.lrn")
+        open(path, "w").write("\n".join(lines) + "\n")
+        cdir = os.path.join(wd, "clusters")
+        os.makedirs(cdir)
+        out = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "lrn_dump"), files["names"], files["fasta"], files["info"], path, str(N), cdir, "2"],
+                             check=True, capture_output=True, text=True).stdout.strip().split("\n")
+        text = open(os.path.join(cdir, "c1.lrn"), "rb").read()
+    rows = [ln.split("\t") for ln in out[1:]]
+    iids = np.array([int(r[1]) for r in rows])
+    values = np.zeros((D, N))                                                     # [dimension][internal dp id - 1], as the reference holds them
+    for r in rows:
+        values[:, int(r[1]) - 1] = [float(x) for x in r[2:]]
+    body = text.split(b"\n", 4)[4]
+    dps = np.array([int(ln.split(b"\t")[0]) for ln in body.split(b"\n") if ln], dtype=np.int64)   # the row order the reference chose
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "lrn_c.npz"), values=values, dps=dps,
+                        text=np.frombuffer(text, dtype=np.uint8), n_header_bytes=len(text) - len(body))
+    print("cluster case:", len(dps), "of", N, "rows x", D, "columns,", len(body), "bytes of rows; loaded ids", len(iids))
+
+
+cluster_case()

@@ -59,6 +59,12 @@ def test_random_reads_bit_exact_vs_oracle(ctx, seed, n_scaf, n_reads):
     ref = orc.coverage(seg_scaf, seg_start, seg_end, n_scaf, rs, rp, rl)
     assert np.array_equal(cov.view(np.uint64), ref.view(np.uint64))
     assert ref.max() > 0
+    # a coordinate-sorted file: another order of the additions inside every segment, so another oracle run
+    order = np.lexsort((rp, rs))
+    rs2, rp2, rl2 = rs[order], rp[order], np.full(n_reads, 150, dtype=np.uint32)
+    cov2 = coverage.accumulate(ctx, seg_scaf, seg_start, seg_end, n_scaf, rs2, rp2, rl2)
+    ref2 = orc.coverage(seg_scaf, seg_start, seg_end, n_scaf, rs2, rp2, rl2)
+    assert np.array_equal(cov2.view(np.uint64), ref2.view(np.uint64))
 
 
 def test_empty_inputs(ctx):

@@ -94,3 +94,61 @@ def test_writer_round_trip_and_format(ctx, N, D, first):
         head = (f"% {N}\n% {D + 1}\n% 9" + "\t1" * D + "\n% Key" + "".join(f"\tc{j}" for j in range(D)) + "\n").encode()
         names, keys, _ = lrn.lrn_parse(ctx, np.frombuffer(head + text, np.uint8))
         assert np.array_equal(names, first + np.arange(N)) and np.array_equal(keys.T, m)
+
+
+# ---- cluster writer: ClusterEsomWriter::write_clustering_info_file (reference src/ClusterWriter.cpp:92-98) --------
+def test_cluster_writer_reproduces_the_reference_file(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "lrn_c.npz"))
+    want = bytes(g["text"])[int(g["n_header_bytes"]):]
+    assert bytes(lrn.lrn_emit_rows(ctx, g["values"], g["dps"])) == want
+
+
+def _wild_table(rng, D, N):
+    v = rng.random((D, N))
+    v[1::4] *= 10.0 ** rng.integers(-9, 12, size=v[1::4].shape)
+    v[2::4] = -v[2::4] * 1000
+    v[3::4] = rng.integers(0, 4_000_001, size=v[3::4].shape) / 2.0 ** rng.integers(0, 30, size=v[3::4].shape)   # dyadic: exact ties
+    v[0, :8] = [0.0, -0.0, 5e-324, -1e-9, 0.9999995, 999999.9999995, 9.2e12, 0.0078125][:min(8, N)] if N >= 8 else v[0, :8]
+    return v
+
+
+@pytest.mark.parametrize("N,D,n_rows", [(4000, 189, 2500), (50, 700, 50), (1, 1, 1), (300, 64, 900)])
+def test_cluster_writer_matches_oracle(ctx, N, D, n_rows):
+    rng = np.random.default_rng(N + D)
+    v = _wild_table(rng, D, N)
+    dps = rng.integers(1, N + 1, size=n_rows).astype(np.int64)               # any order, repeats allowed
+    got = lrn.lrn_emit_rows(ctx, v, dps)
+    want = orc.lrn_emit_rows(v, dps)
+    assert np.array_equal(got, want)
+
+
+def test_cluster_writer_resident_table(ctx):
+    """abw_lrn_emit_rows_dev: the table stays on the device, two clusters one after the other (the second smaller)."""
+    import torch
+    rng = np.random.default_rng(3)
+    v = _wild_table(rng, 37, 1000)
+    t_v = torch.from_numpy(v).cuda()
+    for n_rows in (800, 13):
+        dps = rng.permutation(1000)[:n_rows].astype(np.int64) + 1
+        t_d = torch.from_numpy(dps).cuda()
+        need = lrn.lrn_emit_rows_dev(ctx, t_v, t_d, None)
+        t_text = torch.zeros(need, dtype=torch.uint8, device="cuda")
+        assert lrn.lrn_emit_rows_dev(ctx, t_v, t_d, t_text) == need
+        assert np.array_equal(t_text.cpu().numpy(), orc.lrn_emit_rows(v, dps))
+
+
+def test_cluster_writer_errors(ctx):
+    v = np.arange(12, dtype=np.float64).reshape(3, 4)
+    assert len(lrn.lrn_emit_rows(ctx, v, np.zeros(0, dtype=np.int64))) == 0
+    for dps, bad_v, code, what in [([1, 5], None, _lib.ABW_ERR_ARG, "outside"), ([0], None, _lib.ABW_ERR_ARG, "outside"),
+                                   ([2], np.inf, _lib.ABW_ERR_FORMAT, "finite"), ([2], np.nan, _lib.ABW_ERR_FORMAT, "finite"),
+                                   ([2], 9.3e12, _lib.ABW_ERR_FORMAT, "9.2e12")]:
+        w = v.copy()
+        if bad_v is not None:
+            w[1, 1] = bad_v
+        with pytest.raises(_lib.AbwError) as e:
+            lrn.lrn_emit_rows(ctx, w, np.array(dps, dtype=np.int64))
+        assert e.value.code == code and what in str(e.value)
+    with pytest.raises(_lib.AbwError) as e:                                    # more columns than the staging buffer takes
+        lrn.lrn_emit_rows(ctx, np.zeros((800, 2)), np.array([1], dtype=np.int64))
+    assert e.value.code == _lib.ABW_ERR_ARG

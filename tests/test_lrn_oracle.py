@@ -23,3 +23,13 @@ def test_oracle_lrn_rejects_wrong_field_count():
     text = b"% 1\n% 3\n% 9\t1\t1\n% Key\ta\tb\n1\t0.5\n"
     assert orc.lrn_parse(np.frombuffer(text, np.uint8), 4)[0] == -2
     assert orc.lrn_parse(np.frombuffer(b"% 1\n% 3\n% 9\t1\n% Key\ta\tb\n", np.uint8), 4)[0] == -1
+
+
+def test_oracle_cluster_rows_match_reference_writer(golden_dir):
+    """abw_or_lrn_emit_rows == the rows the reference's ClusterEsomWriter wrote (tests/golden/lrn_c.npz: ties at the
+    seventh decimal, carries into a new digit, -0, subnormals, 17-digit values)."""
+    g = np.load(os.path.join(golden_dir, "lrn_c.npz"))
+    want = g["text"][int(g["n_header_bytes"]):]
+    got = orc.lrn_emit_rows(g["values"], g["dps"])
+    assert np.array_equal(got, want)
+    assert b"\t0.007812\t" in bytes(want) or b"\t0.007812\n" in bytes(want)    # 0.0078125: the tie goes to the even digit
