@@ -203,6 +203,7 @@ def cov_case(tag, seed, n_scaf, n_samples=3, read_len=150):
                         "-c", os.path.join(wd, "s0.sam")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         dp, header, milli = synth.read_lrn(os.path.join(out, "abawaca.lrn"))
         rows = synth.read_names(os.path.join(out, "abawaca.names"))
+        files = {k: np.frombuffer(open(os.path.join(out, "abawaca." + k), "rb").read(), dtype=np.uint8) for k in ("lrn", "names", "info")}
         name2idx = {n: i for i, n in enumerate(asm.names)}
         rs, rp, rl, rf, roff = [], [], [], [], [0]
         for smp in range(n_samples):
@@ -228,6 +229,16 @@ def cov_case(tag, seed, n_scaf, n_samples=3, read_len=150):
                         read_len=np.array(rl, dtype=np.uint32), read_flag=np.array(rf, dtype=np.uint32),
                         read_off=np.array(roff, dtype=np.int64), header=np.array(header[179:179 + n_samples]))
     print(f"cov_{tag}: {len(asm.names)} scaffolds, {len(rows)} segments, {len(rs)} SAM lines")
+    # the whole stage: the same inputs with the assembly itself and the three files the reference wrote, byte for byte
+    blob = np.concatenate(asm.seqs)
+    off = np.zeros(len(asm.seqs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(s) for s in asm.seqs])
+    np.savez_compressed(os.path.join(OUT, f"build_{tag}.npz"), ascii=blob, scaf_off=off, scaf_names=np.array(asm.names),
+                        read_scaf=np.array(rs, dtype=np.uint32), read_pos1=np.array(rp, dtype=np.int64),
+                        read_len=np.array(rl, dtype=np.uint32), read_flag=np.array(rf, dtype=np.uint32),
+                        read_off=np.array(roff, dtype=np.int64), sample_names=np.array(header[179:179 + n_samples]),
+                        lrn=files["lrn"], names=files["names"], info=files["info"])
+    print(f"build_{tag}: lrn {len(files['lrn'])} B, names {len(files['names'])} B, info {len(files['info'])} B")
 
 
 if __name__ == "__main__":
