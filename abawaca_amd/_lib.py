@@ -99,7 +99,7 @@ def lib():
     L.abw_lrn_parse.argtypes = [vp, vp, u64, i64, i32, vp, vp]
     L.abw_lrn_emit.argtypes = [vp, vp, i64, i32, u64, vp, u64, C.POINTER(u64)]
     L.abw_lrn_emit_rows.argtypes = [vp, vp, i64, i32, vp, i64, vp, u64, C.POINTER(u64)]
-    L.abw_lrn_emit_rows_dev.argtypes = [vp, vp, i64, i32, vp, i64, vp, u64, C.POINTER(u64)]
+    L.abw_lrn_emit_rows_dev.argtypes = [vp, vp, i64, i32, vp, i64, vp, u64, C.POINTER(u64), vp]
     L.abw_km_load.argtypes = [vp, vp, i32, i64, vp, i32]
     L.abw_km_node.argtypes = [vp, vp, i32, i32, u32, i32, i32, C.POINTER(KmSplit), vp, vp]
     L.abw_km_auto_chunk.argtypes = [vp, i64, i32]

@@ -564,7 +564,7 @@ int abw_lrn_emit(abw_ctx* ctx, const int32_t* milli, int64_t n_rows, int32_t n_c
 }
 
 int abw_lrn_emit_rows_dev(abw_ctx* ctx, const double* d_values, int64_t ld, int32_t n_cols, const int64_t* d_dps, int64_t n_rows,
-                          uint8_t* d_text, uint64_t text_cap, uint64_t* text_len)
+                          uint8_t* d_text, uint64_t text_cap, uint64_t* text_len, uint64_t* d_row_off)
 {
     if (!ctx) return ABW_ERR_ARG;
     if (!d_values || !text_len || n_rows < 0 || ld < 1 || n_cols < 1 || (n_rows > 0 && !d_dps))
@@ -600,7 +600,11 @@ int abw_lrn_emit_rows_dev(abw_ctx* ctx, const double* d_values, int64_t ld, int3
         return abw_fail(ctx, ABW_ERR_FORMAT, "abw_lrn_emit_rows: row %llu holds a value that is not finite or not below 9.2e12", (unsigned long long)(err >> 8));
     }
     *text_len = total;
-    if (!d_text || total > text_cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_lrn_emit_rows: the rows take %llu bytes, capacity %llu", (unsigned long long)total, (unsigned long long)text_cap);
+    if (d_row_off) ABW_HIP(ctx, hipMemcpyAsync(d_row_off, row_off, ((size_t)n_rows + 1) * 8, hipMemcpyDeviceToDevice, st));
+    if (!d_text || total > text_cap) {
+        ABW_HIP(ctx, hipStreamSynchronize(st));
+        return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_lrn_emit_rows: the rows take %llu bytes, capacity %llu", (unsigned long long)total, (unsigned long long)text_cap);
+    }
     {
         ABW_PROF(ctx, "lrn_emit_rows");
         hipLaunchKernelGGL(lrn_emit6_kernel, dim3(gr), dim3(256), 0, st, d_values, ld, n_cols, d_dps, n_rows, row_off, d_text);
@@ -629,13 +633,13 @@ int abw_lrn_emit_rows(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_
     ABW_HIP(ctx, hipMemcpyAsync(ctx->scratch[5].p, dps, db, hipMemcpyHostToDevice, st));
     // the length pass sizes the text
     uint64_t need = 0;
-    rc = abw_lrn_emit_rows_dev(ctx, (const double*)ctx->scratch[6].p, ld, n_cols, (const int64_t*)ctx->scratch[5].p, n_rows, NULL, 0, &need);
+    rc = abw_lrn_emit_rows_dev(ctx, (const double*)ctx->scratch[6].p, ld, n_cols, (const int64_t*)ctx->scratch[5].p, n_rows, NULL, 0, &need, NULL);
     if (rc != ABW_ERR_CAPACITY) return rc;
     *text_len = need;
     if (!text || need > text_cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_lrn_emit_rows: the rows take %llu bytes, capacity %llu", (unsigned long long)need, (unsigned long long)text_cap);
     if ((rc = abw_reserve(ctx, ctx->scratch[0], need + 64))) return rc;
     if ((rc = abw_lrn_emit_rows_dev(ctx, (const double*)ctx->scratch[6].p, ld, n_cols, (const int64_t*)ctx->scratch[5].p, n_rows,
-                                    (uint8_t*)ctx->scratch[0].p, need, &need))) return rc;
+                                    (uint8_t*)ctx->scratch[0].p, need, &need, NULL))) return rc;
     ABW_HIP(ctx, hipMemcpyAsync(text, ctx->scratch[0].p, need, hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));
     return ABW_OK;

@@ -210,21 +210,27 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
                 const int tl = min(max(rel_b - 16 * lane, 0), 19);
                 const int th = min(max(rel_e - 16 * lane, 0), 19);
                 V &= ((1u << (19 - tl)) - 1u) & ~((1u << (19 - th)) - 1u);
-                const uint32_t Vn = ~V;
+                // full 4-mer windows: base (bit sh) and the three before it (bits sh+1..sh+3) all valid
+                const uint32_t M1 = V & (V >> 1), M2 = M1 & (V >> 2), M3 = M2 & (V >> 3);
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const int sh = 15 - i;                                       // bit of base i in V
-                    const uint32_t cur = __builtin_amdgcn_ubfe(V, sh, 1);        // 1 iff this base is valid
-                    const uint32_t sel = __builtin_amdgcn_ubfe(Vn, sh + 1, 3);   // which of the 3 bases before it are NOT
-                    // run length r = 1 + (valid bases directly before, up to 3); byte table -> 255 - (4^r - 1)
-                    const uint32_t mi = __builtin_amdgcn_perm(0xFCF0FCC0u, 0xFCF0FC00u, sel);
                     const uint32_t w = (sh <= 12) ? __builtin_amdgcn_ubfe(S_lo, 2 * sh, 8)
                                                   : (__builtin_amdgcn_alignbit(S_hi, S_lo, 2 * sh) & 0xFFu);
-                    // word (w & m) + 2*(255 - m) = (w | mi) + mi with mi = 255 - m; the byte offset in one
-                    // v_add_lshl (left to itself the compiler distributes the shift: one more op per base)
-                    uint32_t boff;
-                    asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(boff) : "v"(w | mi), "v"(mi));
-                    atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tab) + boff), cur);   // adds 0 for an invalid base
+                    atomicAdd(tab + LDS_T4 + w, __builtin_amdgcn_ubfe(M3, sh, 1));   // adds 0 unless the window is a whole 4-mer
+                }
+                // heads: valid bases whose run is shorter than 4 (the first three of a run: after the segment's start, an N
+                // or any other letter) -- rare, one at a time.  Run length r = 1 + (M1 bit) + (M2 bit); word
+                // (w & m) + 2*(255 - m) with m = 4^r - 1.
+                uint32_t H = V & ~M3 & 0xFFFFu;
+                while (H) {
+                    const int sh = 31 - __builtin_clz(H);
+                    H &= ~(1u << sh);
+                    const uint32_t r2 = (M2 >> sh) & 1u, r1 = (M1 >> sh) & 1u;
+                    const uint32_t m = r2 ? 63u : r1 ? 15u : 3u;
+                    const uint64_t S64 = ((uint64_t)S_hi << 32) | S_lo;
+                    const uint32_t w = (uint32_t)(S64 >> (2 * sh)) & m;
+                    atomicAdd(tab + w + 2u * (255u - m), 1u);
                 }
             }
         }

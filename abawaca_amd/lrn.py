@@ -68,13 +68,14 @@ def lrn_emit_rows(ctx: Context, values: np.ndarray, dps: np.ndarray) -> np.ndarr
     return text[:n.value]
 
 
-def lrn_emit_rows_dev(ctx: Context, t_values, t_dps, t_text=None):
-    """Device-resident form: torch tensors values f64 [n_cols, ld], dps int64 [n_rows], text uint8 (or None: size only).
-    -> number of bytes the rows take."""
+def lrn_emit_rows_dev(ctx: Context, t_values, t_dps, t_text=None, t_row_off=None):
+    """Device-resident form: torch tensors values f64 [n_cols, ld], dps int64 [n_rows], text uint8 (or None: size only),
+    row_off int64/uint64 [n_rows + 1] (or None).  -> number of bytes the rows take."""
     n_cols, ld = t_values.shape
     n = C.c_uint64(0)
     rc = lib().abw_lrn_emit_rows_dev(ctx.handle, C.c_void_p(t_values.data_ptr()), ld, n_cols, C.c_void_p(t_dps.data_ptr()), t_dps.numel(),
-                                     C.c_void_p(t_text.data_ptr()) if t_text is not None else None, t_text.numel() if t_text is not None else 0, C.byref(n))
+                                     C.c_void_p(t_text.data_ptr()) if t_text is not None else None, t_text.numel() if t_text is not None else 0, C.byref(n),
+                                     C.c_void_p(t_row_off.data_ptr()) if t_row_off is not None else None)
     if not (t_text is None and rc == -3):
         ctx.check(rc)
     return int(n.value)

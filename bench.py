@@ -302,6 +302,19 @@ def lrn_bench(ctx, with_cpu):
                                  roofline=dict(kernel="lrn_emit6_kernel (+ row lengths)", bound="hbm", achieved=round((16.0 * D * N + cbytes) / c_s / 1e9, 1),
                                                peak=HBM_PEAK_GBS, unit="GB/s", frac=round((16.0 * D * N + cbytes) / c_s / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
                                                note="algorithmic bytes: every value read twice (length pass, print pass) + the text once"))
+    # the same clusters in ONE call (concatenated lists, row offsets back): no longer bound by five launches per cluster
+    t_all = torch.empty(cbytes, dtype=torch.uint8, device="cuda")
+    t_off = torch.empty(n_cl * per + 1, dtype=torch.int64, device="cuda")
+    lrn.lrn_emit_rows_dev(ctx, t_vals, perm[:n_cl * per], t_all, t_off)
+    ctx.prof_reset(); ctx.prof_enable(True)
+    for _ in range(reps):
+        lrn.lrn_emit_rows_dev(ctx, t_vals, perm[:n_cl * per], t_all, t_off)
+    no, mso = ctx.prof_read("lrn_emit_rows")
+    ctx.prof_enable(False)
+    o_s = mso / reps * 1e-3
+    res["cluster_writer"]["one_call"] = dict(value=cbytes / o_s / 1e9, unit="GB/s of text (kernels)", ms_kernels=round(o_s * 1e3, 3),
+                                             roofline_frac=round((16.0 * D * N + cbytes) / o_s / 1e9 / HBM_PEAK_GBS, 4))
+    del t_all, t_off
     if with_cpu:
         import _oracle as orc
         hv = t_vals.cpu().numpy()

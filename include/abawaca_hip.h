@@ -232,9 +232,11 @@ int abw_lrn_emit(abw_ctx* ctx, const int32_t* milli, int64_t n_rows, int32_t n_c
  * stay with the caller.  *text_len = bytes the rows take, also when they do not fit text_cap (ABW_ERR_CAPACITY, nothing
  * written; text may then be NULL).  A dp outside [1, ld]: ABW_ERR_ARG; a value that is not finite or not below 9.2e12 in
  * magnitude: ABW_ERR_FORMAT.  _dev: values, dps and text are device pointers (the table stays resident between clusters);
- * the other form takes host pointers and copies. */
+ * d_row_off (device, n_rows + 1 entries, or NULL) receives the byte offset of every row, so that one call can print the
+ * concatenated datapoint lists of many clusters and the caller cuts the text at the clusters' first rows.
+ * The other form takes host pointers and copies. */
 int abw_lrn_emit_rows_dev(abw_ctx* ctx, const double* d_values, int64_t ld, int32_t n_cols, const int64_t* d_dps, int64_t n_rows,
-                          uint8_t* d_text, uint64_t text_cap, uint64_t* text_len);
+                          uint8_t* d_text, uint64_t text_cap, uint64_t* text_len, uint64_t* d_row_off);
 int abw_lrn_emit_rows(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_cols, const int64_t* dps, int64_t n_rows,
                       uint8_t* text, uint64_t text_cap, uint64_t* text_len);
 

@@ -135,6 +135,18 @@ def test_cluster_writer_resident_table(ctx):
         t_text = torch.zeros(need, dtype=torch.uint8, device="cuda")
         assert lrn.lrn_emit_rows_dev(ctx, t_v, t_d, t_text) == need
         assert np.array_equal(t_text.cpu().numpy(), orc.lrn_emit_rows(v, dps))
+    # three clusters in one call: the row offsets cut the text where each cluster starts
+    lists = [rng.permutation(1000)[:n].astype(np.int64) + 1 for n in (300, 1, 450)]
+    t_d = torch.from_numpy(np.concatenate(lists)).cuda()
+    t_off = torch.zeros(len(t_d) + 1, dtype=torch.int64, device="cuda")
+    need = lrn.lrn_emit_rows_dev(ctx, t_v, t_d, None)
+    t_text = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    lrn.lrn_emit_rows_dev(ctx, t_v, t_d, t_text, t_off)
+    off, text, first = t_off.cpu().numpy(), t_text.cpu().numpy(), 0
+    assert off[0] == 0 and off[-1] == need
+    for dl in lists:
+        assert np.array_equal(text[off[first]:off[first + len(dl)]], orc.lrn_emit_rows(v, dl))
+        first += len(dl)
 
 
 def test_cluster_writer_errors(ctx):
