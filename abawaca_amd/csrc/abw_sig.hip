@@ -9,11 +9,13 @@
 //   truncation     src/abawaca-build.cpp:603      (int(1000.0*x))
 //
 // Kernel design (gfx950): one wave64 per segment.  Each lane takes aligned 16-byte pieces of the
-// segment (one coalesced 1 KiB read per wave-instruction) plus a 3-base halo, keeps a rolling
-// 8-bit 4-mer code `w` and a run mask `m` (how many of the last 4 bases are valid and in the
-// segment), and issues exactly ONE LDS atomic per valid base into a wave-private 340-counter table:
+// segment (one coalesced 1 KiB read per wave-instruction) plus a 3-base halo, packs them into a
+// 2-bit code stream and a validity bit stream (valid = ACGT and inside the segment), and counts every
+// valid base ONCE in a wave-private 340-counter LDS table, by the length of the valid run it ends:
 //   run >= 4 -> 4-mer table[w]           run == 3 -> head 3-mer table[w & 63]
 //   run == 2 -> head 2-mer table[w & 15] run == 1 -> head 1-mer table[w & 3]
+// The 4-mer table takes one LDS atomic per base (3 vector instructions: window, address, 0/1 addend);
+// heads exist only at the start of a run (segment start, after an N) and go through a rare extra pass.
 // The k = 3, 2, 1 counts the reference obtains by three more passes then follow exactly from suffix
 // marginals: cnt3[s] = head3[s] + sum_x cnt4[x s], and so on down (a k-mer window that is not the
 // suffix of a valid (k+1)-mer window is precisely a "head" at the start of a valid run).
@@ -92,15 +94,15 @@ const SigTables& host_tables()
 // ---------------------------------------------------------------------------------------------
 // Four bases at once (one dword of ASCII, lowest address = oldest base = byte 0).
 //   codes: byte i = 2-bit code of base i (A0 C1 T2 G3 = (toupper(c) >> 1) & 3)
-//   match: byte i = 0x80 iff toupper(c) is one of ACGT (a valid base), else 0
+//   miss:  byte i = 0x80 iff toupper(c) is NOT one of ACGT (not a valid base), else 0
 // Both are turned into bit streams by v_dot4_u32_u8 with power-of-two weights (a 4-way gather).
-__device__ __forceinline__ void classify4(uint32_t q, uint32_t& codes, uint32_t& match)
+__device__ __forceinline__ void classify4(uint32_t q, uint32_t& codes, uint32_t& miss)
 {
     const uint32_t u = q & 0xDFDFDFDFu;                      // toupper for letters; only 'a'..'z' can map onto 'A'..'Z'
     codes = (u >> 1) & 0x03030303u;
     const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, codes);   // byte i = "ACTG"[code i]
     const uint32_t diff = u ^ expect;
-    match = ~(((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff | 0x7F7F7F7Fu);   // exact zero-byte detector
+    miss = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;     // exact nonzero-byte detector
 }
 // oldest base (byte 0) -> highest position
 constexpr uint32_t DOT_PACK = 0x01041040u;      // codes  -> c0<<6 | c1<<4 | c2<<2 | c3
@@ -204,12 +206,12 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
                 const uint32_t v_lo = __builtin_amdgcn_udot4(z3, DOT_BITS_LO, __builtin_amdgcn_udot4(z2, DOT_BITS_HI, 0u, false), false);
                 const uint32_t v_mi = __builtin_amdgcn_udot4(z1, DOT_BITS_LO, __builtin_amdgcn_udot4(z0, DOT_BITS_HI, 0u, false), false);
                 const uint32_t v_hi = __builtin_amdgcn_udot4(zh, DOT_BITS_LO & 0xFFFFFF00u, 0u, false);
-                uint32_t V = ((v_hi << 16) + (v_mi << 8) + v_lo) >> 7;
+                const uint32_t Vmiss = ((v_hi << 16) + (v_mi << 8) + v_lo) >> 7;   // bit 18 - t: base t is not a valid base
                 // only bases inside [seg_b, seg_e) count, as window members too (ref :105-173 works on
                 // the segment's own substring): t in [tl, th)
                 const int tl = min(max(rel_b - 16 * lane, 0), 19);
                 const int th = min(max(rel_e - 16 * lane, 0), 19);
-                V &= ((1u << (19 - tl)) - 1u) & ~((1u << (19 - th)) - 1u);
+                const uint32_t V = ~Vmiss & ((1u << (19 - tl)) - 1u) & ~((1u << (19 - th)) - 1u);
                 // full 4-mer windows: base (bit sh) and the three before it (bits sh+1..sh+3) all valid
                 const uint32_t M1 = V & (V >> 1), M2 = M1 & (V >> 2), M3 = M2 & (V >> 3);
 #pragma unroll
@@ -220,17 +222,17 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
                     atomicAdd(tab + LDS_T4 + w, __builtin_amdgcn_ubfe(M3, sh, 1));   // adds 0 unless the window is a whole 4-mer
                 }
                 // heads: valid bases whose run is shorter than 4 (the first three of a run: after the segment's start, an N
-                // or any other letter) -- rare, one at a time.  Run length r = 1 + (M1 bit) + (M2 bit); word
-                // (w & m) + 2*(255 - m) with m = 4^r - 1.
-                uint32_t H = V & ~M3 & 0xFFFFu;
-                while (H) {
-                    const int sh = 31 - __builtin_clz(H);
-                    H &= ~(1u << sh);
-                    const uint32_t r2 = (M2 >> sh) & 1u, r1 = (M1 >> sh) & 1u;
-                    const uint32_t m = r2 ? 63u : r1 ? 15u : 3u;
+                // or any other letter) -- rare.  H1/H2/H3: run of exactly 1/2/3; word (w & m) + 2*(255 - m), m = 4^r - 1.
+                // A run start puts one bit into each of the three, so one pass takes one head of each kind; more passes
+                // only for a lane with several run starts in its 16 bases.
+                uint32_t H1 = V & ~M1 & 0xFFFFu, H2 = M1 & ~M2 & 0xFFFFu, H3 = M2 & ~M3 & 0xFFFFu;
+                if (__builtin_amdgcn_ballot_w64((H1 | H2 | H3) != 0u) != 0ull) {
                     const uint64_t S64 = ((uint64_t)S_hi << 32) | S_lo;
-                    const uint32_t w = (uint32_t)(S64 >> (2 * sh)) & m;
-                    atomicAdd(tab + w + 2u * (255u - m), 1u);
+                    do {
+                        if (H1) { const int sh = __builtin_ctz(H1); H1 &= H1 - 1u; atomicAdd(tab + LDS_T1 + ((uint32_t)(S64 >> (2 * sh)) & 3u), 1u); }
+                        if (H2) { const int sh = __builtin_ctz(H2); H2 &= H2 - 1u; atomicAdd(tab + LDS_T2 + ((uint32_t)(S64 >> (2 * sh)) & 15u), 1u); }
+                        if (H3) { const int sh = __builtin_ctz(H3); H3 &= H3 - 1u; atomicAdd(tab + LDS_T3 + ((uint32_t)(S64 >> (2 * sh)) & 63u), 1u); }
+                    } while (H1 | H2 | H3);
                 }
             }
         }
