@@ -659,22 +659,22 @@ int abw_sig_segment_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len
     if (n_scaf == 0) return ABW_OK;
     const uint64_t nblk = total_len / SEGBLK + 1;                 // + partial / empty tail block
     // scratch[0]: blk_nonN u32[nblk] | scratch[1]: blk_prefix u64[nblk+1] | scratch[2]: ScafSeg[n_scaf]
-    // scratch[3]: nseg u64[n_scaf] | scratch[4]: seg_off u64[n_scaf+1] | scratch[5]: flag
+    // scratch[3]: nseg u64[n_scaf] | scratch[4]: seg_off u64[n_scaf+1] + the lower-case-n flag (one copy brings both back)
     int rc;
     if ((rc = abw_reserve(ctx, ctx->scratch[0], nblk * 4))) return rc;
     if ((rc = abw_reserve(ctx, ctx->scratch[1], (nblk + 1) * 8))) return rc;
     if ((rc = abw_reserve(ctx, ctx->scratch[2], n_scaf * sizeof(ScafSeg)))) return rc;
     if ((rc = abw_reserve(ctx, ctx->scratch[3], n_scaf * 8))) return rc;
-    if ((rc = abw_reserve(ctx, ctx->scratch[4], (n_scaf + 1) * 8))) return rc;
-    if ((rc = abw_reserve(ctx, ctx->scratch[5], 64))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[4], (n_scaf + 2) * 8))) return rc;
+    if ((rc = abw_reserve_pinned(ctx, 16))) return rc;
     uint32_t* blk_nonN = (uint32_t*)ctx->scratch[0].p;
     uint64_t* blk_prefix = (uint64_t*)ctx->scratch[1].p;
     ScafSeg* info = (ScafSeg*)ctx->scratch[2].p;
     uint64_t* nseg = (uint64_t*)ctx->scratch[3].p;
     uint64_t* seg_off = (uint64_t*)ctx->scratch[4].p;
-    int* flag = (int*)ctx->scratch[5].p;
+    int* flag = (int*)(seg_off + n_scaf + 1);
     hipStream_t st = ctx->stream;
-    ABW_HIP(ctx, hipMemsetAsync(flag, 0, 4, st));
+    ABW_HIP(ctx, hipMemsetAsync(flag, 0, 8, st));
     const int grid = ctx->num_cu * 8;
     ABW_PROF(ctx, "sig_segment");
     hipLaunchKernelGGL(seg_blockcount_kernel, dim3(grid), dim3(256), 0, st, d_ascii, total_len, blk_nonN, nblk, flag);
@@ -683,11 +683,11 @@ int abw_sig_segment_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len
     hipLaunchKernelGGL(seg_scaf_kernel, dim3(grid), dim3(256), 0, st, d_ascii, d_scaf_off, n_scaf, blk_prefix, window, info, nseg);
     ABW_LAUNCH_CHECK(ctx);
     if ((rc = device_scan<uint64_t>(ctx, nseg, n_scaf, seg_off))) return rc;
-    uint64_t total = 0;
-    int h_flag = 0;
-    ABW_HIP(ctx, hipMemcpyAsync(&total, seg_off + n_scaf, 8, hipMemcpyDeviceToHost, st));
-    ABW_HIP(ctx, hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, st));
+    uint64_t* back = (uint64_t*)ctx->pinned;                      // [0] number of segments, [1] flag
+    ABW_HIP(ctx, hipMemcpyAsync(back, seg_off + n_scaf, 16, hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));
+    const uint64_t total = back[0];
+    const int h_flag = (int)back[1];
     if (h_flag) return abw_fail(ctx, ABW_ERR_LOWER_N, "lower-case 'n' in sequence data (the reference throws Illegal_DNAString)");
     *n_seg = total;
     if (total > seg_cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "segment capacity %llu < %llu", (unsigned long long)seg_cap, (unsigned long long)total);
