@@ -22,7 +22,7 @@ EXPORTS = [
     "abw_abi_version", "abw_prof_enable", "abw_prof_reset", "abw_prof_read", "abw_sig_dim_names", "abw_sig_segment_host", "abw_sig_segment_dev", "abw_sig_count_dev",
     "abw_sig_build", "abw_sep_load", "abw_sep_node", "abw_sep_dev_keys", "abw_km_run_dev", "abw_km_run",
     "abw_km_features_from_keys", "abw_km_tinymt_selftest", "abw_km_auto_chunk",
-    "abw_cov_accumulate", "abw_cov_accumulate_dev", "abw_km_load", "abw_km_node", "abw_lrn_header", "abw_lrn_parse", "abw_lrn_emit", "abw_lrn_emit_rows", "abw_lrn_emit_rows_dev",
+    "abw_cov_accumulate", "abw_cov_accumulate_dev", "abw_km_load", "abw_km_node", "abw_lrn_header", "abw_lrn_parse", "abw_lrn_emit", "abw_lrn_emit_rows", "abw_lrn_emit_rows_dev", "abw_lrn_table_load",
     "abw_sep_shard_load", "abw_sep_shard_accum", "abw_sep_shard_eval", "abw_sep_shard_decide",
     "abw_km_shard_begin", "abw_km_shard_ready", "abw_km_shard_step", "abw_km_shard_update", "abw_km_shard_finish",
 ]
@@ -99,6 +99,7 @@ def lib():
     L.abw_lrn_parse.argtypes = [vp, vp, u64, i64, i32, vp, vp]
     L.abw_lrn_emit.argtypes = [vp, vp, i64, i32, u64, vp, u64, C.POINTER(u64)]
     L.abw_lrn_emit_rows.argtypes = [vp, vp, i64, i32, vp, i64, vp, u64, C.POINTER(u64)]
+    L.abw_lrn_table_load.argtypes = [vp, vp, i64, i32]
     L.abw_lrn_emit_rows_dev.argtypes = [vp, vp, i64, i32, vp, i64, vp, u64, C.POINTER(u64), vp]
     L.abw_km_load.argtypes = [vp, vp, i32, i64, vp, i32]
     L.abw_km_node.argtypes = [vp, vp, i32, i32, u32, i32, i32, C.POINTER(KmSplit), vp, vp]

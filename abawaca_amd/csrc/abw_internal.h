@@ -95,6 +95,9 @@ struct abw_ctx {
     int         num_cu = 256;
     void*       pinned = nullptr;      // grow-only pinned host staging (results of a call leave the GPU in one batch)
     size_t      pinned_cap = 0;
+    abw_devbuf  lrn_table;             // resident [n_cols][ld] doubles of the cluster writer (abw_lrn_table_load)
+    int64_t     lrn_ld = 0;
+    int32_t     lrn_cols = 0;
 };
 
 int abw_fail(abw_ctx* ctx, int code, const char* fmt, ...);

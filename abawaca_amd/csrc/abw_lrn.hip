@@ -614,31 +614,53 @@ int abw_lrn_emit_rows_dev(abw_ctx* ctx, const double* d_values, int64_t ld, int3
     return ABW_OK;
 }
 
+int abw_lrn_table_load(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_cols)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    abw_device_guard g(ctx->device);
+    ctx->lrn_ld = 0; ctx->lrn_cols = 0;
+    if (!values) { abw_release(ctx->lrn_table); return ABW_OK; }          // unload
+    if (ld < 1 || n_cols < 1) return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_table_load: bad argument");
+    const size_t vb = (size_t)ld * (size_t)n_cols * 8;
+    int rc;
+    if ((rc = abw_reserve(ctx, ctx->lrn_table, vb))) return rc;
+    ABW_HIP(ctx, hipMemcpyAsync(ctx->lrn_table.p, values, vb, hipMemcpyHostToDevice, ctx->stream));
+    ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->lrn_ld = ld; ctx->lrn_cols = n_cols;
+    return ABW_OK;
+}
+
 int abw_lrn_emit_rows(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_cols, const int64_t* dps, int64_t n_rows,
                       uint8_t* text, uint64_t text_cap, uint64_t* text_len)
 {
     if (!ctx) return ABW_ERR_ARG;
-    if (!values || !text_len || n_rows < 0 || ld < 1 || n_cols < 1 || (n_rows > 0 && !dps))
+    if (!text_len || n_rows < 0 || ld < 1 || n_cols < 1 || (n_rows > 0 && !dps))
         return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_emit_rows: bad argument");
+    if (!values && (ctx->lrn_ld != ld || ctx->lrn_cols != n_cols))
+        return abw_fail(ctx, ABW_ERR_STATE, "abw_lrn_emit_rows: no values given and no resident table of %lld x %d (abw_lrn_table_load)", (long long)ld, n_cols);
     *text_len = 0;
     if (n_rows == 0) return ABW_OK;
     abw_device_guard g(ctx->device);
     hipStream_t st = ctx->stream;
     int rc;
-    // scratch[6]: the table | scratch[5]: the datapoint list | scratch[0]: text
+    // scratch[6]: the table (unless resident) | scratch[5]: the datapoint list | scratch[0]: text
     const size_t vb = (size_t)ld * (size_t)n_cols * 8, db = (size_t)n_rows * 8;
-    if ((rc = abw_reserve(ctx, ctx->scratch[6], vb))) return rc;
+    const double* d_values = (const double*)ctx->lrn_table.p;
+    if (values) {
+        if ((rc = abw_reserve(ctx, ctx->scratch[6], vb))) return rc;
+        ABW_HIP(ctx, hipMemcpyAsync(ctx->scratch[6].p, values, vb, hipMemcpyHostToDevice, st));
+        d_values = (const double*)ctx->scratch[6].p;
+    }
     if ((rc = abw_reserve(ctx, ctx->scratch[5], db))) return rc;
-    ABW_HIP(ctx, hipMemcpyAsync(ctx->scratch[6].p, values, vb, hipMemcpyHostToDevice, st));
     ABW_HIP(ctx, hipMemcpyAsync(ctx->scratch[5].p, dps, db, hipMemcpyHostToDevice, st));
     // the length pass sizes the text
     uint64_t need = 0;
-    rc = abw_lrn_emit_rows_dev(ctx, (const double*)ctx->scratch[6].p, ld, n_cols, (const int64_t*)ctx->scratch[5].p, n_rows, NULL, 0, &need, NULL);
+    rc = abw_lrn_emit_rows_dev(ctx, d_values, ld, n_cols, (const int64_t*)ctx->scratch[5].p, n_rows, NULL, 0, &need, NULL);
     if (rc != ABW_ERR_CAPACITY) return rc;
     *text_len = need;
     if (!text || need > text_cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_lrn_emit_rows: the rows take %llu bytes, capacity %llu", (unsigned long long)need, (unsigned long long)text_cap);
     if ((rc = abw_reserve(ctx, ctx->scratch[0], need + 64))) return rc;
-    if ((rc = abw_lrn_emit_rows_dev(ctx, (const double*)ctx->scratch[6].p, ld, n_cols, (const int64_t*)ctx->scratch[5].p, n_rows,
+    if ((rc = abw_lrn_emit_rows_dev(ctx, d_values, ld, n_cols, (const int64_t*)ctx->scratch[5].p, n_rows,
                                     (uint8_t*)ctx->scratch[0].p, need, &need, NULL))) return rc;
     ABW_HIP(ctx, hipMemcpyAsync(text, ctx->scratch[0].p, need, hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));

@@ -239,6 +239,10 @@ int abw_lrn_emit_rows_dev(abw_ctx* ctx, const double* d_values, int64_t ld, int3
                           uint8_t* d_text, uint64_t text_cap, uint64_t* text_len, uint64_t* d_row_off);
 int abw_lrn_emit_rows(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_cols, const int64_t* dps, int64_t n_rows,
                       uint8_t* text, uint64_t text_cap, uint64_t* text_len);
+/* Keeps a copy of the table on the device for the host-pointer form: after abw_lrn_table_load, abw_lrn_emit_rows with
+ * values == NULL (and the same ld, n_cols) prints from the resident copy -- what a driver that writes one .lrn per
+ * cluster of the recursion (ref: src/abawaca.cpp:161-182) wants.  values == NULL here drops the copy. */
+int abw_lrn_table_load(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_cols);
 
 /* ---- extension: k-means restarts (NO counterpart in the reference, see DESIGN.md "K-means";
  *      RNG = TinyMT32, ref: src/misc.cpp:24-36, src/TinyMT-src-1.0.1/tinymt/tinymt32.{c,h}) -------- */

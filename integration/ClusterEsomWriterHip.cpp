@@ -1,0 +1,83 @@
+// See ClusterEsomWriterHip.h.
+#include "ClusterEsomWriterHip.h"
+#include "abawaca_hip.h"
+#include <stdexcept>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+namespace {
+
+struct WriterStore {
+	abw_ctx*		ctx = NULL;
+	const ClusterData*	root = NULL;
+	size_t			N = 0, D = 0;
+};
+WriterStore g_writer;
+
+void load_table(const ScafDpData& scaf_db, const ClusterData& root)
+{
+	WriterStore& st = g_writer;
+	if(!st.ctx && abw_ctx_create(0, &st.ctx) != ABW_OK)
+		throw std::runtime_error("ClusterEsomWriterHip: no MI355X / HIP device available");
+	const size_t N = scaf_db.ndps(), D = root.ndimensions();
+	std::vector<double> values(D * N, 0.0);				// [D][N], column dp-1 = datapoint dp
+	for(size_t d = 0; d < D; d++) {
+		const Dimension& dim = root.get_dimension(d + 1);
+		for(auto it = dim.begin(); it != dim.end(); it++)
+			values[d * N + (it->dp - 1)] = it->value;
+	}
+	if(abw_lrn_table_load(st.ctx, values.data(), (int64_t)N, (int32_t)D) != ABW_OK)
+		throw std::runtime_error(std::string("ClusterEsomWriterHip: abw_lrn_table_load failed: ") + abw_last_error(st.ctx));
+	st.root = &root; st.N = N; st.D = D;
+}
+
+}	// namespace
+
+//////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
+ClusterEsomWriterHip::ClusterEsomWriterHip(string _out_dir, const ScafDpData& _scaf_db, const ClusterData& _root) :
+	ClusterWriter(_out_dir, _scaf_db), root(_root)
+{
+	if(g_writer.ctx == NULL || g_writer.root != &_root)
+		load_table(_scaf_db, _root);
+}
+
+//////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
+void ClusterEsomWriterHip::shutdown()
+{
+	if(g_writer.ctx) abw_ctx_destroy(g_writer.ctx);
+	g_writer = WriterStore();
+}
+
+//////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
+void ClusterEsomWriterHip::write_clustering_info_file(const ClusterData& clustering_db, const char* cluster_name) const
+{
+	const WriterStore& st = g_writer;
+	string	lrn_file = out_dir + "/" + cluster_name + ".lrn";
+	FILE*	fp = fopen(lrn_file.c_str(), "w");
+	if(fp == NULL) {
+		cerr << "Fatal error, " << __FILE__ << " (" << __LINE__ << "): could write to file " << lrn_file << endl << endl;
+		exit(-1);
+	}
+	// the four header lines, as reference src/ClusterWriter.cpp:81-90 prints them (names from the root table)
+	fprintf(fp, "%c %lu\n", '%', clustering_db.ndps());
+	fprintf(fp, "%c %lu\n", '%', st.D + 1);
+	fprintf(fp, "%c 9", '%');
+	for(size_t i = 1; i <= st.D; i++) fprintf(fp, "\t1");
+	fprintf(fp, "\n%c Key", '%');
+	for(size_t i = 1; i <= st.D; i++) fprintf(fp, "\t%s", root.get_dimension(i).get_dimension_name().c_str());
+	fprintf(fp, "\n");
+
+	// the rows (:92-98) in the order the reference walks the cluster's datapoints
+	const unordered_set<size_t>& dps = clustering_db.datapoints();
+	std::vector<int64_t> list(dps.begin(), dps.end());
+	uint64_t len = 0;
+	int rc = abw_lrn_emit_rows(st.ctx, NULL, (int64_t)st.N, (int32_t)st.D, list.data(), (int64_t)list.size(), NULL, 0, &len);
+	if(rc != ABW_OK && rc != ABW_ERR_CAPACITY)
+		throw std::runtime_error(std::string("ClusterEsomWriterHip: abw_lrn_emit_rows failed: ") + abw_last_error(st.ctx));
+	std::vector<uint8_t> text(len);
+	if(len > 0 && abw_lrn_emit_rows(st.ctx, NULL, (int64_t)st.N, (int32_t)st.D, list.data(), (int64_t)list.size(), text.data(), len, &len) != ABW_OK)
+		throw std::runtime_error(std::string("ClusterEsomWriterHip: abw_lrn_emit_rows failed: ") + abw_last_error(st.ctx));
+	fwrite(text.data(), 1, len, fp);
+	fclose(fp);
+}

@@ -4,6 +4,8 @@
 #include "abawaca_hip.h"
 #include <algorithm>
 #include <map>
+#include <set>
+#include <unordered_map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -140,29 +142,46 @@ bool ClusterSeparatorHip::separate()
 	if(!out.legal || out.dimension <= 0)
 		return false;								// reference src/ClusterSeparator.cpp:83-84
 
-	// raw sets (reference :87-90): dps listed scaffold by scaffold, ascending dp id inside a scaffold
+	// dps are listed to the library scaffold by scaffold, ascending dp id inside a scaffold
 	std::vector<std::vector<size_t> > scaf_dps(m);
-	{
-		std::map<size_t, size_t> pos;
-		for(int32_t i = 0; i < m; i++) pos[(size_t)scaf_ids[i] + 1] = i;
-		for(auto it = dps.begin(); it != dps.end(); it++) scaf_dps[pos[scaf_db.dp2scaf(*it)]].push_back(*it);
-		for(int32_t i = 0; i < m; i++) std::sort(scaf_dps[i].begin(), scaf_dps[i].end());
-	}
+	std::map<size_t, size_t> pos;
+	for(int32_t i = 0; i < m; i++) pos[(size_t)scaf_ids[i] + 1] = i;
+	for(auto it = dps.begin(); it != dps.end(); it++) scaf_dps[pos[scaf_db.dp2scaf(*it)]].push_back(*it);
+	for(int32_t i = 0; i < m; i++) std::sort(scaf_dps[i].begin(), scaf_dps[i].end());
+	std::unordered_map<size_t, uint8_t> raw_of;
+	raw_of.reserve(dps.size() * 2);
 	size_t k = 0;
 	for(int32_t i = 0; i < m; i++)
 		for(size_t j = 0; j < scaf_dps[i].size(); j++, k++)
-			(raw[k] == 1 ? raw_dps_cluster1 : raw_dps_cluster2).insert(scaf_dps[i][j]);
+			raw_of[scaf_dps[i][j]] = raw[k];
+
+	// The two clusters are built by the reference's own sequence of set operations, so that their unordered_sets
+	// iterate in the reference's order (the cluster files are written in that order, reference
+	// src/ClusterWriter.cpp:92-93).  Raw clusters (reference src/ClusterSeparator.cpp:36-47): the separating
+	// Dimension is walked in the order of the node's datapoint set (reference src/Dimension.cpp:25-26).
+	this->cluster1 = new Cluster(scaf_db);
+	this->cluster2 = new Cluster(scaf_db);
+	for(auto it = dps.begin(); it != dps.end(); it++)
+		*(raw_of[*it] == 1 ? this->cluster1 : this->cluster2) += *it;
+	for(auto sit = cluster1->dps_begin(); sit != cluster1->dps_end(); sit++) raw_dps_cluster1.insert(*sit);	// reference :87-90
+	for(auto sit = cluster2->dps_begin(); sit != cluster2->dps_end(); sit++) raw_dps_cluster2.insert(*sit);
 
 	if(!out.split) {								// reference :125-132
+		delete(this->cluster1);
+		delete(this->cluster2);
+		this->cluster1 = this->cluster2 = NULL;
 		best->reset();
 		return false;
 	}
-	this->cluster1 = new Cluster(scaf_db);
-	this->cluster2 = new Cluster(scaf_db);
-	for(int32_t i = 0; i < m; i++) {
-		Cluster* c = (side[i] == 1) ? this->cluster1 : this->cluster2;
-		for(size_t j = 0; j < scaf_dps[i].size(); j++) *c += scaf_dps[i][j];
-		c->add_assigned_scaf((size_t)scaf_ids[i] + 1);
-	}
+	for(int32_t i = 0; i < m; i++)							// reference :94-101, decided by the library
+		(side[i] == 1 ? this->cluster1 : this->cluster2)->add_assigned_scaf((size_t)scaf_ids[i] + 1);
+	std::set<size_t> moved;								// reference :104-122
+	for(auto sit = cluster1->dps_begin(); sit != cluster1->dps_end(); sit++)
+		if(!cluster1->assigned(scaf_db.dp2scaf(*sit))) moved.insert(*sit);
+	for(auto sit = moved.begin(); sit != moved.end(); sit++) { *cluster1 -= *sit; *cluster2 += *sit; }
+	moved.clear();
+	for(auto sit = cluster2->dps_begin(); sit != cluster2->dps_end(); sit++)
+		if(!cluster2->assigned(scaf_db.dp2scaf(*sit))) moved.insert(*sit);
+	for(auto sit = moved.begin(); sit != moved.end(); sit++) { *cluster1 += *sit; *cluster2 -= *sit; }
 	return true;
 }

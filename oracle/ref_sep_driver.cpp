@@ -5,7 +5,9 @@
 // work-list recursion as the reference's main loop (reference src/abawaca.cpp:95-197), but
 //   * takes the SCG-list path as an argument (the reference hard-codes an absolute path,
 //     src/abawaca.cpp:42, which does not exist here),
-//   * skips ClusterEsomWriter / fasta output (out of scope),
+//   * skips the fasta output, and writes the clusters' files (ClusterEsomWriter, reference src/abawaca.cpp:161-182)
+//     only when the environment names a directory for them: ABW_CLUSTER_DIR=<dir>; the GPU builds then use
+//     integration/ClusterEsomWriterHip instead.  <out_prefix>.writer.tsv: microseconds spent writing, clusters written,
 //   * writes machine-readable results with full double precision, and the wall time of every
 //     separate() call (this is what bench.py's cpu_baseline "reference" leg reads).
 //
@@ -35,8 +37,10 @@
 #else
 #define SEPARATOR_CLASS ClusterSeparatorBySensitivitySpecificity
 #endif
+#include "ClusterWriter.h"
 #if defined(ABW_USE_HIP_SEPARATOR) || defined(ABW_USE_KMEANS_SEPARATOR)
 #include "ClusterDataView.h"
+#include "ClusterEsomWriterHip.h"
 #endif
 #include "Semaphore.h"
 #include "SCGdb.h"
@@ -66,6 +70,8 @@ int main(int argc, const char** argv)
 		fprintf(fm, "%lu\t%lu\n", dp, scaf_db.dp2scaf(dp));
 	fclose(fm);
 
+	const char* cluster_dir = getenv("ABW_CLUSTER_DIR");
+	long write_usec = 0, written = 0;
 	std::map<size_t, Cluster*> work;
 	std::map<size_t, size_t> dp2cluster, scaf2cluster;
 	size_t next_id = 1, visited = 0;
@@ -110,6 +116,23 @@ int main(int argc, const char** argv)
 				(long)sep.get_separating_dimension(), sep.get_separating_value(),
 				sep.get_best_specificity(), sep.get_best_sensitivity(),
 				c1, sep.get_cluster1()->ndps(), c2, sep.get_cluster2()->ndps(), usec);
+			if(cluster_dir) {		// reference src/abawaca.cpp:161-182
+				auto w0 = std::chrono::steady_clock::now();
+				char name1[128], name2[128];
+				sprintf(name1, "%lu", c1);
+				sprintf(name2, "%lu", c2);
+#if defined(ABW_USE_HIP_SEPARATOR) || defined(ABW_USE_KMEANS_SEPARATOR)
+				ClusterEsomWriterHip writer(cluster_dir, scaf_db, clustering_db);
+				ClusterDataView cluster1(clustering_db, sep.get_cluster1()->get_dps()), cluster2(clustering_db, sep.get_cluster2()->get_dps());
+#else
+				ClusterEsomWriter writer(cluster_dir, scaf_db);
+				ClusterData cluster1(*node_db, sep.get_cluster1()->get_dps()), cluster2(*node_db, sep.get_cluster2()->get_dps());
+#endif
+				writer.write(cluster1, sep.get_cluster1()->get_assigned_scafs(), sep.get_raw_dps_cluster1(), name1);
+				writer.write(cluster2, sep.get_cluster2()->get_assigned_scafs(), sep.get_raw_dps_cluster2(), name2);
+				write_usec += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - w0).count();
+				written += 2;
+			}
 			work[c1] = sep.get_cluster1();
 			work[c2] = sep.get_cluster2();
 		}
@@ -118,6 +141,10 @@ int main(int argc, const char** argv)
 		delete cur;
 	}
 	fclose(fn);
+	if(cluster_dir) {
+		FILE* fw = fopen((prefix + ".writer.tsv").c_str(), "w");
+		if(fw) { fprintf(fw, "%ld\t%ld\n", write_usec, written); fclose(fw); }
+	}
 
 	FILE* fs = fopen((prefix + ".scaf2cluster.tsv").c_str(), "w");
 	FILE* fd = fopen((prefix + ".dp2cluster.tsv").c_str(), "w");

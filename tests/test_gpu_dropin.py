@@ -43,3 +43,33 @@ def test_reference_main_loop_with_hip_separator(golden_dir, case):
     for row, r in zip(ref[0], gold):
         assert [int(row[0]), int(row[1]), int(row[2]), int(row[3])] == [int(r[0]), int(r[1]), int(r[2]), int(r[3])]
         assert float(row[4]) == r[4] and float(row[5]) == r[5] and float(row[6]) == r[6]
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HIP)), reason="oracle/_ref drivers not built")
+@pytest.mark.parametrize("case", ["sep_g4tight", "sep_g6"])
+def test_cluster_files_written_by_the_gpu_writer_are_the_reference_files(golden_dir, case):
+    """Row N4, output side of the drop-in: with ABW_CLUSTER_DIR set both drivers write the files of every cluster the
+    recursion creates (reference src/abawaca.cpp:161-182) -- the reference through its ClusterEsomWriter, the GPU build
+    through integration/ClusterEsomWriterHip (rows printed by abw_lrn_emit_rows from the resident table).  Every file
+    must be byte-identical: <id>.lrn, <id>.scaf-stats.txt, <id>.scaf-cluster.txt."""
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    with tempfile.TemporaryDirectory(prefix="abwdropw_") as wd:
+        files = synth.write_build_dir(wd, g["milli"], g["dp2scaf"], g["scaf_len"], g["scg_scaf"], g["scg_id"], int(g["n_scg"]))
+        dirs = {}
+        for tag, exe in (("ref", REF), ("hip", HIP)):
+            dirs[tag] = os.path.join(wd, "clusters_" + tag)
+            os.makedirs(dirs[tag])
+            _run(exe, files, os.path.join(wd, tag), dict(os.environ, ABW_CLUSTER_DIR=dirs[tag]))
+        names = sorted(os.listdir(dirs["ref"]))
+        assert names == sorted(os.listdir(dirs["hip"])) and len(names) >= 6 and len(names) % 3 == 0
+        n_rows = 0
+        for nm in names:
+            a = open(os.path.join(dirs["ref"], nm), "rb").read()
+            b = open(os.path.join(dirs["hip"], nm), "rb").read()
+            assert a == b, nm
+            if nm.endswith(".lrn"):
+                n_rows += a.count(b"\n") - 4
+        assert n_rows > len(g["dp2scaf"]) // 2
+        w_ref = open(os.path.join(wd, "ref.writer.tsv")).read().split()
+        w_hip = open(os.path.join(wd, "hip.writer.tsv")).read().split()
+        assert w_ref[1] == w_hip[1] == str(len(names) // 3)
