@@ -384,6 +384,26 @@ def recursion_c1(ctx):
                                          and np.array_equal(hrows[:, :11], np.loadtxt(os.path.join(wd, "ref.nodes.tsv"), ndmin=2)[:, :11])),
                                      note="reference main loop + reference containers + ClusterSeparatorHip (C++ adapter over the C ABI); "
                                           "first_node_s includes building the column store from the reference's Dimension objects and abw_sep_load")
+            # the same two drivers writing every cluster's files (reference src/abawaca.cpp:161-182): the reference's
+            # ClusterEsomWriter (fprintf per value) beside integration/ClusterEsomWriterHip (rows printed on the GPU)
+            if os.path.exists(hip_exe):
+                wr = {}
+                for tag, e in (("ref", exe), ("hip", hip_exe)):
+                    cdir = os.path.join(wd, "clusters_" + tag)
+                    os.makedirs(cdir)
+                    t0 = time.perf_counter()
+                    subprocess.run([e, files["names"], files["fasta"], files["info"], files["lrn"], files["scg"], files["scg_list"],
+                                    str(cores), os.path.join(wd, tag + "w")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                   env=dict(os.environ, ABW_CLUSTER_DIR=cdir))
+                    w = time.perf_counter() - t0
+                    us, n = open(os.path.join(wd, tag + "w.writer.tsv")).read().split()
+                    wr[tag] = dict(wall_s=round(w, 2), writer_s=round(int(us) / 1e6, 3), clusters=int(n),
+                                   bytes=sum(os.path.getsize(os.path.join(cdir, x)) for x in os.listdir(cdir)))
+                same = all(open(os.path.join(wd, "clusters_ref", x), "rb").read() == open(os.path.join(wd, "clusters_hip", x), "rb").read()
+                           for x in os.listdir(os.path.join(wd, "clusters_ref")))
+                res["with_cluster_files"] = dict(reference=wr["ref"], dropin=wr["hip"], identical_files=bool(same and wr["ref"]["bytes"] == wr["hip"]["bytes"]),
+                                                 note="writer_s: time inside ClusterWriter::write for all clusters (+ the subset tables the "
+                                                      "reference builds for it); the GPU writer's first call also uploads the root table")
             rows = np.loadtxt(os.path.join(wd, "ref.nodes.tsv"), ndmin=2)
             ref_s2c = np.array([int(ln.split("\t")[1]) for ln in open(os.path.join(wd, "ref.scaf2cluster.tsv"))], dtype=np.int32)
         same_tree = len(rows) == len(nodes) and all(
