@@ -164,3 +164,24 @@ def test_cluster_writer_errors(ctx):
     with pytest.raises(_lib.AbwError) as e:                                    # more columns than the staging buffer takes
         lrn.lrn_emit_rows(ctx, np.zeros((800, 2)), np.array([1], dtype=np.int64))
     assert e.value.code == _lib.ABW_ERR_ARG
+
+
+def test_cluster_writer_host_form_with_resident_table(ctx):
+    """abw_lrn_table_load + abw_lrn_emit_rows(values = NULL): what integration/ClusterEsomWriterHip calls."""
+    import ctypes as C
+    rng = np.random.default_rng(9)
+    v = np.ascontiguousarray(_wild_table(rng, 21, 500))
+    dps = (rng.permutation(500)[:77] + 1).astype(np.int64)
+    L = _lib.lib()
+    n = C.c_uint64(0)
+    args = (21, C.c_void_p(dps.ctypes.data), len(dps))
+    rc = L.abw_lrn_emit_rows(ctx.handle, None, 500, *args, None, 0, C.byref(n))              # nothing resident yet
+    assert rc == _lib.ABW_ERR_STATE
+    ctx.check(L.abw_lrn_table_load(ctx.handle, C.c_void_p(v.ctypes.data), 500, 21))
+    assert L.abw_lrn_emit_rows(ctx.handle, None, 500, *args, None, 0, C.byref(n)) == _lib.ABW_ERR_CAPACITY
+    text = np.empty(n.value, dtype=np.uint8)
+    ctx.check(L.abw_lrn_emit_rows(ctx.handle, None, 500, *args, C.c_void_p(text.ctypes.data), len(text), C.byref(n)))
+    assert np.array_equal(text, orc.lrn_emit_rows(v, dps))
+    assert L.abw_lrn_emit_rows(ctx.handle, None, 400, *args, None, 0, C.byref(n)) == _lib.ABW_ERR_STATE   # another shape
+    ctx.check(L.abw_lrn_table_load(ctx.handle, None, 0, 0))                                    # unload
+    assert L.abw_lrn_emit_rows(ctx.handle, None, 500, *args, None, 0, C.byref(n)) == _lib.ABW_ERR_STATE
