@@ -5,7 +5,6 @@
 #include <algorithm>
 #include <map>
 #include <set>
-#include <unordered_map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -20,6 +19,7 @@ struct HipStore {
 	size_t					N = 0, D = 0, S = 0;
 	std::vector<std::vector<double> >	values;		// [D] sorted distinct values: key -> .lrn value
 	std::vector<std::string>		dim_names;
+	std::vector<uint8_t>			raw_of;		// [N + 1] scratch of separate(): raw side of a datapoint
 };
 HipStore g_store;
 
@@ -41,6 +41,7 @@ void load_store(const ScafDpData& scaf_db, const SCGdb& scg_db, const ClusterDat
 	st.scaf_db = &scaf_db; st.N = N; st.D = D; st.S = S;
 	st.values.assign(D, std::vector<double>());
 	st.dim_names.assign(D, "");
+	st.raw_of.assign(N + 1, 0);
 
 	// keys: rank of every value among the column's distinct values (order-preserving, exact for any
 	// .lrn; for abawaca-build's 3-decimal output the table has <= 1001 entries per signature column)
@@ -148,8 +149,7 @@ bool ClusterSeparatorHip::separate()
 	for(int32_t i = 0; i < m; i++) pos[(size_t)scaf_ids[i] + 1] = i;
 	for(auto it = dps.begin(); it != dps.end(); it++) scaf_dps[pos[scaf_db.dp2scaf(*it)]].push_back(*it);
 	for(int32_t i = 0; i < m; i++) std::sort(scaf_dps[i].begin(), scaf_dps[i].end());
-	std::unordered_map<size_t, uint8_t> raw_of;
-	raw_of.reserve(dps.size() * 2);
+	std::vector<uint8_t>& raw_of = st.raw_of;					// by datapoint id; only the node's entries are read
 	size_t k = 0;
 	for(int32_t i = 0; i < m; i++)
 		for(size_t j = 0; j < scaf_dps[i].size(); j++, k++)
