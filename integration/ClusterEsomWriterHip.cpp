@@ -4,6 +4,7 @@
 #include <stdexcept>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string>
 #include <vector>
 
 namespace {
@@ -59,14 +60,13 @@ void ClusterEsomWriterHip::write_clustering_info_file(const ClusterData& cluster
 		cerr << "Fatal error, " << __FILE__ << " (" << __LINE__ << "): could write to file " << lrn_file << endl << endl;
 		exit(-1);
 	}
-	// the four header lines, as reference src/ClusterWriter.cpp:81-90 prints them (names from the root table)
-	fprintf(fp, "%c %lu\n", '%', clustering_db.ndps());
-	fprintf(fp, "%c %lu\n", '%', st.D + 1);
-	fprintf(fp, "%c 9", '%');
-	for(size_t i = 1; i <= st.D; i++) fprintf(fp, "\t1");
-	fprintf(fp, "\n%c Key", '%');
-	for(size_t i = 1; i <= st.D; i++) fprintf(fp, "\t%s", root.get_dimension(i).get_dimension_name().c_str());
-	fprintf(fp, "\n");
+	// the four header lines (same bytes as reference src/ClusterWriter.cpp:81-90; dimension names from the root table)
+	std::string head = "% " + std::to_string(clustering_db.ndps()) + "\n% " + std::to_string(st.D + 1) + "\n% 9";
+	for(size_t i = 0; i < st.D; i++) head += "\t1";
+	head += "\n% Key";
+	for(size_t i = 1; i <= st.D; i++) head += "\t" + root.get_dimension(i).get_dimension_name();
+	head += "\n";
+	fwrite(head.data(), 1, head.size(), fp);
 
 	// the rows (:92-98) in the order the reference walks the cluster's datapoints
 	const unordered_set<size_t>& dps = clustering_db.datapoints();
