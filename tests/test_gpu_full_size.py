@@ -8,6 +8,9 @@
               every point sits with the nearer returned centroid (float64 check, near-ties aside); inertia == direct sum
   signature : counts of every k sum to the number of valid windows computed independently; every segment's
               dimensions sum to 4; segments tile every scaffold's non-N bases in windows of [2000, 4000)
+  .lrn      : the table written as abawaca.lrn rows (abw_lrn_emit) and as the rows of clusters (abw_lrn_emit_rows, all
+              the clusters of a partition in one call) parses back (abw_lrn_parse) to the same keys; the row offsets cut
+              the text at line starts; every row has the column count; "%lf" of a 3-decimal value is "%.3lf" + "000"
 """
 import os
 import sys
@@ -18,7 +21,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (the bench's generators are the BASELINE configs)
-from abawaca_amd import _lib, kmeans, multi, separator, signature  # noqa: E402
+from abawaca_amd import _lib, kmeans, lrn, multi, separator, signature  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -167,5 +170,51 @@ def test_signature_300mbp_of_configs3():
         assert (~clean).sum() > 0 and np.all(tot[~clean, 3] < (e - b)[~clean] - 3)
         dims = t_dims.cpu().numpy()
         assert np.allclose(dims.sum(1), 4.0, atol=1e-12)
+    finally:
+        ctx.close()
+
+
+def test_lrn_writers_round_trip_at_configs1(table):
+    import torch
+    keys = table["keys"]                                         # [189][N] thousandths
+    D, N = keys.shape
+    ctx = _lib.Context(0)
+    try:
+        head = (f"% {N}\n% {D + 1}\n% 9" + "\t1" * D + "\n% Key" + "".join(f"\tc{j}" for j in range(D)) + "\n").encode()
+        # build writer: rows 1..N in order
+        rows = np.ascontiguousarray(keys.T.astype(np.int32))
+        text = lrn.lrn_emit(ctx, rows, 1)
+        assert int((text == 10).sum()) == N and int((text == 9).sum()) == N * D
+        dp, k2, _ = lrn.lrn_parse(ctx, np.concatenate([np.frombuffer(head, np.uint8), text]))
+        assert np.array_equal(dp, np.arange(1, N + 1)) and np.array_equal(k2, keys)
+        # cluster writer: a random partition into 64 clusters, all of them in one call; values = key / 1000.0 as the
+        # reference's atof holds them
+        rng = np.random.default_rng(1)
+        perm = rng.permutation(N).astype(np.int64) + 1
+        cuts = np.sort(rng.choice(np.arange(1, N), size=63, replace=False))
+        first = np.concatenate([[0], cuts, [N]])
+        t_vals = torch.from_numpy(keys.astype(np.float64) / 1000.0).cuda()
+        t_dps = torch.from_numpy(perm).cuda()
+        t_off = torch.zeros(N + 1, dtype=torch.int64, device="cuda")
+        need = lrn.lrn_emit_rows_dev(ctx, t_vals, t_dps, None)
+        t_text = torch.empty(need, dtype=torch.uint8, device="cuda")
+        assert lrn.lrn_emit_rows_dev(ctx, t_vals, t_dps, t_text, t_off) == need
+        ctext, off = t_text.cpu().numpy(), t_off.cpu().numpy()
+        assert off[0] == 0 and off[-1] == need and np.all(np.diff(off) > 0)
+        assert np.all(ctext[off[1:] - 1] == 10) and int((ctext == 10).sum()) == N      # every row ends where the next starts
+        assert int((ctext == 9).sum()) == N * D
+        # all clusters concatenated are one table with shuffled keys: the loader reads it back (6 decimals, the last three "000")
+        dp3, k3, _ = lrn.lrn_parse(ctx, np.concatenate([np.frombuffer(head, np.uint8), ctext]))
+        assert np.array_equal(dp3, perm) and np.array_equal(k3, keys[:, perm - 1])
+        # one cluster cut out by its offsets == the same cluster written alone
+        c = 17
+        lo, hi = int(first[c]), int(first[c + 1])
+        alone = torch.empty(int(off[hi] - off[lo]), dtype=torch.uint8, device="cuda")
+        assert lrn.lrn_emit_rows_dev(ctx, t_vals, t_dps[lo:hi], alone) == alone.numel()
+        assert np.array_equal(alone.cpu().numpy(), ctext[off[lo]:off[hi]])
+        # "%lf" of a 3-decimal value is its "%.3lf" text followed by "000": compare the first rows of both writers
+        r0 = bytes(ctext[off[0]:off[1]]).rstrip(b"\n").split(b"\t")
+        b0 = (b"\n" + bytes(text)).split(b"\n" + str(int(perm[0])).encode() + b"\t", 1)[1].split(b"\n", 1)[0].split(b"\t")
+        assert r0[0] == str(int(perm[0])).encode() and [x + b"000" for x in b0] == r0[1:]
     finally:
         ctx.close()
