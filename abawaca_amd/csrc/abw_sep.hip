@@ -633,9 +633,11 @@ struct GlobalRes { int32_t found; int32_t dim; int32_t bin; int32_t legal; doubl
 
 // In dimension order that rule picks, among the dimensions that found a winner, the largest product and on equal
 // products the smallest dimension: a strict order, so one wave reduces it (lanes stride over the dimensions).
-__global__ __launch_bounds__(64) void sep_global_kernel(const DimBestDev* __restrict__ db, int32_t D, GlobalRes* __restrict__ out)
+__global__ __launch_bounds__(64) void sep_global_kernel(const DimBestDev* __restrict__ db, int32_t D, GlobalRes* __restrict__ out,
+                                                       unsigned long long* __restrict__ totals)
 {
     const int lane = threadIdx.x;
+    if (lane < 2 && totals) totals[lane] = 0;             // sep_assign adds to them
     double bp = -1.0;                                      // products are >= 0: -1 = nothing found yet
     int bd = -1;
     for (int d = lane; d < D; d += 64) {
@@ -660,36 +662,21 @@ __global__ __launch_bounds__(64) void sep_global_kernel(const DimBestDev* __rest
     *out = r;
 }
 
-// per-scaffold count of dps with bin <= t in the winning dimension and the raw flag of each dp
-__global__ __launch_bounds__(256) void sep_final_kernel(SepDev P, const GlobalRes* __restrict__ win, const int32_t* __restrict__ node_scaf,
-                                                       const int32_t* __restrict__ node_dpoff, int32_t m,
-                                                       int32_t* __restrict__ nle, uint8_t* __restrict__ raw)
-{
-    const int ls = blockIdx.x * 256 + threadIdx.x;
-    if (ls >= m || !win->legal) return;                   // no legal winner: nothing to reconstruct (ref ClusterSeparator.cpp:27-28)
-    const int d = win->dim, tbin = win->bin;
-    const int s = node_scaf ? node_scaf[ls] : ls;
-    const int f = P.scaf_first[s], n = P.scaf_ndps[s];
-    const int64_t o = node_dpoff ? node_dpoff[ls] : f;
-    const int32_t* col = P.bins + (int64_t)d * P.N;
-    int c = 0;
-    for (int i = 0; i < n; i++) { const int le = col[f + i] <= tbin; c += le; raw[o + i] = (uint8_t)le; }
-    nle[ls] = c;
-}
-
-// ref ClusterSeparator.cpp:35-53,87-122 on the device: cluster1 is the raw side with fewer dps (tie: the
-// "<=" side); a scaffold goes to cluster1 iff at least half of its dps are there; raw flags become 1 / 2.
+// ref ClusterSeparator.cpp:35-53,87-122 on the device, one thread per scaffold of the node: the dps with bin <= t in
+// the winning dimension are the raw "<=" side; cluster1 is the raw side with fewer dps (tie: the "<=" side); a scaffold
+// goes to cluster1 iff at least half of its dps are there; raw flags are written as 1 / 2.
 // n = dps of the whole node and le = those on the "<=" side (size1 of the winning threshold, known from
 // the histogram scan; both are totals over ALL shards when the node is sharded).
-// totals: [0], [1] = dps of this shard's scaffolds assigned to cluster1 / cluster2 (out)
+// totals: [0], [1] = dps of this shard's scaffolds assigned to cluster1 / cluster2 (out; zeroed by sep_global_kernel)
 __global__ __launch_bounds__(256) void sep_assign_kernel(SepDev P, const int32_t* __restrict__ node_scaf,
                                                         const int32_t* __restrict__ node_dpoff, int32_t m, const GlobalRes* __restrict__ win,
-                                                        const int32_t* __restrict__ nle, uint8_t* __restrict__ raw,
-                                                        uint8_t* __restrict__ side, unsigned long long* __restrict__ totals)
+                                                        uint8_t* __restrict__ raw, uint8_t* __restrict__ side,
+                                                        unsigned long long* __restrict__ totals)
 {
     __shared__ unsigned long long b1, b2;
-    if (!win->legal) return;                              // uniform
+    if (!win->legal) return;                              // uniform: no legal winner, nothing to reconstruct (ref :27-28)
     const long long n = win->n, le = win->size1;
+    const int d = win->dim, tbin = win->bin;
     if (threadIdx.x == 0) { b1 = 0; b2 = 0; }
     __syncthreads();
     const bool swap = n - le < le;
@@ -698,11 +685,17 @@ __global__ __launch_bounds__(256) void sep_assign_kernel(SepDev P, const int32_t
         const int s = node_scaf ? node_scaf[ls] : ls;
         const int f = P.scaf_first[s], tot = P.scaf_ndps[s];
         const int64_t o = node_dpoff ? node_dpoff[ls] : f;
-        const int c1 = swap ? tot - nle[ls] : nle[ls];
+        const int32_t* col = P.bins + (int64_t)d * P.N;
+        int c = 0;
+        for (int i = 0; i < tot; i++) {
+            const bool le_i = col[f + i] <= tbin;
+            c += le_i;
+            raw[o + i] = (le_i != swap) ? 1 : 2;          // ref :87-90
+        }
+        const int c1 = swap ? tot - c : c;
         const bool to1 = c1 > 0 && 2 * (long long)c1 >= tot;
         side[ls] = to1 ? 1 : 2;
         atomicAdd(to1 ? &b1 : &b2, (unsigned long long)tot);
-        for (int i = 0; i < tot; i++) raw[o + i] = ((raw[o + i] != 0) != swap) ? 1 : 2;      // ref :87-90
     }
     __syncthreads();
     if (threadIdx.x == 0) { if (b1) atomicAdd(&totals[0], b1); if (b2) atomicAdd(&totals[1], b2); }
@@ -1093,7 +1086,17 @@ static int sep_eval_phase(abw_ctx* ctx, const char* who, int32_t min_ndps, abw_s
     int rc;
 
     const unsigned nch = (unsigned)H.chunks.size();
-    DimBestDev* d_dimbest = (DimBestDev*)s.dimbest.p;
+    // everything that goes back to the host lies in ONE device block, so that one copy brings it:
+    // winners of the dimensions | global winner | 2 totals | scaffold sides | raw flags of the dps
+    const size_t b_db = (size_t)s.D * sizeof(DimBestDev) + sizeof(GlobalRes);
+    const size_t o_tot = (b_db + 15) & ~(size_t)15, o_side = o_tot + 16, o_raw = o_side + (((size_t)m + 15) & ~(size_t)15);
+    if ((rc = abw_reserve(ctx, s.dimbest, o_raw + (size_t)n + 16))) return rc;
+    uint8_t* d_back = (uint8_t*)s.dimbest.p;
+    DimBestDev* d_dimbest = (DimBestDev*)d_back;
+    GlobalRes* d_win = (GlobalRes*)(d_dimbest + s.D);
+    unsigned long long* d_tot = (unsigned long long*)(d_back + o_tot);
+    uint8_t* d_side = d_back + o_side;
+    uint8_t* d_raw = d_back + o_raw;
     {
     ABW_PROF(ctx, "sep_eval");
     hipLaunchKernelGGL(sep_chunk_sums_kernel, dim3(nch), dim3(256), 0, st, P, H.d_chunks, H.d_chunk_sums);
@@ -1106,37 +1109,17 @@ static int sep_eval_phase(abw_ctx* ctx, const char* who, int32_t min_ndps, abw_s
     ABW_LAUNCH_CHECK(ctx);
     }
     // the global winner and this context's part of the finalisation follow on the device without a host round trip
-    GlobalRes* d_win = (GlobalRes*)(d_dimbest + s.D);
-    hipLaunchKernelGGL(sep_global_kernel, dim3(1), dim3(64), 0, st, d_dimbest, s.D, d_win);
+    hipLaunchKernelGGL(sep_global_kernel, dim3(1), dim3(64), 0, st, d_dimbest, s.D, d_win, d_tot);
     ABW_LAUNCH_CHECK(ctx);
-    unsigned long long* d_tot = nullptr;
-    uint8_t* d_side = nullptr;
     if (m > 0) {
-        if ((rc = abw_reserve(ctx, s.nle, (size_t)m * 4))) return rc;
-        if ((rc = abw_reserve(ctx, s.raw, (size_t)n))) return rc;
-        if ((rc = abw_reserve(ctx, ctx->scratch[9], (size_t)m + 64))) return rc;
-        d_tot = (unsigned long long*)ctx->scratch[9].p;                       // 2 totals, then the scaffold sides
-        d_side = (uint8_t*)ctx->scratch[9].p + 32;
-        ABW_HIP(ctx, hipMemsetAsync(d_tot, 0, 16, st));
-        hipLaunchKernelGGL(sep_final_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, d_win, d_node_scaf, d_node_dpoff, m,
-                           (int32_t*)s.nle.p, (uint8_t*)s.raw.p);
-        ABW_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(sep_assign_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, d_node_scaf, d_node_dpoff, m, d_win,
-                           (const int32_t*)s.nle.p, (uint8_t*)s.raw.p, d_side, d_tot);
+        hipLaunchKernelGGL(sep_assign_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, d_node_scaf, d_node_dpoff, m, d_win, d_raw, d_side, d_tot);
         ABW_LAUNCH_CHECK(ctx);
     }
-    // one copy batch through pinned memory, one synchronisation: winners | global winner | totals | sides | raw flags
-    const size_t b_db = (size_t)s.D * sizeof(DimBestDev) + sizeof(GlobalRes);
-    const size_t o_tot = (b_db + 15) & ~(size_t)15, o_side = o_tot + 16, o_raw = o_side + (((size_t)m + 15) & ~(size_t)15);
     const bool want_side = scaf_side && m > 0, want_raw = dp_raw_side && n > 0;
+    const size_t back_bytes = want_raw ? o_raw + (size_t)n : want_side ? o_side + (size_t)m : o_side;
     if ((rc = abw_reserve_pinned(ctx, o_raw + (size_t)n + 16))) return rc;
     uint8_t* hp = (uint8_t*)ctx->pinned;
-    ABW_HIP(ctx, hipMemcpyAsync(hp, d_dimbest, b_db, hipMemcpyDeviceToHost, st));
-    if (m > 0) {
-        ABW_HIP(ctx, hipMemcpyAsync(hp + o_tot, d_tot, 16, hipMemcpyDeviceToHost, st));
-        if (want_side) ABW_HIP(ctx, hipMemcpyAsync(hp + o_side, d_side, (size_t)m, hipMemcpyDeviceToHost, st));
-        if (want_raw) ABW_HIP(ctx, hipMemcpyAsync(hp + o_raw, s.raw.p, (size_t)n, hipMemcpyDeviceToHost, st));
-    }
+    ABW_HIP(ctx, hipMemcpyAsync(hp, d_back, back_bytes, hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));
     const DimBestDev* db = (const DimBestDev*)hp;
     const GlobalRes win = *(const GlobalRes*)(hp + (size_t)s.D * sizeof(DimBestDev));
