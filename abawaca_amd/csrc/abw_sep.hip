@@ -1003,9 +1003,14 @@ static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_
     int64_t n = 0;
     int rc;
     if (!all && m > 0) {
-        std::vector<int32_t>& dpoff = s.h_node_dpoff;                // both outlive the asynchronous copies below
-        dpoff.resize((size_t)m + 1);
-        s.h_node_ids.assign(scaf_ids, scaf_ids + m);
+        // ids and dp offsets go up in one copy from pinned memory (the block is sized for the results of any node of this
+        // table, too, so that the evaluation phase never has to grow it while this copy is in flight)
+        const size_t out_bytes = (((size_t)s.D * sizeof(DimBestDev) + sizeof(GlobalRes) + 15) & ~(size_t)15) + 16 + (((size_t)s.S + 15) & ~(size_t)15) +
+                                 (size_t)s.N + 16;
+        if ((rc = abw_reserve_pinned(ctx, std::max(out_bytes, ((size_t)2 * m + 1) * 4)))) return rc;
+        int32_t* h_ids = (int32_t*)ctx->pinned;
+        int32_t* dpoff = h_ids + m;
+        memcpy(h_ids, scaf_ids, (size_t)m * 4);
         // duplicate check in O(m): a stamp per scaffold, a new stamp value per call
         if (s.h_stamp.size() != (size_t)s.S) { s.h_stamp.assign((size_t)s.S, 0); s.stamp = 0; }
         if (++s.stamp == 0) { std::fill(s.h_stamp.begin(), s.h_stamp.end(), 0u); s.stamp = 1; }
@@ -1018,10 +1023,8 @@ static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_
             n += s.h_scaf_ndps[sc];
         }
         dpoff[m] = (int32_t)n;
-        if ((rc = abw_reserve(ctx, s.node_scaf, (size_t)m * 4))) return rc;
-        if ((rc = abw_reserve(ctx, s.node_dpoff, ((size_t)m + 1) * 4))) return rc;
-        ABW_HIP(ctx, hipMemcpyAsync(s.node_scaf.p, s.h_node_ids.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
-        ABW_HIP(ctx, hipMemcpyAsync(s.node_dpoff.p, dpoff.data(), ((size_t)m + 1) * 4, hipMemcpyHostToDevice, st));
+        if ((rc = abw_reserve(ctx, s.node_scaf, ((size_t)2 * m + 1) * 4))) return rc;      // ids[m] then dp offsets[m + 1]
+        ABW_HIP(ctx, hipMemcpyAsync(s.node_scaf.p, h_ids, ((size_t)2 * m + 1) * 4, hipMemcpyHostToDevice, st));
     } else if (all) n = s.N;
     const int32_t* d_node_scaf = all ? nullptr : (const int32_t*)s.node_scaf.p;
 
@@ -1079,7 +1082,7 @@ static int sep_eval_phase(abw_ctx* ctx, const char* who, int32_t min_ndps, abw_s
     const int32_t m = s.node_m;
     const int64_t n = s.node_n;
     const int32_t* d_node_scaf = s.node_all ? nullptr : (const int32_t*)s.node_scaf.p;
-    const int32_t* d_node_dpoff = s.node_all ? nullptr : (const int32_t*)s.node_dpoff.p;
+    const int32_t* d_node_dpoff = s.node_all ? nullptr : (const int32_t*)s.node_scaf.p + s.node_m;
     memset(out, 0, sizeof(*out));
     out->dimension = -1; out->key = -1;
     SepDev P = sep_params(s, H);
