@@ -334,6 +334,8 @@ __global__ __launch_bounds__(256) void sep_clear_kernel(SepDev P, const ChunkDes
 __global__ void sep_range_reset_kernel(SepDev P, int32_t D, const int32_t* __restrict__ widelist, int32_t n_wide, int wide_full)
 {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    // the SCG lo / hi lists of the node start empty (lo = INT_MAX, hi = -1)
+    for (int64_t i = d; i < (int64_t)D * P.n_scg; i += (int64_t)gridDim.x * blockDim.x) { P.scg_lo[i] = INT_MAX; P.scg_hi[i] = -1; }
     if (d >= D) return;
     bool wide = false;
     for (int w = 0; w < n_wide; w++) wide |= widelist[w] == d;
@@ -1035,13 +1037,6 @@ static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_
     ABW_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(sep_range_reset_kernel, dim3((s.D + 63) / 64), dim3(64), 0, st, P, s.D, H.d_wide, (int32_t)H.wide_dims.size(), scatter ? 0 : 1);
     ABW_LAUNCH_CHECK(ctx);
-    if (s.n_scg > 0) {
-        const int64_t cnt = (int64_t)s.D * s.n_scg;
-        hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)std::min<int64_t>(1024, (cnt + 255) / 256)), dim3(256), 0, st, P.scg_lo, cnt, INT_MAX);
-        ABW_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)std::min<int64_t>(1024, (cnt + 255) / 256)), dim3(256), 0, st, P.scg_hi, cnt, -1);
-        ABW_LAUNCH_CHECK(ctx);
-    }
     if (m > 0) {
         const unsigned gx = (unsigned)((m + ACC_SPB - 1) / ACC_SPB);
         ABW_PROF(ctx, "sep_accum");
