@@ -38,7 +38,6 @@ struct abw_sep_state {
     std::vector<int32_t> h_binval;
     std::vector<int32_t> h_scaf_first, h_scaf_ndps;
     std::vector<uint32_t> h_stamp; uint32_t stamp = 0;   // duplicate check of a node's scaffold list
-    std::vector<int32_t> h_node_ids, h_node_dpoff;   // host copies of the current node's lists (sources of async copies)
     int64_t   TB = 0;                 // total bins
     bool      node_open = false, node_all = false;   // a node accumulated and not yet evaluated
     int32_t   node_m = 0;             // its scaffolds held here
@@ -46,11 +45,8 @@ struct abw_sep_state {
     // per-node scratch
     abw_devbuf hist;                  // 3 x int32[TB] + int64[TB]
     abw_devbuf scg_lohi;              // 2 x int32[D][n_scg]
-    abw_devbuf node_scaf;             // int32[m]
-    abw_devbuf node_dpoff;            // int32[m+1]
-    abw_devbuf dimbest;               // per-dimension results
-    abw_devbuf nle;                   // int32[m]
-    abw_devbuf raw;                   // uint8[n]
+    abw_devbuf node_scaf;             // int32[m] scaffold ids, then int32[m+1] dp offsets (one upload)
+    abw_devbuf dimbest;               // everything a node returns: winners | global winner | totals | scaffold sides | raw flags
 };
 
 struct abw_prof_rec { int id; hipEvent_t a, b; };

@@ -703,11 +703,6 @@ __global__ __launch_bounds__(256) void sep_assign_kernel(SepDev P, const int32_t
     if (threadIdx.x == 0) { if (b1) atomicAdd(&totals[0], b1); if (b2) atomicAdd(&totals[1], b2); }
 }
 
-__global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v)
-{
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
-}
-
 struct SepHost {
     std::vector<int32_t> narrow_dims, wide_dims;
     std::vector<ChunkDesc> chunks;
@@ -751,8 +746,8 @@ extern "C" void abw_sep_free(abw_ctx* ctx)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     s.d_keys = s.d_bins = s.d_scaf_first = s.d_scaf_ndps = s.d_scg_off = s.d_scg_ids = s.d_T = s.d_binval = nullptr;
     s.d_scaf_len = s.d_Toff = s.d_binval_off = nullptr;
-    abw_release(s.hist); abw_release(s.scg_lohi); abw_release(s.node_scaf); abw_release(s.node_dpoff);
-    abw_release(s.dimbest); abw_release(s.nle); abw_release(s.raw);
+    abw_release(s.hist); abw_release(s.scg_lohi); abw_release(s.node_scaf);
+    abw_release(s.dimbest);
     s.loaded = false;
     abw_sep_extra* e = nullptr;
     {
