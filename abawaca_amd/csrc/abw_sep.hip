@@ -144,12 +144,20 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t*
                 ABW_CX(1, 2) ABW_CX(3, 4) ABW_CX(5, 6)
 #undef ABW_CX
                 ts = (k == 1) ? w[1] : (k == 2) ? w[2] : (k == 3) ? w[3] : w[4];
-            }
+                // one LDS atomic per DISTINCT value of the scaffold (its segments often share a 3-decimal value): runs of the
+                // sorted copy; the padding (INT_MAX) ends the last run
+                uint32_t run = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (i < n) {
-                    atomicAdd(&my_size[v[i]], 1u);
-                    if (v[i] > ts) atomicAdd(&my_tp1[v[i]], 1u); else tp_ts++;
+                for (int i = 0; i < 8; i++) {
+                    if (i < n) {
+                        run++;
+                        const int nextv = (i < 7) ? w[i + 1] : INT_MAX;
+                        if (nextv != w[i]) {
+                            atomicAdd(&my_size[w[i]], run);
+                            if (w[i] > ts) atomicAdd(&my_tp1[w[i]], run); else tp_ts += run;
+                            run = 0;
+                        }
+                    }
                 }
             }
         } else {
