@@ -1,0 +1,32 @@
+"""bench.py's output line (the driver's contract): one JSON object on stdout with the metric of BASELINE.json, the
+timing fields, the roofline of the dominant kernel measured live and the CPU baseline beside it.  Runs last (file name)
+because it is the slowest GPU test (the CPU baselines take about half a minute)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_default_run_prints_the_contract_line():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["dtype"] == "f32" and isinstance(d["config"], dict) and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 1e10 and d["ms_per_step"] > 0 and d["unit"] == "point*iterations/s"
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and 0 < r["frac"] <= 1 and r["peak"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    for leg in ("separator", "signature", "coverage", "lrn"):
+        assert leg in d and d[leg]["value"] > 0
