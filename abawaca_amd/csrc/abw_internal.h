@@ -123,7 +123,9 @@ struct abw_prof_scope {
     abw_prof_scope(abw_ctx* c, const char* name);
     ~abw_prof_scope();
 };
-#define ABW_PROF(ctx, name) abw_prof_scope prof_scope_##__LINE__((ctx), (name))
+#define ABW_CAT2(a, b) a##b
+#define ABW_CAT(a, b) ABW_CAT2(a, b)
+#define ABW_PROF(ctx, name) abw_prof_scope ABW_CAT(prof_scope_, __LINE__)((ctx), (name))
 
 // RAII device guard: every entry point runs with the context's device current.
 struct abw_device_guard {
