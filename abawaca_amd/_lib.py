@@ -19,7 +19,7 @@ SIG_NDIMS, SIG_NCOLS, SIG_NMERS = 180, 179, 340
 # every symbol include/abawaca_hip.h declares (tests/test_abi.py checks the two lists agree)
 EXPORTS = [
     "abw_ctx_create", "abw_ctx_destroy", "abw_ctx_set_stream", "abw_ctx_synchronize", "abw_last_error",
-    "abw_abi_version", "abw_prof_enable", "abw_prof_reset", "abw_prof_read", "abw_sig_dim_names", "abw_sig_segment_host", "abw_sig_segment_dev", "abw_sig_count_dev",
+    "abw_abi_version", "abw_prof_enable", "abw_prof_reset", "abw_prof_read", "abw_sig_dim_names", "abw_sig_segment_host", "abw_sig_segment_dev", "abw_sig_segment_static", "abw_sig_count_dev",
     "abw_sig_build", "abw_sep_load", "abw_sep_node", "abw_sep_dev_keys", "abw_km_run_dev", "abw_km_run",
     "abw_km_features_from_keys", "abw_km_tinymt_selftest", "abw_km_auto_chunk",
     "abw_cov_accumulate", "abw_cov_accumulate_dev", "abw_km_load", "abw_km_node", "abw_lrn_header", "abw_lrn_parse", "abw_lrn_emit", "abw_lrn_emit_rows", "abw_lrn_emit_rows_dev", "abw_lrn_table_load",
@@ -74,6 +74,7 @@ def lib():
     L.abw_sig_dim_names.argtypes = [C.c_char_p, u64]
     L.abw_sig_segment_host.argtypes = [vp, vp, u64, u32, u64, vp, vp, vp, C.POINTER(u64)]
     L.abw_sig_segment_dev.argtypes = [vp, vp, u64, vp, u64, u32, u64, vp, vp, vp, C.POINTER(u64)]
+    L.abw_sig_segment_static.argtypes = [vp, vp, u64, vp, u64, u32, u64, vp, vp, vp, vp]
     L.abw_sig_count_dev.argtypes = [vp, vp, u64, vp, vp, vp, vp, u64, vp, vp, vp]
     L.abw_sig_build.argtypes = [vp, vp, vp, u64, u32, u64, vp, vp, vp, vp, vp, C.POINTER(u64)]
     L.abw_sep_load.argtypes = [vp, vp, i32, i64, vp, vp, i32, vp, vp, i32]

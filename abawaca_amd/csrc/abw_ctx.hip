@@ -2,6 +2,8 @@
 #include "abw_internal.h"
 #include <stdarg.h>
 
+int abw_sig_static_init(abw_ctx* ctx);   // abw_sig.hip
+
 int abw_fail(abw_ctx* ctx, int code, const char* fmt, ...)
 {
     char buf[1024];
@@ -130,6 +132,12 @@ int abw_ctx_create(int device, abw_ctx** out)
     ctx->stream = ctx->own_stream;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    if (abw_sig_static_init(ctx) != ABW_OK) {          // once per context, with its device current
+        fprintf(stderr, "abawaca_hip: %s\n", ctx->err.c_str());
+        (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return ABW_ERR_HIP;
+    }
     *out = ctx;
     return ABW_OK;
 }

@@ -7,7 +7,7 @@
 #include <vector>
 #include "../../include/abawaca_hip.h"
 
-#define ABW_ABI_VERSION 1
+#define ABW_ABI_VERSION 2
 
 // Grow-only device buffer owned by a context.
 struct abw_devbuf {
@@ -91,6 +91,7 @@ struct abw_ctx {
     int         num_cu = 256;
     void*       pinned = nullptr;      // grow-only pinned host staging (results of a call leave the GPU in one batch)
     size_t      pinned_cap = 0;
+    void*       sig_static = nullptr;  // this device's address of abw_sig.hip's static workspace (abw_sig_segment_static)
     abw_devbuf  lrn_table;             // resident [n_cols][ld] doubles of the cluster writer (abw_lrn_table_load)
     int64_t     lrn_ld = 0;
     int32_t     lrn_cols = 0;

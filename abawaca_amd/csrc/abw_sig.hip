@@ -485,6 +485,9 @@ __global__ __launch_bounds__(256) void seg_emit_kernel(const uint8_t* __restrict
 {
     const int lane = threadIdx.x & 63;
     const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    // n_seg = the launch's capacity; the count itself is on the device (seg_off[n_scaf]) -- a caller that read it back
+    // passes it as the capacity, one that did not (abw_sig_segment_static) launches over its whole capacity
+    n_seg = min(n_seg, seg_off[n_scaf]);
     const bool active = g < n_seg;
     uint64_t s = 0, j = 0, sb = 0, nseg = 0, pos = 0;     // pos: blob offset of the closing byte
     bool need = false;
@@ -538,18 +541,16 @@ __global__ __launch_bounds__(256) void seg_emit_kernel(const uint8_t* __restrict
         seg_scaf[g] = (uint32_t)s;
         seg_end[g] = rel + 1;
         if (j == 0) seg_start[g] = 1;                      // ref :209 sit = seq.begin()
-        if (j + 1 < nseg) seg_start[g + 1] = rel + 2;      // ref :221-222 sit = it + 1
+        if (j + 1 < nseg && g + 1 < n_seg) seg_start[g + 1] = rel + 2;      // ref :221-222 sit = it + 1
     }
 }
 
-// scratch[8] is used for the group totals / offsets of the two-level scan
+// tmp: (2 * ceil(n / 1024) + 2) uint64 for the group totals / offsets of the two-level scan
 template <typename TIN>
-int device_scan(abw_ctx* ctx, const TIN* in, uint64_t n, uint64_t* out)
+int device_scan_tmp(abw_ctx* ctx, const TIN* in, uint64_t n, uint64_t* out, uint64_t* tmp)
 {
     const uint64_t ngroups = (n + 1023) / 1024;
-    int rc = abw_reserve(ctx, ctx->scratch[8], (2 * ngroups + 2) * 8);
-    if (rc) return rc;
-    uint64_t* gtot = (uint64_t*)ctx->scratch[8].p;
+    uint64_t* gtot = tmp;
     uint64_t* goff = gtot + ngroups;
     hipLaunchKernelGGL(scan_group_totals_kernel<TIN>, dim3((unsigned)ngroups), dim3(1024), 0, ctx->stream, in, n, gtot);
     ABW_LAUNCH_CHECK(ctx);
@@ -559,6 +560,62 @@ int device_scan(abw_ctx* ctx, const TIN* in, uint64_t n, uint64_t* out)
     ABW_LAUNCH_CHECK(ctx);
     return ABW_OK;
 }
+
+// scratch[8] is used for the temporary
+template <typename TIN>
+int device_scan(abw_ctx* ctx, const TIN* in, uint64_t n, uint64_t* out)
+{
+    const uint64_t ngroups = (n + 1023) / 1024;
+    int rc = abw_reserve(ctx, ctx->scratch[8], (2 * ngroups + 2) * 8);
+    if (rc) return rc;
+    return device_scan_tmp<TIN>(ctx, in, n, out, (uint64_t*)ctx->scratch[8].p);
+}
+
+// The arrays the segmentation works in, wherever they live (grow-only buffers of the context, or the static workspace).
+struct SegWork {
+    uint32_t* blk_nonN;      // [nblk]
+    uint64_t* blk_prefix;    // [nblk + 1]
+    ScafSeg*  info;          // [n_scaf]
+    uint64_t* nseg;          // [n_scaf]
+    uint64_t* seg_off;       // [n_scaf + 1], then the lower-case-n flag (8 bytes)
+    uint64_t* scan_tmp;      // [2 * ceil(max(nblk, n_scaf) / 1024) + 2]
+};
+
+// passes 1-4: block counts, their scan, per-scaffold segment counts, their scan.  Leaves seg_off[n_scaf] = number of
+// segments and, behind it, the lower-case-n flag.  Asynchronous.
+int segment_counts(abw_ctx* ctx, const SegWork& w, const uint8_t* d_ascii, uint64_t total_len, const uint64_t* d_scaf_off,
+                   uint64_t n_scaf, uint32_t window)
+{
+    const uint64_t nblk = total_len / SEGBLK + 1;
+    hipStream_t st = ctx->stream;
+    int* flag = (int*)(w.seg_off + n_scaf + 1);
+    ABW_HIP(ctx, hipMemsetAsync(flag, 0, 8, st));
+    const int grid = ctx->num_cu * 8;
+    int rc;
+    hipLaunchKernelGGL(seg_blockcount_kernel, dim3(grid), dim3(256), 0, st, d_ascii, total_len, w.blk_nonN, nblk, flag);
+    ABW_LAUNCH_CHECK(ctx);
+    if ((rc = device_scan_tmp<uint32_t>(ctx, w.blk_nonN, nblk, w.blk_prefix, w.scan_tmp))) return rc;
+    hipLaunchKernelGGL(seg_scaf_kernel, dim3(grid), dim3(256), 0, st, d_ascii, d_scaf_off, n_scaf, w.blk_prefix, window, w.info, w.nseg);
+    ABW_LAUNCH_CHECK(ctx);
+    if ((rc = device_scan_tmp<uint64_t>(ctx, w.nseg, n_scaf, w.seg_off, w.scan_tmp))) return rc;
+    return ABW_OK;
+}
+
+// ---- abw_sig_segment_static: the same work without any allocation.  Its arrays live in `scratch`, a file-scope device
+// array sized for ABW_SIG_STATIC_MAX_LEN bytes of sequence and ABW_SIG_STATIC_MAX_SCAF scaffolds per call (about 11 MB,
+// held by every GPU the library runs on until the process ends).  Host code never uses the array's name as an address:
+// abw_sig_static_init resolves this device's copy once (hipGetSymbolAddress) and the context keeps the pointer.
+constexpr uint64_t align256(uint64_t x) { return (x + 255) & ~(uint64_t)255; }
+constexpr uint64_t STATIC_NBLK = ABW_SIG_STATIC_MAX_LEN / SEGBLK + 1;
+constexpr uint64_t STATIC_SCAN_N = (STATIC_NBLK > ABW_SIG_STATIC_MAX_SCAF ? STATIC_NBLK : ABW_SIG_STATIC_MAX_SCAF);
+constexpr uint64_t STATIC_OFF_BLK = 0;
+constexpr uint64_t STATIC_OFF_PREFIX = STATIC_OFF_BLK + align256(STATIC_NBLK * 4);
+constexpr uint64_t STATIC_OFF_INFO = STATIC_OFF_PREFIX + align256((STATIC_NBLK + 1) * 8);
+constexpr uint64_t STATIC_OFF_NSEG = STATIC_OFF_INFO + align256(ABW_SIG_STATIC_MAX_SCAF * sizeof(ScafSeg));
+constexpr uint64_t STATIC_OFF_SEGOFF = STATIC_OFF_NSEG + align256(ABW_SIG_STATIC_MAX_SCAF * 8);
+constexpr uint64_t STATIC_OFF_SCAN = STATIC_OFF_SEGOFF + align256((ABW_SIG_STATIC_MAX_SCAF + 2) * 8);
+constexpr uint64_t STATIC_BYTES = STATIC_OFF_SCAN + align256((2 * ((STATIC_SCAN_N + 1023) / 1024) + 2) * 8);
+static __device__ __align__(256) unsigned char scratch[STATIC_BYTES];
 
 bool g_tables_uploaded[64] = {};
 
@@ -572,6 +629,15 @@ int upload_tables(abw_ctx* ctx)
 }
 
 }  // namespace
+
+// Called by abw_ctx_create with the context's device current: this device's address of the static workspace.
+int abw_sig_static_init(abw_ctx* ctx)
+{
+    void* p = nullptr;
+    ABW_HIP(ctx, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    ctx->sig_static = p;
+    return ABW_OK;
+}
 
 // shared with abw_cov.hip
 int abw_device_scan_u32(abw_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out) { return device_scan<uint32_t>(ctx, in, n, out); }
@@ -660,31 +726,22 @@ int abw_sig_segment_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len
     const uint64_t nblk = total_len / SEGBLK + 1;                 // + partial / empty tail block
     // scratch[0]: blk_nonN u32[nblk] | scratch[1]: blk_prefix u64[nblk+1] | scratch[2]: ScafSeg[n_scaf]
     // scratch[3]: nseg u64[n_scaf] | scratch[4]: seg_off u64[n_scaf+1] + the lower-case-n flag (one copy brings both back)
+    // scratch[8]: temporary of the scans
     int rc;
     if ((rc = abw_reserve(ctx, ctx->scratch[0], nblk * 4))) return rc;
     if ((rc = abw_reserve(ctx, ctx->scratch[1], (nblk + 1) * 8))) return rc;
     if ((rc = abw_reserve(ctx, ctx->scratch[2], n_scaf * sizeof(ScafSeg)))) return rc;
     if ((rc = abw_reserve(ctx, ctx->scratch[3], n_scaf * 8))) return rc;
     if ((rc = abw_reserve(ctx, ctx->scratch[4], (n_scaf + 2) * 8))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[8], (2 * ((std::max(nblk, n_scaf) + 1023) / 1024) + 2) * 8))) return rc;
     if ((rc = abw_reserve_pinned(ctx, 16))) return rc;
-    uint32_t* blk_nonN = (uint32_t*)ctx->scratch[0].p;
-    uint64_t* blk_prefix = (uint64_t*)ctx->scratch[1].p;
-    ScafSeg* info = (ScafSeg*)ctx->scratch[2].p;
-    uint64_t* nseg = (uint64_t*)ctx->scratch[3].p;
-    uint64_t* seg_off = (uint64_t*)ctx->scratch[4].p;
-    int* flag = (int*)(seg_off + n_scaf + 1);
+    SegWork w = {(uint32_t*)ctx->scratch[0].p, (uint64_t*)ctx->scratch[1].p, (ScafSeg*)ctx->scratch[2].p,
+                 (uint64_t*)ctx->scratch[3].p, (uint64_t*)ctx->scratch[4].p, (uint64_t*)ctx->scratch[8].p};
     hipStream_t st = ctx->stream;
-    ABW_HIP(ctx, hipMemsetAsync(flag, 0, 8, st));
-    const int grid = ctx->num_cu * 8;
     ABW_PROF(ctx, "sig_segment");
-    hipLaunchKernelGGL(seg_blockcount_kernel, dim3(grid), dim3(256), 0, st, d_ascii, total_len, blk_nonN, nblk, flag);
-    ABW_LAUNCH_CHECK(ctx);
-    if ((rc = device_scan<uint32_t>(ctx, blk_nonN, nblk, blk_prefix))) return rc;
-    hipLaunchKernelGGL(seg_scaf_kernel, dim3(grid), dim3(256), 0, st, d_ascii, d_scaf_off, n_scaf, blk_prefix, window, info, nseg);
-    ABW_LAUNCH_CHECK(ctx);
-    if ((rc = device_scan<uint64_t>(ctx, nseg, n_scaf, seg_off))) return rc;
+    if ((rc = segment_counts(ctx, w, d_ascii, total_len, d_scaf_off, n_scaf, window))) return rc;
     uint64_t* back = (uint64_t*)ctx->pinned;                      // [0] number of segments, [1] flag
-    ABW_HIP(ctx, hipMemcpyAsync(back, seg_off + n_scaf, 16, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipMemcpyAsync(back, w.seg_off + n_scaf, 16, hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));
     const uint64_t total = back[0];
     const int h_flag = (int)back[1];
@@ -694,8 +751,44 @@ int abw_sig_segment_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len
     if (total == 0) return ABW_OK;
     if (!d_seg_scaf || !d_seg_start || !d_seg_end) return abw_fail(ctx, ABW_ERR_ARG, "null segment output");
     hipLaunchKernelGGL(seg_emit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_ascii, total_len, d_scaf_off, n_scaf,
-                       blk_prefix, info, seg_off, total, d_seg_scaf, d_seg_start, d_seg_end);
+                       w.blk_prefix, w.info, w.seg_off, total, d_seg_scaf, d_seg_start, d_seg_end);
     ABW_LAUNCH_CHECK(ctx);
+    return ABW_OK;
+}
+
+int abw_sig_segment_static(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len, const uint64_t* d_scaf_off,
+                           uint64_t n_scaf, uint32_t window, uint64_t seg_cap, uint32_t* d_seg_scaf,
+                           uint64_t* d_seg_start, uint64_t* d_seg_end, uint64_t* d_result)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!d_result || window == 0 || (n_scaf && (!d_ascii || !d_scaf_off)) || (seg_cap && (!d_seg_scaf || !d_seg_start || !d_seg_end)))
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_sig_segment_static: bad argument");
+    if (total_len > ABW_SIG_STATIC_MAX_LEN || n_scaf > ABW_SIG_STATIC_MAX_SCAF || seg_cap > 0xFFFFFF00ull * 256)
+        return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_sig_segment_static: %llu bytes / %llu scaffolds pass the static workspace "
+                        "(at most %llu bytes and %llu scaffolds per call; use abw_sig_segment_dev)", (unsigned long long)total_len,
+                        (unsigned long long)n_scaf, (unsigned long long)ABW_SIG_STATIC_MAX_LEN, (unsigned long long)ABW_SIG_STATIC_MAX_SCAF);
+    if (!ctx->sig_static) return abw_fail(ctx, ABW_ERR_STATE, "abw_sig_segment_static: the static workspace of device %d was not resolved", ctx->device);
+    abw_device_guard g(ctx->device);
+    if (n_scaf == 0) { ABW_HIP(ctx, hipMemsetAsync(d_result, 0, 16, ctx->stream)); return ABW_OK; }
+    // the same arrays as abw_sig_segment_dev, carved out of this device's copy of `scratch` (sized for the maxima)
+    uint8_t* base = (uint8_t*)ctx->sig_static;
+    SegWork w;
+    w.blk_nonN = (uint32_t*)(base + STATIC_OFF_BLK);
+    w.blk_prefix = (uint64_t*)(base + STATIC_OFF_PREFIX);
+    w.info = (ScafSeg*)(base + STATIC_OFF_INFO);
+    w.nseg = (uint64_t*)(base + STATIC_OFF_NSEG);
+    w.seg_off = (uint64_t*)(base + STATIC_OFF_SEGOFF);
+    w.scan_tmp = (uint64_t*)(base + STATIC_OFF_SCAN);
+    hipStream_t st = ctx->stream;
+    int rc;
+    if ((rc = segment_counts(ctx, w, d_ascii, total_len, d_scaf_off, n_scaf, window))) return rc;
+    // the count and the flag stay on the device (no read-back, no synchronisation): seg_off[n_scaf], flag -> d_result[0], [1]
+    ABW_HIP(ctx, hipMemcpyAsync(d_result, w.seg_off + n_scaf, 16, hipMemcpyDeviceToDevice, st));
+    if (seg_cap) {
+        hipLaunchKernelGGL(seg_emit_kernel, dim3((unsigned)((seg_cap + 255) / 256)), dim3(256), 0, st, d_ascii, total_len, d_scaf_off, n_scaf,
+                           w.blk_prefix, w.info, w.seg_off, seg_cap, d_seg_scaf, d_seg_start, d_seg_end);
+        ABW_LAUNCH_CHECK(ctx);
+    }
     return ABW_OK;
 }
 

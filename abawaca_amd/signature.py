@@ -81,6 +81,16 @@ def segment_dev(ctx: Context, t_ascii, total_len: int, t_scaf_off, window, t_seg
     return int(n.value)
 
 
+def segment_static(ctx: Context, t_ascii, total_len: int, t_scaf_off, window, t_seg_scaf, t_seg_start, t_seg_end, t_result):
+    """abw_sig_segment_static: no allocation, no synchronisation; t_result (int64[2] on the device) receives the number
+    of segments and the lower-case-n flag."""
+    ctx.check(lib().abw_sig_segment_static(ctx.handle, C.c_void_p(t_ascii.data_ptr()), int(total_len),
+                                           C.c_void_p(t_scaf_off.data_ptr()), int(t_scaf_off.numel() - 1), int(window),
+                                           int(t_seg_scaf.numel()), C.c_void_p(t_seg_scaf.data_ptr()),
+                                           C.c_void_p(t_seg_start.data_ptr()), C.c_void_p(t_seg_end.data_ptr()),
+                                           C.c_void_p(t_result.data_ptr())))
+
+
 def count_dev(ctx: Context, t_ascii, total_len: int, t_scaf_off, t_seg_scaf, t_seg_start, t_seg_end, n_seg: int,
               t_dims=None, t_milli=None, t_counts=None):
     def p(t):

@@ -79,6 +79,23 @@ int abw_sig_segment_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len
                         uint64_t n_scaf, uint32_t window, uint64_t seg_cap, uint32_t* d_seg_scaf,
                         uint64_t* d_seg_start, uint64_t* d_seg_end, uint64_t* n_seg);
 
+/* The same segmentation for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  It calls no hipMalloc / hipFree / hipHostMalloc or any other
+ * allocating routine and does not synchronise: the working arrays that abw_sig_segment_dev keeps in grow-only buffers
+ * (block counts and their prefix sums, per-scaffold segment counts and offsets, scan temporaries) live in a file-scope
+ * device array of the library, sized for at most ABW_SIG_STATIC_MAX_LEN bytes of sequence and ABW_SIG_STATIC_MAX_SCAF
+ * scaffolds per call (about 11 MB, held by every GPU the library runs on until the process ends); larger inputs are
+ * rejected with ABW_ERR_CAPACITY.  Inputs and outputs are the caller's device memory as in abw_sig_segment_dev, except
+ * that nothing comes back to the host: d_result (device, 2 x uint64) receives [0] the number of segments of the input
+ * (also when it exceeds seg_cap: then only the first seg_cap segments were written) and [1] non-zero iff the sequence
+ * holds a lower-case 'n' (ABW_ERR_LOWER_N of the other entry points).  Asynchronous on the context's stream.
+ * Every call on one GPU -- from any context -- works in that GPU's one array: calls that overlap on a GPU race. */
+#define ABW_SIG_STATIC_MAX_LEN   (64ull << 20)
+#define ABW_SIG_STATIC_MAX_SCAF  (256ull << 10)
+int abw_sig_segment_static(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len, const uint64_t* d_scaf_off,
+                           uint64_t n_scaf, uint32_t window, uint64_t seg_cap, uint32_t* d_seg_scaf,
+                           uint64_t* d_seg_start, uint64_t* d_seg_end, uint64_t* d_result);
+
 /* Counting + finalisation of n_seg segments: the body of Scaf_segment::Scaf_segment (ref: :103-174)
  * for every segment at once.  Segment s covers blob bytes
  *   [d_scaf_off[d_seg_scaf[s]] + d_seg_start[s] - 1,  d_scaf_off[d_seg_scaf[s]] + d_seg_end[s]).
