@@ -19,7 +19,7 @@ SIG_NDIMS, SIG_NCOLS, SIG_NMERS = 180, 179, 340
 # every symbol include/abawaca_hip.h declares (tests/test_abi.py checks the two lists agree)
 EXPORTS = [
     "abw_ctx_create", "abw_ctx_destroy", "abw_ctx_set_stream", "abw_ctx_synchronize", "abw_last_error",
-    "abw_abi_version", "abw_prof_enable", "abw_prof_reset", "abw_prof_read", "abw_sig_dim_names", "abw_sig_segment_host", "abw_sig_segment_dev", "abw_sig_segment_static", "abw_sig_count_dev",
+    "abw_abi_version", "abw_prof_enable", "abw_prof_reset", "abw_prof_read", "abw_sig_dim_names", "abw_sig_segment_host", "abw_sig_segment_dev", "abw_sig_segment_static", "abw_sig_count_dev", "abw_sig_selftest_division",
     "abw_sig_build", "abw_sep_load", "abw_sep_node", "abw_sep_dev_keys", "abw_km_run_dev", "abw_km_run",
     "abw_km_features_from_keys", "abw_km_tinymt_selftest", "abw_km_auto_chunk",
     "abw_cov_accumulate", "abw_cov_accumulate_dev", "abw_km_load", "abw_km_node", "abw_lrn_header", "abw_lrn_parse", "abw_lrn_emit", "abw_lrn_emit_rows", "abw_lrn_emit_rows_dev", "abw_lrn_table_load",
@@ -40,7 +40,8 @@ class DimBest(C.Structure):
 
 class KmSplit(C.Structure):
     _fields_ = [("split", C.c_int32), ("best_restart", C.c_int32), ("inertia", C.c_double), ("agreement", C.c_double),
-                ("ndps", C.c_int64), ("raw1", C.c_int64), ("ndps1", C.c_int64), ("ndps2", C.c_int64)]
+                ("ndps", C.c_int64), ("raw1", C.c_int64), ("ndps1", C.c_int64), ("ndps2", C.c_int64),
+                ("chunk", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Split(C.Structure):
@@ -75,6 +76,7 @@ def lib():
     L.abw_sig_segment_host.argtypes = [vp, vp, u64, u32, u64, vp, vp, vp, C.POINTER(u64)]
     L.abw_sig_segment_dev.argtypes = [vp, vp, u64, vp, u64, u32, u64, vp, vp, vp, C.POINTER(u64)]
     L.abw_sig_segment_static.argtypes = [vp, vp, u64, vp, u64, u32, u64, vp, vp, vp, vp]
+    L.abw_sig_selftest_division.argtypes = [vp, u32, u32, u32, u32, C.POINTER(u64), vp]
     L.abw_sig_count_dev.argtypes = [vp, vp, u64, vp, vp, vp, vp, u64, vp, vp, vp]
     L.abw_sig_build.argtypes = [vp, vp, vp, u64, u32, u64, vp, vp, vp, vp, vp, C.POINTER(u64)]
     L.abw_sep_load.argtypes = [vp, vp, i32, i64, vp, vp, i32, vp, vp, i32]
@@ -103,7 +105,7 @@ def lib():
     L.abw_lrn_table_load.argtypes = [vp, vp, i64, i32]
     L.abw_lrn_emit_rows_dev.argtypes = [vp, vp, i64, i32, vp, i64, vp, u64, C.POINTER(u64), vp]
     L.abw_km_load.argtypes = [vp, vp, i32, i64, vp, i32]
-    L.abw_km_node.argtypes = [vp, vp, i32, i32, u32, i32, i32, C.POINTER(KmSplit), vp, vp]
+    L.abw_km_node.argtypes = [vp, vp, i32, i32, u32, i32, i32, i32, C.POINTER(KmSplit), vp, vp]
     L.abw_km_auto_chunk.argtypes = [vp, i64, i32]
     L.abw_km_auto_chunk.restype = i32
     _LIB = L

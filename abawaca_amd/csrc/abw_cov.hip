@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256) void cov_span_kernel(const uint32_t* __restric
     const uint64_t sc = read_scaf[r];
     uint64_t lo = 0, hi = 0;
     const uint64_t s = read_pos[r], l = read_len[r];
-    if (sc < n_scaf && l > 0) read_span(seg_start, seg_end, seg_first[sc], seg_first[sc + 1], s, s + l - 1, lo, hi);
+    // l = 0 is not special-cased: e = s + l - 1 wraps in 64 bits exactly as the reference's size_t does (ref :233) -- at
+    // s = 0 every segment of the scaffold then receives 1.0, elsewhere a contribution of 0.0
+    if (sc < n_scaf) read_span(seg_start, seg_end, seg_first[sc], seg_first[sc + 1], s, s + l - 1, lo, hi);
     count[r] = (uint32_t)(hi - lo);
     first[r] = (uint32_t)lo;
 }

@@ -155,6 +155,7 @@ void abw_ctx_destroy(abw_ctx* ctx)
     for (auto& r : ctx->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto& e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (auto& b : ctx->scratch) abw_release(b);
+    for (auto& b : ctx->km_buf) abw_release(b);
     abw_release(ctx->lrn_table);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -87,7 +87,8 @@ struct abw_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     abw_sep_state sep;
-    abw_devbuf  scratch[12];           // general-purpose grow-only scratch
+    abw_devbuf  scratch[12];           // general-purpose grow-only scratch (valid only inside one entry-point call)
+    abw_devbuf  km_buf[3];             // state of a k-means run in progress (abw_km_shard_*): lives across calls
     int         num_cu = 256;
     void*       pinned = nullptr;      // grow-only pinned host staging (results of a call leave the GPU in one batch)
     size_t      pinned_cap = 0;

@@ -620,21 +620,23 @@ int abw_km_shard_begin(abw_ctx* ctx, const float* d_x, int64_t N_local, int64_t 
     k.ngroups = (k.nchunks + KM_GROUP - 1) / KM_GROUP;
     k.elems = (int64_t)k.Rp * k.W;
     int rc;
-    // scratch[1]: col_term + moments (totals, squares) + sums + centroids + discriminant operand ;
-    // scratch[2]: slabs ; scratch[5]: fp64 group sums
+    // The run's state lives in buffers of its own (ctx->km_buf), not in the shared scratch slots: control returns to the
+    // caller between the phases, and any other entry point may grow (= free) a scratch slot in between.
+    // km_buf[0]: col_term + moments (totals, squares) + sums + centroids + discriminant operand ;
+    // km_buf[1]: slabs ; km_buf[2]: fp64 group sums
     const size_t cent_bytes = (size_t)k.Rp * 2 * k.W * 4, dt_bytes = (size_t)k.Rp * k.W * 4;
     const size_t term_bytes = (size_t)k.Rp * 2 * 8, mom_bytes = (size_t)(k.W + d) * 8, sums_bytes = (size_t)k.elems * 8;
-    if ((rc = abw_reserve(ctx, ctx->scratch[1], term_bytes + mom_bytes + sums_bytes + cent_bytes + dt_bytes + 64))) return rc;
-    if ((rc = abw_reserve(ctx, ctx->scratch[2], (size_t)k.nchunks * k.elems * 4))) return rc;
-    if ((rc = abw_reserve(ctx, ctx->scratch[5], (size_t)k.ngroups * k.elems * 8))) return rc;
-    uint8_t* base = (uint8_t*)ctx->scratch[1].p;
+    if ((rc = abw_reserve(ctx, ctx->km_buf[0], term_bytes + mom_bytes + sums_bytes + cent_bytes + dt_bytes + 64))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->km_buf[1], (size_t)k.nchunks * k.elems * 4))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->km_buf[2], (size_t)k.ngroups * k.elems * 8))) return rc;
+    uint8_t* base = (uint8_t*)ctx->km_buf[0].p;
     k.col_term = (double*)base;
     k.moments = (double*)(base + term_bytes);
     k.sums = (double*)(base + term_bytes + mom_bytes);
     k.cent = (float*)(base + term_bytes + mom_bytes + sums_bytes);
     k.dT = (float*)(base + term_bytes + mom_bytes + sums_bytes + cent_bytes);
-    k.slabs = (float*)ctx->scratch[2].p;
-    k.gsum = (double*)ctx->scratch[5].p;
+    k.slabs = (float*)ctx->km_buf[1].p;
+    k.gsum = (double*)ctx->km_buf[2].p;
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(km_init_kernel, dim3(k.Rp), dim3(256), 0, st, d_x, N_local, first_point, N_total, d, k.W, R, base_seed, k.cent);
     ABW_LAUNCH_CHECK(ctx);

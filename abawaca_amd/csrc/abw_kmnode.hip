@@ -127,12 +127,12 @@ int abw_km_load(abw_ctx* ctx, const float* x, int32_t D, int64_t N, const int32_
 }
 
 int abw_km_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t R, uint32_t base_seed, int32_t iters,
-                int32_t min_ndps, abw_km_split* out, uint8_t* scaf_side, uint8_t* dp_raw_side)
+                int32_t chunk, int32_t min_ndps, abw_km_split* out, uint8_t* scaf_side, uint8_t* dp_raw_side)
 {
     if (!ctx) return ABW_ERR_ARG;
     abw_km_store& k = ctx->kmst;
     if (!k.loaded) return abw_fail(ctx, ABW_ERR_STATE, "abw_km_node: call abw_km_load first");
-    if (!out || R < 1 || iters < 0 || min_ndps < 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_node: bad argument");
+    if (!out || R < 1 || iters < 0 || min_ndps < 0 || chunk < 0 || (chunk & 31)) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_node: bad argument (chunk: 0 or a multiple of 32)");
     if (scaf_ids && n_scaf <= 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_node: empty node");
     abw_device_guard g(ctx->device);
     hipStream_t st = ctx->stream;
@@ -184,7 +184,11 @@ int abw_km_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t R
         d_xn = (const float*)ctx->scratch[3].p;
         d_node_scaf = p_scaf; d_node_dpoff = p_dpoff;
     }
-    if ((rc = abw_km_run_dev(ctx, d_xn, n, k.D, R, base_seed, iters, 0, d_assign, nullptr, d_in))) return rc;
+    // the chunk bounds the fp32 partial sums, i.e. it is part of the result: 0 = sized for this device (abw_km_auto_chunk),
+    // and what was used is reported so that the node can be reproduced on another device
+    if (chunk == 0) chunk = abw_km_auto_chunk(ctx, n, R);
+    out->chunk = chunk;
+    if ((rc = abw_km_run_dev(ctx, d_xn, n, k.D, R, base_seed, iters, chunk, d_assign, nullptr, d_in))) return rc;
     ABW_HIP(ctx, hipMemsetAsync(d_res, 0, 64, st));
     hipLaunchKernelGGL(kmn_best_kernel, dim3(1), dim3(256), 0, st, d_in, R, d_assign, n, d_res);
     ABW_LAUNCH_CHECK(ctx);

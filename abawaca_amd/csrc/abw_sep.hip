@@ -782,6 +782,12 @@ static int upload(abw_ctx* ctx, T** dst, const T* src, size_t n)
     return ABW_OK;
 }
 
+static int sep_load_upload(abw_ctx* ctx, std::vector<int32_t>& st_first, std::vector<int32_t>& st_ndps, std::vector<int32_t>& st_T,
+                           std::vector<int64_t>& st_Toff, std::vector<int64_t>& st_binval_off, std::vector<std::vector<int32_t>>& uniq,
+                           std::vector<int32_t>& bins, std::vector<char>& is_wide, const int32_t* keys, int32_t D, int64_t N,
+                           const int32_t* dp2scaf, const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
+                           int32_t n_scg, bool sharded);
+
 // dict_off == NULL: the table is the whole problem, the bin layout follows from it (narrow dimension:
 // T = max key + 1; wide: the column's own distinct keys).  dict_off != NULL: the table is ONE SHARD of a
 // scaffold-sharded problem and every shard must lay its histograms out identically: a dimension with an
@@ -807,9 +813,9 @@ static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int
     }
     abw_device_guard g(ctx->device);
     ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    abw_sep_free(ctx);
-    abw_sep_state& s = ctx->sep;
-    SepHost& H = g_extra_of(ctx)->h;
+    // Everything that can reject the input is checked BEFORE the resident table is touched: a refused reload leaves
+    // the previous table usable.  The new layout is built in locals and moved in once it is known to be good.
+    struct Staged { std::vector<int32_t> h_scaf_first, h_scaf_ndps, h_T; std::vector<int64_t> h_Toff, h_binval_off; } s;
 
     // scaffold layout (ref: ScafDpData.cpp:91-99 numbers dps scaffold by scaffold)
     s.h_scaf_first.assign(S, 0);
@@ -898,6 +904,24 @@ static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int
             if (bad_dim[d] == 2) return abw_fail(ctx, ABW_ERR_ARG, "%s: a key of dimension %d is missing from its dictionary", who, d);
         }
     }
+    // the input is good: drop the previous table, move the staged layout in
+    abw_sep_free(ctx);
+    Staged staged = std::move(s);
+    return sep_load_upload(ctx, staged.h_scaf_first, staged.h_scaf_ndps, staged.h_T, staged.h_Toff, staged.h_binval_off, uniq, bins, is_wide,
+                           keys, D, N, dp2scaf, scaf_len, S, scg_off, scg_ids, n_scg, dict_off != nullptr);
+}
+
+// second half of sep_load_impl: builds the chunk tables and uploads.  On any failure the half-built table is freed.
+static int sep_load_upload_impl(abw_ctx* ctx, std::vector<int32_t>& st_first, std::vector<int32_t>& st_ndps, std::vector<int32_t>& st_T,
+                                std::vector<int64_t>& st_Toff, std::vector<int64_t>& st_binval_off, std::vector<std::vector<int32_t>>& uniq,
+                                std::vector<int32_t>& bins, std::vector<char>& is_wide, const int32_t* keys, int32_t D, int64_t N,
+                                const int32_t* dp2scaf, const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
+                                int32_t n_scg, bool sharded)
+{
+    abw_sep_state& s = ctx->sep;
+    SepHost& H = g_extra_of(ctx)->h;
+    s.h_scaf_first = std::move(st_first); s.h_scaf_ndps = std::move(st_ndps); s.h_T = std::move(st_T);
+    s.h_Toff = std::move(st_Toff); s.h_binval_off = std::move(st_binval_off);
     s.h_binval.clear();
     H.narrow_dims.clear(); H.wide_dims.clear(); H.chunks.clear();
     H.dim_first_chunk.assign(D, 0); H.dim_nchunks.assign(D, 0);
@@ -974,12 +998,24 @@ static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int
         for (int32_t d = 0; d < D; d++) { none[2 * d] = INT_MAX; none[2 * d + 1] = -1; }   // nothing touched yet
         if ((rc = upload(ctx, &H.d_range, none.data(), none.size()))) return rc;
     }
-    H.sharded = dict_off != nullptr;
+    H.sharded = sharded;
     if ((rc = abw_reserve(ctx, s.scg_lohi, (size_t)std::max<int64_t>(1, (int64_t)D * n_scg) * 8))) return rc;
     if ((rc = abw_reserve(ctx, s.dimbest, (size_t)D * sizeof(DimBestDev) + sizeof(GlobalRes)))) return rc;
     s.loaded = true;
     s.node_open = false;
     return ABW_OK;
+}
+
+static int sep_load_upload(abw_ctx* ctx, std::vector<int32_t>& st_first, std::vector<int32_t>& st_ndps, std::vector<int32_t>& st_T,
+                           std::vector<int64_t>& st_Toff, std::vector<int64_t>& st_binval_off, std::vector<std::vector<int32_t>>& uniq,
+                           std::vector<int32_t>& bins, std::vector<char>& is_wide, const int32_t* keys, int32_t D, int64_t N,
+                           const int32_t* dp2scaf, const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
+                           int32_t n_scg, bool sharded)
+{
+    const int rc = sep_load_upload_impl(ctx, st_first, st_ndps, st_T, st_Toff, st_binval_off, uniq, bins, is_wide, keys, D, N, dp2scaf,
+                                        scaf_len, S, scg_off, scg_ids, n_scg, sharded);
+    if (rc) { const std::string msg = ctx->err; abw_sep_free(ctx); ctx->err = msg; }      // no half-populated table behind an error
+    return rc;
 }
 
 static SepDev sep_params(abw_sep_state& s, SepHost& H)

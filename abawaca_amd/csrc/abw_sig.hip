@@ -144,6 +144,32 @@ __device__ __forceinline__ double quot(uint32_t n, const Recip& R)
     return __builtin_fma(e, R.r, q);
 }
 
+// Known-answer aid for recip_of / quot: thread i takes the divisor t = t_lo + i * t_step and every dividend n in [0, t]
+// (t <= n_max: all of them; above: the n_max + 1 values floor(j * t / n_max), j = 0..n_max), compares quot(n, recip_of(t))
+// with the compiler's own IEEE division bit for bit, and sums the bit patterns of the quotients (mod 2^64) so that the
+// host can check them against its own division.
+__global__ __launch_bounds__(256) void div_selftest_kernel(uint32_t t_lo, uint32_t t_step, uint32_t count, uint32_t n_max,
+                                                          unsigned long long* __restrict__ mismatches, unsigned long long* __restrict__ checksum)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t t = t_lo + i * t_step;
+    const Recip R = recip_of(t);
+    const double td = (double)t;
+    unsigned long long bad = 0, sum = 0;
+    const uint32_t steps = t <= n_max ? t : n_max;
+    for (uint32_t j = 0; j <= steps; j++) {
+        const uint32_t n = t <= n_max ? j : (uint32_t)((unsigned long long)j * t / n_max);
+        const double q = quot(n, R);
+        volatile double nd = (double)n;                       // keeps the reference division a plain runtime fp64 division
+        const double ref = nd / td;
+        bad += __double_as_longlong(q) != __double_as_longlong(ref);
+        sum += (unsigned long long)__double_as_longlong(q);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+    if (checksum) checksum[i] = sum;
+}
+
 __global__ __launch_bounds__(256) void sig_count_kernel(
     const uint8_t* __restrict__ ascii, uint64_t total_len, const uint64_t* __restrict__ scaf_off,
     const uint32_t* __restrict__ seg_scaf, const uint64_t* __restrict__ seg_start,
@@ -655,6 +681,27 @@ int abw_sig_dim_names(char* buf, uint64_t buf_len)
     if (buf_len < need) return ABW_ERR_CAPACITY;
     char* p = buf;
     for (auto& s : names) { memcpy(p, s.c_str(), s.size() + 1); p += s.size() + 1; }
+    return ABW_OK;
+}
+
+int abw_sig_selftest_division(abw_ctx* ctx, uint32_t t_lo, uint32_t t_step, uint32_t count, uint32_t n_max,
+                              uint64_t* mismatches, uint64_t* checksums)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!mismatches || t_lo == 0 || count == 0 || n_max == 0 || t_step == 0 || (uint64_t)t_lo + (uint64_t)(count - 1) * t_step > 0x7FFFFFFFull)
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_sig_selftest_division: divisors must lie in [1, 2^31)");
+    abw_device_guard g(ctx->device);
+    int rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[0], 8 + (size_t)count * 8))) return rc;
+    unsigned long long* d_bad = (unsigned long long*)ctx->scratch[0].p;
+    unsigned long long* d_sum = d_bad + 1;
+    hipStream_t st = ctx->stream;
+    ABW_HIP(ctx, hipMemsetAsync(d_bad, 0, 8, st));
+    hipLaunchKernelGGL(div_selftest_kernel, dim3((count + 255) / 256), dim3(256), 0, st, t_lo, t_step, count, n_max, d_bad, d_sum);
+    ABW_LAUNCH_CHECK(ctx);
+    ABW_HIP(ctx, hipMemcpyAsync(mismatches, d_bad, 8, hipMemcpyDeviceToHost, st));
+    if (checksums) ABW_HIP(ctx, hipMemcpyAsync(checksums, d_sum, (size_t)count * 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
     return ABW_OK;
 }
 

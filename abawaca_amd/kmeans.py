@@ -126,8 +126,9 @@ class KmColumnStore:
                                     C.c_void_p(self.dp2scaf.ctypes.data), self.S))
 
 
-def km_node(store: KmColumnStore, scaf_ids, R: int, base_seed: int, iters: int, min_ndps: int = 100):
-    """One node (scaf_ids ascending, None = all).  -> (KmSplit, scaf_side u8[m], dp_raw_side u8[n])"""
+def km_node(store: KmColumnStore, scaf_ids, R: int, base_seed: int, iters: int, min_ndps: int = 100, chunk: int = 0):
+    """One node (scaf_ids ascending, None = all).  chunk = 0: the library's choice for this device, reported in
+    KmSplit.chunk.  -> (KmSplit, scaf_side u8[m], dp_raw_side u8[n])"""
     from ._lib import KmSplit
     ids = None if scaf_ids is None else np.ascontiguousarray(scaf_ids, dtype=np.int32)
     m = store.S if ids is None else len(ids)
@@ -136,6 +137,6 @@ def km_node(store: KmColumnStore, scaf_ids, R: int, base_seed: int, iters: int, 
     side = np.zeros(max(m, 1), dtype=np.uint8)
     raw = np.zeros(max(n, 1), dtype=np.uint8)
     store.ctx.check(lib().abw_km_node(store.ctx.handle, C.c_void_p(ids.ctypes.data) if ids is not None else None, m, int(R),
-                                      int(base_seed) & 0xFFFFFFFF, int(iters), int(min_ndps), C.byref(out),
+                                      int(base_seed) & 0xFFFFFFFF, int(iters), int(chunk), int(min_ndps), C.byref(out),
                                       C.c_void_p(side.ctypes.data), C.c_void_p(raw.ctypes.data)))
     return out, side[:m], raw[:n]

@@ -108,6 +108,16 @@ int abw_sig_count_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len, 
                       const uint32_t* d_seg_scaf, const uint64_t* d_seg_start, const uint64_t* d_seg_end,
                       uint64_t n_seg, double* d_dims, int32_t* d_milli, uint32_t* d_counts);
 
+/* Known-answer aid (no counterpart in the reference): the finalisation divides counts by totals with a hand-scheduled
+ * fp64 sequence (reciprocal hoisted per total) that must equal the IEEE division of ref :171 bit for bit.  For the
+ * divisors t = t_lo + i * t_step, i < count (all in [1, 2^31)) and every dividend n in [0, t] -- all of them when
+ * t <= n_max, else the n_max + 1 values floor(j * t / n_max) -- *mismatches receives the number of (n, t) whose quotient
+ * differs from the compiler's own fp64 division on the device, and checksums[i] (host, may be NULL) the sum mod 2^64 of
+ * the quotients' bit patterns, which a host can compare with its own division.  tests/test_gpu_signature.py runs the
+ * whole domain a segment below 65 536 bases can produce (t in [1, 65535], n in [0, t]). */
+int abw_sig_selftest_division(abw_ctx* ctx, uint32_t t_lo, uint32_t t_step, uint32_t count, uint32_t n_max,
+                              uint64_t* mismatches, uint64_t* checksums);
+
 /* Whole stage with host buffers: segmentation on the GPU, H2D, counting, D2H.  This is what the
  * reference's FASTA loop (ref: src/abawaca-build.cpp:483-490) would call once per batch of
  * scaffolds instead of constructing Scaf objects.  dims/milli may be NULL. */
@@ -322,6 +332,9 @@ int abw_km_shard_finish(abw_ctx* ctx, float* d_centroids, double* d_inertia);
  *      tie: the library's side 0; :94-101 a scaffold goes to cluster1 iff at least half of its dps are there;
  *      :103-122 dps follow their scaffold; :125-132 both children need min_ndps dps).  Outputs as abw_sep_node:
  *      scaf_side [n_scaf] 1/2, dp_raw_side [node dps] 1/2, zero when there is no split candidate.
+ *      chunk: points per fp32 partial sum as in abw_km_run_dev -- it is part of the result's bits; 0 lets the library size
+ *      it for this device (abw_km_auto_chunk over the node's dps) and out->chunk reports what was used, so a caller that
+ *      wants the same bits on another device passes that value there.
  *      out->split = 1 says the sizes allow a split; ACCEPTING it (agreement level, the SCG gate
  *      ClusterQuality::is_split_better, ref: src/ClusterQuality.cpp:96-136) stays with the caller. */
 typedef struct {
@@ -332,10 +345,12 @@ typedef struct {
     int64_t ndps;           /* dps of the node */
     int64_t raw1;           /* dps on the smaller raw side */
     int64_t ndps1, ndps2;   /* children sizes after dps followed their scaffolds */
+    int32_t chunk;          /* points per fp32 partial sum the run used (= the argument, or the library's choice for 0) */
+    int32_t reserved;
 } abw_km_split;
 int abw_km_load(abw_ctx* ctx, const float* x, int32_t D, int64_t N, const int32_t* dp2scaf, int32_t S);
 int abw_km_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t R, uint32_t base_seed, int32_t iters,
-                int32_t min_ndps, abw_km_split* out, uint8_t* scaf_side, uint8_t* dp_raw_side);
+                int32_t chunk, int32_t min_ndps, abw_km_split* out, uint8_t* scaf_side, uint8_t* dp_raw_side);
 
 /* Host-buffer convenience: x is host [d][N]; outputs host. */
 int abw_km_run(abw_ctx* ctx, const float* x, int64_t N, int32_t d, int32_t R, uint32_t base_seed,

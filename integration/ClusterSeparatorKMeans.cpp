@@ -19,8 +19,23 @@ struct KmStore {
 	std::vector<float>	x;		// [D][N] z-scored over the root, dp id - 1 is the column (staging for abw_km_load)
 	int			restarts = 16, iterations = 20;
 	unsigned		base_seed = 20240;
+	int			chunk = -1;	// points per fp32 partial sum: -1 = km_default_chunk (device-independent), 0 = the library's choice for the device
 };
 KmStore g_km;
+
+// The chunk bounds the fp32 partial sums and so is part of the result's bits.  abw_km_node(chunk = 0) sizes it for the
+// device it runs on; the adapter instead passes the size that rule gives on a 256-CU device (MI355X) WHATEVER the device
+// is, so that a run is reproducible bit for bit across devices.  abw_km_split::chunk reports what was used.
+int32_t km_default_chunk(int64_t n, int R)
+{
+	const int tiles_r = (R + 31) / 32, cw = tiles_r >= 3 ? 4 : tiles_r;
+	const int pt = 4 / cw, gy = (tiles_r + cw - 1) / cw;
+	const int64_t slots = std::max<int64_t>(1, 256 / gy) * pt, tiles = (n + 31) / 32;
+	for(int64_t rounds = 1;; rounds++) {
+		const int64_t per = (tiles + slots * rounds - 1) / (slots * rounds);
+		if(per <= 64) return (int32_t)(32 * std::max<int64_t>(1, per));
+	}
+}
 
 void km_fail(const std::string& what)
 {
@@ -67,9 +82,9 @@ ClusterSeparatorKMeans::ClusterSeparatorKMeans(const ScafDpData& scaf_db, const 
 	ClusterSeparator(scaf_db, scg_db, clustering_db, threads_semaphore, new Result())
 {}
 
-void ClusterSeparatorKMeans::set_parameters(int restarts, int iterations, unsigned base_seed)
+void ClusterSeparatorKMeans::set_parameters(int restarts, int iterations, unsigned base_seed, int chunk)
 {
-	g_km.restarts = restarts; g_km.iterations = iterations; g_km.base_seed = base_seed;
+	g_km.restarts = restarts; g_km.iterations = iterations; g_km.base_seed = base_seed; g_km.chunk = chunk;
 }
 
 void ClusterSeparatorKMeans::shutdown()
@@ -116,7 +131,8 @@ bool ClusterSeparatorKMeans::separate()
 	const size_t n = node_dps.size();
 	abw_km_split out;
 	std::vector<uint8_t> side(m), raw(n);
-	if(abw_km_node(st.ctx, scaf_ids.data(), m, st.restarts, st.base_seed, st.iterations, (int32_t)this->cluster_ndps_threshold,
+	const int32_t chunk = st.chunk >= 0 ? st.chunk : km_default_chunk((int64_t)n, st.restarts);
+	if(abw_km_node(st.ctx, scaf_ids.data(), m, st.restarts, st.base_seed, st.iterations, chunk, (int32_t)this->cluster_ndps_threshold,
 			&out, side.data(), raw.data()) != ABW_OK)
 		km_fail("ClusterSeparatorKMeans: abw_km_node failed");
 	if(out.best_restart < 0 || out.raw1 < (int64_t)this->cluster_ndps_threshold)

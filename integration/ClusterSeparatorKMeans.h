@@ -39,7 +39,9 @@ public:
 	double		get_best_specificity() const		{return static_cast<Result*>(best_separation)->agreement;}
 	double		get_best_inertia() const		{return static_cast<Result*>(best_separation)->inertia;}
 	friend ostream&	operator << (ostream& os, ClusterSeparatorKMeans& cs);
-	static void	set_parameters(int restarts, int iterations, unsigned base_seed);	// defaults 16, 20, 20240
+	// defaults 16, 20, 20240, -1.  chunk = points per fp32 partial sum (part of the result's bits): -1 = a rule that depends
+	// on the node's size only (the same bits on any device), 0 = sized by the library for the device, else a multiple of 32
+	static void	set_parameters(int restarts, int iterations, unsigned base_seed, int chunk = -1);
 	static void	shutdown();
 protected:
 	void		separate_dimension(size_t) override	{}	// separate() is replaced as a whole

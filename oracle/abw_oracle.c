@@ -419,7 +419,8 @@ int abw_or_coverage(const uint32_t* seg_scaf, const uint64_t* seg_start, const u
     first[n_scaf + 1] = n_seg;
     for (uint64_t r = 0; r < n_reads; r++) {
         const uint64_t sc = read_scaf[r];
-        if (sc >= n_scaf || read_len[r] == 0) continue;                 /* ref :550-552: unknown reference name */
+        if (sc >= n_scaf) continue;                                     /* ref :550-552: unknown reference name */
+        /* read_len 0: e wraps like the reference's size_t (ref :233) */
         const uint64_t s = read_pos[r], e = read_pos[r] + read_len[r] - 1;
         for (uint64_t q = first[sc]; q < first[sc + 1]; q++) {
             if (s > seg_end[q]) continue;                               /* ref :235-236 */

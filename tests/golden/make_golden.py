@@ -241,8 +241,30 @@ def cov_case(tag, seed, n_scaf, n_samples=3, read_len=150):
     print(f"build_{tag}: lrn {len(files['lrn'])} B, names {len(files['names'])} B, info {len(files['info'])} B")
 
 
+def sep_c1_case():
+    """configs[0] (BASELINE.json): the 10 000-scaffold table of bench.py --c1 through the reference's separator, whole
+    recursion.  Only what the reference PRINTED is committed (its nodes table and scaf2cluster); the table itself is
+    regenerated from the seed by synth.make_features wherever the test runs."""
+    f = synth.make_features(20240, 10000, 25, 3)
+    with tempfile.TemporaryDirectory(prefix="abwgold_") as wd:
+        files = synth.write_build_dir(wd, f["milli"], f["dp2scaf"], f["scaf_len"], f["scg_scaf"], f["scg_id"], f["n_scg"])
+        prefix = os.path.join(wd, "ref")
+        subprocess.run([os.path.join(REF, "ref_sep_driver"), files["names"], files["fasta"], files["info"], files["lrn"], files["scg"],
+                        files["scg_list"], str(os.cpu_count() or 8), prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        nodes_txt = open(prefix + ".nodes.tsv").read()
+        nodes = np.loadtxt(prefix + ".nodes.tsv", dtype=np.float64, ndmin=2)
+        s2c = np.array([int(ln.split("\t")[1]) for ln in open(prefix + ".scaf2cluster.tsv")], dtype=np.int32)
+    # the nodes table as the driver printed it ("%.17g" doubles), without the timing column
+    lines = ["\t".join(ln.split("\t")[:11]) for ln in nodes_txt.strip().split("\n")]
+    np.savez_compressed(os.path.join(OUT, "recursion_c1.npz"), nodes=nodes[:, :11], nodes_text=np.array(lines), scaf2cluster=s2c,
+                        shape=np.array(f["milli"].shape), checksum=np.array([int(f["milli"].astype(np.int64).sum())]))
+    print(f"recursion_c1: N={f['milli'].shape[1]} D={f['milli'].shape[0]} nodes={len(nodes)} bins={int((nodes[:, 2] == 0).sum())}")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sig", "sep", "tinymt", "cov"]
+    if "c1" in which:
+        sep_c1_case()
     if "cov" in which:
         cov_case("a", 31, 24)
     if "sig" in which:

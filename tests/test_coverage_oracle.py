@@ -35,3 +35,13 @@ def test_chunked_accumulation_continues_the_same_sums(golden_dir):
     part = orc.coverage(g["seg_scaf"], g["seg_start"], g["seg_end"], int(g["n_scaf"]), rs[:cut], rp[:cut], rl[:cut])
     part = orc.coverage(g["seg_scaf"], g["seg_start"], g["seg_end"], int(g["n_scaf"]), rs[cut:], rp[cut:], rl[cut:], cov=part)
     assert np.array_equal(part.view(np.uint64), whole.view(np.uint64))
+
+
+def test_zero_length_read_follows_the_references_size_t_arithmetic():
+    """reference src/abawaca-build.cpp:233 computes e = pos + len - 1 in size_t: with len 0 at pos 0 it wraps and every
+    segment of the scaffold receives (end - start + 1) / (end - start + 1) = 1.0; at pos > 0 the segment holding pos - 1
+    and pos receives 0 bases.  (Not reachable from a SAM line the reference's parser accepts -- SEQ is never empty --
+    so this case has no golden: it restates the arithmetic.)"""
+    seg_scaf, seg_start, seg_end = [0, 0, 1, 1, 1], [1, 2001, 1, 1501, 3001], [2000, 4100, 1500, 3000, 4600]
+    cov = orc.coverage(seg_scaf, seg_start, seg_end, 2, [1, 0, 1], [0, 2500, 1500], [0, 0, 0])
+    assert cov.tolist() == [0.0, 0.0, 1.0, 1.0, 1.0]

@@ -67,6 +67,14 @@ def test_random_reads_bit_exact_vs_oracle(ctx, seed, n_scaf, n_reads):
     assert np.array_equal(cov2.view(np.uint64), ref2.view(np.uint64))
 
 
+def test_zero_length_reads_as_the_reference_computes_them(ctx):
+    seg_scaf, seg_start, seg_end = [0, 0, 1, 1, 1], [1, 2001, 1, 1501, 3001], [2000, 4100, 1500, 3000, 4600]
+    rs, rp, rl = [1, 0, 1, 0, 1], [0, 2500, 1500, 100, 0], [0, 0, 0, 150, 7]
+    cov = coverage.accumulate(ctx, seg_scaf, seg_start, seg_end, 2, rs, rp, rl)
+    ref = orc.coverage(seg_scaf, seg_start, seg_end, 2, rs, rp, rl)
+    assert np.array_equal(cov.view(np.uint64), ref.view(np.uint64)) and cov[3] == 1.0 and cov[1] == 0.0
+
+
 def test_empty_inputs(ctx):
     z = np.zeros(0)
     assert coverage.accumulate(ctx, z, z, z, 0, z, z, z).shape == (0,)

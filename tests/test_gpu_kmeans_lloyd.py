@@ -1,0 +1,67 @@
+"""K-means extension against an INDEPENDENT plain float64 Lloyd (tests/lloyd_textbook.py: two distances, two means) on
+configs[1]-shaped data, all 20 iterations: the documented tolerance of DESIGN.md §3.5.  The library runs one fp32
+discriminant per point on the MFMA and rounds its centroids to fp32 every iteration; the textbook run keeps doubles.
+Assignments may therefore differ at near-ties and the trajectories drift apart slightly; this test bounds both:
+
+  * after EVERY iteration (0 = assignment by the seed points ... 20) at most FLIP_TOL of the points sit in the other cluster
+  * the final inertia agrees to INERTIA_TOL (relative)
+
+(The bit-exact check is against oracle/abw_oracle.c, which restates the library's own fp32 arithmetic --
+tests/test_gpu_kmeans.py; the reference itself has no k-means: parity unpinned.)"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import lloyd_textbook as lt  # noqa: E402
+from abawaca_amd import _lib, kmeans  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+FLIP_TOL = 1e-5        # share of points in the other cluster than the float64 run, any iteration, any restart (measured r2: 0)
+INERTIA_TOL = 1e-6     # relative difference of the final inertia (measured r2: 4.1e-8)
+
+
+def test_twenty_iterations_against_float64_lloyd():
+    import torch
+    dev = torch.device("cuda", 0)
+    keys_t, _dp2scaf, _len, _genome, _G = bench.make_points(20241, 200_000, 10, dev)
+    x_t = bench.standardise(keys_t)                               # fp32 [189, N], what bench.py clusters
+    D, N = x_t.shape
+    x64 = x_t.to(torch.float64)
+    R, iters, seed = 4, 20, 20240
+    ctx = _lib.Context(0)
+    try:
+        chunk = kmeans.auto_chunk(ctx, N, R)
+        # the library's assignment after `it` iterations, for every it (a run of `it` iterations ends with an assign pass)
+        lib_assign, lib_inertia = [], None
+        for it in range(iters + 1):
+            a = torch.empty((R, N), dtype=torch.uint8, device=dev)
+            i = torch.empty(R, dtype=torch.float64, device=dev)
+            kmeans.kmeans_restarts_dev(ctx, x_t, N, D, R, seed, it, chunk, a, None, i)
+            ctx.synchronize()
+            lib_assign.append(a)
+            lib_inertia = i
+        worst_flip, worst_inertia, flips = 0.0, 0.0, []
+        for r in range(R):
+            row = []
+            for it, mem, _c0, _c1, inert in lt.lloyd(torch, x64, seed, r, iters):
+                frac = float((mem != lib_assign[it][r].to(torch.bool)).double().mean())
+                row.append(frac)
+            flips.append(row)
+            worst_flip = max(worst_flip, max(row))
+            worst_inertia = max(worst_inertia, abs(inert - float(lib_inertia[r])) / inert)
+            assert 0 < int(mem.sum()) < N
+        out = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out):
+            json.dump(dict(N=N, D=D, R=R, iters=iters, chunk=chunk, worst_flip_fraction=worst_flip, worst_inertia_rel=worst_inertia,
+                           flip_fraction_per_restart_and_iteration=flips), open(os.path.join(out, "lloyd_tolerance.json"), "w"))
+        assert worst_flip <= FLIP_TOL, flips
+        assert worst_inertia <= INERTIA_TOL
+    finally:
+        ctx.close()

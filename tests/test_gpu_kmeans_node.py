@@ -12,7 +12,7 @@ from abawaca_amd import _lib, kmeans, synth
 pytestmark = pytest.mark.gpu
 
 
-def _long_way(ctx, x, dp2scaf, ids, R, seed, iters, min_ndps):
+def _long_way(ctx, x, dp2scaf, ids, R, seed, iters, min_ndps, chunk=0):
     S = int(dp2scaf.max()) + 1
     ndps = np.bincount(dp2scaf, minlength=S)
     first = np.concatenate([[0], np.cumsum(ndps)[:-1]])
@@ -22,8 +22,8 @@ def _long_way(ctx, x, dp2scaf, ids, R, seed, iters, min_ndps):
     if n < 2 * min_ndps or n < 32:
         return dict(best=-1, split=0, n=n)
     xa = np.ascontiguousarray(x[:, dps])
-    assign, _c, inertia = kmeans.kmeans_restarts(ctx, xa, R, seed, iters, 0)
-    oa, _oc, oi = orc.kmeans(xa, R, seed, iters, kmeans.auto_chunk(ctx, n, R))
+    assign, _c, inertia = kmeans.kmeans_restarts(ctx, xa, R, seed, iters, chunk)
+    oa, _oc, oi = orc.kmeans(xa, R, seed, iters, chunk or kmeans.auto_chunk(ctx, n, R))
     assert np.array_equal(assign, oa) and np.array_equal(inertia, oi)          # the restarts are the oracle's
     best = int(np.argmin(inertia))
     side = assign[best]
@@ -59,6 +59,7 @@ def test_node_matches_the_long_way(seed, n_scaf, G):
                 out, side, raw = kmeans.km_node(store, ids, 8, 77, 6, min_ndps)
                 want = _long_way(ctx, x, f["dp2scaf"], ids, 8, 77, 6, min_ndps)
                 assert out.ndps == want["n"] and out.best_restart == want["best"] and out.split == want["split"]
+                assert out.chunk == (kmeans.auto_chunk(ctx, want["n"], 8) if want["best"] >= 0 else 0)      # what chunk = 0 became
                 if want["best"] < 0 or want.get("nosplit"):
                     assert not side.any() and not raw.any()
                     continue
@@ -67,6 +68,13 @@ def test_node_matches_the_long_way(seed, n_scaf, G):
                 assert np.array_equal(side, want["side"]) and np.array_equal(raw, want["raw"])
         out, side, raw = kmeans.km_node(store, None, 8, 77, 6, 100)
         assert out.split == 1 and out.agreement > 0.8                           # planted genomes come apart
+        # an explicit chunk: the node is the oracle's run with THAT chunk (reproducible whatever the device would pick)
+        for chunk in (96, 1024):
+            o2, s2, r2 = kmeans.km_node(store, nodes[1], 8, 77, 6, 100, chunk=chunk)
+            w2 = _long_way(ctx, x, f["dp2scaf"], nodes[1], 8, 77, 6, 100, chunk=chunk)
+            assert o2.chunk == chunk and o2.inertia == w2["inertia"] and np.array_equal(r2, w2["raw"]) and np.array_equal(s2, w2["side"])
+        with pytest.raises(_lib.AbwError):
+            kmeans.km_node(store, None, 8, 77, 6, 100, chunk=100)                # not a multiple of 32
         with pytest.raises(_lib.AbwError):
             kmeans.km_node(store, np.array([5, 3], dtype=np.int32), 8, 77, 6)    # not ascending
     finally:

@@ -128,3 +128,24 @@ def test_degenerate_columns_match_oracle(ctx):
     _compare_node(store, None, arrays)
     sub = np.sort(rng.choice(S, size=S // 10, replace=False)).astype(np.int32)      # small node: the scatter path
     _compare_node(store, sub, arrays, min_ndps=20)
+
+
+def test_configs0_whole_recursion_matches_the_reference(ctx, golden_dir):
+    """BASELINE configs[0]: the 10 000-scaffold table, the whole recursion.  tests/golden/recursion_c1.npz holds what the
+    reference's own separator (oracle/_ref/ref_sep_driver: reference objects, reference main loop) printed for it --
+    49 nodes with "%.17g" doubles, and scaf2cluster; the table is regenerated from its seed."""
+    g = np.load(os.path.join(golden_dir, "recursion_c1.npz"))
+    f = synth.make_features(20240, 10000, 25, 3)
+    assert tuple(g["shape"]) == f["milli"].shape and int(g["checksum"][0]) == int(f["milli"].astype(np.int64).sum())
+    S = len(f["scaf_len"])
+    off, ids = separator.scg_csr(f["scg_scaf"], f["scg_id"], S)
+    store = separator.ColumnStore(ctx, f["milli"], f["dp2scaf"], f["scaf_len"], off, ids, f["n_scg"])
+    nodes, s2c, _d2c = separator.binning(store)
+    ref = g["nodes"]
+    assert len(nodes) == len(ref) == 49
+    for a, r in zip(nodes, ref):
+        assert (a["id"], a["ndps"], a["split"], a["dim"]) == (int(r[0]), int(r[1]), int(r[2]), int(r[3]))
+        assert a["dim"] <= 0 or a["key"] / 1000.0 == r[4]
+        assert a["spec"] == r[5] and a["sens"] == r[6]                          # the reference's doubles, bit for bit
+        assert (a["c1"], a["n1"], a["c2"], a["n2"]) == (int(r[7]), int(r[8]), int(r[9]), int(r[10]))
+    assert np.array_equal(s2c, g["scaf2cluster"])

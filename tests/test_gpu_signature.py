@@ -160,3 +160,35 @@ def test_segmentation_with_many_N(ctx):
         assert n == len(exp)
         got = list(zip(t_scaf[:n].cpu().tolist(), t_st[:n].cpu().tolist(), t_en[:n].cpu().tolist()))
         assert got == exp
+
+
+def test_division_sequence_is_ieee_on_the_whole_domain():
+    """The finalisation's hand-scheduled fp64 division (recip_of / quot in abw_sig.hip) against the IEEE division the
+    reference performs (src/abawaca-build.cpp:171): EVERY (n, t) a segment below 65 536 bases can produce -- t in
+    [1, 65535], n in [0, t], 2.1e9 pairs -- compared on the device with the compiler's own division, and the quotients'
+    bit patterns of a few hundred divisors checked against numpy's division on the host; plus sampled dividends for
+    divisors up to 2^31 (segments of any length)."""
+    import ctypes as C
+    ctx = _lib.Context(0)
+    try:
+        L = _lib.lib()
+        bad = C.c_uint64(123)
+        sums = np.zeros(65535, dtype=np.uint64)
+        ctx.check(L.abw_sig_selftest_division(ctx.handle, 1, 1, 65535, 65535, C.byref(bad), C.c_void_p(sums.ctypes.data)))
+        assert bad.value == 0
+        for t in list(range(1, 400)) + list(range(401, 65535, 257)) + [65535, 65521, 49999, 32768, 32767]:
+            n = np.arange(t + 1, dtype=np.float64)
+            want = int((n / float(t)).view(np.uint64).sum(dtype=np.uint64))
+            assert int(sums[t - 1]) == want, t
+        # larger totals (windows above 65 535 bases): 4097 sampled dividends for each of 8191 divisors up to 2^31
+        step = 262139
+        cnt = (2 ** 31 - 1 - 65536) // step
+        sums2 = np.zeros(cnt, dtype=np.uint64)
+        ctx.check(L.abw_sig_selftest_division(ctx.handle, 65536, step, cnt, 4096, C.byref(bad), C.c_void_p(sums2.ctypes.data)))
+        assert bad.value == 0
+        for i in (0, 1, cnt // 2, cnt - 1):
+            t = 65536 + i * step
+            n = (np.arange(4097, dtype=np.uint64) * np.uint64(t) // np.uint64(4096)).astype(np.float64)
+            assert int(sums2[i]) == int((n / float(t)).view(np.uint64).sum(dtype=np.uint64))
+    finally:
+        ctx.close()

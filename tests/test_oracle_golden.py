@@ -69,6 +69,25 @@ def test_separator_matches_reference(path):
     assert np.array_equal(d2c, g["dp2cluster"])
 
 
+def test_configs0_recursion_matches_reference(golden_dir):
+    """BASELINE configs[0] (10 000 scaffolds, 182 columns, whole recursion): the oracle against what the reference's
+    separator printed (tests/golden/recursion_c1.npz, made by make_golden.py c1); the table comes from its seed."""
+    from abawaca_amd import synth
+    g = np.load(os.path.join(golden_dir, "recursion_c1.npz"))
+    f = synth.make_features(20240, 10000, 25, 3)
+    assert tuple(g["shape"]) == f["milli"].shape and int(g["checksum"][0]) == int(f["milli"].astype(np.int64).sum())
+    off, ids = orc.scg_csr(f["scg_scaf"], f["scg_id"], len(f["scaf_len"]))
+    nodes, s2c, _d2c = orc.recursive_bins(f["milli"], f["dp2scaf"], f["scaf_ndps"], f["scaf_len"], off, ids, f["n_scg"])
+    ref = g["nodes"]
+    assert len(nodes) == len(ref) == 49
+    for mine, r in zip(nodes, ref):
+        assert (mine["id"], mine["ndps"], mine["split"], mine["dim"]) == (int(r[0]), int(r[1]), int(r[2]), int(r[3]))
+        assert mine["dim"] <= 0 or mine["key"] / 1000.0 == r[4]
+        assert mine["spec"] == r[5] and mine["sens"] == r[6]
+        assert (mine["c1"], mine["n1"], mine["c2"], mine["n2"]) == tuple(int(v) for v in r[7:11])
+    assert np.array_equal(s2c, g["scaf2cluster"])
+
+
 def test_tinymt_kat(golden_dir):
     kat = json.load(open(os.path.join(golden_dir, "tinymt32_kat.json")))
     for seed, outs in kat["outputs"].items():
