@@ -133,6 +133,18 @@ class Context:
     def set_stream(self, hip_stream_ptr):
         self.check(lib().abw_ctx_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
 
+    shares_torch_stream = False
+
+    def use_torch_stream(self, on=True):
+        """Run the library on torch's current stream of this device (or back on its own): work that alternates between
+        the library and torch / RCCL is then ordered on the device and needs no host synchronisation in between."""
+        import torch
+        if on:
+            self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        else:
+            self.set_stream(0)
+        self.shares_torch_stream = bool(on)
+
     def prof_enable(self, on=True):
         self.check(lib().abw_prof_enable(self._h, 1 if on else 0))
 

@@ -93,17 +93,27 @@ def kmeans_sharded_dev(ctx: Context, t_x_local, first_point: int, N_total: int, 
     from . import multi
     d, N_local = t_x_local.shape
     run = ShardRun(ctx, t_x_local, N_local, first_point, N_total, d, R, base_seed, chunk)
-    ctx.synchronize()
+    # library stream != torch's: order the two by hand; shared (ctx.use_torch_stream): the device orders them
+    shared = ctx.shares_torch_stream
+
+    def lib_done():
+        if not shared:
+            ctx.synchronize()
+
+    def torch_done():
+        if not shared:
+            torch.cuda.synchronize(t_x_local.device)
+    lib_done()
     multi.combine_int_sum(run.init, dist)
     multi.combine_ordered_sum(run.moments, dist)
-    torch.cuda.synchronize(t_x_local.device)
+    torch_done()
     run.ready()
     for it in range(iters + 1):
         last = it == iters
         run.step(t_assign if last else None)
-        ctx.synchronize()
+        lib_done()
         multi.combine_ordered_sum(run.sums, dist)
-        torch.cuda.synchronize(t_x_local.device)
+        torch_done()
         run.update(last)
     run.finish(t_centroids, t_inertia)
     return run

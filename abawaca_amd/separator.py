@@ -300,7 +300,8 @@ def carve_shard(keys, dp2scaf, scaf_len, scaf_ids, scg_scaf=(), scg_id=()):
     S = len(scaf_len)
     ndps = np.bincount(dp2scaf, minlength=S)
     first = np.concatenate([[0], np.cumsum(ndps)[:-1]])
-    dps = np.concatenate([np.arange(first[s], first[s] + ndps[s]) for s in scaf_ids]).astype(np.int64)
+    cnt = ndps[scaf_ids].astype(np.int64)
+    dps = np.repeat(first[scaf_ids], cnt) + (np.arange(int(cnt.sum()), dtype=np.int64) - np.repeat(np.cumsum(cnt) - cnt, cnt))
     local_of = np.full(S, -1, dtype=np.int64)
     local_of[scaf_ids] = np.arange(len(scaf_ids))
     scg_scaf = np.asarray(scg_scaf, dtype=np.int64)

@@ -4,13 +4,22 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Headline (BASELINE.json "metric"): k-means point·iterations/s over the whole node on the workload
-of configs[1] (200k scaffolds -> ~0.8 M dps, 179 signature + 10 coverage dims, 64 restarts), plus
-the signature build in Gbp/s and the real separator in dimension·points/s as extra keys of the same
-JSON line.  A "step" is one full pass: one k-means run of `--iters` Lloyd iterations over all
-restarts, inputs already resident in HBM.  With N GPUs every rank runs its own 64 restarts on a
-replica of the points (the north-star's "restarts spread across GPUs"): weak scaling, no data-path
-collective; value = units of all ranks / max time over ranks.
+Headline (BASELINE.json "metric"): k-means point·iterations/s over the whole node, plus the signature
+build in Gbp/s and the real separator in dimension·points/s as extra keys of the same JSON line.  A
+"step" is one full pass: one k-means run of `--iters` Lloyd iterations over all restarts, inputs already
+resident in HBM.
+
+  N = 1 : configs[1] (200k scaffolds -> ~0.8 M dps, 179 signature + 10 coverage dims, 64 restarts) -- the
+          configuration the metric is quoted on; configs[2]'s job on the one GPU is an extra key.
+  N > 1 : configs[2] -- ONE job of 256 restarts on the 1M-scaffold table (~4.0 M dps x 199 dims), strong
+          scaling, under both partitions the north-star names:
+            "restarts" : rank k runs restarts [256k/N, 256(k+1)/N) on a replica of the points; no data-path
+                         collective, one gather of the inertias picks the winner
+            "points"   : rank k holds 1/N of the points and runs all 256 restarts; per pass one exchange of
+                         the cluster-1 partial sums (all-gather + rank-ordered fp64 adds over RCCL)
+          value = the better of the two (both are in the line); the old weak-scaling run (64 restarts per
+          GPU on the configs[1] table) stays as the extra key "weak_restarts".  The scaffold-sharded
+          separator leg is configs[4]'s shape: 2M scaffolds in total, 1/N of them on every rank.
 
 The JSON line also carries
   roofline     : the dominant kernel (km_step) against the dense fp32 MFMA peak, its duration taken
@@ -44,9 +53,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scaffolds", type=int, default=200_000)
-    ap.add_argument("--samples", type=int, default=10)
-    ap.add_argument("--restarts", type=int, default=64)
+    ap.add_argument("--scaffolds", type=int, default=0, help="0 = the configuration's own (configs[1]: 200 000; N > 1, configs[2]: 1 000 000)")
+    ap.add_argument("--samples", type=int, default=0, help="0 = the configuration's own (10 / 20)")
+    ap.add_argument("--restarts", type=int, default=0, help="restarts of the whole job; 0 = the configuration's own (64 / 256)")
+    ap.add_argument("--genomes", type=int, default=0, help="planted genomes; 0 = the configuration's own (100 / 200)")
+    ap.add_argument("--sep-scaffolds", type=int, default=2_000_000, help="N > 1: scaffolds of the sharded separator leg in total (configs[4])")
+    ap.add_argument("--sep-nodes", type=int, default=127, help="N > 1: nodes of the sharded recursion to run (0 = all)")
+    ap.add_argument("--no-c2", action="store_true", help="N = 1: skip the configs[2] job on the one GPU")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--chunk", type=int, default=0, help="points per fp32 partial sum; 0 = the library's choice (abw_km_auto_chunk)")
     ap.add_argument("--sig-mbp", type=int, default=1000, help="signature side bench: assembly size in Mbp")
@@ -61,7 +74,7 @@ def parse():
     return ap.parse_args()
 
 
-def make_points(seed, n_scaf, n_samples, device):
+def make_points(seed, n_scaf, n_samples, device, n_genomes=0):
     """configs[1]-shaped feature table generated on the GPU (same model as abawaca_amd.synth.make_features:
     per-genome GC -> expected canonical k-mer frequencies + sampling noise, truncated to thousandths;
     coverage c_{g,s}(1+N(0,0.1))).  -> (keys int32 [D, N] on device, dp2scaf, scaf_len, genome)"""
@@ -69,7 +82,7 @@ def make_points(seed, n_scaf, n_samples, device):
     from abawaca_amd import synth
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    G = max(2, n_scaf // 2000)
+    G = n_genomes or max(2, n_scaf // 2000)
     rng = synth.rng_for(seed)
     mer2dim, _names = synth.canonical_mer_table()
     gc = np.linspace(0.30, 0.70, G)
@@ -420,6 +433,134 @@ def recursion_c1(ctx):
     return res
 
 
+def make_scgs(seed, genome, G, n_scg=30):
+    """30 SCG names, 30 carrying scaffolds per genome.  -> (scg_scaf int32[M], scg_id int32[M])"""
+    rng = np.random.Generator(np.random.PCG64(seed + 77))
+    order = np.argsort(genome, kind="stable")
+    bounds = np.searchsorted(genome[order], np.arange(G + 1))
+    scg_scaf, scg_id = [], []
+    for g in range(G):
+        members = order[bounds[g]:bounds[g + 1]]
+        if len(members) == 0:
+            continue
+        k = min(n_scg, len(members))
+        scg_scaf.append(rng.choice(members, size=k, replace=False))
+        scg_id.append(np.arange(k))
+    return np.concatenate(scg_scaf).astype(np.int32), np.concatenate(scg_id).astype(np.int32)
+
+
+# BASELINE.json configs (SURVEY §8(d) generator parameters)
+CONFIGS = {1: dict(scaffolds=200_000, samples=10, genomes=100, restarts=64),
+           2: dict(scaffolds=1_000_000, samples=20, genomes=200, restarts=256),
+           4: dict(scaffolds=2_000_000, samples=20, genomes=400)}
+
+
+def timed_steps(step, warmup, steps, barrier, ctx, prof_name="km_step"):
+    """The bench contract: `warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides.
+    -> (elapsed seconds of this rank, launches of `prof_name`, their summed ms)"""
+    import torch
+    for _ in range(warmup):
+        step()
+    barrier()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_launch, ms_launch = ctx.prof_read(prof_name)
+    ctx.prof_enable(False)
+    return elapsed, n_launch, ms_launch
+
+
+def separator_leg(ctx, keys_host, dp2scaf, scaf_len, genome, G, seed, label, traffic=None):
+    """The real separator (reference ClusterSeparatorBySensitivitySpecificity with the SCG gate) on a resident table: the
+    root node through abw_sep_node, then the whole recursion of reference src/abawaca.cpp:95-197."""
+    from abawaca_amd import separator
+    D, N = keys_host.shape
+    S = len(scaf_len)
+    scg_scaf, scg_id = make_scgs(seed, genome, G)
+    so, si = separator.scg_csr(scg_scaf, scg_id, S)
+    t0 = time.perf_counter()
+    store = separator.ColumnStore(ctx, keys_host, dp2scaf, scaf_len, so, si, 30)
+    load_s = time.perf_counter() - t0
+    sep = separator.ClusterSeparatorHip(store)
+    sep.separate()
+    ctx.prof_reset(); ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    reps = 3
+    call_s = 0.0
+    for _ in range(reps):
+        sep.separate()
+        call_s += sep.last_call_s
+    wrap_s = (time.perf_counter() - t0) / reps            # with the Python glue (numpy buffers, ctypes structs)
+    sep_s = call_s / reps                                 # abw_sep_node alone: host node list in, host sides out
+    na, msa = ctx.prof_read("sep_accum")
+    ne, mse = ctx.prof_read("sep_eval")
+    ctx.prof_enable(False)
+    alg_bytes = 4.0 * D * N + 4.0 * N + 16.0 * D * 1001
+    res = dict(value=D * N / sep_s, unit="dimension*points/s", ms_per_node=sep_s * 1e3, ms_per_node_with_python_glue=round(wrap_s * 1e3, 3), node="root",
+               table=f"{label}: {S} scaffolds -> {N} dps x {D} dims, 30 SCGs x {G} genomes",
+               split=int(sep._res.split), dimension=int(sep._res.dimension), load_s=round(load_s, 2),
+               roofline=dict(kernel="sep_accum_kernel", bound="hbm", achieved=round(alg_bytes / (msa / na * 1e-3) / 1e9, 1),
+                             peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg_bytes / (msa / na * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             traffic=traffic, ms_per_launch=round(msa / na, 4), eval_ms=round(mse / max(ne, 1), 4)))
+    # the whole recursion on this table (reference src/abawaca.cpp:95-197 with the GPU separator)
+    t0 = time.perf_counter()
+    nodes_all, s2c_all, _d2c = separator.binning(store)
+    rec_s = time.perf_counter() - t0
+    bins = [r for r in nodes_all if not r["split"]]
+    # planted genomes vs bins: share of scaffolds whose bin's majority genome is their own
+    lab = np.asarray(genome)
+    order = np.argsort(s2c_all, kind="stable")
+    cuts = np.flatnonzero(np.diff(s2c_all[order])) + 1
+    agree = sum(int(np.bincount(g).max()) for g in np.split(lab[order], cuts) if len(g))
+    res["recursion"] = dict(s=round(rec_s, 3), c_abi_s=round(sum(r["call_s"] for r in nodes_all), 3), nodes=len(nodes_all), bins=len(bins),
+                            ms_per_node=round(rec_s / len(nodes_all) * 1e3, 3), planted_genomes=int(G),
+                            scaffolds_in_their_bins_majority_genome=round(agree / len(lab), 4),
+                            note="whole recursive binning of the table, GPU separator + Python work-list loop")
+    del store
+    return res
+
+
+def configs2_on_one_gpu(ctx, dev, args):
+    """configs[2]'s job -- 256 restarts on the 1M-scaffold table -- and the separator's recursion on that table, on ONE GPU:
+    the base of the strong-scaling curve `bench.py --gpus N` measures."""
+    import torch
+    from abawaca_amd import kmeans
+    cfg = CONFIGS[2]
+    keys_t, dp2scaf, scaf_len, genome, G = make_points(20242, cfg["scaffolds"], cfg["samples"], dev, cfg["genomes"])
+    D, N = keys_t.shape
+    x_t = standardise(keys_t)
+    R, iters = cfg["restarts"], args.iters
+    chunk = kmeans.auto_chunk(ctx, N, R)
+    t_in = torch.empty(R, dtype=torch.float64, device=dev)
+    t_as = torch.empty((R, N), dtype=torch.uint8, device=dev)
+
+    def step():
+        kmeans.kmeans_restarts_dev(ctx, x_t, N, D, R, 20240, iters, chunk, t_as, None, t_in)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+    steps = max(1, min(args.steps, 2))
+    elapsed, nl, ms = timed_steps(step, 1, steps, barrier, ctx)
+    ms_avg = ms / max(nl, 1)
+    tf = N * R * 4.0 * (D + 1) / (ms_avg * 1e-3) / 1e12
+    res = dict(workload=f"configs[2]: {cfg['scaffolds']} scaffolds -> {N} dps x {D} dims, ONE job of {R} restarts x {iters} iterations, one GPU",
+               value=N * R * iters * steps / elapsed, unit="point*iterations/s", ms_per_step=elapsed / steps * 1e3, chunk=chunk,
+               roofline=dict(kernel="km_step_kernel", bound="mfma", achieved=round(tf, 3), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                             frac=round(tf / FP32_MFMA_PEAK_TFLOPS, 4), ms_per_launch=round(ms_avg, 4), traffic=None))
+    del t_as, x_t
+    if not args.no_extras:
+        keys_host = keys_t.cpu().numpy()
+        del keys_t
+        res["separator"] = separator_leg(ctx, keys_host, dp2scaf, scaf_len, genome, G, 20242, "configs[2]")
+    return res
+
+
 def main():
     args = parse()
     import torch
@@ -443,65 +584,144 @@ def main():
     from abawaca_amd import _lib, kmeans, multi, separator, signature
     ctx = _lib.Context(dev_index)
 
-    # ---------------- workload: configs[1] -------------------------------------------------------
-    keys_t, dp2scaf, scaf_len, genome, G = make_points(20241, args.scaffolds, args.samples, dev)
-    D, N = keys_t.shape
-    x_t = standardise(keys_t)
-    R, iters = args.restarts, args.iters
-    if args.chunk == 0:
-        args.chunk = kmeans.auto_chunk(ctx, N, R)   # what the library itself picks for chunk = 0
-    # weak scaling: the job is world*R restarts, rank k owns restart ids [k*R, (k+1)*R) (abawaca_amd/multi.py)
-    first_restart, _n = multi.restart_range(world * R, rank, world)
-    seed = multi.rank_seed(20240, first_restart)
-    t_inertia = torch.empty(R, dtype=torch.float64, device=dev)
-    t_cent = torch.empty((R, 2, D), dtype=torch.float32, device=dev)
-    t_assign = torch.empty((R, N), dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
-
-    def step():
-        kmeans.kmeans_restarts_dev(ctx, x_t, N, D, R, seed, iters, args.chunk, t_assign, t_cent, t_inertia)
-
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ctx.prof_reset()
-    ctx.prof_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    n_launch, ms_launch = ctx.prof_read("km_step")
-    ctx.prof_enable(False)
-    if dist is not None:
-        elapsed = multi.max_elapsed(elapsed, dist, dev)
-        winner = multi.best_restart(t_inertia, first_restart, dist, dev)   # the job's result: (restart id, inertia, owner)
-        dist.barrier()
-    else:
+    # ---------------- workload: configs[1] on one GPU, configs[2] on several ---------------------
+    cfg_no = 1 if world == 1 else 2
+    cfg = CONFIGS[cfg_no]
+    args.scaffolds = args.scaffolds or cfg["scaffolds"]
+    args.samples = args.samples or cfg["samples"]
+    args.restarts = args.restarts or cfg["restarts"]
+    args.genomes = args.genomes or (cfg["genomes"] if args.scaffolds == cfg["scaffolds"] else 0)
+    keys_t, dp2scaf, scaf_len, genome, G = make_points(20240 + cfg_no, args.scaffolds, args.samples, dev, args.genomes)
+    D, N = keys_t.shape
+    x_t = standardise(keys_t)
+    R_job, iters = args.restarts, args.iters
+    legs = {}
+    if world == 1:
+        # ---- one GPU: the whole job
+        R = R_job
+        if args.chunk == 0:
+            args.chunk = kmeans.auto_chunk(ctx, N, R)   # what the library itself picks for chunk = 0
+        first_restart, seed = 0, 20240
+        t_inertia = torch.empty(R, dtype=torch.float64, device=dev)
+        t_cent = torch.empty((R, 2, D), dtype=torch.float32, device=dev)
+        t_assign = torch.empty((R, N), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+
+        def step():
+            kmeans.kmeans_restarts_dev(ctx, x_t, N, D, R, seed, iters, args.chunk, t_assign, t_cent, t_inertia)
+        elapsed, n_launch, ms_launch = timed_steps(step, args.warmup, args.steps, barrier, ctx)
         winner = multi.best_restart(t_inertia.cpu(), first_restart)
-    units_per_step = N * R * iters
-    value = world * units_per_step * args.steps / elapsed
+        value = N * R * iters * args.steps / elapsed
+        kernel_N, kernel_R = N, R
+        parallelism, scaling = "single GPU", "weak"
+        del t_assign
+    else:
+        # ---- leg A, "restarts": rank k owns restart ids [first, first + R_a) of the job's R_job, points replicated
+        first_restart, R_a = multi.restart_range(R_job, rank, world)
+        seed_a = multi.rank_seed(20240, first_restart)
+        chunk_a = args.chunk or kmeans.auto_chunk(ctx, N, R_a)
+        t_inertia = torch.empty(R_a, dtype=torch.float64, device=dev)
+        t_cent = torch.empty((R_a, 2, D), dtype=torch.float32, device=dev)
+        t_assign = torch.empty((R_a, N), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+
+        def step_a():
+            kmeans.kmeans_restarts_dev(ctx, x_t, N, D, R_a, seed_a, iters, chunk_a, t_assign, t_cent, t_inertia)
+        el_a, nl_a, ms_a = timed_steps(step_a, args.warmup, args.steps, barrier, ctx)
+        el_a = multi.max_elapsed(el_a, dist, dev)
+        winner_a = multi.best_restart(t_inertia, first_restart, dist, dev)     # the job's result: (restart id, inertia, owner)
+        dist.barrier()
+        del t_assign
+        legs["restarts"] = dict(value=N * R_job * iters * args.steps / el_a, ms_per_step=el_a / args.steps * 1e3, restarts_per_gpu=R_a,
+                                points_per_gpu=N, chunk=chunk_a, km_step_ms=round(ms_a / max(nl_a, 1), 4),
+                                collective="none on the data path; one gather of the inertias")
+        # ---- leg B, "points": rank k holds points [b[k], b[k+1]) and runs all R_job restarts; per pass one exchange of the
+        # cluster-1 partial sums [Rp][W] fp64.  The library's stream is torch's current stream for this leg, so its kernels,
+        # the RCCL collectives and the adds are ordered on the device without host synchronisation.
+        b = multi.shard_bounds(N, world)
+        n_loc = b[rank + 1] - b[rank]
+        x_loc = x_t[:, b[rank]:b[rank + 1]].contiguous()
+        torch.cuda.synchronize()
+        chunk_b = args.chunk or kmeans.auto_chunk(ctx, n_loc, R_job)
+        t_a = torch.empty((R_job, n_loc), dtype=torch.uint8, device=dev)
+        t_c2 = torch.empty((R_job, 2, D), dtype=torch.float32, device=dev)
+        t_i2 = torch.empty(R_job, dtype=torch.float64, device=dev)
+        ctx.use_torch_stream(args.backend == "nccl")
+
+        def step_b():
+            kmeans.kmeans_sharded_dev(ctx, x_loc, b[rank], N, R_job, 20240, iters, chunk_b, dist, t_a, t_c2, t_i2)
+        el_b, nl_b, ms_b = timed_steps(step_b, args.warmup, args.steps, barrier, ctx)
+        ctx.use_torch_stream(False)
+        el_b = multi.max_elapsed(el_b, dist, dev)
+        chk = t_i2.clone()
+        multi._all_reduce(chk, dist.ReduceOp.MAX, dist)                      # every rank must hold the same inertia bits
+        winner_b = multi.best_restart(t_i2.cpu(), 0)
+        Wp = (D + 1 + 31) // 32 * 32
+        legs["points"] = dict(value=N * R_job * iters * args.steps / el_b, ms_per_step=el_b / args.steps * 1e3, restarts_per_gpu=R_job,
+                              points_per_gpu=int(n_loc), chunk=chunk_b, km_step_ms=round(ms_b / max(nl_b, 1), 4),
+                              identical_on_all_ranks=bool(torch.equal(chk, t_i2)),
+                              exchange_bytes_per_pass=int(8 * ((R_job + 31) // 32 * 32) * Wp), passes_per_step=iters + 1,
+                              collective=f"all-gather + rank-ordered fp64 adds per pass over {args.backend}")
+        del t_a, x_loc
+        dist.barrier()
+        best = "points" if legs["points"]["value"] >= legs["restarts"]["value"] else "restarts"
+        value = legs[best]["value"]
+        elapsed = legs[best]["ms_per_step"] * 1e-3 * args.steps
+        if best == "points":
+            n_launch, ms_launch, kernel_N, kernel_R, winner, args.chunk = nl_b, ms_b, int(n_loc), R_job, winner_b, chunk_b
+        else:
+            n_launch, ms_launch, kernel_N, kernel_R, winner, args.chunk = nl_a, ms_a, N, R_a, winner_a, chunk_a
+        R = R_job
+        parallelism, scaling = f"{best} x{world} (strong scaling of one {R_job}-restart job; both partitions in `partitions`)", "strong"
+
+    # ---------------- multi-rank only: the old weak-scaling run (64 restarts per GPU on the configs[1] table) --------
+    weak = None
+    if dist is not None and not args.no_sep_sharded:
+        c1 = CONFIGS[1]
+        k1, _d, _l, _g, _G1 = make_points(20241, c1["scaffolds"], c1["samples"], dev, c1["genomes"])
+        x1 = standardise(k1)
+        D1, N1 = k1.shape
+        R1 = c1["restarts"]
+        f1, _n1 = multi.restart_range(world * R1, rank, world)
+        ch1 = kmeans.auto_chunk(ctx, N1, R1)
+        ti = torch.empty(R1, dtype=torch.float64, device=dev)
+
+        def step_w():
+            kmeans.kmeans_restarts_dev(ctx, x1, N1, D1, R1, multi.rank_seed(20240, f1), iters, ch1, None, None, ti)
+        el_w, _nl, _ms = timed_steps(step_w, 1, args.steps, barrier, ctx)
+        el_w = multi.max_elapsed(el_w, dist, dev)
+        weak = dict(value=world * N1 * R1 * iters * args.steps / el_w, unit="point*iterations/s", scaling="weak", ms_per_step=el_w / args.steps * 1e3,
+                    workload=f"configs[1] table ({N1} dps x {D1}), {R1} restarts per GPU = {world * R1} in total")
+        del k1, x1
+        dist.barrier()
 
     # ---------------- multi-rank only: the real separator with the SCAFFOLDS sharded over the ranks -----------
-    # (SURVEY §8(e), configs[4] shape: every rank holds its own scaffolds; per node one integer all-reduce of the
-    # histograms + min/max of the SCG flip values.)  Weak scaling: rank k holds a table of the configs[1] size
-    # generated from its own seed; the node timed is the root of the union.
+    # (SURVEY §8(e), configs[4]: 2M scaffolds in total, every rank holds 1/world of them -- generated from its own seed --
+    # per node one integer all-reduce of the histograms + min/max of the SCG flip values.)  The recursion is run for
+    # --sep-nodes nodes (0 = to the end).
     sep_sharded = None
     if dist is not None and not args.no_sep_sharded:
-        keys_k, dp2scaf_k, scaf_len_k, _g, _G = make_points(20241 + 1000 * rank, args.scaffolds, args.samples, dev)
+        c4 = CONFIGS[4]
+        s_loc = args.sep_scaffolds // world
+        keys_k, dp2scaf_k, scaf_len_k, genome_k, G4 = make_points(20244 + 1000 * rank, s_loc, c4["samples"], dev, c4["genomes"])
+        scg_scaf_k, scg_id_k = make_scgs(20244 + 1000 * rank, genome_k, G4)
+        so_k, si_k = separator.scg_csr(scg_scaf_k, scg_id_k, s_loc)
         keys_k_host = keys_k.cpu().numpy()
+        n_k = keys_k.shape[1]
+        del keys_k
         t0 = time.perf_counter()
         dv, do = multi.global_dictionary(keys_k_host, dist, dev)
         dict_s = time.perf_counter() - t0
         sctx = _lib.Context(dev_index)
-        sstore = separator.ShardedColumnStore(sctx, keys_k_host, dp2scaf_k, scaf_len_k, dv, do)
+        t0 = time.perf_counter()
+        sstore = separator.ShardedColumnStore(sctx, keys_k_host, dp2scaf_k, scaf_len_k, dv, do, so_k, si_k, 30)
+        load_s = time.perf_counter() - t0
         nd = separator.separate_sharded(sstore, None, dist, dev)          # warm-up (RCCL channels, buffers)
         barrier()
         t0 = time.perf_counter()
@@ -510,40 +730,25 @@ def main():
             nd = separator.separate_sharded(sstore, None, dist, dev)
         torch.cuda.synchronize()
         sh_s = multi.max_elapsed((time.perf_counter() - t0) / reps, dist, dev)
-        n_all = multi.sum_counts([keys_k.shape[1]], dist, dev)[0]
-        sep_sharded = dict(value=D * n_all / sh_s, unit="dimension*points/s", ms_per_node=sh_s * 1e3, node="root of the union of the ranks' tables",
-                           dps_total=int(n_all), split=int(nd.out.split), dimension=int(nd.out.dimension), key=int(nd.out.key),
-                           exchange_bytes_per_node=int(nd.hist.numel() * 8), dictionary_s=round(dict_s, 2),
-                           collective=f"all-reduce SUM int64 x{nd.hist.numel()} per node over {args.backend}")
-        del sstore, nd
-        sctx.close()
-        dist.barrier()
-
-    # ---------------- multi-rank only: k-means with the POINTS sharded over the ranks ---------------------------
-    # (SURVEY §8(e) second way, configs[2] shape: every rank holds its own points, the same R restarts run over
-    # the union; per pass one exchange of the cluster-1 partial sums [Rp][W] fp64, added in rank order.)
-    km_sharded = None
-    if dist is not None and not args.no_sep_sharded:
-        n_loc = (N // 32) * 32                                              # whole MFMA tiles per shard
-        x_loc = x_t[:, :n_loc].contiguous()
-        n_tot = n_loc * world
-        t_a = torch.empty((R, n_loc), dtype=torch.uint8, device=dev)
-        t_c2 = torch.empty((R, 2, D), dtype=torch.float32, device=dev)
-        t_i2 = torch.empty(R, dtype=torch.float64, device=dev)
-        it_sh = max(2, iters // 4)
-        kmeans.kmeans_sharded_dev(ctx, x_loc, rank * n_loc, n_tot, R, 20240, 1, args.chunk, dist, t_a, t_c2, t_i2)   # warm-up
+        n_all = multi.sum_counts([n_k], dist, dev)[0]
+        hist_words = int(nd.hist.numel())
+        root = (int(nd.out.split), int(nd.out.dimension), int(nd.out.key))
         barrier()
         t0 = time.perf_counter()
-        kmeans.kmeans_sharded_dev(ctx, x_loc, rank * n_loc, n_tot, R, 20240, it_sh, args.chunk, dist, t_a, t_c2, t_i2)
-        ctx.synchronize(); torch.cuda.synchronize()
-        ks = multi.max_elapsed(time.perf_counter() - t0, dist, dev)
-        chk = t_i2.clone()
-        multi._all_reduce(chk, dist.ReduceOp.MAX, dist)                      # every rank must hold the same inertia bits
-        km_sharded = dict(value=n_tot * R * it_sh / ks, unit="point*iterations/s", points_total=int(n_tot), restarts=R, iterations=it_sh,
-                          ms_per_iteration=round(ks / (it_sh + 1) * 1e3, 3), identical_on_all_ranks=bool(torch.equal(chk, t_i2)),
-                          exchange_bytes_per_pass=int(8 * ((R + 31) // 32 * 32) * ((D + 1 + 31) // 32 * 32)),
-                          collective=f"all-gather + rank-ordered fp64 adds per pass over {args.backend}")
-        del x_loc, t_a
+        nodes_sh, _s2c = separator.binning_sharded(sstore, lambda ids: separator.separate_sharded(sstore, ids, dist, dev),
+                                                   max_nodes=args.sep_nodes or (1 << 30))
+        torch.cuda.synchronize()
+        rec_s = multi.max_elapsed(time.perf_counter() - t0, dist, dev)
+        sep_sharded = dict(value=D * n_all / sh_s, unit="dimension*points/s", ms_per_node=sh_s * 1e3, node="root of the union of the ranks' tables",
+                           workload=f"configs[4] shape: {s_loc * world} scaffolds in total, {s_loc} per rank, {c4['samples']} coverage samples, 30 SCGs",
+                           dps_total=int(n_all), split=root[0], dimension=root[1], key=root[2],
+                           exchange_bytes_per_node=hist_words * 8, dictionary_s=round(dict_s, 2), load_s=round(load_s, 2),
+                           recursion=dict(nodes=len(nodes_sh), s=round(rec_s, 3), ms_per_node=round(rec_s / max(1, len(nodes_sh)) * 1e3, 3),
+                                          splits=int(sum(r["split"] for r in nodes_sh)), whole=bool(args.sep_nodes == 0 or len(nodes_sh) < args.sep_nodes),
+                                          exchange_bytes_total=hist_words * 8 * len(nodes_sh)),
+                           collective=f"all-reduce SUM int64 x{hist_words} per node over {args.backend}")
+        del sstore, nd
+        sctx.close()
         dist.barrier()
 
     # ---------------- multi-rank only: signature build, scaffolds dealt to the ranks (no exchange) ---------------
@@ -589,7 +794,7 @@ def main():
     # the 7d-based figure is reported beside it (it can exceed the peak: work the algebra removed).
     flops_per_unit = 4 * (D + 1)
     ms_avg = ms_launch / max(n_launch, 1)
-    achieved = N * R * flops_per_unit / (ms_avg * 1e-3) / 1e12
+    achieved = kernel_N * kernel_R * flops_per_unit / (ms_avg * 1e-3) / 1e12      # per launch: the points and restarts ONE GPU's launch covers
     # HBM bytes per launch from the committed PMC passes (profiles/pmc_r01.json; collected on this
     # workload with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as the microarchitecture guide says)
     pmc_all = {}
@@ -597,27 +802,30 @@ def main():
         pmc_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_r01.json")))
     except Exception:
         pmc_all = {}
-    default_workload = (args.scaffolds, args.samples, R, args.sig_mbp) == (200000, 10, 64, 1000)
+    default_workload = world == 1 and (args.scaffolds, args.samples, R, args.sig_mbp) == (200000, 10, 64, 1000)
     traffic = pmc_all.get("km_step_kernel", {}).get("hbm_bytes_per_launch") if default_workload else None
     roofline = dict(kernel="km_step_kernel", bound="mfma", achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TFLOPS,
                     unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                     launches=n_launch, ms_per_launch=round(ms_avg, 4), flops_per_unit=flops_per_unit,
                     survey_flops_per_unit=7 * D,
-                    achieved_at_survey_count=round(N * R * 7.0 * D / (ms_avg * 1e-3) / 1e12, 3),
-                    hbm_algorithmic_GBs=round((4.0 * N * D + 4.0 * R * (D + 1)) / (ms_avg * 1e-3) / 1e9, 1))
+                    achieved_at_survey_count=round(kernel_N * kernel_R * 7.0 * D / (ms_avg * 1e-3) / 1e12, 3),
+                    hbm_algorithmic_GBs=round((4.0 * kernel_N * D + 4.0 * kernel_R * (D + 1)) / (ms_avg * 1e-3) / 1e9, 1),
+                    per_launch=dict(points=int(kernel_N), restarts=int(kernel_R)))
 
     out = dict(metric="k-means point·iterations/sec (whole node) + signature build Gbp/s",
                value=value, unit="point*iterations/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-               ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+               ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling=scaling, vs_baseline=None,
                dtype="f32", data="synthetic",
-               config=dict(workload=f"configs[1]: {args.scaffolds} scaffolds -> {N} dps, 179 signature + {args.samples} coverage dims "
-                                    f"(z-scored), k=2, {R} restarts x {iters} Lloyd iterations per GPU, chunk {args.chunk}",
-                           parallelism=f"restarts x{world}" if world > 1 else "single GPU"),
+               config=dict(workload=f"configs[{cfg_no}]: {args.scaffolds} scaffolds -> {N} dps, 179 signature + {args.samples} coverage dims "
+                                    f"(z-scored), {G} planted genomes, k=2, ONE job of {R} restarts x {iters} Lloyd iterations, chunk {args.chunk}",
+                           parallelism=parallelism),
                roofline=roofline, best_restart=dict(id=int(winner[0]), inertia=float(winner[1]), rank=int(winner[2])))
+    if legs:
+        out["partitions"] = legs
+    if weak is not None:
+        out["weak_restarts"] = weak
     if sep_sharded is not None:
         out["separator_sharded"] = sep_sharded
-    if km_sharded is not None:
-        out["kmeans_point_sharded"] = km_sharded
     if sig_sharded is not None:
         out["signature_sharded"] = sig_sharded
 
@@ -625,47 +833,8 @@ def main():
     keys_host = None
     if not args.no_extras:
         keys_host = keys_t.cpu().numpy()
-        t0 = time.perf_counter()
-        store = separator.ColumnStore(ctx, keys_host, dp2scaf, scaf_len)
-        load_s = time.perf_counter() - t0
-        sep = separator.ClusterSeparatorHip(store)
-        sep.separate()
-        ctx.prof_reset(); ctx.prof_enable(True)
-        t0 = time.perf_counter()
-        reps = 3
-        call_s = 0.0
-        for _ in range(reps):
-            sep.separate()
-            call_s += sep.last_call_s
-        wrap_s = (time.perf_counter() - t0) / reps            # with the Python glue (numpy buffers, ctypes structs)
-        sep_s = call_s / reps                                 # abw_sep_node alone: host node list in, host sides out
-        na, msa = ctx.prof_read("sep_accum")
-        ne, mse = ctx.prof_read("sep_eval")
-        ctx.prof_enable(False)
-        alg_bytes = 4.0 * D * N + 4.0 * N + 16.0 * D * 1001
-        out["separator"] = dict(value=D * N / sep_s, unit="dimension*points/s", ms_per_node=sep_s * 1e3, ms_per_node_with_python_glue=round(wrap_s * 1e3, 3), node="root",
-                                split=int(sep._res.split), dimension=int(sep._res.dimension), load_s=round(load_s, 2),
-                                roofline=dict(kernel="sep_accum_kernel", bound="hbm", achieved=round(alg_bytes / (msa / na * 1e-3) / 1e9, 1),
-                                              peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg_bytes / (msa / na * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                              traffic=pmc_all.get("sep_accum_kernel", {}).get("hbm_bytes_per_launch_raw") if default_workload else None,
-                                              ms_per_launch=round(msa / na, 4), eval_ms=round(mse / max(ne, 1), 4)))
-        # the whole recursion on this table (reference src/abawaca.cpp:95-197 with the GPU separator): every node is one
-        # abw_sep_node call on the resident column store, given its scaffold list
-        t0 = time.perf_counter()
-        nodes_all, s2c_all, _d2c = separator.binning(store)
-        rec_s = time.perf_counter() - t0
-        bins = [r for r in nodes_all if not r["split"]]
-        # planted genomes vs bins: share of scaffolds whose bin's majority genome is their own
-        lab = np.asarray(genome)
-        agree = 0
-        for r in bins:
-            mem = lab[s2c_all == r["id"]]
-            if len(mem):
-                agree += int(np.bincount(mem).max())
-        out["separator"]["recursion"] = dict(s=round(rec_s, 3), c_abi_s=round(sum(r["call_s"] for r in nodes_all), 3), nodes=len(nodes_all), bins=len(bins), ms_per_node=round(rec_s / len(nodes_all) * 1e3, 3),
-                                             planted_genomes=int(G), scaffolds_in_their_bins_majority_genome=round(agree / len(lab), 4),
-                                             note="whole recursive binning of the configs[1] table, GPU separator + Python work-list loop")
-        del store
+        out["separator"] = separator_leg(ctx, keys_host, dp2scaf, scaf_len, genome, G, 20240 + cfg_no, f"configs[{cfg_no}]",
+                                         pmc_all.get("sep_accum_kernel", {}).get("hbm_bytes_per_launch_raw") if default_workload else None)
 
         blob, off = make_assembly_blob(20244, args.sig_mbp)
         total = len(blob)
@@ -759,13 +928,20 @@ def main():
         del t_ascii, t_dims
         out["lrn"] = lrn_bench(ctx, world == 1 and not args.no_cpu)
 
+    # ---------------- one GPU: configs[2]'s job and table on this GPU (the base of the N > 1 strong-scaling runs) ------
+    x_host = x_t[:, :min(N, 200_000)].cpu().numpy() if (world == 1 and not args.no_cpu) else None
+    if world == 1 and not args.no_c2:
+        del x_t, keys_t
+        x_t = keys_t = None
+        torch.cuda.empty_cache()
+        out["configs2_one_gpu"] = configs2_on_one_gpu(ctx, dev, args)
+
     # ---------------- optional: configs[0], the reference's own CPU-runnable case, end to end -----------------
     if args.c1 and world == 1:
         out["recursion_c1"] = recursion_c1(ctx)
 
     # ---------------- CPU baselines (rank 0, N = 1 only) -------------------------------------------
     if world == 1 and not args.no_cpu:
-        x_host = x_t[:, :min(N, 200_000)].cpu().numpy()
         out["cpu_baseline"] = cpu_kmeans_baseline(x_host, R, iters, args.chunk)
         out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         if not args.no_extras:

@@ -93,6 +93,7 @@ def test_kmeans_64_restarts_of_configs1(table):
     keys_t = table["keys_t"]
     D, N = keys_t.shape
     x_t = bench.standardise(keys_t)
+    torch.cuda.synchronize()          # the library runs on its own stream: x_t must be complete before it reads it
     dev = x_t.device
     ctx = _lib.Context(0)
     try:

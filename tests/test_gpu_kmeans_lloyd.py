@@ -32,6 +32,7 @@ def test_twenty_iterations_against_float64_lloyd():
     dev = torch.device("cuda", 0)
     keys_t, _dp2scaf, _len, _genome, _G = bench.make_points(20241, 200_000, 10, dev)
     x_t = bench.standardise(keys_t)                               # fp32 [189, N], what bench.py clusters
+    torch.cuda.synchronize()          # the library runs on its own stream: x_t must be complete before it reads it
     D, N = x_t.shape
     x64 = x_t.to(torch.float64)
     R, iters, seed = 4, 20, 20240
