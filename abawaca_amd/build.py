@@ -26,7 +26,10 @@ def build_tables(ctx: Context, names: Sequence[str], ascii_blob: np.ndarray, sca
                  window: int = 2000):
     """names/ascii_blob/scaf_off: the assembly (any order; the reference keeps a std::map by name, :482-488).
     samples: per SAM file (dimension name = the file's path, :511-512; read_scaf = index into names or 0xFFFFFFFF,
-    read_pos1 = SAM POS, read_len, read_flag), in the order of the reference's glob.
+    read_pos1 = SAM POS, read_len, read_flag[, read_nsnps]), in the order of the reference's glob.  read_nsnps =
+    coverage.count_snps(CIGAR, MD:Z) per record; this function applies the whole filter of ref :546 (unmapped, more than
+    15 SNPs, secondary) before both the coverage sums and the .info coverage.  Without the sixth field no record is taken
+    to carry an MD:Z tag.
     -> dict(lrn=bytes, names=bytes, info=bytes, milli=int32[n_dps, 179 + n_samples])"""
     blob = np.ascontiguousarray(ascii_blob, dtype=np.uint8)
     off = np.ascontiguousarray(scaf_off, dtype=np.int64)
@@ -36,8 +39,9 @@ def build_tables(ctx: Context, names: Sequence[str], ascii_blob: np.ndarray, sca
     n_seg = len(seg_scaf)
     cols = [r["milli"].astype(np.int64)]
     nbps = np.zeros(n_scaf, dtype=np.int64)
-    for s, (_dim, rs, rp1, rl, rf) in enumerate(samples):
-        fs, fp, fl = coverage.filter_reads(rs, rp1, rl, rf)
+    for s, smp in enumerate(samples):
+        _dim, rs, rp1, rl, rf = smp[:5]
+        fs, fp, fl = coverage.filter_reads(rs, rp1, rl, rf, smp[5] if len(smp) > 5 else None)
         cov = coverage.accumulate(ctx, seg_scaf, seg_start, seg_end, n_scaf, fs, fp, fl)
         cols.append(coverage.milli(cov)[:, None])
         if s == this_sample:                                  # Scaf::nbps, ref :242-243: every accepted read of a known scaffold

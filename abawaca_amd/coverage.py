@@ -1,8 +1,10 @@
 """Row N1 — per-segment read coverage on the GPU (abw_cov_accumulate), host-side glue.
 
-`filter_reads` is the part of reference src/abawaca-build.cpp:546 the caller keeps (unmapped, secondary;
-the > 15 SNPs rule needs the MD tag and stays with the reference's SAM parser) and the 1-based SAM POS ->
-0-based position of reference src/ReadMapping.cpp:41."""
+`filter_reads` is the filter of reference src/abawaca-build.cpp:546 -- unmapped (FLAG 0x4), more than max_snps = 15
+SNPs (:437), secondary (FLAG 0x100) -- and the 1-based SAM POS -> 0-based position of reference src/ReadMapping.cpp:41.
+The SNP count of a mapping is what the reference's ReadMapping::determine_snps collects (src/ReadMapping.cpp:78-185):
+`count_snps` restates the count for callers that parse SAM text themselves; a caller that keeps the reference's
+SAMReader (integration/abawaca_build_hip.cpp) applies the reference's own filter instead."""
 from __future__ import annotations
 
 import ctypes as C
@@ -12,10 +14,40 @@ import numpy as np
 from ._lib import Context, lib
 
 
-def filter_reads(read_scaf, read_pos1, read_len, read_flag):
-    """-> (scaf u32, pos0 u64, len u32) of the mappings the reference accumulates, order kept."""
+MAX_SNPS = 15      # reference src/abawaca-build.cpp:437
+
+
+def count_snps(cigar: str, mdz: str) -> int:
+    """num_snps() of a mapping (reference src/ReadMapping.cpp:78-185): without an MD:Z tag nothing is collected (:80-81);
+    otherwise one SNP per mismatched base and per deleted base of the MD:Z string (:105-121) plus one per 'I' operation
+    of the CIGAR string, whatever its length (:158-171).  mdz: the tag's value with or without the "MD:Z:" prefix."""
+    if not mdz:
+        return 0
+    md = mdz[5:] if mdz.startswith("MD:Z:") else mdz
+    n, i = 0, 0
+    while i < len(md) and md[i].isdigit():
+        i += 1
+    while i < len(md):
+        if md[i] == "^":
+            i += 1
+            while i < len(md) and not md[i].isdigit():
+                n += 1
+                i += 1
+        else:
+            n += 1
+            i += 1
+        while i < len(md) and md[i].isdigit():
+            i += 1
+    return n + sum(1 for ch in cigar if ch == "I")
+
+
+def filter_reads(read_scaf, read_pos1, read_len, read_flag, read_nsnps=None):
+    """-> (scaf u32, pos0 u64, len u32) of the mappings the reference accumulates, order kept.  read_nsnps: per mapping
+    count_snps(CIGAR, MD:Z); None = no mapping carries an MD:Z tag (then the reference counts no SNPs either)."""
     read_flag = np.asarray(read_flag)
     keep = ((read_flag & 0x4) == 0) & ((read_flag & 0x100) == 0)
+    if read_nsnps is not None:
+        keep &= np.asarray(read_nsnps) <= MAX_SNPS
     pos0 = np.asarray(read_pos1, dtype=np.int64)[keep] - 1
     return (np.ascontiguousarray(np.asarray(read_scaf, dtype=np.uint32)[keep]),
             np.ascontiguousarray(pos0.astype(np.uint64)),

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 
 int abw_sig_static_init(abw_ctx* ctx);   // abw_sig.hip
+void abw_sig_pipe_free(abw_ctx* ctx);    // abw_sig.hip
 
 int abw_fail(abw_ctx* ctx, int code, const char* fmt, ...)
 {
@@ -152,6 +153,7 @@ void abw_ctx_destroy(abw_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     abw_sep_free(ctx);
     abw_kmstore_free(ctx);
+    abw_sig_pipe_free(ctx);
     for (auto& r : ctx->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto& e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (auto& b : ctx->scratch) abw_release(b);

@@ -78,6 +78,8 @@ struct abw_km_store {
     std::vector<int32_t> h_scaf_first, h_scaf_ndps, h_node_ids, h_node_dpoff;
 };
 
+struct abw_sig_pipe;                   // abw_sig.hip: streams, pinned staging ring and events of the pipelined abw_sig_build
+
 struct abw_ctx {
     int         device = 0;
     abw_km_state km;
@@ -92,6 +94,7 @@ struct abw_ctx {
     int         num_cu = 256;
     void*       pinned = nullptr;      // grow-only pinned host staging (results of a call leave the GPU in one batch)
     size_t      pinned_cap = 0;
+    abw_sig_pipe* sig_pipe = nullptr;
     void*       sig_static = nullptr;  // this device's address of abw_sig.hip's static workspace (abw_sig_segment_static)
     abw_devbuf  lrn_table;             // resident [n_cols][ld] doubles of the cluster writer (abw_lrn_table_load)
     int64_t     lrn_ld = 0;

@@ -24,6 +24,11 @@
 #include <string.h>
 #include <algorithm>
 #include <thread>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 
 namespace {
 
@@ -174,9 +179,14 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
     const uint8_t* __restrict__ ascii, uint64_t total_len, const uint64_t* __restrict__ scaf_off,
     const uint32_t* __restrict__ seg_scaf, const uint64_t* __restrict__ seg_start,
     const uint64_t* __restrict__ seg_end, uint64_t n_seg,
-    double* __restrict__ dims, int32_t* __restrict__ milli, uint32_t* __restrict__ counts)
+    double* __restrict__ dims, int32_t* __restrict__ milli, uint32_t* __restrict__ counts,
+    const uint64_t* __restrict__ n_seg_dev, uint32_t scaf_base)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[4][LDS_WORDS];
+    // n_seg_dev: the count is still on the device (pipelined build: no read-back between segmentation and counting);
+    // n_seg is then the capacity of the tables.  scaf_base: seg_scaf holds scaffold numbers of the whole job, the blob
+    // and scaf_off are one chunk of it that starts at scaffold scaf_base.
+    if (n_seg_dev) n_seg = min(n_seg, *n_seg_dev);
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: segment bookkeeping stays scalar
     uint32_t* tab = lds[wid];
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        const uint64_t sb = scaf_off[seg_scaf[s]];
+        const uint64_t sb = scaf_off[seg_scaf[s] - scaf_base];
         const uint64_t seg_b = sb + seg_start[s] - 1;           // absolute, inclusive
         const uint64_t seg_e = sb + seg_end[s];                 // absolute, exclusive
         const uint64_t a0 = seg_b & ~(uint64_t)15;
@@ -507,7 +517,8 @@ __global__ __launch_bounds__(256) void seg_emit_kernel(const uint8_t* __restrict
                                                       const uint64_t* __restrict__ blk_prefix,
                                                       const ScafSeg* __restrict__ info, const uint64_t* __restrict__ seg_off,
                                                       uint64_t n_seg, uint32_t* __restrict__ seg_scaf,
-                                                      uint64_t* __restrict__ seg_start, uint64_t* __restrict__ seg_end)
+                                                      uint64_t* __restrict__ seg_start, uint64_t* __restrict__ seg_end,
+                                                      uint32_t scaf_base)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -564,7 +575,7 @@ __global__ __launch_bounds__(256) void seg_emit_kernel(const uint8_t* __restrict
     }
     if (active) {
         const uint64_t rel = pos - sb;                     // 0-based inside the scaffold
-        seg_scaf[g] = (uint32_t)s;
+        seg_scaf[g] = (uint32_t)s + scaf_base;
         seg_end[g] = rel + 1;
         if (j == 0) seg_start[g] = 1;                      // ref :209 sit = seq.begin()
         if (j + 1 < nseg && g + 1 < n_seg) seg_start[g + 1] = rel + 2;      // ref :221-222 sit = it + 1
@@ -653,6 +664,317 @@ int upload_tables(abw_ctx* ctx)
     if (ctx->device < 64) g_tables_uploaded[ctx->device] = true;
     return ABW_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// abw_sig_build: host buffers in, host buffers out, as a PIPELINE over chunks of whole scaffolds.
+//   host worker threads copy chunk i+1 of the caller's (pageable) sequence into a pinned staging buffer
+//   | copy stream: H2D of chunk i+1 | compute stream: segmentation + counting of chunk i (no read-back in between: the
+//   segment count stays on the device, seg_emit and sig_count run over the chunk's capacity) | copy-back stream: D2H of
+//   chunk i-1's tables into pinned memory | host worker threads copy them to the caller's arrays.
+// PCIe runs both ways at once and the kernels (1.4 ms per Gbp) hide behind the copies; what bounds the rate is the
+// host's copy into / out of pinned memory, hence several threads.  Chunks hold whole scaffolds, so the segmentation is
+// exactly the one of the unchunked call.
+// ---------------------------------------------------------------------------------------------
+constexpr uint64_t PIPE_CHUNK = 48ull << 20;      // bytes of sequence per chunk (a longer scaffold makes a longer chunk)
+constexpr int PIPE_SLOTS = 4;
+
+// A small persistent pool of host threads for the staging copies (created on first use, lives until the process ends).
+class CopyPool {
+public:
+    static CopyPool& get() { static CopyPool* p = new CopyPool(); return *p; }
+    // memcpy(dst, src, n) cut into slices that the workers run; *pending counts the slices not yet done
+    void submit(void* dst, const void* src, size_t n, std::atomic<int>* pending)
+    {
+        if (n == 0) return;
+        const size_t slice = 2u << 20;
+        std::vector<std::function<void()>> jobs;
+        for (size_t o = 0; o < n; o += slice) {
+            const size_t len = std::min(slice, n - o);
+            pending->fetch_add(1);
+            jobs.push_back([=] { memcpy((char*)dst + o, (const char*)src + o, len); pending->fetch_sub(1); });
+        }
+        { std::lock_guard<std::mutex> l(m_); for (auto& j : jobs) q_.push_back(std::move(j)); }
+        cv_.notify_all();
+    }
+    // the caller helps with whatever is queued until its own slices are done
+    void wait(std::atomic<int>* pending)
+    {
+        while (pending->load() != 0) {
+            std::function<void()> job;
+            { std::lock_guard<std::mutex> l(m_); if (!q_.empty()) { job = std::move(q_.front()); q_.pop_front(); } }
+            if (job) job(); else std::this_thread::yield();
+        }
+    }
+private:
+    CopyPool()
+    {
+        const unsigned nt = std::max(2u, std::min(8u, std::thread::hardware_concurrency() / 2));
+        for (unsigned t = 0; t + 1 < nt; t++) {
+            std::thread([this] {
+                for (;;) {
+                    std::function<void()> job;
+                    { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [this] { return !q_.empty(); }); job = std::move(q_.front()); q_.pop_front(); }
+                    job();
+                }
+            }).detach();
+        }
+    }
+    std::deque<std::function<void()>> q_;
+    std::mutex m_;
+    std::condition_variable cv_;
+};
+
+}  // namespace
+
+struct PipeSlot {
+    uint8_t* pin_in = nullptr;  size_t pin_in_cap = 0;      // sequence of the chunk + its scaffold offsets
+    uint8_t* pin_out = nullptr; size_t pin_out_cap = 0;     // count/flag, segment tables, rows
+    abw_devbuf d_in, d_out, d_work;
+    hipEvent_t e_h2d = nullptr, e_compute = nullptr, e_count = nullptr, e_d2h = nullptr;
+    std::atomic<int> out_pending{0};                        // slices of this slot's copy-out still running
+    // the chunk in flight
+    uint64_t first_scaf = 0, n_scaf = 0, bytes = 0, cap = 0, count = 0, out_base = 0;
+    bool used = false, wrote = false;
+};
+
+struct abw_sig_pipe {
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    PipeSlot slot[PIPE_SLOTS];
+};
+
+namespace {
+
+int pin_reserve(abw_ctx* ctx, uint8_t*& p, size_t& cap, size_t bytes)
+{
+    if (bytes <= cap) return ABW_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = bytes + bytes / 8 + 4096;
+    ABW_HIP(ctx, hipHostMalloc((void**)&p, want, hipHostMallocDefault));
+    cap = want;
+    return ABW_OK;
+}
+
+int sig_build_pipeline(abw_ctx* ctx, const uint8_t* ascii, const uint64_t* scaf_off, uint64_t n_scaf, uint32_t window,
+                       uint64_t seg_cap, uint32_t* seg_scaf, uint64_t* seg_start, uint64_t* seg_end,
+                       double* dims, int32_t* milli, uint64_t* n_seg)
+{
+    int rc;
+    if ((rc = upload_tables(ctx))) return rc;
+    if (!ctx->sig_pipe) {
+        abw_sig_pipe* P = new abw_sig_pipe();
+        ctx->sig_pipe = P;
+        ABW_HIP(ctx, hipStreamCreateWithFlags(&P->s_h2d, hipStreamNonBlocking));
+        ABW_HIP(ctx, hipStreamCreateWithFlags(&P->s_d2h, hipStreamNonBlocking));
+        for (auto& sl : P->slot) {
+            ABW_HIP(ctx, hipEventCreateWithFlags(&sl.e_h2d, hipEventDisableTiming));
+            ABW_HIP(ctx, hipEventCreateWithFlags(&sl.e_compute, hipEventDisableTiming));
+            ABW_HIP(ctx, hipEventCreateWithFlags(&sl.e_count, hipEventDisableTiming));
+            ABW_HIP(ctx, hipEventCreateWithFlags(&sl.e_d2h, hipEventDisableTiming));
+        }
+    }
+    abw_sig_pipe& P = *ctx->sig_pipe;
+    CopyPool& pool = CopyPool::get();
+    hipStream_t st = ctx->stream;
+    const size_t row_bytes = (dims ? ABW_SIG_NDIMS * 8ull : 0) + (milli ? ABW_SIG_NCOLS * 4ull : 0);
+    for (auto& sl : P.slot) { sl.used = false; sl.wrote = false; }
+
+    // the chunks: whole scaffolds, about PIPE_CHUNK bytes each
+    std::vector<uint64_t> cut{0};
+    while (cut.back() < n_scaf) {
+        const uint64_t s0 = cut.back();
+        uint64_t s1 = s0 + 1;
+        while (s1 < n_scaf && scaf_off[s1 + 1] - scaf_off[s0] <= PIPE_CHUNK && s1 - s0 < (1u << 22)) s1++;
+        cut.push_back(s1);
+    }
+    const int64_t nchunks = (int64_t)cut.size() - 1;
+
+    uint64_t total_seg = 0;          // segments of the chunks whose count has come back
+    bool over = false;               // more segments than seg_cap: keep counting, stop writing
+    int flag_n = 0;
+    std::atomic<int> in_pending{0};
+
+    // stage A: chunk i into its slot -- staging copy, H2D, kernels; nothing here waits for the GPU
+    auto submit = [&](int64_t i) -> int {
+        PipeSlot& sl = P.slot[i % PIPE_SLOTS];
+        const uint64_t s0 = cut[i], s1 = cut[i + 1];
+        const uint64_t bytes = scaf_off[s1] - scaf_off[s0], ns = s1 - s0;
+        const uint64_t blob_bytes = ((bytes + 15) & ~15ull) + 16, off_bytes = (ns + 1) * 8;
+        const uint64_t cap = bytes / window + ns + 64;
+        const uint64_t nblk = bytes / SEGBLK + 1;
+        int rc2;
+        pool.wait(&sl.out_pending);                               // the slot's previous tables have left its pinned buffer
+        if ((rc2 = pin_reserve(ctx, sl.pin_in, sl.pin_in_cap, blob_bytes + off_bytes))) return rc2;
+        if ((rc2 = pin_reserve(ctx, sl.pin_out, sl.pin_out_cap, 64 + cap * (4 + 8 + 8 + row_bytes)))) return rc2;
+        if ((rc2 = abw_reserve(ctx, sl.d_in, blob_bytes + off_bytes))) return rc2;
+        if ((rc2 = abw_reserve(ctx, sl.d_out, 64 + cap * (4 + 8 + 8 + row_bytes)))) return rc2;
+        const size_t w_blk = (nblk * 4 + 255) & ~(size_t)255, w_pre = ((nblk + 1) * 8 + 255) & ~(size_t)255, w_info = (ns * sizeof(ScafSeg) + 255) & ~(size_t)255,
+                     w_nseg = (ns * 8 + 255) & ~(size_t)255, w_off = ((ns + 2) * 8 + 255) & ~(size_t)255,
+                     w_scan = (2 * ((std::max(nblk, ns) + 1023) / 1024) + 2) * 8;
+        if ((rc2 = abw_reserve(ctx, sl.d_work, w_blk + w_pre + w_info + w_nseg + w_off + w_scan))) return rc2;
+        // sequence + rebased offsets into pinned memory (worker threads + this one), then one H2D
+        pool.submit(sl.pin_in, ascii + scaf_off[s0], bytes, &in_pending);
+        memset(sl.pin_in + bytes, 0, blob_bytes - bytes);
+        uint64_t* h_off = (uint64_t*)(sl.pin_in + blob_bytes);
+        for (uint64_t j = 0; j <= ns; j++) h_off[j] = scaf_off[s0 + j] - scaf_off[s0];
+        pool.wait(&in_pending);
+        uint8_t* d_ascii = (uint8_t*)sl.d_in.p;
+        uint64_t* d_off = (uint64_t*)(d_ascii + blob_bytes);
+        if (sl.used) ABW_HIP(ctx, hipStreamWaitEvent(P.s_h2d, sl.e_compute, 0));      // the slot's previous chunk has been counted
+        ABW_HIP(ctx, hipMemcpyAsync(d_ascii, sl.pin_in, blob_bytes + off_bytes, hipMemcpyHostToDevice, P.s_h2d));
+        ABW_HIP(ctx, hipEventRecord(sl.e_h2d, P.s_h2d));
+        // kernels: segmentation (the count stays on the device), emit over the capacity, counting up to the device-side count
+        ABW_HIP(ctx, hipStreamWaitEvent(st, sl.e_h2d, 0));
+        uint8_t* wb = (uint8_t*)sl.d_work.p;
+        SegWork w = {(uint32_t*)wb, (uint64_t*)(wb + w_blk), (ScafSeg*)(wb + w_blk + w_pre), (uint64_t*)(wb + w_blk + w_pre + w_info),
+                     (uint64_t*)(wb + w_blk + w_pre + w_info + w_nseg), (uint64_t*)(wb + w_blk + w_pre + w_info + w_nseg + w_off)};
+        {
+            ABW_PROF(ctx, "sig_segment");
+            if ((rc2 = segment_counts(ctx, w, d_ascii, bytes, d_off, ns, window))) return rc2;
+        }
+        uint8_t* d = (uint8_t*)sl.d_out.p;
+        ABW_HIP(ctx, hipMemcpyAsync(d, w.seg_off + ns, 16, hipMemcpyDeviceToDevice, st));       // count, flag
+        ABW_HIP(ctx, hipMemcpyAsync(sl.pin_out, d, 16, hipMemcpyDeviceToHost, st));
+        ABW_HIP(ctx, hipEventRecord(sl.e_count, st));
+        uint64_t* d_start = (uint64_t*)(d + 64); uint64_t* d_end = d_start + cap;
+        uint8_t* rows = (uint8_t*)(d_end + cap);
+        double* d_dims = dims ? (double*)rows : nullptr;
+        int32_t* d_milli = milli ? (int32_t*)(rows + (dims ? cap * ABW_SIG_NDIMS * 8ull : 0)) : nullptr;
+        uint32_t* d_scaf = (uint32_t*)(rows + cap * row_bytes);
+        {
+            ABW_PROF(ctx, "sig_segment");
+            hipLaunchKernelGGL(seg_emit_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, st, d_ascii, bytes, d_off, ns,
+                               w.blk_prefix, w.info, w.seg_off, cap, d_scaf, d_start, d_end, (uint32_t)s0);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        if (row_bytes) {
+            const uint64_t blocks = std::min<uint64_t>((cap + 3) / 4, (uint64_t)ctx->num_cu * 16);
+            ABW_PROF(ctx, "sig_count");
+            hipLaunchKernelGGL(sig_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_ascii, bytes, d_off, d_scaf, d_start, d_end, cap,
+                               d_dims, d_milli, (uint32_t*)nullptr, (const uint64_t*)w.seg_off + ns, (uint32_t)s0);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        ABW_HIP(ctx, hipEventRecord(sl.e_compute, st));
+        sl.first_scaf = s0; sl.n_scaf = ns; sl.bytes = bytes; sl.cap = cap; sl.used = true; sl.wrote = false;
+        return ABW_OK;
+    };
+
+    // stage B: chunk i's count is back -> its place in the caller's arrays is known -> exact-size D2H into pinned memory
+    auto copy_back = [&](int64_t i) -> int {
+        PipeSlot& sl = P.slot[i % PIPE_SLOTS];
+        ABW_HIP(ctx, hipEventSynchronize(sl.e_count));
+        const uint64_t* res = (const uint64_t*)sl.pin_out;
+        const uint64_t cnt = res[0];
+        if (res[1]) flag_n = 1;
+        sl.count = cnt; sl.out_base = total_seg; sl.wrote = false;
+        total_seg += cnt;
+        if (flag_n || over) return ABW_OK;
+        if (total_seg > seg_cap) { over = true; return ABW_OK; }
+        if (cnt == 0) return ABW_OK;
+        if (!seg_scaf || !seg_start || !seg_end) return abw_fail(ctx, ABW_ERR_ARG, "abw_sig_build: null segment output");
+        if (cnt > sl.cap) {
+            // more segments than the chunk's tables hold (all-N scaffolds make one per base): this chunk alone again with
+            // tables of the right size, synchronously -- rare
+            ABW_HIP(ctx, hipStreamSynchronize(st));
+            const uint64_t blob_bytes = ((sl.bytes + 15) & ~15ull) + 16;
+            uint8_t* d_ascii = (uint8_t*)sl.d_in.p;
+            uint64_t* d_off = (uint64_t*)(d_ascii + blob_bytes);
+            int rc2;
+            abw_devbuf big;
+            if ((rc2 = abw_reserve(ctx, big, 64 + cnt * (4 + 8 + 8 + row_bytes)))) return rc2;
+            uint64_t* d_start = (uint64_t*)((uint8_t*)big.p + 64); uint64_t* d_end = d_start + cnt;
+            uint8_t* rows = (uint8_t*)(d_end + cnt);
+            uint32_t* d_scaf = (uint32_t*)(rows + cnt * row_bytes);
+            double* d_dims = dims ? (double*)rows : nullptr;
+            int32_t* d_milli = milli ? (int32_t*)(rows + (dims ? cnt * ABW_SIG_NDIMS * 8ull : 0)) : nullptr;
+            uint64_t n2 = 0;
+            rc2 = abw_sig_segment_dev(ctx, d_ascii, sl.bytes, d_off, sl.n_scaf, window, cnt, d_scaf, d_start, d_end, &n2);
+            if (!rc2 && row_bytes) rc2 = abw_sig_count_dev(ctx, d_ascii, sl.bytes, d_off, d_scaf, d_start, d_end, cnt, d_dims, d_milli, nullptr);
+            if (!rc2) {
+                std::vector<uint32_t> h_scaf(cnt);
+                hipError_t e = hipMemcpyAsync(h_scaf.data(), d_scaf, cnt * 4, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(seg_start + sl.out_base, d_start, cnt * 8, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(seg_end + sl.out_base, d_end, cnt * 8, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess && dims) e = hipMemcpyAsync(dims + sl.out_base * ABW_SIG_NDIMS, d_dims, cnt * ABW_SIG_NDIMS * 8ull, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess && milli) e = hipMemcpyAsync(milli + sl.out_base * ABW_SIG_NCOLS, d_milli, cnt * ABW_SIG_NCOLS * 4ull, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                if (e != hipSuccess) rc2 = abw_fail(ctx, ABW_ERR_HIP, "abw_sig_build: copy back failed: %s", hipGetErrorString(e));
+                else for (uint64_t j = 0; j < cnt; j++) seg_scaf[sl.out_base + j] = h_scaf[j] + (uint32_t)sl.first_scaf;
+            }
+            abw_release(big);
+            return rc2;
+        }
+        const uint8_t* d = (const uint8_t*)sl.d_out.p;
+        uint8_t* h = sl.pin_out;
+        const size_t o_start = 64, o_end = o_start + sl.cap * 8, o_rows = o_end + sl.cap * 8, o_scaf = o_rows + sl.cap * row_bytes;
+        const size_t o_milli = o_rows + (dims ? sl.cap * ABW_SIG_NDIMS * 8ull : 0);
+        ABW_HIP(ctx, hipStreamWaitEvent(P.s_d2h, sl.e_compute, 0));
+        ABW_HIP(ctx, hipMemcpyAsync(h + o_start, d + o_start, cnt * 8, hipMemcpyDeviceToHost, P.s_d2h));
+        ABW_HIP(ctx, hipMemcpyAsync(h + o_end, d + o_end, cnt * 8, hipMemcpyDeviceToHost, P.s_d2h));
+        if (dims) ABW_HIP(ctx, hipMemcpyAsync(h + o_rows, d + o_rows, cnt * ABW_SIG_NDIMS * 8ull, hipMemcpyDeviceToHost, P.s_d2h));
+        if (milli) ABW_HIP(ctx, hipMemcpyAsync(h + o_milli, d + o_milli, cnt * ABW_SIG_NCOLS * 4ull, hipMemcpyDeviceToHost, P.s_d2h));
+        ABW_HIP(ctx, hipMemcpyAsync(h + o_scaf, d + o_scaf, cnt * 4, hipMemcpyDeviceToHost, P.s_d2h));
+        ABW_HIP(ctx, hipEventRecord(sl.e_d2h, P.s_d2h));
+        sl.wrote = true;
+        return ABW_OK;
+    };
+
+    // stage C: chunk i's tables are in pinned memory -> worker threads move them into the caller's arrays
+    auto hand_over = [&](int64_t i) -> int {
+        PipeSlot& sl = P.slot[i % PIPE_SLOTS];
+        if (!sl.wrote) return ABW_OK;
+        ABW_HIP(ctx, hipEventSynchronize(sl.e_d2h));
+        const uint64_t cnt = sl.count, at = sl.out_base;
+        uint8_t* h = sl.pin_out;
+        const size_t o_start = 64, o_end = o_start + sl.cap * 8, o_rows = o_end + sl.cap * 8, o_scaf = o_rows + sl.cap * row_bytes;
+        const size_t o_milli = o_rows + (dims ? sl.cap * ABW_SIG_NDIMS * 8ull : 0);
+        pool.submit(seg_start + at, h + o_start, cnt * 8, &sl.out_pending);
+        pool.submit(seg_end + at, h + o_end, cnt * 8, &sl.out_pending);
+        if (dims) pool.submit(dims + at * ABW_SIG_NDIMS, h + o_rows, cnt * ABW_SIG_NDIMS * 8ull, &sl.out_pending);
+        if (milli) pool.submit(milli + at * ABW_SIG_NCOLS, h + o_milli, cnt * ABW_SIG_NCOLS * 4ull, &sl.out_pending);
+        pool.submit(seg_scaf + at, h + o_scaf, cnt * 4, &sl.out_pending);
+        sl.wrote = false;
+        return ABW_OK;
+    };
+
+    rc = ABW_OK;
+    for (int64_t i = 0; i < nchunks + 2 && !rc && !flag_n; i++) {
+        if (i < nchunks) rc = submit(i);
+        if (!rc && i >= 1 && i - 1 < nchunks) rc = copy_back(i - 1);
+        if (!rc && i >= 2 && i - 2 < nchunks) rc = hand_over(i - 2);
+    }
+    // quiesce whatever the outcome: nothing of this call may still touch the caller's memory or the slots afterwards
+    (void)hipStreamSynchronize(P.s_h2d);
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamSynchronize(P.s_d2h);
+    for (auto& sl : P.slot) pool.wait(&sl.out_pending);
+    if (rc) return rc;
+    if (flag_n) return abw_fail(ctx, ABW_ERR_LOWER_N, "lower-case 'n' in sequence data (the reference throws Illegal_DNAString)");
+    *n_seg = total_seg;
+    if (over || total_seg > seg_cap)
+        return abw_fail(ctx, ABW_ERR_CAPACITY, "segment capacity %llu < %llu", (unsigned long long)seg_cap, (unsigned long long)total_seg);
+    return ABW_OK;
+}
+
+}  // namespace
+
+void abw_sig_pipe_free(abw_ctx* ctx)
+{
+    abw_sig_pipe* P = ctx->sig_pipe;
+    if (!P) return;
+    for (auto& sl : P->slot) {
+        if (sl.pin_in) (void)hipHostFree(sl.pin_in);
+        if (sl.pin_out) (void)hipHostFree(sl.pin_out);
+        abw_release(sl.d_in); abw_release(sl.d_out); abw_release(sl.d_work);
+        for (hipEvent_t e : {sl.e_h2d, sl.e_compute, sl.e_count, sl.e_d2h}) if (e) (void)hipEventDestroy(e);
+    }
+    if (P->s_h2d) (void)hipStreamDestroy(P->s_h2d);
+    if (P->s_d2h) (void)hipStreamDestroy(P->s_d2h);
+    delete P;
+    ctx->sig_pipe = nullptr;
+}
+
+namespace {
 
 }  // namespace
 
@@ -798,7 +1120,7 @@ int abw_sig_segment_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len
     if (total == 0) return ABW_OK;
     if (!d_seg_scaf || !d_seg_start || !d_seg_end) return abw_fail(ctx, ABW_ERR_ARG, "null segment output");
     hipLaunchKernelGGL(seg_emit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_ascii, total_len, d_scaf_off, n_scaf,
-                       w.blk_prefix, w.info, w.seg_off, total, d_seg_scaf, d_seg_start, d_seg_end);
+                       w.blk_prefix, w.info, w.seg_off, total, d_seg_scaf, d_seg_start, d_seg_end, 0u);
     ABW_LAUNCH_CHECK(ctx);
     return ABW_OK;
 }
@@ -833,7 +1155,7 @@ int abw_sig_segment_static(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_
     ABW_HIP(ctx, hipMemcpyAsync(d_result, w.seg_off + n_scaf, 16, hipMemcpyDeviceToDevice, st));
     if (seg_cap) {
         hipLaunchKernelGGL(seg_emit_kernel, dim3((unsigned)((seg_cap + 255) / 256)), dim3(256), 0, st, d_ascii, total_len, d_scaf_off, n_scaf,
-                           w.blk_prefix, w.info, w.seg_off, seg_cap, d_seg_scaf, d_seg_start, d_seg_end);
+                           w.blk_prefix, w.info, w.seg_off, seg_cap, d_seg_scaf, d_seg_start, d_seg_end, 0u);
         ABW_LAUNCH_CHECK(ctx);
     }
     return ABW_OK;
@@ -856,7 +1178,7 @@ int abw_sig_count_dev(abw_ctx* ctx, const uint8_t* d_ascii, uint64_t total_len, 
     if (blocks > maxb) blocks = maxb;
     ABW_PROF(ctx, "sig_count");
     hipLaunchKernelGGL(sig_count_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, total_len, d_scaf_off,
-                       d_seg_scaf, d_seg_start, d_seg_end, n_seg, d_dims, d_milli, d_counts);
+                       d_seg_scaf, d_seg_start, d_seg_end, n_seg, d_dims, d_milli, d_counts, (const uint64_t*)nullptr, 0u);
     ABW_LAUNCH_CHECK(ctx);
     return ABW_OK;
 }
@@ -866,47 +1188,14 @@ int abw_sig_build(abw_ctx* ctx, const uint8_t* ascii, const uint64_t* scaf_off, 
                   double* dims, int32_t* milli, uint64_t* n_seg)
 {
     if (!ctx) return ABW_ERR_ARG;
-    if (!scaf_off || !n_seg) return abw_fail(ctx, ABW_ERR_ARG, "abw_sig_build: null argument");
+    if (!scaf_off || !n_seg || window == 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sig_build: null argument");
     abw_device_guard g(ctx->device);
     *n_seg = 0;
     if (n_scaf == 0) return ABW_OK;
-    const uint64_t total_len = scaf_off[n_scaf];
-    int rc;
-    // scratch[6]: blob (padded) + scaffold offsets ; scratch[7]: segment tables + outputs
-    const uint64_t blob_bytes = ((total_len + 15) & ~15ull) + 16;
-    const uint64_t off_bytes = (n_scaf + 1) * 8;
-    if ((rc = abw_reserve(ctx, ctx->scratch[6], blob_bytes + off_bytes))) return rc;
-    uint8_t* d_ascii = (uint8_t*)ctx->scratch[6].p;
-    uint64_t* d_off = (uint64_t*)(d_ascii + blob_bytes);
-    hipStream_t st = ctx->stream;
-    if (total_len) ABW_HIP(ctx, hipMemcpyAsync(d_ascii, ascii, total_len, hipMemcpyHostToDevice, st));
-    ABW_HIP(ctx, hipMemcpyAsync(d_off, scaf_off, off_bytes, hipMemcpyHostToDevice, st));
-    const uint64_t cap = seg_cap;
-    const uint64_t seg_bytes = cap * (4 + 8 + 8);
-    const uint64_t out_bytes = cap * ((dims ? ABW_SIG_NDIMS * 8ull : 0) + (milli ? ABW_SIG_NCOLS * 4ull : 0));
-    if ((rc = abw_reserve(ctx, ctx->scratch[7], seg_bytes + out_bytes + 64))) return rc;
-    uint64_t* d_start = (uint64_t*)ctx->scratch[7].p;
-    uint64_t* d_end = d_start + cap;
-    double* d_dims = dims ? (double*)(d_end + cap) : nullptr;
-    uint8_t* tail = (uint8_t*)(d_end + cap) + (dims ? cap * ABW_SIG_NDIMS * 8ull : 0);
-    int32_t* d_milli = milli ? (int32_t*)tail : nullptr;
-    tail += milli ? cap * ABW_SIG_NCOLS * 4ull : 0;
-    uint32_t* d_scaf = (uint32_t*)tail;
-    uint64_t n = 0;
-    rc = abw_sig_segment_dev(ctx, d_ascii, total_len, d_off, n_scaf, window, cap, d_scaf, d_start, d_end, &n);
-    *n_seg = n;
-    if (rc) return rc;
-    if (n == 0) return ABW_OK;
-    if (!seg_scaf || !seg_start || !seg_end) return abw_fail(ctx, ABW_ERR_ARG, "abw_sig_build: null segment output");
-    rc = abw_sig_count_dev(ctx, d_ascii, total_len, d_off, d_scaf, d_start, d_end, n, d_dims, d_milli, nullptr);
-    if (rc) return rc;
-    ABW_HIP(ctx, hipMemcpyAsync(seg_scaf, d_scaf, n * 4, hipMemcpyDeviceToHost, st));
-    ABW_HIP(ctx, hipMemcpyAsync(seg_start, d_start, n * 8, hipMemcpyDeviceToHost, st));
-    ABW_HIP(ctx, hipMemcpyAsync(seg_end, d_end, n * 8, hipMemcpyDeviceToHost, st));
-    if (dims) ABW_HIP(ctx, hipMemcpyAsync(dims, d_dims, n * ABW_SIG_NDIMS * 8ull, hipMemcpyDeviceToHost, st));
-    if (milli) ABW_HIP(ctx, hipMemcpyAsync(milli, d_milli, n * ABW_SIG_NCOLS * 4ull, hipMemcpyDeviceToHost, st));
-    ABW_HIP(ctx, hipStreamSynchronize(st));
-    return ABW_OK;
+    if (scaf_off[n_scaf] && !ascii) return abw_fail(ctx, ABW_ERR_ARG, "abw_sig_build: null sequence");
+    for (uint64_t i = 0; i < n_scaf; i++)
+        if (scaf_off[i + 1] < scaf_off[i]) return abw_fail(ctx, ABW_ERR_ARG, "abw_sig_build: scaf_off must ascend");
+    return sig_build_pipeline(ctx, ascii, scaf_off, n_scaf, window, seg_cap, seg_scaf, seg_start, seg_end, dims, milli, n_seg);
 }
 
 }  // extern "C"

@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--chunk", type=int, default=0, help="points per fp32 partial sum; 0 = the library's choice (abw_km_auto_chunk)")
     ap.add_argument("--sig-mbp", type=int, default=1000, help="signature side bench: assembly size in Mbp")
+    ap.add_argument("--sig10-mbp", type=int, default=10_000, help="configs[3] leg: assembly size in Mbp (0 = skip)")
     ap.add_argument("--cov-mreads", type=int, default=20, help="coverage side bench: million reads of 150 bp")
     ap.add_argument("--no-extras", action="store_true", help="only the k-means headline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1: nccl (= RCCL over xGMI); "
@@ -475,6 +476,106 @@ def timed_steps(step, warmup, steps, barrier, ctx, prof_name="km_step"):
     return elapsed, n_launch, ms_launch
 
 
+def host_build_leg(ctx, blob, off, window=2000):
+    """abw_sig_build with HOST buffers in and out (the boundary the reference's FASTA loop would call): pageable input,
+    pre-faulted pageable outputs (a caller's re-used buffers), milli rows (716 B per segment) back."""
+    from abawaca_amd import _lib
+    L = _lib.lib()
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    offu = np.ascontiguousarray(off, dtype=np.uint64)
+    n_scaf = len(offu) - 1
+    cap = int(len(blob) // window + n_scaf + 16)
+    seg_scaf = np.zeros(cap, dtype=np.uint32); st = np.zeros(cap, dtype=np.uint64); en = np.zeros(cap, dtype=np.uint64)
+    milli = np.zeros((cap, 179), dtype=np.int32)
+    n = C.c_uint64(0)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+
+    def run(nsc):
+        ctx.check(L.abw_sig_build(ctx.handle, p(blob), p(offu), nsc, window, cap, p(seg_scaf), p(st), p(en), None, p(milli), C.byref(n)))
+    run(min(n_scaf, 20_000))                                  # warm-up: streams, pinned ring, worker threads
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run(n_scaf)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    k = int(n.value)
+    bytes_in, bytes_out = len(blob), k * (4 + 8 + 8 + 179 * 4)
+    return dict(value=round(len(blob) / best / 1e9, 2), unit="Gbp/s", mbp=len(blob) // 1_000_000, segments=k, s=round(best, 4),
+                pcie=dict(h2d_GBs=round(bytes_in / best / 1e9, 1), d2h_GBs=round(bytes_out / best / 1e9, 1),
+                          bound="PCIe 5.0 x16: ~55-60 GB/s each way in practice, i.e. <= ~55 Gbp/s of ASCII whatever the kernels do"),
+                note="abw_sig_build on pageable host memory: chunks of whole scaffolds staged through pinned buffers by worker threads, "
+                     "H2D | segmentation + counting | D2H overlapped; milli rows back (716 B per segment) into pre-faulted arrays; best of 3")
+
+
+def make_assembly_blob_gpu(seed, mbp, dev):
+    """make_assembly_blob's shape generated on the GPU (10 kbp scaffolds, iid ACGT, a run of 50 N in 2 % of them):
+    -> (uint8 tensor on `dev`, padded for 16-byte reads; total bases; int64 offsets on `dev`)"""
+    import torch
+    n_scaf, Ls = mbp * 100, 10_000
+    total = n_scaf * Ls
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    t = torch.empty(total + 32, dtype=torch.uint8, device=dev)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    step = 1 << 28
+    for o in range(0, total, step):
+        m = min(step, total - o)
+        t[o:o + m] = lut[torch.randint(0, 4, (m,), device=dev, generator=g, dtype=torch.uint8).to(torch.int64)]
+    t[total:] = 0
+    withn = torch.randperm(n_scaf, device=dev, generator=g)[: max(1, n_scaf // 50)]
+    at = withn * Ls + torch.randint(0, Ls - 50, (len(withn),), device=dev, generator=g)
+    idx = (at[:, None] + torch.arange(50, device=dev)[None, :]).reshape(-1)
+    t[idx] = ord("N")
+    off = torch.arange(n_scaf + 1, dtype=torch.int64, device=dev) * Ls
+    return t, total, off
+
+
+def signature_10g_leg(ctx, dev, mbp):
+    """configs[3]: the signature build of a 10 Gbp assembly (1M scaffolds of 10 kbp), resident in HBM (10 GB of ASCII in,
+    7.2 GB of fp64 rows out) and streamed from host memory through abw_sig_build."""
+    import torch
+    from abawaca_amd import signature
+    t_ascii, total, t_off = make_assembly_blob_gpu(20243, mbp, dev)
+    cap = total // 2000 + t_off.numel() + 16
+    t_scaf = torch.empty(cap, dtype=torch.int32, device=dev)
+    t_st = torch.empty(cap, dtype=torch.int64, device=dev)
+    t_en = torch.empty(cap, dtype=torch.int64, device=dev)
+    t_dims = torch.empty((cap, 180), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        n = signature.segment_dev(ctx, t_ascii, total, t_off, 2000, t_scaf, t_st, t_en)
+        signature.count_dev(ctx, t_ascii, total, t_off, t_scaf, t_st, t_en, n, t_dims=t_dims)
+        return n
+    n_seg = step()
+    ctx.synchronize()
+    ctx.prof_reset(); ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        step()
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    nc, msc = ctx.prof_read("sig_count")
+    ns, mss = ctx.prof_read("sig_segment")
+    ctx.prof_enable(False)
+    alg = total + 1440.0 * n_seg
+    # every segment's 180 dimensions sum to 4 (one per k): a checksum of the whole table
+    chk = float(t_dims[:n_seg].sum()) / n_seg
+    res = dict(workload=f"configs[3]: {mbp} Mbp, {t_off.numel() - 1} scaffolds of 10 kbp", value=total / dt / 1e9, unit="Gbp/s", segments=int(n_seg),
+               ms_per_pass=dt * 1e3, resident="ASCII in HBM; segmentation + counting + fp64 finalisation timed", mean_row_sum=round(chk, 9),
+               roofline=dict(kernel="sig_count_kernel", bound="hbm", achieved=round(alg / (msc / nc * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=round(alg / (msc / nc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=None, ms_per_launch=round(msc / nc, 4),
+                             segment_ms=round(mss / max(ns, 1), 4)))
+    del t_dims, t_scaf, t_st, t_en
+    blob = t_ascii[:total].cpu().numpy()
+    off = t_off.cpu().numpy()
+    del t_ascii
+    torch.cuda.empty_cache()
+    res["host_buffers"] = host_build_leg(ctx, blob, off)
+    return res
+
+
 def separator_leg(ctx, keys_host, dp2scaf, scaf_len, genome, G, seed, label, traffic=None):
     """The real separator (reference ClusterSeparatorBySensitivitySpecificity with the SCG gate) on a resident table: the
     root node through abw_sep_node, then the whole recursion of reference src/abawaca.cpp:95-197."""
@@ -871,18 +972,13 @@ def main():
                                               peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg / (msc / nc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                               traffic=pmc_all.get("sig_count_kernel", {}).get("hbm_bytes_per_launch") if default_workload else None,
                                               ms_per_launch=round(msc / nc, 4), segment_ms=round(mss / max(ns, 1), 4)))
-        # the boundary with HOST buffers (abw_sig_build: H2D of the ASCII, segmentation + counting, D2H of the rows):
-        # PCIe-inclusive, never the headline
-        sub = min(total, 200_000_000)
-        n_sub = int(np.searchsorted(off, sub, side="right")) - 1
-        hb, ho = blob[:int(off[n_sub])], off[:n_sub + 1]
-        signature.build_signatures(ctx, hb[:10_000_000], off[:1001], want_dims=False)      # warm-up (buffers)
-        t0 = time.perf_counter()
-        r_host = signature.build_signatures(ctx, hb, ho, want_dims=False)
-        host_s = time.perf_counter() - t0
-        out["signature"]["host_buffers"] = dict(value=round(len(hb) / host_s / 1e9, 2), unit="Gbp/s", mbp=len(hb) // 1_000_000, segments=int(len(r_host["seg_scaf"])),
-                                                note="abw_sig_build on pageable host memory, milli rows back (716 B per segment): PCIe both ways + allocation of the outputs")
-        del r_host
+        # the boundary with HOST buffers (abw_sig_build: the caller's pageable ASCII through a ring of pinned staging
+        # buffers, H2D / kernels / D2H overlapped chunk by chunk, milli rows back): PCIe-inclusive, never the headline
+        out["signature"]["host_buffers"] = host_build_leg(ctx, blob, off)
+        del t_dims
+        if args.sig10_mbp and world == 1:
+            out["signature"]["configs3_10gbp"] = signature_10g_leg(ctx, dev, args.sig10_mbp)
+        t_dims = None
         # ---- row N1: coverage accumulation on the same segments (20 M reads of 150 bp ~ depth 3 of this assembly)
         n_scaf_sig = len(off) - 1
         n_reads = args.cov_mreads * 1_000_000
@@ -925,7 +1021,7 @@ def main():
             out["coverage"]["cpu_baseline"] = dict(value=ns / dt / 1e6, unit="M reads/s", cores=1, kind="port",
                                                    sample=f"oracle abw_or_coverage (the reference's loops, its SAM text parsing not included), "
                                                           f"first {ns} reads, {dt:.1f} s")
-        del t_ascii, t_dims
+        del t_ascii
         out["lrn"] = lrn_bench(ctx, world == 1 and not args.no_cpu)
 
     # ---------------- one GPU: configs[2]'s job and table on this GPU (the base of the N > 1 strong-scaling runs) ------

@@ -1,0 +1,279 @@
+// abawaca_build_hip — the reference-side binding of libabawaca_hip.so for `abawaca-build`.
+//
+// A replacement for the `main` of the reference's src/abawaca-build.cpp that keeps everything the reference does on the
+// host with the reference's OWN classes -- the command line (ref :449-479), the FASTA reader
+// (Bio::SeqIORead_fasta<Bio::DNASequence>, ref src/SeqIORead_fasta.h:51-103, with DNAString's upper-casing and its
+// exception for a lower-case n, ref src/String.cpp:37-51), the SAM reader and record parser (Bio::SAMReader,
+// Bio::ReadMapping: ref src/ReadMappingReader.cpp:80-116, src/ReadMapping.cpp:23-185), the read filter (ref :546), the
+// scaffold order of its std::map (ref :482,596), and the text of abawaca.names / abawaca.info / the abawaca.lrn header
+// (ref :578-599) -- and hands the three data-parallel pieces to the GPU through the C ABI:
+//
+//     Scaf::Scaf + Scaf_segment::Scaf_segment   (ref :103-228)      ->  abw_sig_build       (one call for the assembly)
+//     Scaf::add_mapped_read / Scaf_segment::... (ref :231-244,177-185) ->  abw_cov_accumulate  (per chunk of a SAM file)
+//     the row loop of abawaca.lrn               (ref :600-605)      ->  abw_lrn_emit
+//
+// It is linked with the reference's unmodified ReadMapping.cpp, ReadMappingReader.cpp, common.cpp and String.cpp
+// (oracle/Makefile: oracle/_ref/hip_build_driver); it contains none of the reference's code.  tests/test_gpu_build_driver.py
+// runs it beside the reference's own abawaca-build and requires byte-identical abawaca.lrn / .names / .info.
+//
+// Not done here, as in the rest of this repository: the paired-end links file (ref :249-367,519-557) and the
+// gene / SCG prediction that shells out to prodigal (ref :401-431); data.txt is written with the same keys.
+//
+// Two deliberate differences, both where the reference's behaviour is undefined:
+//   * a segment that received no read in the LAST samples is printed with 0.000 in those columns; the reference reads
+//     its vector out of bounds there (get_dimension, ref :188-193 against the resize of :179-180);
+//   * two FASTA records with the same name: the reference counts the segments of both in the header but keeps only the
+//     first in its map; here the second is refused.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <iostream>
+#include <map>
+#include <string>
+#include <vector>
+#include "ReadMappingReader.h"
+#include "SeqIORead_fasta.h"
+#include "String.h"
+#include "common.h"
+#include "abawaca_hip.h"
+
+using namespace std;
+
+namespace {
+
+void die(abw_ctx* ctx, const char* what)
+{
+	cerr << "abawaca-build (hip): " << what << ": " << (ctx ? abw_last_error(ctx) : "no context") << endl;
+	exit(-1);
+}
+
+struct ScafRec {
+	string		name;
+	size_t		len, ns;
+	double		gc;
+	size_t		nbps;		// Scaf::nbps, ref :242-243
+};
+
+}	// namespace
+
+int main(int argc, const char* argv[])
+{
+	const size_t	window_size = 2000;			// ref :436
+	const size_t	max_snps = 15;				// ref :437
+	const size_t	sam_chunk = (size_t)1 << 22;		// mappings per abw_cov_accumulate call
+
+	if(argc < 5) {
+		cerr << endl << "Usage: " << argv[0] << " -f <fasta-file> -o <out-directory> -s <sam-files-glob> -c <source-sam-file>" << endl << endl;
+		return -1;
+	}
+	string	assembly_file, out_directory, sam_glob, this_sample_str;
+	for(int i=1; i+1<argc; i+=2) {				// ref :449-462
+		if(!strcmp(argv[i], "-f"))		assembly_file = argv[i+1];
+		else if(!strcmp(argv[i], "-o"))		out_directory = argv[i+1];
+		else if(!strcmp(argv[i], "-s"))		sam_glob = argv[i+1];
+		else if(!strcmp(argv[i], "-c"))		this_sample_str = argv[i+1];
+		else { cerr << endl << "Unknown option " << argv[i] << endl << endl; return -1; }
+	}
+	if(assembly_file.empty() || out_directory.empty() || sam_glob.empty() || this_sample_str.empty()) {
+		cerr << endl << "Error: -f, -o, -s and -c are all required" << endl << endl;
+		return -1;
+	}
+
+	abw_ctx* ctx = NULL;
+	if(abw_ctx_create(0, &ctx) != ABW_OK) {
+		cerr << "abawaca-build (hip): no MI355X / HIP device available" << endl;
+		return -1;
+	}
+
+	// ---- the assembly (ref :481-490): the reference's reader; sequences go into one blob instead of Scaf objects
+	cerr << time_since_epoch() << "Reading assembly file (" << assembly_file << ")" << endl;
+	vector<ScafRec>		recs;
+	map<string, size_t>	by_name;			// the reference's std::map order = byte-wise name order
+	vector<uint8_t>		blob;
+	vector<uint64_t>	off(1, 0);
+	{
+		Bio::SeqIORead_fasta<Bio::DNASequence>	in(assembly_file);
+		Bio::DNASequence*			seq = NULL;
+		while((seq = in.next_seq()) != NULL) {
+			const Bio::DNAString& dna = seq->seq();
+			const string s = string(dna);
+			if(!by_name.insert(pair<string, size_t>(seq->display_id(), recs.size())).second) {
+				cerr << "abawaca-build (hip): two sequences named " << seq->display_id() << endl;
+				return -1;
+			}
+			ScafRec r;
+			r.name = seq->display_id(); r.len = s.size(); r.ns = Bio::Ns(dna); r.gc = Bio::gc(dna); r.nbps = 0;
+			recs.push_back(r);
+			blob.insert(blob.end(), s.begin(), s.end());
+			off.push_back(blob.size());
+			delete seq;
+		}
+	}
+	const size_t n_scaf = recs.size();
+
+	// ---- segments + signatures of every scaffold in one call (ref :198-228, :103-174)
+	uint64_t		n_seg = 0, cap = blob.size() / window_size + n_scaf + 16;
+	vector<uint32_t>	seg_scaf;
+	vector<uint64_t>	seg_start, seg_end;
+	vector<int32_t>		sig_milli;			// [n_seg][179]: int(1000.0 * x) of every printed signature column
+	for(;;) {
+		seg_scaf.resize(cap); seg_start.resize(cap); seg_end.resize(cap); sig_milli.resize(cap * ABW_SIG_NCOLS);
+		int rc = abw_sig_build(ctx, blob.data(), off.data(), n_scaf, (uint32_t)window_size, cap, seg_scaf.data(), seg_start.data(),
+		                       seg_end.data(), NULL, sig_milli.data(), &n_seg);
+		if(rc == ABW_ERR_CAPACITY) { cap = n_seg; continue; }		// scaffolds of N only make a segment per base
+		// (ABW_ERR_LOWER_N cannot happen: DNAString's constructor already threw on a lower-case n, ref src/String.cpp:45-49)
+		if(rc != ABW_OK) die(ctx, "abw_sig_build");
+		break;
+	}
+
+	// ---- coverage (ref :507-559): the reference's SAM reader and filter, sums on the GPU in SAM order
+	vector<string>		sample_names;
+	vector<vector<double> >	cov;				// [sample][n_seg]
+	size_t			this_sample = (size_t)-1;
+	{
+		vector<string>	sam_files = glob(sam_glob);
+		for(auto vit=sam_files.begin(); vit!=sam_files.end(); vit++) {
+			cerr << time_since_epoch() << "Reading SAM file " << *vit << endl;
+			const size_t dimension = sample_names.size();
+			sample_names.push_back(*vit);
+			if(this_sample_str == *vit)
+				this_sample = dimension;
+			cov.push_back(vector<double>(n_seg, 0.0));
+			vector<uint32_t>	r_scaf;
+			vector<uint64_t>	r_pos;
+			vector<uint32_t>	r_len;
+			auto flush = [&]() {
+				if(r_scaf.empty()) return;
+				if(abw_cov_accumulate(ctx, seg_scaf.data(), seg_start.data(), seg_end.data(), n_seg, n_scaf, r_scaf.data(), r_pos.data(),
+				                      r_len.data(), r_scaf.size(), cov.back().data()) != ABW_OK)
+					die(ctx, "abw_cov_accumulate");
+				r_scaf.clear(); r_pos.clear(); r_len.clear();
+			};
+			Bio::SAMReader	reader(*vit);
+			while(reader.good()) {
+				Bio::ReadMappingPtr mapping(reader.next_mapping());
+				if(mapping == NULL)
+					break;
+				if(mapping->unmapped() || (mapping->num_snps() > max_snps) || mapping->multiple_hits())	// ref :546
+					continue;
+				auto mit = by_name.find(mapping->ref_name());
+				if(mit == by_name.end())
+					continue;							// ref :550-552
+				r_scaf.push_back((uint32_t)mit->second);
+				r_pos.push_back((uint64_t)mapping->ref_pos());
+				r_len.push_back((uint32_t)mapping->read_length());
+				if(dimension == this_sample)
+					recs[mit->second].nbps += mapping->read_length();		// ref :242-243
+				if(r_scaf.size() >= sam_chunk)
+					flush();
+			}
+			flush();
+		}
+	}
+	const size_t n_samples = sample_names.size();
+
+	// ---- rows in the reference's order: scaffolds by name, their segments by position (ref :596-598)
+	vector<uint64_t>	first_seg(n_scaf + 1, 0);			// segments arrive grouped by scaffold, in input order
+	for(uint64_t g = 0; g < n_seg; g++) first_seg[seg_scaf[g] + 1]++;
+	for(size_t s = 0; s < n_scaf; s++) first_seg[s + 1] += first_seg[s];
+	const int32_t		n_cols = (int32_t)(ABW_SIG_NCOLS + n_samples);
+	vector<int32_t>		rows((size_t)n_seg * n_cols);
+	vector<uint64_t>	row_seg;
+	row_seg.reserve(n_seg);
+	for(auto it=by_name.begin(); it!=by_name.end(); it++)
+		for(uint64_t g = first_seg[it->second]; g < first_seg[it->second + 1]; g++)
+			row_seg.push_back(g);
+	for(uint64_t r = 0; r < n_seg; r++) {
+		const uint64_t g = row_seg[r];
+		memcpy(&rows[r * n_cols], &sig_milli[g * ABW_SIG_NCOLS], ABW_SIG_NCOLS * sizeof(int32_t));
+		for(size_t s = 0; s < n_samples; s++) {
+			const double v = 1000.0 * cov[s][g];				// ref :603: int(1000.0 * x)
+			if(!(v > -2147483648.0 && v < 2147483648.0)) { cerr << "abawaca-build (hip): coverage value out of range" << endl; return -1; }
+			rows[r * n_cols + ABW_SIG_NCOLS + s] = (int32_t)v;
+		}
+	}
+
+	char names_file[1024], lrn_file[1024], info_file[1024], links_file[1024];
+	sprintf(names_file, "%s/abawaca.names", out_directory.c_str());
+	sprintf(lrn_file, "%s/abawaca.lrn", out_directory.c_str());
+	sprintf(info_file, "%s/abawaca.info", out_directory.c_str());
+	sprintf(links_file, "%s/abawaca.links", out_directory.c_str());
+	cerr << time_since_epoch() << "Creating .lrn (" << lrn_file << ") and .names (" << names_file << ") files" << endl;
+	if(!directory_exists(out_directory.c_str())) {
+		char cmd[1024];
+		sprintf(cmd, "mkdir %s", out_directory.c_str());
+		system(cmd);
+	}
+	FILE* fout = fopen(names_file, "w");
+	FILE* flrn = fopen(lrn_file, "w");
+	FILE* finfo = fopen(info_file, "w");
+	if(fout == NULL || flrn == NULL || finfo == NULL) {
+		cerr << "Could not write to " << out_directory << endl << endl;
+		return -1;
+	}
+
+	// headers (ref :578-593): the dimension count includes the unprinted "A"
+	vector<char>	dim_buf(1024);
+	if(abw_sig_dim_names(dim_buf.data(), dim_buf.size()) != ABW_OK) die(ctx, "abw_sig_dim_names");
+	vector<string>	dim_names;
+	for(const char* p = dim_buf.data(); dim_names.size() < ABW_SIG_NDIMS; p += strlen(p) + 1) dim_names.push_back(p);
+	fprintf(fout, "%c %lu\n", '%', (unsigned long)n_seg);
+	fprintf(flrn, "%c %lu\n", '%', (unsigned long)n_seg);
+	fprintf(flrn, "%c %lu\n", '%', (unsigned long)(ABW_SIG_NDIMS + n_samples));
+	fprintf(flrn, "%c 9", '%');
+	for(int32_t c = 0; c < n_cols; c++) fprintf(flrn, "\t1");
+	fprintf(flrn, "\n");
+	fprintf(flrn, "%c Key", '%');
+	for(size_t d = 1; d < dim_names.size(); d++) fprintf(flrn, "\t%s", dim_names[d].c_str());
+	for(size_t s = 0; s < n_samples; s++) fprintf(flrn, "\t%s", sample_names[s].c_str());
+	fprintf(flrn, "\n");
+
+	// the rows of abawaca.lrn (ref :600-605) printed on the GPU
+	if(n_seg > 0) {
+		uint64_t text_len = 0;
+		int rc = abw_lrn_emit(ctx, rows.data(), (int64_t)n_seg, n_cols, 1, NULL, 0, &text_len);
+		if(rc != ABW_ERR_CAPACITY && rc != ABW_OK) die(ctx, "abw_lrn_emit");
+		vector<uint8_t> text(text_len);
+		if(abw_lrn_emit(ctx, rows.data(), (int64_t)n_seg, n_cols, 1, text.data(), text.size(), &text_len) != ABW_OK) die(ctx, "abw_lrn_emit");
+		fwrite(text.data(), 1, text_len, flrn);
+	}
+
+	// abawaca.info and abawaca.names (ref :596-599; the segment's name and description are those of ref :214-219)
+	uint64_t i = 0;
+	for(auto it=by_name.begin(); it!=by_name.end(); it++) {
+		const ScafRec& r = recs[it->second];
+		const double cvg = double(r.nbps) / r.len;					// Scaf::cvg, ref :57
+		fprintf(finfo, "%s\t%lu\t%.3lf\t%.3lf\t%lu\n", r.name.c_str(), (unsigned long)r.len, int(1000.0*cvg)/1000.0, int(1000.0*r.gc)/1000.0, (unsigned long)r.ns);
+		size_t k = 0;
+		for(uint64_t g = first_seg[it->second]; g < first_seg[it->second + 1]; g++) {
+			const uint8_t* p = blob.data() + off[it->second] + seg_start[g] - 1;
+			const size_t size = (size_t)(seg_end[g] - seg_start[g] + 1);
+			size_t nn = 0;
+			for(size_t j = 0; j < size; j++) nn += p[j] == 'N';
+			fprintf(fout, "%lu\t%s_%lu\t%s:(%lu, %lu), %lu/%lu non-Ns bps\n", (unsigned long)++i, r.name.c_str(), (unsigned long)++k, r.name.c_str(),
+			        (unsigned long)seg_start[g], (unsigned long)seg_end[g], (unsigned long)(size - nn), (unsigned long)size);
+		}
+	}
+	fclose(fout);
+	fclose(flrn);
+	fclose(finfo);
+
+	// data.txt (ref :615-630) with the same keys; the SCG table is not predicted here (external tools, ref :401-431)
+	char data[2048];
+	sprintf(data, "%s/data.txt", out_directory.c_str());
+	FILE* fp = fopen(data, "w");
+	if(fp != NULL) {
+		size_t l = assembly_file.rfind('/');
+		string out_name = (l == string::npos)? assembly_file : assembly_file.substr(l+1);
+		fprintf(fp, "SCG\t%s/%s.proteins.faa.bacteria.scg\n", out_directory.c_str(), out_name.c_str());
+		fprintf(fp, "Links\t%s\n", links_file);
+		fprintf(fp, "Info\t%s\n", info_file);
+		fprintf(fp, "Names\t%s\n", names_file);
+		fprintf(fp, "Lrn\t%s\n", lrn_file);
+		fprintf(fp, "Assembly\t%s\n", assembly_file.c_str());
+		fclose(fp);
+	}
+	abw_ctx_destroy(ctx);
+	cerr << time_since_epoch() << "Finished successfully" << endl;
+	return 0;
+}

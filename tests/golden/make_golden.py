@@ -176,8 +176,11 @@ def tinymt_case():
     print("tinymt32_kat:", len(kat), "seeds")
 
 
-def cov_case(tag, seed, n_scaf, n_samples=3, read_len=150):
-    """Row N1: the coverage columns abawaca-build prints for SAM files we wrote, with the reads as arrays."""
+def cov_case(tag, seed, n_scaf, n_samples=3, read_len=150, snp_lines=False):
+    """Row N1: the coverage columns abawaca-build prints for SAM files we wrote, with the reads as arrays.
+    snp_lines: also records with MD:Z / CIGAR strings on both sides of the reference's max_snps = 15 rule
+    (src/abawaca-build.cpp:546, src/ReadMapping.cpp:78-185), and the SAM text itself is kept (the compiled build driver
+    reads files)."""
     asm = synth.make_assembly(seed, n_scaf, 3, n_samples, frac_n_run=0.2)
     asm.cov[:] = np.exp(synth.rng_for(seed + 1).normal(np.log(5.0), 0.5, size=asm.cov.shape))
     with tempfile.TemporaryDirectory(prefix="abwgold_") as wd:
@@ -197,6 +200,18 @@ def cov_case(tag, seed, n_scaf, n_samples=3, read_len=150):
                 f.write(f"x3\t0\t{asm.names[0]}\t1\t255\t{read_len}M\t*\t0\t0\t{seq}\t{'I' * read_len}\n")
                 f.write(f"x4\t0\t{asm.names[0]}\t{L0 - 20}\t255\t{read_len}M\t*\t0\t0\t{seq}\t{'I' * read_len}\n")
                 f.write(f"x5\t16\t{asm.names[1]}\t2\t255\t{read_len}M\t*\t0\t0\t{seq}\t{'I' * read_len}\n")
+                if snp_lines:
+                    assert read_len == 150
+                    q = "I" * read_len
+                    md15 = "MD:Z:" + "8A" * 15 + "15"            # 15 mismatches: kept
+                    md16 = "MD:Z:" + "8A" * 16 + "6"             # 16 mismatches: dropped
+                    for k, (nm, pos) in enumerate(((asm.names[0], 40), (asm.names[2], 700), (asm.names[3], 1900))):
+                        f.write(f"y{k}a\t0\t{nm}\t{pos}\t255\t150M\t*\t0\t0\t{seq}\t{q}\tXA:i:0\t{md15}\tNM:i:15\n")
+                        f.write(f"y{k}b\t0\t{nm}\t{pos + 7}\t255\t150M\t*\t0\t0\t{seq}\t{q}\tXA:i:0\t{md16}\tNM:i:16\n")
+                        f.write(f"y{k}c\t0\t{nm}\t{pos + 11}\t255\t70M2I78M\t*\t0\t0\t{seq}\t{q}\tMD:Z:148\n")                      # 1 insertion: kept
+                        f.write(f"y{k}d\t0\t{nm}\t{pos + 13}\t255\t60M1I10M1I78M\t*\t0\t0\t{seq}\t{q}\tMD:Z:" + "8A" * 14 + "22\n")   # 14 + 2 = 16: dropped
+                        f.write(f"y{k}e\t0\t{nm}\t{pos + 17}\t255\t75M3D75M\t*\t0\t0\t{seq}\t{q}\tMD:Z:75^ACG" + "5A" * 12 + "3\n")    # 3 deleted + 12 = 15: kept
+                        f.write(f"y{k}f\t0\t{nm}\t{pos + 19}\t255\t75M4D75M\t*\t0\t0\t{seq}\t{q}\tMD:Z:75^ACGT" + "5A" * 12 + "3\n")   # 4 deleted + 12 = 16: dropped
         out = os.path.join(wd, "build")
         os.makedirs(out, exist_ok=True)
         subprocess.run([os.path.join(REF, "abawaca-build"), "-f", fasta, "-o", out, "-s", os.path.join(wd, "s*.sam"),
@@ -205,8 +220,10 @@ def cov_case(tag, seed, n_scaf, n_samples=3, read_len=150):
         rows = synth.read_names(os.path.join(out, "abawaca.names"))
         files = {k: np.frombuffer(open(os.path.join(out, "abawaca." + k), "rb").read(), dtype=np.uint8) for k in ("lrn", "names", "info")}
         name2idx = {n: i for i, n in enumerate(asm.names)}
-        rs, rp, rl, rf, roff = [], [], [], [], [0]
+        from abawaca_amd import coverage as _cov
+        rs, rp, rl, rf, rn, roff, sam_text = [], [], [], [], [], [0], []
         for smp in range(n_samples):
+            sam_text.append(np.frombuffer(open(os.path.join(wd, f"s{smp}.sam"), "rb").read(), dtype=np.uint8))
             for ln in open(os.path.join(wd, f"s{smp}.sam")):
                 if ln.startswith("@"):
                     continue
@@ -215,6 +232,7 @@ def cov_case(tag, seed, n_scaf, n_samples=3, read_len=150):
                 rp.append(int(fs[3]))                       # SAM POS as written (1-based; 0 for unmapped)
                 rl.append(len(fs[9]))
                 rf.append(int(fs[1]))
+                rn.append(_cov.count_snps(fs[5], next((x for x in fs[11:] if x.startswith("MD:Z:")), "")))
             roff.append(len(rs))
     seg_scaf = np.array([asm.names.index(r[2]) for r in rows], dtype=np.int32)
     seg_start = np.array([r[3] for r in rows], dtype=np.int64)
@@ -227,7 +245,8 @@ def cov_case(tag, seed, n_scaf, n_samples=3, read_len=150):
                         cov_milli=cov[order].astype(np.int32),
                         read_scaf=np.array(rs, dtype=np.uint32), read_pos1=np.array(rp, dtype=np.int64),
                         read_len=np.array(rl, dtype=np.uint32), read_flag=np.array(rf, dtype=np.uint32),
-                        read_off=np.array(roff, dtype=np.int64), header=np.array(header[179:179 + n_samples]))
+                        read_off=np.array(roff, dtype=np.int64), header=np.array(header[179:179 + n_samples]),
+                        **({"read_nsnps": np.array(rn, dtype=np.int32)} if snp_lines else {}))
     print(f"cov_{tag}: {len(asm.names)} scaffolds, {len(rows)} segments, {len(rs)} SAM lines")
     # the whole stage: the same inputs with the assembly itself and the three files the reference wrote, byte for byte
     blob = np.concatenate(asm.seqs)
@@ -237,7 +256,8 @@ def cov_case(tag, seed, n_scaf, n_samples=3, read_len=150):
                         read_scaf=np.array(rs, dtype=np.uint32), read_pos1=np.array(rp, dtype=np.int64),
                         read_len=np.array(rl, dtype=np.uint32), read_flag=np.array(rf, dtype=np.uint32),
                         read_off=np.array(roff, dtype=np.int64), sample_names=np.array(header[179:179 + n_samples]),
-                        lrn=files["lrn"], names=files["names"], info=files["info"])
+                        lrn=files["lrn"], names=files["names"], info=files["info"],
+                        **({"read_nsnps": np.array(rn, dtype=np.int32), **{f"sam{i}": t for i, t in enumerate(sam_text)}} if snp_lines else {}))
     print(f"build_{tag}: lrn {len(files['lrn'])} B, names {len(files['names'])} B, info {len(files['info'])} B")
 
 
@@ -267,6 +287,8 @@ if __name__ == "__main__":
         sep_c1_case()
     if "cov" in which:
         cov_case("a", 31, 24)
+    if "covb" in which or "cov" in which:
+        cov_case("b", 32, 16, snp_lines=True)
     if "sig" in which:
         sig_case("edge", edge_assembly())
         sig_case("rand", synth.make_assembly(11, 40, 4, 1, frac_n_run=0.25))

@@ -23,7 +23,16 @@ def ctx():
 def _samples(z):
     ro = z["read_off"]
     return [(str(z["sample_names"][s]), z["read_scaf"][ro[s]:ro[s + 1]], z["read_pos1"][ro[s]:ro[s + 1]],
-             z["read_len"][ro[s]:ro[s + 1]], z["read_flag"][ro[s]:ro[s + 1]]) for s in range(len(ro) - 1)]
+             z["read_len"][ro[s]:ro[s + 1]], z["read_flag"][ro[s]:ro[s + 1]]) +
+            ((z["read_nsnps"][ro[s]:ro[s + 1]],) if "read_nsnps" in z else ()) for s in range(len(ro) - 1)]
+
+
+def test_max_snps_rule_in_the_whole_stage(ctx, golden_dir):
+    """build_b: records with 15 and 16 SNPs in their MD:Z / CIGAR strings; .lrn coverage columns and the .info coverage
+    (which sums the accepted reads' lengths, ref :242-243) both depend on the rule of ref :546."""
+    z = np.load(os.path.join(golden_dir, "build_b.npz"))
+    out = build.build_tables(ctx, [str(n) for n in z["scaf_names"]], z["ascii"], z["scaf_off"], _samples(z), this_sample=0)
+    assert out["lrn"] == bytes(z["lrn"]) and out["names"] == bytes(z["names"]) and out["info"] == bytes(z["info"])
 
 
 def test_three_files_byte_identical_to_the_reference(ctx, golden_dir):

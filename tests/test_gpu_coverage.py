@@ -36,6 +36,15 @@ def test_reference_coverage_columns(ctx, golden_dir):
         assert np.array_equal(part.view(np.uint64), ref.view(np.uint64))
 
 
+def test_reference_columns_with_the_max_snps_rule(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "cov_b.npz"))
+    for s in range(len(g["read_off"]) - 1):
+        a, b = int(g["read_off"][s]), int(g["read_off"][s + 1])
+        rs, rp, rl = coverage.filter_reads(g["read_scaf"][a:b], g["read_pos1"][a:b], g["read_len"][a:b], g["read_flag"][a:b], g["read_nsnps"][a:b])
+        cov = coverage.accumulate(ctx, g["seg_scaf"], g["seg_start"], g["seg_end"], int(g["n_scaf"]), rs, rp, rl)
+        assert np.array_equal(coverage.milli(cov), g["cov_milli"][:, s])
+
+
 @pytest.mark.parametrize("seed,n_scaf,n_reads", [(1, 50, 20000), (2, 3, 5000), (3, 400, 300000)])
 def test_random_reads_bit_exact_vs_oracle(ctx, seed, n_scaf, n_reads):
     rng = np.random.default_rng(seed)

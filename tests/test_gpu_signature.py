@@ -192,3 +192,47 @@ def test_division_sequence_is_ieee_on_the_whole_domain():
             assert int(sums2[i]) == int((n / float(t)).view(np.uint64).sum(dtype=np.uint64))
     finally:
         ctx.close()
+
+
+def test_pipelined_build_over_several_chunks_equals_the_resident_path():
+    """abw_sig_build streams host buffers through a ring of pinned staging buffers in chunks of whole scaffolds (48 MB):
+    160 Mbp = 4 chunks, with scaffolds of N only in the middle of one (their per-base segments overflow the chunk's
+    tables: the synchronous redo path) -- against segmentation + counting of the same blob resident on the device."""
+    import torch
+    import bench
+    blob, off = bench.make_assembly_blob(7, 160)
+    blob = blob.copy()
+    off = off.astype(np.int64)
+    s = 9000                                                      # scaffold 9000 (chunk 2) becomes 10 000 N: 10 000 segments
+    blob[off[s]:off[s + 1]] = ord("N")
+    total = len(blob)
+    ctx = _lib.Context(0)
+    try:
+        r = signature.build_signatures(ctx, blob, off, want_dims=True, want_milli=True)
+        dev = torch.device("cuda", 0)
+        t_ascii = torch.from_numpy(np.concatenate([blob, np.zeros((-total) % 16 + 16, np.uint8)])).to(dev)
+        t_off = torch.from_numpy(off).to(dev)
+        cap = len(r["seg_scaf"]) + 8
+        t_scaf = torch.empty(cap, dtype=torch.int32, device=dev)
+        t_st = torch.empty(cap, dtype=torch.int64, device=dev)
+        t_en = torch.empty(cap, dtype=torch.int64, device=dev)
+        n = signature.segment_dev(ctx, t_ascii, total, t_off, 2000, t_scaf, t_st, t_en)
+        assert n == len(r["seg_scaf"]) and n > 85_000
+        t_dims = torch.empty((n, 180), dtype=torch.float64, device=dev)
+        t_milli = torch.empty((n, 179), dtype=torch.int32, device=dev)
+        signature.count_dev(ctx, t_ascii, total, t_off, t_scaf, t_st, t_en, n, t_dims=t_dims, t_milli=t_milli)
+        ctx.synchronize()
+        assert np.array_equal(r["seg_scaf"], t_scaf[:n].cpu().numpy().astype(np.uint32))
+        assert np.array_equal(r["seg_start"], t_st[:n].cpu().numpy()) and np.array_equal(r["seg_end"], t_en[:n].cpu().numpy())
+        assert np.array_equal(r["dims"].view(np.uint64), t_dims.cpu().numpy().view(np.uint64))
+        assert np.array_equal(r["milli"], t_milli.cpu().numpy())
+        # a capacity below the count: the count comes back with ABW_ERR_CAPACITY, nothing else is promised
+        import ctypes as C
+        k = C.c_uint64(0)
+        small = np.empty(1000, dtype=np.uint32), np.empty(1000, dtype=np.uint64), np.empty(1000, dtype=np.uint64)
+        offu = off.astype(np.uint64)
+        rc = _lib.lib().abw_sig_build(ctx.handle, C.c_void_p(blob.ctypes.data), C.c_void_p(offu.ctypes.data), len(off) - 1, 2000, 1000,
+                                      C.c_void_p(small[0].ctypes.data), C.c_void_p(small[1].ctypes.data), C.c_void_p(small[2].ctypes.data), None, None, C.byref(k))
+        assert rc == _lib.ABW_ERR_CAPACITY and k.value == n
+    finally:
+        ctx.close()
