@@ -23,6 +23,7 @@
 // (2) chunked scan of the histograms and evaluation of every threshold; (3) per-scaffold counts for the
 // final assignment.
 #include "abw_internal.h"
+#include "abw_sep_common.h"
 #include <string.h>
 #include <algorithm>
 #include <thread>
@@ -30,167 +31,29 @@
 
 namespace {
 
-constexpr int NARROW_T = 1024;      // dimensions with keys in [0, NARROW_T) use the key itself as bin
-constexpr int SCAN_CH = 2048;       // bins per scan chunk
-#ifndef ABW_ACC_SPB
-#define ABW_ACC_SPB 2048
-#endif
-#ifndef ABW_ACC_COPIES
-#define ABW_ACC_COPIES 1
-#endif
-constexpr int ACC_SPB = ABW_ACC_SPB;       // scaffolds per workgroup in sep_accum
-constexpr int MAX_SCG = 4096;
 
-struct DimBestDev { int32_t found; int32_t bin; double sens; double spec; double prod; long long size1; long long n; };
-
-struct ChunkDesc { int32_t dim; int32_t start; int32_t len; int32_t first_chunk_of_dim; };
-
-struct SepDev {
-    const int32_t* bins; int64_t N;
-    const int32_t* scaf_first; const int32_t* scaf_ndps; const int64_t* scaf_len;
-    const int32_t* scg_off; const int32_t* scg_ids; int32_t n_scg;
-    const int32_t* T; const int64_t* Toff;
-    unsigned long long* h_st;          // per bin: size (low 32 bits) and tp1 (high 32 bits), updated by one 64-bit atomic
-    uint32_t* h_tot; unsigned long long* h_bp;
-    int32_t* scg_lo; int32_t* scg_hi;
-    int32_t* range;                    // [D][2] bins the current node touched in each dimension (lo, hi inclusive; hi < lo: none)
-};
-
-// k-th smallest (0-based) of the n values at col[0..n), n > 8: binary search on the answer.
-__device__ inline int32_t select_kth_mem(const int32_t* __restrict__ col, int n, int k, int T)
-{
-    int lo = 0;
-    int bit = 1;
-    while ((bit << 1) < T && bit < (1 << 29)) bit <<= 1;
-    for (; bit > 0; bit >>= 1) {
-        const int cand = lo | bit;
-        if (cand >= T) continue;
-        int cnt = 0;
-        for (int i = 0; i < n; i++) cnt += col[i] < cand;
-        if (cnt <= k) lo = cand;
-    }
-    return lo;
-}
 
 // Narrow dimensions (keys in [0, NARROW_T): every signature column).  One thread per (scaffold, dimension):
 // the flip value by a sorting network, then per dp size[v] += 1 and tp1[max(v, t_s)] += 1 (the dps at or below
 // the flip value are credited to bin t_s in one add), per scaffold tot[t_s] += n and bp[t_s] += len -- all
 // in a histogram private to the workgroup (LDS, 32-bit atomics), flushed to the node's histogram at the end.
-constexpr int ACC_COPIES = ABW_ACC_COPIES;       // LDS copies of the (size, tp1) histograms, by lane.  Measured (r01): 1 copy 0.25 ms,
-                                    // 4 copies 0.40 ms for the 179 narrow dimensions -- zeroing and flushing cost more than
-                                    // the same-bin contention they remove
-
+// Same-bin contention: a signature column uses few bins (a 4-mer frequency is about 0.004: thousandths 0..15), so the 64
+// lanes of an LDS atomic mostly hit the same handful of words and serialise.  The histograms are therefore kept in as many
+// LDS COPIES as fit into the space one full-range column needs (T <= 1024 bins): copies = 1024 / T rounded down to a power
+// of two, at most 32; a lane uses copy (lane mod copies); the copies lie T|1 words apart -- an odd stride, so that one bin
+// of different copies falls into different banks.  Zeroing and flushing touch copies * T <= 1056 words whatever T is.
+// (Measured r01 with a fixed 4 copies of 1024 bins: slower, the zero / flush passes grew 4x; here they do not grow.)
 __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t* __restrict__ dimlist,
                                                        const int32_t* __restrict__ node_scaf, int32_t m)
 {
-    __shared__ uint32_t s_size[ACC_COPIES * NARROW_T];    // LDS atomics: 32-bit ones are the fast ones
-    __shared__ uint32_t s_tp1[ACC_COPIES * NARROW_T];
-    __shared__ uint32_t s_tot[NARROW_T];
-    __shared__ unsigned long long s_bp[NARROW_T];
+    __shared__ uint32_t s_size[ACC_LDS_WORDS];            // LDS atomics: 32-bit ones are the fast ones
+    __shared__ uint32_t s_tp1[ACC_LDS_WORDS];
+    __shared__ uint32_t s_tot[ACC_LDS_WORDS];
+    __shared__ unsigned long long s_bp[ACC_LDS_WORDS];
     const int d = dimlist[blockIdx.y];
-    const int T = P.T[d];
-    const int64_t toff = P.Toff[d];
-    const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
-    for (int t = threadIdx.x; t < T; t += 256) {
-#pragma unroll
-        for (int c = 0; c < ACC_COPIES; c++) { s_size[c * NARROW_T + t] = 0; s_tp1[c * NARROW_T + t] = 0; }
-        s_tot[t] = 0; s_bp[t] = 0;
-    }
-    __syncthreads();
-    unsigned long long* g_st = P.h_st + toff;
-    uint32_t* g_tot = P.h_tot + toff;
-    unsigned long long* g_bp = P.h_bp + toff;
-    uint32_t* my_size = s_size + (threadIdx.x & (ACC_COPIES - 1)) * NARROW_T;
-    uint32_t* my_tp1 = s_tp1 + (threadIdx.x & (ACC_COPIES - 1)) * NARROW_T;
-
-    // The loads of a scaffold are a dependent chain (list -> scaffold table -> column values); the next scaffold's are
-    // issued before this one is processed.
-    struct Item { int s, f, n; long long len; int v[8]; };
-    auto fetch = [&](int ls, Item& it) {
-        it.s = node_scaf ? node_scaf[ls] : ls;
-        it.f = P.scaf_first[it.s];
-        it.n = P.scaf_ndps[it.s];
-        it.len = P.scaf_len[it.s];
-#pragma unroll
-        for (int i = 0; i < 8; i++) it.v[i] = (i < it.n) ? col[it.f + i] : INT_MAX;      // the first 8 values (all, for n <= 8)
-    };
-    const int ls_end = min(m, (int)(blockIdx.x + 1) * ACC_SPB);
-    Item cur, nxt;
-    int ls = blockIdx.x * ACC_SPB + threadIdx.x;
-    if (ls < ls_end) fetch(ls, cur);
-    for (; ls < ls_end; ls += 256) {
-        if (ls + 256 < ls_end) fetch(ls + 256, nxt);
-        const int s = cur.s, f = cur.f, n = cur.n;
-        const long long slen = cur.len;
-        const int k = n >> 1;                              // 0-based index of the flip value
-        int ts;
-        uint32_t tp_ts = 0;                                // dps at or below the flip value: tp1 credits bin t_s
-        if (n <= 8) {
-            int v[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = cur.v[i];
-            {
-                // k-th smallest of the n values (the tail is padded with INT_MAX): Batcher's 19-comparator
-                // network on a copy, then the element at k = n/2 (1..4)
-                int w[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) w[i] = v[i];
-#define ABW_CX(a, b) { const int lo_ = min(w[a], w[b]), hi_ = max(w[a], w[b]); w[a] = lo_; w[b] = hi_; }
-                ABW_CX(0, 1) ABW_CX(2, 3) ABW_CX(4, 5) ABW_CX(6, 7)
-                ABW_CX(0, 2) ABW_CX(1, 3) ABW_CX(4, 6) ABW_CX(5, 7)
-                ABW_CX(1, 2) ABW_CX(5, 6)
-                ABW_CX(0, 4) ABW_CX(1, 5) ABW_CX(2, 6) ABW_CX(3, 7)
-                ABW_CX(2, 4) ABW_CX(3, 5)
-                ABW_CX(1, 2) ABW_CX(3, 4) ABW_CX(5, 6)
-#undef ABW_CX
-                ts = (k == 1) ? w[1] : (k == 2) ? w[2] : (k == 3) ? w[3] : w[4];
-                // one LDS atomic per DISTINCT value of the scaffold (its segments often share a 3-decimal value): runs of the
-                // sorted copy; the padding (INT_MAX) ends the last run
-                uint32_t run = 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    if (i < n) {
-                        run++;
-                        const int nextv = (i < 7) ? w[i + 1] : INT_MAX;
-                        if (nextv != w[i]) {
-                            atomicAdd(&my_size[w[i]], run);
-                            if (w[i] > ts) atomicAdd(&my_tp1[w[i]], run); else tp_ts += run;
-                            run = 0;
-                        }
-                    }
-                }
-            }
-        } else {
-            ts = select_kth_mem(col + f, n, k, T);
-            for (int i = 0; i < n; i++) {
-                const int v = col[f + i];
-                atomicAdd(&my_size[v], 1u);
-                if (v > ts) atomicAdd(&my_tp1[v], 1u); else tp_ts++;
-            }
-        }
-        atomicAdd(&my_tp1[ts], tp_ts);
-        atomicAdd(&s_tot[ts], (uint32_t)n);
-        atomicAdd(&s_bp[ts], (unsigned long long)slen);
-        if (P.n_scg > 0) {
-            for (int e = P.scg_off[s]; e < P.scg_off[s + 1]; e++) {
-                const int g = P.scg_ids[e];
-                atomicMin(&P.scg_lo[(int64_t)d * P.n_scg + g], ts);
-                atomicMax(&P.scg_hi[(int64_t)d * P.n_scg + g], ts);
-            }
-        }
-        cur = nxt;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 256) {
-        unsigned long long a = 0;
-#pragma unroll
-        for (int c = 0; c < ACC_COPIES; c++) a += (unsigned long long)s_size[c * NARROW_T + t] | ((unsigned long long)s_tp1[c * NARROW_T + t] << 32);
-        const uint32_t c3 = s_tot[t];
-        const unsigned long long e = s_bp[t];
-        if (a) atomicAdd(&g_st[t], a);
-        if (c3) atomicAdd(&g_tot[t], c3);
-        if (e) atomicAdd(&g_bp[t], e);
-    }
+    const int ls_begin = blockIdx.x * ACC_SPB;
+    accum_tile(P, d, node_scaf, ls_begin, min(m, ls_begin + ACC_SPB), P.h_st + P.Toff[d], P.h_tot + P.Toff[d], P.h_bp + P.Toff[d],
+               P.scg_lo + (int64_t)d * P.n_scg, P.scg_hi + (int64_t)d * P.n_scg, s_size, s_tp1, s_tot, s_bp);
 }
 
 // ---- wide dimensions (coverage: about as many distinct keys as dps) -----------------------------------
@@ -444,10 +307,6 @@ __global__ __launch_bounds__(256) void sep_wide_hist_kernel(SepDev P, WideDev W,
 }
 
 // ---- chunked scan + evaluation ----------------------------------------------------------------
-struct Sums { unsigned long long size, tp1, tot, bp; };
-
-__device__ __forceinline__ Sums sums_add(Sums a, Sums b) { return {a.size + b.size, a.tp1 + b.tp1, a.tot + b.tot, a.bp + b.bp}; }
-
 __device__ __forceinline__ Sums wave_incl_scan(Sums x, int lane)
 {
 #pragma unroll
@@ -507,24 +366,6 @@ __global__ __launch_bounds__(64) void sep_chunk_scan_kernel(const int32_t* __res
         run = sums_add(run, last);
     }
     if (lane == 0) dim_total[d] = run;
-}
-
-struct Cand { double prod; int32_t bin; int32_t found; double sens; double spec; long long size1; };
-
-__device__ __forceinline__ bool cand_better(const Cand& a, const Cand& b)   // is a better than b
-{
-    if (!a.found) return false;
-    if (!b.found) return true;
-    if (a.prod != b.prod) return a.prod > b.prod;
-    return a.bin < b.bin;                        // equal products keep the smaller threshold
-}
-
-__device__ __forceinline__ Cand cand_shfl_xor(const Cand& c, int o)
-{
-    Cand r;
-    r.prod = __shfl_xor(c.prod, o, 64); r.bin = __shfl_xor(c.bin, o, 64); r.found = __shfl_xor(c.found, o, 64);
-    r.sens = __shfl_xor(c.sens, o, 64); r.spec = __shfl_xor(c.spec, o, 64); r.size1 = __shfl_xor(c.size1, o, 64);
-    return r;
 }
 
 // phase C: rescan each chunk with its carry-in, evaluate every threshold, keep the chunk's best
@@ -639,8 +480,6 @@ __global__ __launch_bounds__(64) void sep_dimbest_kernel(const int32_t* __restri
 // ClusterSeparator.cpp:11-16) applied in dimension order from the reset best_separation (dimension = (size_t)-1,
 // value = -1, sens = spec = 0): a larger product wins, equal products keep the smaller dimension -- and a
 // dimension whose winner has product 0 still replaces the reset state.  Then is_legal (ref .h:31-35).
-struct GlobalRes { int32_t found; int32_t dim; int32_t bin; int32_t legal; double sens; double spec; long long size1; long long n; };
-
 // In dimension order that rule picks, among the dimensions that found a winner, the largest product and on equal
 // products the smallest dimension: a strict order, so one wave reduces it (lanes stride over the dimensions).
 __global__ __launch_bounds__(64) void sep_global_kernel(const DimBestDev* __restrict__ db, int32_t D, GlobalRes* __restrict__ out,
@@ -711,23 +550,8 @@ __global__ __launch_bounds__(256) void sep_assign_kernel(SepDev P, const int32_t
     if (threadIdx.x == 0) { if (b1) atomicAdd(&totals[0], b1); if (b2) atomicAdd(&totals[1], b2); }
 }
 
-struct SepHost {
-    std::vector<int32_t> narrow_dims, wide_dims;
-    std::vector<ChunkDesc> chunks;
-    std::vector<int32_t> dim_first_chunk, dim_nchunks;
-    int32_t *d_narrow = nullptr, *d_wide = nullptr, *d_dim_first_chunk = nullptr, *d_dim_nchunks = nullptr;
-    ChunkDesc* d_chunks = nullptr;
-    Sums *d_chunk_sums = nullptr, *d_dim_total = nullptr;
-    Cand* d_chunk_best = nullptr;
-    // wide dimensions: dps sorted by bin (static) and the per-node flip-value records
-    int32_t *d_sscaf = nullptr, *d_sbin = nullptr, *d_wts = nullptr, *d_wbelow = nullptr;
-    int32_t* d_range = nullptr;        // [D][2] bins touched by the current node
-    bool sharded = false;              // table loaded with a shared bin layout (abw_sep_shard_load)
-};
-
 }  // namespace
 
-struct abw_sep_extra { SepHost h; };
 static abw_sep_extra* g_extra_of(abw_ctx* ctx);
 
 // The context keeps the host-side extras in a side table keyed by the context pointer (keeps
@@ -736,6 +560,8 @@ static abw_sep_extra* g_extra_of(abw_ctx* ctx);
 #include <mutex>
 static std::map<abw_ctx*, abw_sep_extra*> g_extras;
 static std::mutex g_extras_mtx;
+SepHost& abw_sep_host(abw_ctx* ctx) { return g_extra_of(ctx)->h; }
+
 static abw_sep_extra* g_extra_of(abw_ctx* ctx)
 {
     std::lock_guard<std::mutex> l(g_extras_mtx);
@@ -765,8 +591,8 @@ extern "C" void abw_sep_free(abw_ctx* ctx)
     }
     if (e) {
         void* q[] = {e->h.d_narrow, e->h.d_wide, e->h.d_dim_first_chunk, e->h.d_dim_nchunks, e->h.d_chunks,
-                     e->h.d_chunk_sums, e->h.d_dim_total, e->h.d_chunk_best, e->h.d_sscaf, e->h.d_sbin,
-                     e->h.d_wts, e->h.d_wbelow, e->h.d_range};
+                     e->h.d_chunk_sums, e->h.d_dim_total, e->h.d_chunk_best, e->h.d_sscaf, e->h.d_sbin, e->h.d_sdp,
+                     e->h.d_wts, e->h.d_wbelow, e->h.d_range, e->h.d_ts16, e->h.d_wword, e->h.d_wext, e->h.d_wpack, e->h.d_carriers};
         for (void* p : q) if (p) (void)hipFree(p);
         delete e;
     }
@@ -968,7 +794,7 @@ static int sep_load_upload_impl(abw_ctx* ctx, std::vector<int32_t>& st_first, st
     if (!H.wide_dims.empty()) {
         // dps of every wide dimension in ascending (bin, dp) order: counting sort on the dense ranks
         const size_t Dw = H.wide_dims.size();
-        std::vector<int32_t> sscaf(Dw * (size_t)N), sbin(Dw * (size_t)N);
+        std::vector<int32_t> sscaf(Dw * (size_t)N), sbin(Dw * (size_t)N), sdp(Dw * (size_t)N);
         unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
         auto sort_dim = [&](unsigned t) {
             std::vector<int64_t> start;
@@ -980,7 +806,8 @@ static int sep_load_upload_impl(abw_ctx* ctx, std::vector<int32_t>& st_first, st
                 for (int32_t b = 0; b < s.h_T[d]; b++) start[(size_t)b + 1] += start[b];
                 int32_t* pw = sscaf.data() + w * (size_t)N;
                 int32_t* sw = sbin.data() + w * (size_t)N;
-                for (int64_t p = 0; p < N; p++) { const int64_t at = start[col[p]]++; pw[at] = dp2scaf[p]; sw[at] = col[p]; }
+                int32_t* dw = sdp.data() + w * (size_t)N;
+                for (int64_t p = 0; p < N; p++) { const int64_t at = start[col[p]]++; pw[at] = dp2scaf[p]; sw[at] = col[p]; dw[at] = (int32_t)p; }
             }
         };
         std::vector<std::thread> th3;
@@ -988,6 +815,7 @@ static int sep_load_upload_impl(abw_ctx* ctx, std::vector<int32_t>& st_first, st
         for (auto& x : th3) x.join();
         if ((rc = upload(ctx, &H.d_sscaf, sscaf.data(), sscaf.size()))) return rc;
         if ((rc = upload(ctx, &H.d_sbin, sbin.data(), sbin.size()))) return rc;
+        if ((rc = upload(ctx, &H.d_sdp, sdp.data(), sdp.size()))) return rc;
         if ((rc = upload<int32_t>(ctx, &H.d_wts, nullptr, Dw * (size_t)S))) return rc;
         if ((rc = upload<int32_t>(ctx, &H.d_wbelow, nullptr, Dw * (size_t)S))) return rc;
     }

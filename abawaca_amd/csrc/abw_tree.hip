@@ -1,0 +1,1052 @@
+// Stage 2, the whole recursion in one call: abw_sep_tree = the work-list loop of reference src/abawaca.cpp:95-197 around
+// ClusterSeparator::separate() (src/ClusterSeparator.cpp:25-135, ...BySensitivitySpecificity.cpp:91-161,
+// ClusterQuality.cpp:96-136), run LEVEL BY LEVEL on the resident table of abw_sep_load.
+//
+// The reference takes the node with the smallest id from a std::map and gives the children of a split the next two ids
+// (src/abawaca.cpp:98-100,155-194): nodes are therefore visited in breadth-first order, and the nodes of one level can be
+// evaluated together -- one set of launches per LEVEL instead of per node (abw_sep_node costs ~14 launches and one
+// synchronisation per node, and most nodes of a deep recursion are small).  Same integer formulation as abw_sep.hip, plus
+// three observations:
+//   1. A node always holds WHOLE scaffolds (ref src/ClusterSeparator.cpp:104-122), so the flip value t_s of a scaffold in a
+//      dimension -- the (n_s/2 + 1)-th smallest of its own values -- is the same in every node of the recursion.  It is
+//      computed once per table (tree_static_*): per node nothing is sorted or selected any more.
+//   2. With static flip values a node's histograms are plain sums over its scaffolds, hence
+//      hist(bigger child) = hist(parent) - hist(smaller child): only the SMALLER child of every split is accumulated from
+//      the table, its sibling comes from a subtraction of two histogram slices.  Every dp is accumulated O(log) times
+//      over the whole recursion instead of once per level of a (typically very unbalanced) tree.
+//   3. Wide dimensions (coverage) need NO histogram.  Each keeps its dps sorted by (node, bin, dp): initially the table's
+//      static (bin, dp) order, after every level a stable partition of each node's segment into its two children.  A
+//      node's thresholds in ascending order are then the run ends of its segment and size1 / TP1 / tot1 / bp1 are prefix
+//      sums along it: two passes over 8 B per position (tile sums; rescan + evaluate).  What a position contributes is
+//      static, too, and travels in the position's word: scaffold | [v >= t_s] << 31 | [owner] << 30, the owner being the
+//      first dp of its scaffold on bin t_s, which also carries what the scaffold puts on that bin (one 16-byte gather).
+//   Narrow dimensions (keys < 1024) keep their histograms: LDS-private per tile of scaffolds, flushed into the slice of
+//   the tile's node; one workgroup per (node, dimension) scans the <= 1024 bins and evaluates every threshold.
+//   Then per node the winner over the dimensions, the scaffold sides, the children's sizes: one small read-back per level.
+#include "abw_sep_common.h"
+#include <string.h>
+#include <algorithm>
+
+namespace {
+
+// Tiles are cut at ABSOLUTE multiples of 2048 in the arrays they index (a node's first and last tile are partial), and the
+// per-dimension stride of the position arrays is a multiple of 8: thread t of a tile owns the 8 consecutive items at
+// (tile & ~2047) + 8 t, 32-byte aligned -- two 16-byte loads per array, a wave reads 2 KB in one piece.
+constexpr int TILE_S = 2048;     // scaffolds per tile (256 threads x 8)
+constexpr int TILE_P = 2048;     // sorted positions per tile (256 threads x 8 consecutive)
+constexpr uint32_t PACK_ESCAPE = 0xFFFFFFFFu;
+
+struct NodeDev {
+    int32_t scaf_begin, scaf_end;       // its scaffolds in `order`
+    int32_t dp_begin, dp_end;           // its positions in every wide dimension's sorted arrays
+    int32_t stile_begin, stile_end;     // its scaffold tiles
+    int32_t ptile_begin, ptile_end;     // its position tiles
+};
+struct Tile { int32_t node, begin, end; };
+
+struct NodeRes {                        // per node of a level, device -> host
+    GlobalRes win;
+    unsigned long long n1, n2;          // dps of the scaffolds sent to cluster1 / cluster2
+    uint32_t m1, m2;                    // scaffolds sent to cluster1 / cluster2
+};
+struct NodePart {                       // per node, host -> device for the partition
+    int32_t split, id;
+    int32_t scaf_base1, scaf_base2;     // where the children's scaffolds start in the next level's order
+    int32_t dp_base1, dp_base2;         // ... and their positions in the sorted arrays
+    int32_t slot1, slot2;               // the children's slots in the next level
+};
+
+struct WSums { unsigned long long tp1, tot, bp; };
+
+struct TreeDev {
+    SepDev P;
+    const int32_t* narrow; int32_t n_narrow; const int64_t* toffn; int64_t TBn;       // narrow dims, their offsets inside a node's slice
+    const int32_t* wide; int32_t n_wide;
+    const int32_t* dp2scaf;
+    const int32_t* dim_slot;            // [D]: index among the narrow dimensions, or -(index among the wide ones) - 1
+    const uint16_t* ts16;               // [n_narrow][S]
+    const uint4* wext;                  // [n_wide][S]: x = dps below t_s, y = dps, z = min(length, 500000), w = bin of t_s
+    const uint32_t* wpack;              // [n_wide][S]: x | y << 6 | z << 13 where y <= 127 (4 MB per million scaffolds: L2), else PACK_ESCAPE
+    int32_t D, S;
+};
+
+constexpr uint32_t W_GE = 0x80000000u, W_OWN = 0x40000000u, W_SC = 0x3FFFFFFFu;
+
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* sh)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// exclusive prefix of v over the 256 threads of the block (sh: 5 words)
+__device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long long v, unsigned long long* sh, unsigned long long* total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    unsigned long long x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    __syncthreads();
+    if (lane == 63) sh[wid] = x;
+    __syncthreads();
+    unsigned long long off = 0;
+    for (int k = 0; k < wid; k++) off += sh[k];
+    if (total) *total = sh[0] + sh[1] + sh[2] + sh[3];
+    return off + x - v;
+}
+
+// the 8 consecutive items of this thread in an aligned tile [begin, end); i0 is a multiple of 8 and p + i0 32-byte aligned
+template <typename T>
+__device__ __forceinline__ void load8(const T* __restrict__ p, int i0, int begin, int end, T (&v)[8], T fill)
+{
+    static_assert(sizeof(T) == 4, "32-bit items");
+    if (i0 >= begin && i0 + 8 <= end) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p + i0), b = *reinterpret_cast<const uint4*>(p + i0 + 4);
+        v[0] = (T)a.x; v[1] = (T)a.y; v[2] = (T)a.z; v[3] = (T)a.w; v[4] = (T)b.x; v[5] = (T)b.y; v[6] = (T)b.z; v[7] = (T)b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = (i0 + i >= begin && i0 + i < end) ? p[i0 + i] : fill;
+    }
+}
+
+// ---- level set-up: the SCG lo / hi lists of every (node, dimension) start empty ------------------------------------
+__global__ void tree_scg_reset_kernel(int32_t* __restrict__ lo, int32_t* __restrict__ hi, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { lo[i] = INT_MAX; hi[i] = -1; }
+}
+
+// ---- the static tables (once per loaded table) ------------------------------------------------------------------------
+// flip value of every scaffold in every narrow dimension.  grid (ceil(S / 256), narrow dimensions)
+__global__ __launch_bounds__(256) void tree_static_narrow_kernel(SepDev P, const int32_t* __restrict__ narrow, int32_t S, uint16_t* __restrict__ ts16)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    const int d = narrow[blockIdx.y];
+    const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
+    const int f = P.scaf_first[s], n = P.scaf_ndps[s], k = n >> 1;
+    int ts;
+    if (n <= 8) {
+        int x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = (i < n) ? col[f + i] : INT_MAX;
+        ABW_SORT8(x);
+        ts = (k == 1) ? x[1] : (k == 2) ? x[2] : (k == 3) ? x[3] : x[4];
+    } else ts = select_kth_mem(col + f, n, k, P.T[d]);
+    ts16[(int64_t)blockIdx.y * S + s] = (uint16_t)ts;
+}
+
+// wide dimensions: flip value (as a bin), dps below it, one byte per dp (bit 0: v >= t_s; bit 1: the first dp of the
+// scaffold on bin t_s).  grid (ceil(S / 256), wide dimensions)
+__global__ __launch_bounds__(256) void tree_static_wide_kernel(SepDev P, const int32_t* __restrict__ wide, int32_t S, uint8_t* __restrict__ flags,
+                                                              uint4* __restrict__ wext, uint32_t* __restrict__ wpack)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    const int w = blockIdx.y;
+    const int d = wide[w];
+    const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
+    uint8_t* __restrict__ fl = flags + (int64_t)w * P.N;
+    const int f = P.scaf_first[s], n = P.scaf_ndps[s], k = n >> 1;
+    int ts, nb = 0;
+    bool owned = false;
+    if (n <= 8) {
+        int v[8], x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { v[i] = (i < n) ? col[f + i] : INT_MAX; x[i] = v[i]; }
+        ABW_SORT8(x);
+        ts = (k == 1) ? x[1] : (k == 2) ? x[2] : (k == 3) ? x[3] : x[4];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (i < n) {
+                nb += v[i] < ts;
+                const bool own = !owned && v[i] == ts;
+                owned |= own;
+                fl[f + i] = (uint8_t)((v[i] >= ts ? 1 : 0) | (own ? 2 : 0));
+            }
+        }
+    } else {
+        ts = select_kth_mem(col + f, n, k, P.T[d]);
+        for (int i = 0; i < n; i++) {
+            const int v = col[f + i];
+            nb += v < ts;
+            const bool own = !owned && v == ts;
+            owned |= own;
+            fl[f + i] = (uint8_t)((v >= ts ? 1 : 0) | (own ? 2 : 0));
+        }
+    }
+    const long long len = P.scaf_len[s];
+    const uint32_t lenc = (uint32_t)(len < 500000 ? (len < 0 ? 0 : len) : 500000);
+    wext[(int64_t)w * S + s] = make_uint4((uint32_t)nb, (uint32_t)n, lenc, (uint32_t)ts);
+    wpack[(int64_t)w * S + s] = (n <= 127) ? ((uint32_t)nb | (uint32_t)n << 6 | lenc << 13) : PACK_ESCAPE;      // nb <= n / 2 <= 63
+}
+
+// the word of every sorted position: scaffold | flags.  grid (blocks, wide dimensions)
+__global__ void tree_static_words_kernel(const int32_t* __restrict__ sdp, const uint8_t* __restrict__ flags, const int32_t* __restrict__ dp2scaf,
+                                         int64_t N, int64_t Np, uint32_t* __restrict__ wword)
+{
+    const int64_t base = (int64_t)blockIdx.y * N, obase = (int64_t)blockIdx.y * Np;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int dp = sdp[base + i];
+        const uint8_t f = flags[base + dp];
+        wword[obase + i] = (uint32_t)dp2scaf[dp] | ((f & 1) ? W_GE : 0u) | ((f & 2) ? W_OWN : 0u);
+    }
+}
+
+// ---- narrow dimensions ----------------------------------------------------------------------------------------------
+// Histograms of one tile of scaffolds in one narrow dimension with the static flip values: per dp size[v] += 1 and
+// tp1[max(v, t_s)] += 1 (the dps at or below t_s are credited to bin t_s in one add), per scaffold tot[t_s] += n and
+// bp[t_s] += len -- LDS-private (several copies, see sep_accum_kernel in abw_sep.hip), flushed with one atomic per
+// non-empty bin into the slice of the tile's node.  grid (tiles to accumulate, narrow dimensions)
+__global__ __launch_bounds__(256) void tree_accum_kernel(TreeDev Tr, const Tile* __restrict__ tiles, const int32_t* __restrict__ order,
+                                                        unsigned long long* __restrict__ h_st, unsigned long long* __restrict__ h_bp,
+                                                        uint32_t* __restrict__ h_tot)
+{
+    __shared__ uint32_t s_size[ACC_LDS_WORDS];
+    __shared__ uint32_t s_tp1[ACC_LDS_WORDS];
+    __shared__ uint32_t s_tot[ACC_LDS_WORDS];
+    __shared__ unsigned long long s_bp[ACC_LDS_WORDS];
+    const Tile t = tiles[blockIdx.x];
+    const int dn = blockIdx.y;
+    const int d = Tr.narrow[dn];
+    const int T = Tr.P.T[d];
+    const int32_t* __restrict__ col = Tr.P.bins + (int64_t)d * Tr.P.N;
+    const uint16_t* __restrict__ tsd = Tr.ts16 + (int64_t)dn * Tr.S;
+    const int Tp = T | 1;
+    int copies = 1;
+    while (copies < 32 && 2 * copies * Tp <= ACC_LDS_WORDS) copies <<= 1;
+    for (int i = threadIdx.x; i < copies * Tp; i += 256) { s_size[i] = 0; s_tp1[i] = 0; s_tot[i] = 0; s_bp[i] = 0; }
+    __syncthreads();
+    const int mine = (threadIdx.x & (copies - 1)) * Tp;
+    uint32_t* my_size = s_size + mine;
+    uint32_t* my_tp1 = s_tp1 + mine;
+    for (int ls = t.begin + threadIdx.x; ls < t.end; ls += 256) {
+        const int s = order[ls];
+        const int f = Tr.P.scaf_first[s], n = Tr.P.scaf_ndps[s];
+        const int ts = tsd[s];
+        uint32_t tp_ts = 0;
+        if (n <= 8) {
+            int v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (i < n) ? col[f + i] : 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (i < n) {
+                    atomicAdd(&my_size[v[i]], 1u);
+                    if (v[i] > ts) atomicAdd(&my_tp1[v[i]], 1u); else tp_ts++;
+                }
+            }
+        } else {
+            for (int i = 0; i < n; i++) {
+                const int v = col[f + i];
+                atomicAdd(&my_size[v], 1u);
+                if (v > ts) atomicAdd(&my_tp1[v], 1u); else tp_ts++;
+            }
+        }
+        atomicAdd(&my_tp1[ts], tp_ts);
+        atomicAdd(&s_tot[mine + ts], (uint32_t)n);
+        atomicAdd(&s_bp[mine + ts], (unsigned long long)Tr.P.scaf_len[s]);
+    }
+    __syncthreads();
+    const int64_t at = (int64_t)t.node * Tr.TBn + Tr.toffn[dn];
+    for (int b = threadIdx.x; b < T; b += 256) {
+        unsigned long long a = 0, e = 0;
+        uint32_t c3 = 0;
+        for (int c = 0; c < copies; c++) {
+            const int i = c * Tp + b;
+            a += (unsigned long long)s_size[i] | ((unsigned long long)s_tp1[i] << 32);
+            c3 += s_tot[i];
+            e += s_bp[i];
+        }
+        if (a) atomicAdd(&h_st[at + b], a);
+        if (c3) atomicAdd(&h_tot[at + b], c3);
+        if (e) atomicAdd(&h_bp[at + b], e);
+    }
+}
+
+// slices of the nodes that are accumulated start at zero.  grid (nodes to zero, ceil(TBn / 1024))
+__global__ __launch_bounds__(256) void tree_zero_kernel(const int32_t* __restrict__ slots, int64_t TBn, unsigned long long* __restrict__ h_st,
+                                                       unsigned long long* __restrict__ h_bp, uint32_t* __restrict__ h_tot)
+{
+    const int64_t at = (int64_t)slots[blockIdx.x] * TBn;
+    for (int64_t b = (int64_t)blockIdx.y * 1024 + threadIdx.x; b < std::min<int64_t>(TBn, (int64_t)(blockIdx.y + 1) * 1024); b += 256) {
+        h_st[at + b] = 0; h_bp[at + b] = 0; h_tot[at + b] = 0;
+    }
+}
+
+// hist(bigger child) = hist(parent) - hist(smaller child), slice by slice (the packed size | tp1 words subtract without a
+// borrow between the halves: the child's counts never exceed the parent's).  grid (pairs, ceil(TBn / 1024))
+struct SubJob { int32_t big, parent, small; };
+__global__ __launch_bounds__(256) void tree_sub_kernel(const SubJob* __restrict__ jobs, int64_t TBn, unsigned long long* __restrict__ c_st,
+                                                      unsigned long long* __restrict__ c_bp, uint32_t* __restrict__ c_tot,
+                                                      const unsigned long long* __restrict__ p_st, const unsigned long long* __restrict__ p_bp,
+                                                      const uint32_t* __restrict__ p_tot)
+{
+    const SubJob j = jobs[blockIdx.x];
+    const int64_t big = (int64_t)j.big * TBn, par = (int64_t)j.parent * TBn, sm = (int64_t)j.small * TBn;
+    for (int64_t b = (int64_t)blockIdx.y * 1024 + threadIdx.x; b < std::min<int64_t>(TBn, (int64_t)(blockIdx.y + 1) * 1024); b += 256) {
+        c_st[big + b] = p_st[par + b] - c_st[sm + b];
+        c_bp[big + b] = p_bp[par + b] - c_bp[sm + b];
+        c_tot[big + b] = p_tot[par + b] - c_tot[sm + b];
+    }
+}
+
+// SCG lo / hi of every (node, dimension): min / max of the static flip values over the node's scaffolds that carry the
+// SCG.  One thread per (carrier scaffold, dimension); scaf_slot = the scaffold's node in this level, -1 when it has none.  K: nodes of the level.
+__global__ __launch_bounds__(256) void tree_scg_kernel(TreeDev Tr, const int32_t* __restrict__ carriers, int32_t n_carriers, const int32_t* __restrict__ scaf_slot,
+                                                      int32_t K, int32_t* __restrict__ scg_lo, int32_t* __restrict__ scg_hi)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)n_carriers * Tr.D) return;
+    const int s = carriers[idx / Tr.D], d = (int)(idx % Tr.D);
+    const int k = scaf_slot[s];
+    if (k < 0 || k >= K) return;                              // no node, or a node the cut work list does not reach
+    const int slot = Tr.dim_slot[d];
+    const int ts = slot >= 0 ? (int)Tr.ts16[(int64_t)slot * Tr.S + s] : (int)Tr.wext[(int64_t)(-slot - 1) * Tr.S + s].w;
+    const int64_t sg = ((int64_t)k * Tr.D + d) * Tr.P.n_scg;
+    for (int e = Tr.P.scg_off[s]; e < Tr.P.scg_off[s + 1]; e++) {
+        const int g = Tr.P.scg_ids[e];
+        atomicMin(&scg_lo[sg + g], ts);
+        atomicMax(&scg_hi[sg + g], ts);
+    }
+}
+
+// One threshold of a (node, dimension): size check, small side, sensitivity x specificity in fp64 exactly as the
+// reference's doubles, the SCG / size gate (ref ...Specificity.cpp:146-161, ClusterQuality.cpp:96-136).
+__device__ __forceinline__ void eval_threshold(long long size1, long long tp1, long long tot1, unsigned long long bp1, long long n,
+                                               unsigned long long bp_total, int32_t min_ndps, int bin, int ng, const int32_t* s_lo,
+                                               const int32_t* s_hi, Cand& best)
+{
+    const long long size2 = n - size1, tot2 = n - tot1;
+    const long long tp2 = n - (size1 + tot1 - tp1);
+    if (size1 < min_ndps || size2 < min_ndps) return;              // ref :151
+    const bool small1 = size1 < size2;                             // ref :155 (tie -> cluster2)
+    const long long TP = small1 ? tp1 : tp2, TOT = small1 ? tot1 : tot2, SZ = small1 ? size1 : size2;
+    const double sens = (double)(int)TP / (double)(int)TOT;        // ref .h:75 (int fields)
+    const double spec = (double)(int)TP / (double)(int)SZ;         // ref .h:74
+    const double prod = sens * spec;
+    if (!(prod == prod)) return;                                   // NaN is never better (ref .h:28)
+    const Cand cnd = {prod, bin, 1, sens, spec, size1};
+    if (!cand_better(cnd, best)) return;
+    int cl = 0, chh = 0;
+    for (int g = 0; g < ng; g++) { cl += s_lo[g] <= bin; chh += s_hi[g] <= bin; }
+    const int G1 = cl, G2 = ng - chh, both = cl - chh;
+    bool pass;
+    if (G1 == 0 || G2 == 0) pass = (bp1 >= 500000ull) && (bp_total - bp1 >= 500000ull);
+    else pass = !((double)both / (double)(G1 < G2 ? G1 : G2) < 0.2);
+    if (pass) best = cnd;
+}
+
+// SCGs present in the (node, dimension): lo != INT_MAX, compacted into LDS.  Call by all threads; returns their number.
+__device__ __forceinline__ int compact_scgs(const int32_t* __restrict__ lo, const int32_t* __restrict__ hi, int n_scg, int32_t* s_lo, int32_t* s_hi, int* s_ng)
+{
+    if (threadIdx.x == 0) *s_ng = 0;
+    __syncthreads();
+    for (int g = threadIdx.x; g < n_scg; g += blockDim.x) {
+        const int l = lo[g];
+        if (l != INT_MAX) { const int slot = atomicAdd(s_ng, 1); s_lo[slot] = l; s_hi[slot] = hi[g]; }
+    }
+    __syncthreads();
+    return *s_ng;
+}
+
+__device__ __forceinline__ Cand block_best(Cand best, Cand* wbest)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const Cand other = cand_shfl_xor(best, o); if (cand_better(other, best)) best = other; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+    __syncthreads();
+    Cand b = wbest[0];
+    for (int k = 1; k < 4; k++) if (cand_better(wbest[k], b)) b = wbest[k];
+    return b;
+}
+
+// grid (nodes, narrow dimensions): scan the node's slice (T <= 1024 bins: 4 per thread), evaluate every threshold present,
+// keep the best.  The slice stays: the node's children are derived from it.
+__global__ __launch_bounds__(256) void tree_eval_narrow_kernel(TreeDev Tr, const NodeDev* __restrict__ nodes, int32_t min_ndps,
+                                                              const unsigned long long* __restrict__ h_st, const unsigned long long* __restrict__ h_bp,
+                                                              const uint32_t* __restrict__ h_tot, const int32_t* __restrict__ scg_lo,
+                                                              const int32_t* __restrict__ scg_hi, Cand* __restrict__ cand)
+{
+    __shared__ unsigned long long sh[3][5];
+    __shared__ int32_t s_lo[MAX_SCG], s_hi[MAX_SCG];
+    __shared__ int s_ng;
+    __shared__ Cand wbest[4];
+    const int k = blockIdx.x, dn = blockIdx.y;
+    const int d = Tr.narrow[dn];
+    const int T = Tr.P.T[d];
+    const NodeDev nd = nodes[k];
+    const long long n = nd.dp_end - nd.dp_begin;
+    const int64_t at = (int64_t)k * Tr.TBn + Tr.toffn[dn];
+    const int64_t sg = ((int64_t)k * Tr.D + d) * Tr.P.n_scg;
+    const int ng = compact_scgs(scg_lo + sg, scg_hi + sg, Tr.P.n_scg, s_lo, s_hi, &s_ng);
+    unsigned long long st[4], bp[4];
+    uint32_t tot[4];
+    unsigned long long a_size = 0, a_tp1 = 0, a_tot = 0, a_bp = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int t = 4 * threadIdx.x + i;
+        st[i] = 0; bp[i] = 0; tot[i] = 0;
+        if (t < T) {
+            st[i] = h_st[at + t]; bp[i] = h_bp[at + t]; tot[i] = h_tot[at + t];
+        }
+        a_size += (uint32_t)st[i]; a_tp1 += st[i] >> 32; a_tot += tot[i]; a_bp += bp[i];
+    }
+    // size and tp1 fit 32 bits each (n < 2^31): one packed scan for the pair, one for tot | -, one for bp
+    unsigned long long tot_st = 0, tot_bp = 0, tot_tt = 0;
+    unsigned long long o_st = block_excl_scan_u64(a_size | (a_tp1 << 32), sh[0], &tot_st);
+    unsigned long long o_tt = block_excl_scan_u64(a_tot, sh[1], &tot_tt);
+    unsigned long long o_bp = block_excl_scan_u64(a_bp, sh[2], &tot_bp);
+    Cand best = {0.0, 0, 0, 0.0, 0.0, 0};
+    long long size1 = (long long)(uint32_t)o_st, tp1 = (long long)(o_st >> 32), tot1 = (long long)o_tt;
+    unsigned long long bp1 = o_bp;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t here = (uint32_t)st[i];
+        size1 += here; tp1 += (long long)(st[i] >> 32); tot1 += tot[i]; bp1 += bp[i];
+        if (here) eval_threshold(size1, tp1, tot1, bp1, n, tot_bp, min_ndps, 4 * threadIdx.x + i, ng, s_lo, s_hi, best);
+    }
+    const Cand b = block_best(best, wbest);
+    if (threadIdx.x == 0) cand[(int64_t)k * Tr.D + d] = b;
+}
+
+// ---- wide dimensions ------------------------------------------------------------------------------------------------
+// what the dp at a sorted position adds to the prefix sums of its node (all static: see tree_static_wide_kernel)
+__device__ __forceinline__ WSums position_terms(const TreeDev& Tr, int w, uint32_t word)
+{
+    WSums r = {(unsigned long long)(word >> 31), 0, 0};
+    if (word & W_OWN) {
+        const uint32_t pk = Tr.wpack[(int64_t)w * Tr.S + (word & W_SC)];
+        if (pk != PACK_ESCAPE) { r.tp1 += pk & 63u; r.tot = (pk >> 6) & 127u; r.bp = pk >> 13; }
+        else { const uint4 e = Tr.wext[(int64_t)w * Tr.S + (word & W_SC)]; r.tp1 += e.x; r.tot = e.y; r.bp = e.z; }
+    }
+    return r;
+}
+
+// pass 1: sums of every position tile.  grid (position tiles, wide dimensions)
+__global__ __launch_bounds__(256) void tree_wide_sums_kernel(TreeDev Tr, const Tile* __restrict__ tiles, int32_t n_tiles, const uint32_t* __restrict__ wword,
+                                                            int64_t wstride, WSums* __restrict__ tile_sums)
+{
+    __shared__ unsigned long long sh[8];
+    const Tile t = tiles[blockIdx.x];
+    const int w = blockIdx.y;
+    const uint32_t* __restrict__ words = wword + (int64_t)w * wstride;
+    WSums a = {0, 0, 0};
+    const int i0 = (t.begin & ~(TILE_P - 1)) + 8 * threadIdx.x;
+    uint32_t wd[8];
+    load8(words, i0, t.begin, t.end, wd, 0u);                 // a zero word adds nothing
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const WSums r = position_terms(Tr, w, wd[i]); a.tp1 += r.tp1; a.tot += r.tot; a.bp += r.bp; }
+    const unsigned long long s1 = block_sum_u64(a.tp1, sh);
+    const unsigned long long s3 = block_sum_u64(a.tot, sh + 4);
+    const unsigned long long s2 = block_sum_u64(a.bp, sh);
+    if (threadIdx.x == 0) tile_sums[(int64_t)w * n_tiles + blockIdx.x] = WSums{s1, s3, s2};
+}
+
+// pass 1b: exclusive scan of the tile sums inside every node; node totals.  grid (nodes, wide dimensions), one wave
+__global__ __launch_bounds__(64) void tree_wide_scan_kernel(const NodeDev* __restrict__ nodes, int32_t n_tiles, WSums* __restrict__ tile_sums,
+                                                           WSums* __restrict__ node_total, int32_t K)
+{
+    const int k = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
+    const NodeDev nd = nodes[k];
+    WSums* ts = tile_sums + (int64_t)w * n_tiles;
+    WSums run = {0, 0, 0};
+    for (int i0 = nd.ptile_begin; i0 < nd.ptile_end; i0 += 64) {
+        const int i = i0 + lane;
+        WSums v = {0, 0, 0};
+        if (i < nd.ptile_end) v = ts[i];
+        WSums x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long a = __shfl_up(x.tp1, o, 64), b = __shfl_up(x.tot, o, 64), c = __shfl_up(x.bp, o, 64);
+            if (lane >= o) { x.tp1 += a; x.tot += b; x.bp += c; }
+        }
+        if (i < nd.ptile_end) ts[i] = WSums{run.tp1 + x.tp1 - v.tp1, run.tot + x.tot - v.tot, run.bp + x.bp - v.bp};
+        run.tp1 += __shfl(x.tp1, 63, 64); run.tot += __shfl(x.tot, 63, 64); run.bp += __shfl(x.bp, 63, 64);
+    }
+    if (lane == 0) node_total[(int64_t)w * K + k] = run;
+}
+
+// pass 2: rescan every tile with its carry, evaluate the threshold at every run end (the last position of a bin inside
+// the node), keep the tile's best.  grid (position tiles, wide dimensions)
+__global__ __launch_bounds__(256) void tree_wide_eval_kernel(TreeDev Tr, const Tile* __restrict__ tiles, int32_t n_tiles, const NodeDev* __restrict__ nodes,
+                                                            int32_t K, int32_t min_ndps, const int32_t* __restrict__ wbin, const uint32_t* __restrict__ wword,
+                                                            int64_t wstride, const WSums* __restrict__ tile_carry, const WSums* __restrict__ node_total,
+                                                            const int32_t* __restrict__ scg_lo, const int32_t* __restrict__ scg_hi,
+                                                            Cand* __restrict__ tile_best)
+{
+    __shared__ unsigned long long sh[3][5];
+    __shared__ int32_t s_lo[MAX_SCG], s_hi[MAX_SCG];
+    __shared__ int s_ng;
+    __shared__ Cand wbest[4];
+    const Tile t = tiles[blockIdx.x];
+    const int w = blockIdx.y;
+    const int d = Tr.wide[w];
+    const NodeDev nd = nodes[t.node];
+    const long long n = nd.dp_end - nd.dp_begin;
+    const int64_t sg = ((int64_t)t.node * Tr.D + d) * Tr.P.n_scg;
+    const int ng = compact_scgs(scg_lo + sg, scg_hi + sg, Tr.P.n_scg, s_lo, s_hi, &s_ng);
+    const int32_t* __restrict__ bins = wbin + (int64_t)w * wstride;
+    const uint32_t* __restrict__ words = wword + (int64_t)w * wstride;
+    const unsigned long long bp_total = node_total[(int64_t)w * K + t.node].bp;
+    const int i0 = (t.begin & ~(TILE_P - 1)) + 8 * threadIdx.x;
+    int b[9];
+    uint32_t wd[8];
+    WSums r[8];
+    WSums a = {0, 0, 0};
+    {
+        int b8[8];
+        load8(bins, i0, t.begin, t.end, b8, -1);
+#pragma unroll
+        for (int i = 0; i < 8; i++) b[i] = b8[i];
+        b[8] = (i0 + 8 < nd.dp_end) ? bins[i0 + 8] : -1;            // -1 past the node's end (where a partial tile ends, too): the last run ends there
+    }
+    load8(words, i0, t.begin, t.end, wd, 0u);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { r[i] = position_terms(Tr, w, wd[i]); a.tp1 += r[i].tp1; a.tot += r[i].tot; a.bp += r[i].bp; }
+    const WSums carry = tile_carry[(int64_t)w * n_tiles + blockIdx.x];
+    const unsigned long long o1 = block_excl_scan_u64(a.tp1, sh[0], nullptr);
+    const unsigned long long o3 = block_excl_scan_u64(a.tot, sh[2], nullptr);
+    const unsigned long long o2 = block_excl_scan_u64(a.bp, sh[1], nullptr);
+    long long tp1 = (long long)(carry.tp1 + o1), tot1 = (long long)(carry.tot + o3);
+    unsigned long long bp1 = carry.bp + o2;
+    Cand best = {0.0, 0, 0, 0.0, 0.0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i0 + i >= t.begin && i0 + i < t.end) {
+            tp1 += (long long)r[i].tp1; tot1 += (long long)r[i].tot; bp1 += r[i].bp;
+            if (b[i + 1] != b[i])                                                       // a run end: threshold = this bin
+                eval_threshold((long long)(i0 + i - nd.dp_begin + 1), tp1, tot1, bp1, n, bp_total, min_ndps, b[i], ng, s_lo, s_hi, best);
+        }
+    }
+    const Cand bb = block_best(best, wbest);
+    if (threadIdx.x == 0) tile_best[(int64_t)w * n_tiles + blockIdx.x] = bb;
+}
+
+// best tile of every (node, wide dimension).  grid (nodes, wide dimensions), one wave
+__global__ __launch_bounds__(64) void tree_wide_best_kernel(TreeDev Tr, const NodeDev* __restrict__ nodes, int32_t n_tiles, const Cand* __restrict__ tile_best,
+                                                           Cand* __restrict__ cand)
+{
+    const int k = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
+    const NodeDev nd = nodes[k];
+    Cand c = {0.0, 0, 0, 0.0, 0.0, 0};
+    for (int t = nd.ptile_begin + lane; t < nd.ptile_end; t += 64) { const Cand o = tile_best[(int64_t)w * n_tiles + t]; if (cand_better(o, c)) c = o; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const Cand other = cand_shfl_xor(c, o); if (cand_better(other, c)) c = other; }
+    if (lane == 0) cand[(int64_t)k * Tr.D + Tr.wide[w]] = c;
+}
+
+// ---- the winner of every node ----------------------------------------------------------------------------------------
+// ClusteringResult::is_better over the dimensions in dimension order (ref ...Specificity.h:25-30 + ClusterSeparator.cpp:11-16):
+// the largest product, on equal products the smallest dimension; then is_legal (ref .h:31-35).  grid (nodes), one wave.
+__global__ __launch_bounds__(64) void tree_winner_kernel(TreeDev Tr, const NodeDev* __restrict__ nodes, const Cand* __restrict__ cand, NodeRes* __restrict__ res)
+{
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const NodeDev nd = nodes[k];
+    Cand bc = {0.0, 0, 0, 0.0, 0.0, 0};
+    int bd = -1;
+    // every lane takes dimensions lane, lane + 64, ... in ascending order: a later dimension must be strictly better
+    for (int d = lane; d < Tr.D; d += 64) {
+        const Cand c = cand[(int64_t)k * Tr.D + d];
+        if (c.found && (bd < 0 || c.prod > bc.prod)) { bc = c; bd = d; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const Cand oc = cand_shfl_xor(bc, o);
+        const int od = __shfl_xor(bd, o, 64);
+        if (od >= 0 && (bd < 0 || oc.prod > bc.prod || (oc.prod == bc.prod && od < bd))) { bc = oc; bd = od; }
+    }
+    if (lane != 0) return;
+    NodeRes r;
+    r.win.found = bd >= 0; r.win.dim = bd; r.win.bin = bd >= 0 ? bc.bin : -1;
+    r.win.sens = bd >= 0 ? bc.sens : 0.0; r.win.spec = bd >= 0 ? bc.spec : 0.0;
+    r.win.legal = (bd >= 0) && (bc.sens >= 0.8) && (bc.spec >= 0.8) && (bc.sens + bc.spec >= 1.6) && (bc.sens * bc.spec >= 0.8);
+    r.win.size1 = bd >= 0 ? bc.size1 : 0; r.win.n = nd.dp_end - nd.dp_begin;
+    r.n1 = r.n2 = 0; r.m1 = r.m2 = 0;
+    res[k] = r;
+}
+
+// ---- scaffold sides (ref ClusterSeparator.cpp:35-53,94-122): cluster1 = the raw side with fewer dps (tie: the "<=" side), a
+// scaffold goes to cluster1 iff at least half of its dps are there.  grid (scaffold tiles)
+__global__ __launch_bounds__(256) void tree_assign_kernel(TreeDev Tr, const Tile* __restrict__ tiles, const int32_t* __restrict__ order,
+                                                         NodeRes* __restrict__ res, uint8_t* __restrict__ scaf_side)
+{
+    __shared__ unsigned long long b[4];
+    const Tile t = tiles[blockIdx.x];
+    const GlobalRes win = res[t.node].win;
+    if (!win.legal) return;                                   // uniform for the tile: nothing to reconstruct (ref :27-28)
+    if (threadIdx.x < 4) b[threadIdx.x] = 0;
+    __syncthreads();
+    const bool swap = win.n - win.size1 < win.size1;
+    const int32_t* __restrict__ col = Tr.P.bins + (int64_t)win.dim * Tr.P.N;
+    for (int ls = t.begin + threadIdx.x; ls < t.end; ls += 256) {
+        const int s = order[ls];
+        const int f = Tr.P.scaf_first[s], tot = Tr.P.scaf_ndps[s];
+        int c = 0;
+        for (int i = 0; i < tot; i++) c += col[f + i] <= win.bin;
+        const int c1 = swap ? tot - c : c;
+        const bool to1 = c1 > 0 && 2 * (long long)c1 >= tot;
+        scaf_side[s] = to1 ? 1 : 2;
+        atomicAdd(&b[to1 ? 0 : 1], (unsigned long long)tot);
+        atomicAdd(&b[to1 ? 2 : 3], 1ull);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (b[0]) atomicAdd(&res[t.node].n1, b[0]);
+        if (b[1]) atomicAdd(&res[t.node].n2, b[1]);
+        if (b[2]) atomicAdd(&res[t.node].m1, (uint32_t)b[2]);
+        if (b[3]) atomicAdd(&res[t.node].m2, (uint32_t)b[3]);
+    }
+}
+
+// ---- partition: the next level's order of scaffolds and of every wide dimension's positions ---------------------------
+// count of cluster-1 members per tile, and their mask (one byte per thread of the tile = 8 items: the scatter does not look
+// the sides up again).  items: scaffold ids (order) or position words (scaffold in the low 30 bits); side: per scaffold.
+// grid (tiles, arrays); istride: a multiple of 8
+__global__ __launch_bounds__(256) void tree_part_count_kernel(const Tile* __restrict__ tiles, int32_t n_tiles, const NodePart* __restrict__ part,
+                                                             const uint32_t* __restrict__ items, int64_t istride,
+                                                             const uint8_t* __restrict__ side, uint32_t* __restrict__ tile_cnt, uint8_t* __restrict__ mask)
+{
+    __shared__ unsigned long long sh[4];
+    const Tile t = tiles[blockIdx.x];
+    if (!part[t.node].split) return;                          // uniform: a terminal node's items go nowhere
+    const uint32_t* __restrict__ it = items + (int64_t)blockIdx.y * istride;
+    const int i0 = (t.begin & ~2047) + 8 * threadIdx.x;
+    uint32_t v[8];
+    load8(it, i0, t.begin, t.end, v, 0u);
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) if (i0 + i >= t.begin && i0 + i < t.end) m |= (uint32_t)(side[v[i] & W_SC] == 1) << i;
+    mask[((int64_t)blockIdx.y * n_tiles + blockIdx.x) * 256 + threadIdx.x] = (uint8_t)m;      // by tile: two nodes may share 8 aligned items
+    const unsigned long long s = block_sum_u64((unsigned long long)__popc(m), sh);
+    if (threadIdx.x == 0) tile_cnt[(int64_t)blockIdx.y * n_tiles + blockIdx.x] = (uint32_t)s;
+}
+
+// exclusive scan of the tile counts inside every split node.  grid (nodes, arrays), one wave.  scaf = 1: scaffold tiles
+__global__ __launch_bounds__(64) void tree_part_scan_kernel(const NodeDev* __restrict__ nodes, const NodePart* __restrict__ part, int32_t n_tiles,
+                                                           uint32_t* __restrict__ tile_cnt, int scaf)
+{
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (!part[k].split) return;
+    const NodeDev nd = nodes[k];
+    const int tb = scaf ? nd.stile_begin : nd.ptile_begin, te = scaf ? nd.stile_end : nd.ptile_end;
+    uint32_t* tc = tile_cnt + (int64_t)blockIdx.y * n_tiles;
+    uint32_t run = 0;
+    for (int i0 = tb; i0 < te; i0 += 64) {
+        const int i = i0 + lane;
+        const uint32_t v = (i < te) ? tc[i] : 0;
+        uint32_t x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (i < te) tc[i] = run + x - v;
+        run += __shfl(x, 63, 64);
+    }
+}
+
+// stable scatter of a split node's items into its two children's ranges.  For scaffolds (scaf = 1) every scaffold also
+// learns the slot of its node in the next level (-1: none) and, in a terminal node, its final cluster id.  grid (tiles, arrays)
+__global__ __launch_bounds__(256) void tree_part_scatter_kernel(const Tile* __restrict__ tiles, int32_t n_tiles, const NodeDev* __restrict__ nodes,
+                                                               const NodePart* __restrict__ part, const uint32_t* __restrict__ items,
+                                                               const int32_t* __restrict__ items2, int64_t istride, const uint8_t* __restrict__ mask,
+                                                               const uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ out, int32_t* __restrict__ out2,
+                                                               int scaf, int32_t* __restrict__ scaf2cluster, int32_t* __restrict__ scaf_slot)
+{
+    __shared__ unsigned long long sh[5];
+    const Tile t = tiles[blockIdx.x];
+    const NodePart np = part[t.node];
+    const uint32_t* __restrict__ it = items + (int64_t)blockIdx.y * istride;
+    const int i0 = (t.begin & ~2047) + 8 * threadIdx.x;
+    uint32_t v[8];
+    if (!np.split) {
+        if (scaf) {
+            load8(it, i0, t.begin, t.end, v, 0u);
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (i0 + i >= t.begin && i0 + i < t.end) { scaf_slot[v[i]] = -1; if (np.id > 0) scaf2cluster[v[i]] = np.id; }
+        }
+        return;
+    }
+    const NodeDev nd = nodes[t.node];
+    const int nbeg = scaf ? nd.scaf_begin : nd.dp_begin;
+    const int base1 = scaf ? np.scaf_base1 : np.dp_base1, base2 = scaf ? np.scaf_base2 : np.dp_base2;
+    load8(it, i0, t.begin, t.end, v, 0u);
+    int32_t v2[8];
+    if (items2) load8(items2 + (int64_t)blockIdx.y * istride, i0, t.begin, t.end, v2, 0);
+    const uint32_t m = mask[((int64_t)blockIdx.y * n_tiles + blockIdx.x) * 256 + threadIdx.x];
+    unsigned long long ones_before = block_excl_scan_u64((unsigned long long)__popc(m), sh, nullptr) + tile_cnt[(int64_t)blockIdx.y * n_tiles + blockIdx.x];   // inside the node
+    uint32_t* o1 = out + (int64_t)blockIdx.y * istride;
+    int32_t* o2 = out2 ? out2 + (int64_t)blockIdx.y * istride : nullptr;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i0 + i >= t.begin && i0 + i < t.end) {
+            const uint32_t one = (m >> i) & 1u;
+            const long long rank_in_node = i0 + i - nbeg;
+            const long long dest = one ? base1 + (long long)ones_before : base2 + (rank_in_node - (long long)ones_before);
+            o1[dest] = v[i];
+            if (o2) o2[dest] = v2[i];
+            if (scaf) scaf_slot[v[i]] = one ? np.slot1 : np.slot2;
+            ones_before += one;
+        }
+    }
+}
+
+__global__ void tree_iota_kernel(uint32_t* p, int32_t n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = (uint32_t)i;
+}
+
+void make_tiles(std::vector<Tile>& tiles, int node, int begin, int end, int step, int32_t& tb, int32_t& te)
+{
+    tb = (int32_t)tiles.size();
+    for (int a = begin; a < end; a = (a / step + 1) * step) tiles.push_back(Tile{node, a, std::min(end, (a / step + 1) * step)});   // cut at absolute multiples
+    te = (int32_t)tiles.size();
+}
+
+// a block of host data for one upload: appends v, returns its byte offset (64-byte aligned)
+template <typename T>
+size_t pack(std::vector<uint8_t>& blob, const std::vector<T>& v)
+{
+    const size_t at = (blob.size() + 63) & ~(size_t)63;
+    blob.resize(at + v.size() * sizeof(T));
+    if (!v.empty()) memcpy(blob.data() + at, v.data(), v.size() * sizeof(T));
+    return at;
+}
+
+// The static tables of the loaded table (once; kept with the table until abw_sep_load / abw_ctx_destroy frees them).
+int tree_static_build(abw_ctx* ctx, SepHost& H, const SepDev& P, const int32_t* d_dp2scaf)
+{
+    abw_sep_state& s = ctx->sep;
+    hipStream_t st = ctx->stream;
+    const int32_t S = s.S, n_narrow = (int32_t)H.narrow_dims.size(), n_wide = (int32_t)H.wide_dims.size();
+    const int64_t N = s.N;
+    // a build that failed half-way may have left some of them behind
+    if (H.d_ts16) { (void)hipFree(H.d_ts16); H.d_ts16 = nullptr; }
+    if (H.d_wword) { (void)hipFree(H.d_wword); H.d_wword = nullptr; }
+    if (H.d_wext) { (void)hipFree(H.d_wext); H.d_wext = nullptr; }
+    if (H.d_wpack) { (void)hipFree(H.d_wpack); H.d_wpack = nullptr; }
+    if (H.d_carriers) { (void)hipFree(H.d_carriers); H.d_carriers = nullptr; }
+    if (n_narrow) {
+        ABW_HIP(ctx, hipMalloc((void**)&H.d_ts16, (size_t)n_narrow * S * 2));
+        hipLaunchKernelGGL(tree_static_narrow_kernel, dim3((unsigned)((S + 255) / 256), (unsigned)n_narrow), dim3(256), 0, st, P, H.d_narrow, S, H.d_ts16);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    if (n_wide) {
+        const int64_t Np = (N + 7) & ~(int64_t)7;
+        ABW_HIP(ctx, hipMalloc((void**)&H.d_wword, (size_t)n_wide * Np * 4));
+        ABW_HIP(ctx, hipMalloc((void**)&H.d_wext, (size_t)n_wide * S * 16));
+        ABW_HIP(ctx, hipMalloc((void**)&H.d_wpack, (size_t)n_wide * S * 4));
+        int rc;
+        if ((rc = abw_reserve(ctx, ctx->scratch[3], (size_t)n_wide * N))) return rc;         // per-dp flags, temporary
+        hipLaunchKernelGGL(tree_static_wide_kernel, dim3((unsigned)((S + 255) / 256), (unsigned)n_wide), dim3(256), 0, st, P, H.d_wide, S,
+                           (uint8_t*)ctx->scratch[3].p, (uint4*)H.d_wext, H.d_wpack);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(tree_static_words_kernel, dim3((unsigned)(ctx->num_cu * 8), (unsigned)n_wide), dim3(256), 0, st, H.d_sdp,
+                           (const uint8_t*)ctx->scratch[3].p, d_dp2scaf, N, Np, H.d_wword);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    if (s.n_scg > 0) {
+        std::vector<int32_t> off((size_t)S + 1), carriers;
+        ABW_HIP(ctx, hipMemcpyAsync(off.data(), s.d_scg_off, ((size_t)S + 1) * 4, hipMemcpyDeviceToHost, st));
+        ABW_HIP(ctx, hipStreamSynchronize(st));
+        for (int32_t sc = 0; sc < S; sc++) if (off[sc + 1] > off[sc]) carriers.push_back(sc);
+        H.n_carriers = (int32_t)carriers.size();
+        ABW_HIP(ctx, hipMalloc((void**)&H.d_carriers, std::max<size_t>(4, carriers.size() * 4)));
+        if (!carriers.empty()) ABW_HIP(ctx, hipMemcpy(H.d_carriers, carriers.data(), carriers.size() * 4, hipMemcpyHostToDevice));
+    }
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    return ABW_OK;
+}
+
+}  // namespace
+
+extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, abw_tree_node* nodes_out, int64_t node_cap,
+                            int64_t* n_nodes, int32_t* scaf2cluster)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    abw_sep_state& s = ctx->sep;
+    if (!s.loaded) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_tree: call abw_sep_load first");
+    if (!n_nodes || (node_cap > 0 && !nodes_out) || min_ndps < 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree: bad argument");
+    SepHost& H = abw_sep_host(ctx);
+    if (H.sharded) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_tree: the table is one shard of a sharded problem (abw_sep_shard_load); use abw_sep_shard_*");
+    abw_device_guard g(ctx->device);
+    hipStream_t st = ctx->stream;
+    *n_nodes = 0;
+    if (max_nodes <= 0) max_nodes = INT64_MAX;
+    int rc;
+    const int32_t D = s.D, S = s.S, n_narrow = (int32_t)H.narrow_dims.size(), n_wide = (int32_t)H.wide_dims.size();
+    const int64_t N = s.N, Np = (N + 7) & ~(int64_t)7, Sp = ((int64_t)S + 7) & ~(int64_t)7;      // strides of the position / scaffold arrays
+    if (S > (int32_t)W_SC) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree: more than 2^30 scaffolds");
+
+    // narrow dimensions' offsets inside one node's histogram slice
+    std::vector<int64_t> toffn((size_t)n_narrow + 1, 0);
+    for (int i = 0; i < n_narrow; i++) toffn[i + 1] = toffn[i] + s.h_T[H.narrow_dims[i]];
+    const int64_t TBn = std::max<int64_t>(1, toffn[n_narrow]);
+
+    // buffers of the call (grow-only scratch of the context: scratch is free between entry points)
+    abw_devbuf &b_order = ctx->scratch[0], &b_wbin = ctx->scratch[1], &b_wword = ctx->scratch[2], &b_side = ctx->scratch[4],
+               &b_scg = ctx->scratch[5], &b_lvl = ctx->scratch[6], &b_tile = ctx->scratch[7], &b_misc = ctx->scratch[8], &b_s2c = ctx->scratch[9];
+    abw_devbuf* b_hist[2] = {&ctx->scratch[10], &ctx->scratch[11]};
+    if ((rc = abw_reserve(ctx, b_order, (size_t)2 * Sp * 4))) return rc;
+    if ((rc = abw_reserve(ctx, b_side, (size_t)S + 64 + (size_t)S * 4))) return rc;
+    if ((rc = abw_reserve(ctx, b_s2c, (size_t)S * 4))) return rc;
+    if (n_wide) {
+        if ((rc = abw_reserve(ctx, b_wbin, (size_t)2 * n_wide * Np * 4))) return rc;
+        if ((rc = abw_reserve(ctx, b_wword, (size_t)2 * n_wide * Np * 4))) return rc;
+    }
+    std::vector<int32_t> slot_h((size_t)D, 0);
+    for (int i = 0; i < n_narrow; i++) slot_h[H.narrow_dims[i]] = i;
+    for (int i = 0; i < n_wide; i++) slot_h[H.wide_dims[i]] = -i - 1;
+    const size_t m_toff = (toffn.size() * 8 + 63) & ~(size_t)63, m_slot = ((size_t)D * 4 + 63) & ~(size_t)63;
+    if ((rc = abw_reserve(ctx, b_misc, m_toff + m_slot + (size_t)N * 4 + 64))) return rc;
+    int64_t* d_toffn = (int64_t*)b_misc.p;
+    int32_t* d_slot = (int32_t*)((uint8_t*)b_misc.p + m_toff);
+    int32_t* d_dp2scaf = (int32_t*)((uint8_t*)b_misc.p + m_toff + m_slot);
+    ABW_HIP(ctx, hipMemcpyAsync(d_toffn, toffn.data(), toffn.size() * 8, hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemcpyAsync(d_slot, slot_h.data(), (size_t)D * 4, hipMemcpyHostToDevice, st));
+
+    TreeDev Tr;
+    Tr.P.bins = s.d_bins ? s.d_bins : s.d_keys; Tr.P.N = N;
+    Tr.P.scaf_first = s.d_scaf_first; Tr.P.scaf_ndps = s.d_scaf_ndps; Tr.P.scaf_len = s.d_scaf_len;
+    Tr.P.scg_off = s.d_scg_off; Tr.P.scg_ids = s.d_scg_ids; Tr.P.n_scg = s.n_scg;
+    Tr.P.T = s.d_T; Tr.P.Toff = s.d_Toff;
+    Tr.P.h_st = nullptr; Tr.P.h_tot = nullptr; Tr.P.h_bp = nullptr; Tr.P.scg_lo = nullptr; Tr.P.scg_hi = nullptr; Tr.P.range = nullptr;
+    if ((n_narrow && !H.d_ts16) || (n_wide && !(H.d_wword && H.d_wpack)) || (s.n_scg > 0 && !H.d_carriers)) {
+        // dp -> scaffold (only the static build needs it)
+        std::vector<int32_t> d2s((size_t)N);
+        for (int32_t sc = 0; sc < S; sc++) std::fill(d2s.begin() + s.h_scaf_first[sc], d2s.begin() + s.h_scaf_first[sc] + s.h_scaf_ndps[sc], sc);
+        ABW_HIP(ctx, hipMemcpyAsync(d_dp2scaf, d2s.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
+        ABW_HIP(ctx, hipStreamSynchronize(st));
+        if ((rc = tree_static_build(ctx, H, Tr.P, d_dp2scaf))) return rc;
+    }
+    Tr.narrow = H.d_narrow; Tr.n_narrow = n_narrow; Tr.toffn = d_toffn; Tr.TBn = TBn;
+    Tr.wide = H.d_wide; Tr.n_wide = n_wide; Tr.dp2scaf = d_dp2scaf; Tr.dim_slot = d_slot;
+    Tr.ts16 = H.d_ts16; Tr.wext = (const uint4*)H.d_wext; Tr.wpack = H.d_wpack; Tr.D = D; Tr.S = S;
+
+    uint32_t* order[2] = {(uint32_t*)b_order.p, (uint32_t*)b_order.p + Sp};
+    int32_t* wbin[2] = {(int32_t*)b_wbin.p, n_wide ? (int32_t*)b_wbin.p + (int64_t)n_wide * Np : nullptr};
+    uint32_t* wword[2] = {(uint32_t*)b_wword.p, n_wide ? (uint32_t*)b_wword.p + (int64_t)n_wide * Np : nullptr};
+    uint8_t* d_scaf_side = (uint8_t*)b_side.p;
+    int32_t* d_scaf_slot = (int32_t*)((uint8_t*)b_side.p + (((size_t)S + 63) & ~(size_t)63));
+    hipLaunchKernelGGL(tree_iota_kernel, dim3(ctx->num_cu * 4), dim3(256), 0, st, order[0], S);
+    ABW_LAUNCH_CHECK(ctx);
+    ABW_HIP(ctx, hipMemsetAsync(d_scaf_slot, 0, (size_t)S * 4, st));          // every scaffold starts in node slot 0 (the root)
+    ABW_HIP(ctx, hipMemsetAsync(b_s2c.p, 0, (size_t)S * 4, st));
+    if (n_wide) {
+        ABW_HIP(ctx, hipMemcpy2DAsync(wbin[0], (size_t)Np * 4, H.d_sbin, (size_t)N * 4, (size_t)N * 4, (size_t)n_wide, hipMemcpyDeviceToDevice, st));
+        ABW_HIP(ctx, hipMemcpyAsync(wword[0], H.d_wword, (size_t)n_wide * Np * 4, hipMemcpyDeviceToDevice, st));
+    }
+
+    // node of a level: id, size, and where its histogram comes from
+    struct HostNode { int32_t id; int32_t m; int64_t n; int32_t parent; };      // parent: its slot in the previous level (-1: the root)
+    std::vector<HostNode> level{{1, S, N, -1}};
+    int32_t next_id = 2;
+    int64_t visited = 0;
+    int cur = 0;
+    auto key_of = [&](int32_t d, int32_t bin) -> int32_t {
+        return s.h_binval_off[d] < 0 ? bin : s.h_binval[(size_t)s.h_binval_off[d] + bin];
+    };
+
+    while (!level.empty() && visited < max_nodes) {
+        if ((int64_t)level.size() > max_nodes - visited) level.resize((size_t)(max_nodes - visited));   // the work list is cut in id order
+        const int32_t K = (int32_t)level.size();
+        // ---- node table, tiles, and the plan for the histograms of this level
+        std::vector<NodeDev> nd((size_t)K);
+        std::vector<Tile> stiles, ptiles, atiles;
+        std::vector<int32_t> zero_slots;
+        std::vector<SubJob> subs;
+        int32_t sb = 0, pb = 0;
+        for (int32_t k = 0; k < K; k++) {
+            nd[k].scaf_begin = sb; nd[k].scaf_end = sb + level[k].m;
+            nd[k].dp_begin = pb; nd[k].dp_end = pb + (int32_t)level[k].n;
+            make_tiles(stiles, k, nd[k].scaf_begin, nd[k].scaf_end, TILE_S, nd[k].stile_begin, nd[k].stile_end);
+            make_tiles(ptiles, k, nd[k].dp_begin, nd[k].dp_end, TILE_P, nd[k].ptile_begin, nd[k].ptile_end);
+            sb += level[k].m; pb += (int32_t)level[k].n;
+        }
+        // children come in pairs (2j, 2j + 1) of one parent: the smaller is accumulated, the bigger subtracted; a node without
+        // its sibling in this (cut) level, and the root, are accumulated
+        for (int32_t k = 0; k < K; k++) {
+            const int32_t sib = (level[k].parent >= 0) ? (k ^ 1) : -1;
+            const bool has_sib = sib >= 0 && sib < K && level[sib].parent == level[k].parent;
+            const bool bigger = has_sib && (level[k].n > level[sib].n || (level[k].n == level[sib].n && k > sib));
+            if (bigger) subs.push_back(SubJob{k, level[k].parent, sib});
+            else {
+                zero_slots.push_back(k);
+                int32_t tb, te;
+                make_tiles(atiles, k, nd[k].scaf_begin, nd[k].scaf_end, TILE_S, tb, te);
+            }
+        }
+        const int32_t n_st = (int32_t)stiles.size(), n_pt = (int32_t)ptiles.size(), n_at = (int32_t)atiles.size();
+        std::vector<uint8_t> blob;
+        const size_t o_nodes = pack(blob, nd), o_st = pack(blob, stiles), o_pt = pack(blob, ptiles), o_at = pack(blob, atiles),
+                     o_zero = pack(blob, zero_slots), o_sub = pack(blob, subs);
+        const size_t lvl_bytes = (blob.size() + 63) & ~(size_t)63;
+        const size_t o_res = lvl_bytes, o_part = o_res + (((size_t)K * sizeof(NodeRes) + 63) & ~(size_t)63), all_bytes = o_part + (size_t)K * sizeof(NodePart) + 64;
+        if ((rc = abw_reserve(ctx, b_lvl, all_bytes))) return rc;
+        if ((rc = abw_reserve_pinned(ctx, all_bytes))) return rc;
+        uint8_t* hp = (uint8_t*)ctx->pinned;
+        memcpy(hp, blob.data(), blob.size());
+        ABW_HIP(ctx, hipMemcpyAsync(b_lvl.p, hp, lvl_bytes, hipMemcpyHostToDevice, st));
+        uint8_t* dl = (uint8_t*)b_lvl.p;
+        const NodeDev* d_nodes = (const NodeDev*)(dl + o_nodes);
+        const Tile* d_stiles = (const Tile*)(dl + o_st);
+        const Tile* d_ptiles = (const Tile*)(dl + o_pt);
+        const Tile* d_atiles = (const Tile*)(dl + o_at);
+        const int32_t* d_zero = (const int32_t*)(dl + o_zero);
+        const SubJob* d_subs = (const SubJob*)(dl + o_sub);
+        NodeRes* d_res = (NodeRes*)(dl + o_res);
+        NodePart* d_part = (NodePart*)(dl + o_part);
+
+        // per-level buffers: SCG lo / hi, candidates, tile sums / bests / counts
+        const int64_t scg_n = (int64_t)K * D * s.n_scg;
+        if ((rc = abw_reserve(ctx, b_scg, (size_t)std::max<int64_t>(1, scg_n) * 8))) return rc;
+        int32_t* d_scg_lo = (int32_t*)b_scg.p; int32_t* d_scg_hi = d_scg_lo + scg_n;
+        const size_t t_cand = ((size_t)K * D * sizeof(Cand) + 63) & ~(size_t)63,
+                     t_sums = ((size_t)std::max(1, n_wide) * n_pt * sizeof(WSums) + 63) & ~(size_t)63,
+                     t_best = ((size_t)std::max(1, n_wide) * n_pt * sizeof(Cand) + 63) & ~(size_t)63,
+                     t_tot = ((size_t)std::max(1, n_wide) * K * sizeof(WSums) + 63) & ~(size_t)63,
+                     t_cnt = ((size_t)(std::max(1, n_wide) * (size_t)n_pt + n_st) * 4 + 63) & ~(size_t)63,
+                     t_mask = ((size_t)std::max(1, n_wide) * n_pt + n_st) * 256;
+        if ((rc = abw_reserve(ctx, b_tile, t_cand + t_sums + t_best + t_tot + t_cnt + t_mask))) return rc;
+        Cand* d_cand = (Cand*)b_tile.p;
+        WSums* d_tsums = (WSums*)((uint8_t*)b_tile.p + t_cand);
+        Cand* d_tbest = (Cand*)((uint8_t*)b_tile.p + t_cand + t_sums);
+        WSums* d_ntot = (WSums*)((uint8_t*)b_tile.p + t_cand + t_sums + t_best);
+        uint32_t* d_pcnt = (uint32_t*)((uint8_t*)b_tile.p + t_cand + t_sums + t_best + t_tot);
+        uint32_t* d_scnt = d_pcnt + (size_t)std::max(1, n_wide) * n_pt;
+        uint8_t* d_pmask = (uint8_t*)b_tile.p + t_cand + t_sums + t_best + t_tot + t_cnt;
+        uint8_t* d_smask = d_pmask + (size_t)std::max(1, n_wide) * n_pt * 256;
+        if (scg_n > 0) {
+            hipLaunchKernelGGL(tree_scg_reset_kernel, dim3((unsigned)std::min<int64_t>((scg_n + 255) / 256, ctx->num_cu * 8)), dim3(256), 0, st, d_scg_lo, d_scg_hi, scg_n);
+            ABW_LAUNCH_CHECK(ctx);
+            if (H.n_carriers > 0) {
+                const int64_t work = (int64_t)H.n_carriers * D;
+                hipLaunchKernelGGL(tree_scg_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, Tr, H.d_carriers, H.n_carriers, d_scaf_slot, K, d_scg_lo, d_scg_hi);
+                ABW_LAUNCH_CHECK(ctx);
+            }
+        }
+
+        // ---- narrow dimensions: this level's slices (pool cur) from the table or from the parents' slices (pool cur ^ 1)
+        if (n_narrow) {
+            const size_t slice = (size_t)TBn * 20;
+            if ((size_t)K * slice > ((size_t)48 << 30)) return abw_fail(ctx, ABW_ERR_NOMEM, "abw_sep_tree: %d nodes in one level need %zu bytes of histograms", K, (size_t)K * slice);
+            if ((rc = abw_reserve(ctx, *b_hist[cur], (size_t)K * slice + 64))) return rc;
+            const int64_t capc = (int64_t)((b_hist[cur]->cap - 64) / slice), capp = b_hist[cur ^ 1]->cap > 64 ? (int64_t)((b_hist[cur ^ 1]->cap - 64) / slice) : 0;
+            unsigned long long* c_st = (unsigned long long*)b_hist[cur]->p;
+            unsigned long long* c_bp = c_st + capc * TBn;
+            uint32_t* c_tot = (uint32_t*)(c_bp + capc * TBn);
+            const unsigned long long* p_st = (const unsigned long long*)b_hist[cur ^ 1]->p;
+            const unsigned long long* p_bp = p_st ? p_st + capp * TBn : nullptr;
+            const uint32_t* p_tot = p_st ? (const uint32_t*)(p_bp + capp * TBn) : nullptr;
+            const unsigned gy = (unsigned)((TBn + 1023) / 1024);
+            ABW_PROF(ctx, "sep_accum");
+            if (!zero_slots.empty()) {
+                hipLaunchKernelGGL(tree_zero_kernel, dim3((unsigned)zero_slots.size(), gy), dim3(256), 0, st, d_zero, TBn, c_st, c_bp, c_tot);
+                ABW_LAUNCH_CHECK(ctx);
+            }
+            if (n_at) {
+                hipLaunchKernelGGL(tree_accum_kernel, dim3((unsigned)n_at, (unsigned)n_narrow), dim3(256), 0, st, Tr, d_atiles, (const int32_t*)order[cur], c_st, c_bp, c_tot);
+                ABW_LAUNCH_CHECK(ctx);
+            }
+            if (!subs.empty()) {
+                hipLaunchKernelGGL(tree_sub_kernel, dim3((unsigned)subs.size(), gy), dim3(256), 0, st, d_subs, TBn, c_st, c_bp, c_tot, p_st, p_bp, p_tot);
+                ABW_LAUNCH_CHECK(ctx);
+            }
+            hipLaunchKernelGGL(tree_eval_narrow_kernel, dim3((unsigned)K, (unsigned)n_narrow), dim3(256), 0, st, Tr, d_nodes, min_ndps,
+                               (const unsigned long long*)c_st, (const unsigned long long*)c_bp, (const uint32_t*)c_tot, d_scg_lo, d_scg_hi, d_cand);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        // ---- wide dimensions: prefix sums along every node's sorted segment
+        if (n_wide) {
+            ABW_PROF(ctx, "sep_wide");
+            hipLaunchKernelGGL(tree_wide_sums_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, wword[cur], Np, d_tsums);
+            ABW_LAUNCH_CHECK(ctx);
+            hipLaunchKernelGGL(tree_wide_scan_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, d_nodes, n_pt, d_tsums, d_ntot, K);
+            ABW_LAUNCH_CHECK(ctx);
+            hipLaunchKernelGGL(tree_wide_eval_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, d_nodes, K, min_ndps,
+                               wbin[cur], wword[cur], Np, d_tsums, d_ntot, d_scg_lo, d_scg_hi, d_tbest);
+            ABW_LAUNCH_CHECK(ctx);
+            hipLaunchKernelGGL(tree_wide_best_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, Tr, d_nodes, n_pt, d_tbest, d_cand);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        // ---- winners, sides, read-back
+        {
+            ABW_PROF(ctx, "sep_eval");
+            hipLaunchKernelGGL(tree_winner_kernel, dim3((unsigned)K), dim3(64), 0, st, Tr, d_nodes, d_cand, d_res);
+            ABW_LAUNCH_CHECK(ctx);
+            hipLaunchKernelGGL(tree_assign_kernel, dim3((unsigned)n_st), dim3(256), 0, st, Tr, d_stiles, (const int32_t*)order[cur], d_res, d_scaf_side);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        NodeRes* h_res = (NodeRes*)(hp + o_res);
+        ABW_HIP(ctx, hipMemcpyAsync(h_res, d_res, (size_t)K * sizeof(NodeRes), hipMemcpyDeviceToHost, st));
+        ABW_HIP(ctx, hipStreamSynchronize(st));
+
+        // ---- the level's verdicts (ref ClusterSeparator.cpp:125-132) and the next level
+        std::vector<HostNode> next;
+        NodePart* h_part = (NodePart*)(hp + o_part);
+        int32_t nsb = 0, npb = 0;
+        for (int32_t k = 0; k < K; k++) {
+            const NodeRes& r = h_res[k];
+            abw_tree_node o;
+            memset(&o, 0, sizeof(o));
+            o.id = level[k].id; o.ndps = level[k].n; o.n_scaf = level[k].m; o.dimension = -1; o.key = -1;
+            bool split = false;
+            if (r.win.found) {
+                o.dimension = r.win.dim + 1; o.key = key_of(r.win.dim, r.win.bin);
+                o.sensitivity = r.win.sens; o.specificity = r.win.spec; o.legal = r.win.legal;
+                if (r.win.legal) {
+                    split = (int64_t)r.n1 >= min_ndps && (int64_t)r.n2 >= min_ndps;
+                    if (!split) { o.dimension = -1; o.key = -1; o.sensitivity = 0; o.specificity = 0; }      // best_separation->reset(), ref :130
+                }
+            }
+            NodePart& np = h_part[k];
+            memset(&np, 0, sizeof(np));
+            np.split = split; np.id = o.id; np.slot1 = np.slot2 = -1;
+            if (split) {
+                o.split = 1; o.child1 = next_id; o.child2 = next_id + 1; o.ndps1 = (int64_t)r.n1; o.ndps2 = (int64_t)r.n2;
+                next_id += 2;
+                np.scaf_base1 = nsb; np.scaf_base2 = nsb + (int32_t)r.m1;
+                np.dp_base1 = npb; np.dp_base2 = npb + (int32_t)r.n1;
+                np.slot1 = (int32_t)next.size(); np.slot2 = np.slot1 + 1;
+                nsb += (int32_t)(r.m1 + r.m2); npb += (int32_t)(r.n1 + r.n2);
+                next.push_back(HostNode{o.child1, (int32_t)r.m1, (int64_t)r.n1, k});
+                next.push_back(HostNode{o.child2, (int32_t)r.m2, (int64_t)r.n2, k});
+            }
+            if (visited < node_cap) nodes_out[visited] = o;
+            visited++;
+        }
+        // ---- partition into the next level's order (terminal nodes' scaffolds get their cluster id)
+        ABW_HIP(ctx, hipMemcpyAsync(d_part, h_part, (size_t)K * sizeof(NodePart), hipMemcpyHostToDevice, st));
+        {
+            ABW_PROF(ctx, "sep_partition");
+            hipLaunchKernelGGL(tree_part_count_kernel, dim3((unsigned)n_st, 1), dim3(256), 0, st, d_stiles, n_st, d_part, (const uint32_t*)order[cur], (int64_t)0, d_scaf_side, d_scnt, d_smask);
+            ABW_LAUNCH_CHECK(ctx);
+            hipLaunchKernelGGL(tree_part_scan_kernel, dim3((unsigned)K, 1), dim3(64), 0, st, d_nodes, d_part, n_st, d_scnt, 1);
+            ABW_LAUNCH_CHECK(ctx);
+            hipLaunchKernelGGL(tree_part_scatter_kernel, dim3((unsigned)n_st, 1), dim3(256), 0, st, d_stiles, n_st, d_nodes, d_part, (const uint32_t*)order[cur],
+                               (const int32_t*)nullptr, (int64_t)0, d_smask, d_scnt, order[cur ^ 1], (int32_t*)nullptr, 1, (int32_t*)b_s2c.p, d_scaf_slot);
+            ABW_LAUNCH_CHECK(ctx);
+            if (n_wide && !next.empty()) {
+                hipLaunchKernelGGL(tree_part_count_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, d_ptiles, n_pt, d_part, (const uint32_t*)wword[cur], Np, d_scaf_side, d_pcnt, d_pmask);
+                ABW_LAUNCH_CHECK(ctx);
+                hipLaunchKernelGGL(tree_part_scan_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, d_nodes, d_part, n_pt, d_pcnt, 0);
+                ABW_LAUNCH_CHECK(ctx);
+                hipLaunchKernelGGL(tree_part_scatter_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, d_ptiles, n_pt, d_nodes, d_part, (const uint32_t*)wword[cur],
+                                   (const int32_t*)wbin[cur], Np, d_pmask, d_pcnt, wword[cur ^ 1], wbin[cur ^ 1], 0, (int32_t*)nullptr, (int32_t*)nullptr);
+                ABW_LAUNCH_CHECK(ctx);
+            }
+        }
+        // the level's pinned block is re-used by the next level's upload: the copy of h_part must have left it
+        ABW_HIP(ctx, hipStreamSynchronize(st));
+        cur ^= 1;
+        level.swap(next);
+    }
+    *n_nodes = visited;
+    if (scaf2cluster) {
+        ABW_HIP(ctx, hipMemcpyAsync(scaf2cluster, b_s2c.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+        ABW_HIP(ctx, hipStreamSynchronize(st));
+    }
+    if (visited > node_cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_sep_tree: %lld nodes, capacity %lld", (long long)visited, (long long)node_cap);
+    return ABW_OK;
+}

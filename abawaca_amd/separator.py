@@ -156,6 +156,33 @@ def binning(store: ColumnStore, max_nodes: int = 1 << 30):
     return nodes, scaf2cluster, dp2cluster
 
 
+_TREE_DTYPE = np.dtype([("id", "i4"), ("n_scaf", "i4"), ("ndps", "i8"), ("split", "i4"), ("dim", "i4"), ("key", "i4"), ("legal", "i4"),
+                        ("sens", "f8"), ("spec", "f8"), ("c1", "i4"), ("c2", "i4"), ("n1", "i8"), ("n2", "i8")])      # = struct abw_tree_node
+
+
+def binning_tree(store: ColumnStore, max_nodes: int = 0):
+    """The same recursion in ONE library call (abw_sep_tree: level by level on the device).
+    -> (nodes list of dict as binning(), scaf2cluster int32[S], seconds inside the C ABI)"""
+    cap = max(64, 2 * (store.N // max(1, ClusterSeparatorHip.cluster_ndps_threshold)) + 8)
+    while True:
+        arr = np.zeros(cap, dtype=_TREE_DTYPE)
+        s2c = np.zeros(store.S, dtype=np.int32)
+        n = C.c_int64(0)
+        t0 = time.perf_counter()
+        rc = lib().abw_sep_tree(store.ctx.handle, ClusterSeparatorHip.cluster_ndps_threshold, int(max_nodes), C.c_void_p(arr.ctypes.data), cap,
+                                C.byref(n), C.c_void_p(s2c.ctypes.data))
+        dt = time.perf_counter() - t0
+        if rc == -3 and n.value > cap:                          # ABW_ERR_CAPACITY
+            cap = int(n.value)
+            continue
+        store.ctx.check(rc)
+        break
+    rows = [dict(id=int(r["id"]), ndps=int(r["ndps"]), split=int(r["split"]), dim=int(r["dim"]), key=int(r["key"]), spec=float(r["spec"]),
+                 sens=float(r["sens"]), c1=int(r["c1"]), n1=int(r["n1"]), c2=int(r["c2"]), n2=int(r["n2"]), n_scaf=int(r["n_scaf"]))
+            for r in arr[:int(n.value)]]
+    return rows, s2c, dt
+
+
 # ---- scaffold-sharded separator (SURVEY §8 row e; abw_sep_shard_*) ------------------------------------
 
 class SepExchange(C.Structure):

@@ -173,6 +173,34 @@ int abw_sep_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const 
 int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t min_ndps,
                  abw_split* out, abw_dimbest* per_dim, uint8_t* scaf_side, uint8_t* dp_raw_side);
 
+/* ---- the whole recursion in one call: the work-list loop of ref src/abawaca.cpp:95-197 around separate(), on the table of
+ *      abw_sep_load.  The reference takes the node with the smallest id from its std::map and gives the children of a split
+ *      the next two ids (ref :98-100,155-194), i.e. it visits the nodes breadth first: abw_sep_tree evaluates every LEVEL of
+ *      that order with one set of kernel launches (per node abw_sep_node costs about 14 launches and a synchronisation, and
+ *      most nodes of a deep recursion are small).  Node ids, winners (dimension, key, sensitivity / specificity doubles),
+ *      children and their sizes are those of calling abw_sep_node node by node in id order.
+ *   nodes_out [node_cap] : the visited nodes in id order (id 1 = all scaffolds); *n_nodes = their number, also when it
+ *                          exceeds node_cap (then ABW_ERR_CAPACITY; the first node_cap are written)
+ *   max_nodes            : stop after that many nodes (<= 0: no limit), as a driver that cuts the work list would
+ *   scaf2cluster [S]     : host, may be NULL: the id of the terminal node every scaffold ended in (0: its node was not visited)
+ * dimension is 1-based, -1 when the node found no threshold or was reset by the final size check (ref
+ * src/ClusterSeparator.cpp:125-132); the raw datapoint sets of a split are {value <= key} and its complement in the
+ * winning dimension, cluster1 being the smaller (ref :49-53), should a caller need them. */
+typedef struct {
+    int32_t id;             /* 1.. in the reference's work-list order */
+    int32_t n_scaf;         /* scaffolds of the node */
+    int64_t ndps;           /* datapoints of the node */
+    int32_t split;          /* separate() returned true */
+    int32_t dimension;      /* as abw_split */
+    int32_t key;
+    int32_t legal;
+    double  sensitivity, specificity;
+    int32_t child1, child2; /* ids of the children (0 when !split) */
+    int64_t ndps1, ndps2;   /* their sizes */
+} abw_tree_node;
+int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, abw_tree_node* nodes_out, int64_t node_cap,
+                 int64_t* n_nodes, int32_t* scaf2cluster);
+
 /* ---- the separator with the SCAFFOLDS sharded over several contexts / processes / GPUs (SURVEY §8(e):
  *      "scaffold-sharded" full recursive binning; the reference itself is one process with a thread per
  *      dimension, ref: src/ClusterSeparator.cpp:72-78).  A shard holds whole scaffolds (a node of the
