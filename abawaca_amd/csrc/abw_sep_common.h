@@ -86,7 +86,9 @@ struct SepHost {
     int32_t* d_range = nullptr;        // [D][2] bins touched by the current node
     // abw_sep_tree's static tables, built at its first call on this table (abw_tree.hip): a scaffold's flip value in a
     // dimension depends on the scaffold's own dps only, so it is the same in every node of the recursion
-    uint16_t* d_ts16 = nullptr;        // [n_narrow][S] flip value of every scaffold in every narrow dimension
+    void* d_ts8 = nullptr;             // abw_sep_tree's static tables (abw_tree.hip): [groups][S][8] x 16 bit flip values,
+    void* d_nk16 = nullptr;            //   [groups][N][8] x 16 bit re-coded narrow columns,
+    void* d_srec = nullptr;            //   [S] x 16 bytes: first dp, dps, length
     uint32_t* d_wword = nullptr;       // [n_wide][N] per sorted position: scaffold | (v >= t_s) << 31 | (owner) << 30
     uint32_t* d_wext = nullptr;        // [n_wide][S][4] per scaffold: dps below t_s, dps, min(length, 500000), bin of t_s
     uint32_t* d_wpack = nullptr;       // [n_wide][S] the first three of d_wext in one word (scaffolds of <= 127 dps), else all ones

@@ -22,6 +22,10 @@
 //      first dp of its scaffold on bin t_s, which also carries what the scaffold puts on that bin (one 16-byte gather).
 //   Narrow dimensions (keys < 1024) keep their histograms: LDS-private per tile of scaffolds, flushed into the slice of
 //   the tile's node; one workgroup per (node, dimension) scans the <= 1024 bins and evaluates every threshold.
+//   The scaffolds of a node deep in the tree lie scattered over the table, and in the [dimension][dp] layout each
+//   (scaffold, dimension) would cost a whole cache line for 16 bytes.  The narrow columns are therefore re-coded once per
+//   table in groups of up to 8 dimensions: [group][dp][8] x 16 bit = value | (value > t_s) << 15 -- one 16-byte load per
+//   dp and group, a scaffold's dps contiguous -- with the flip values as [group][scaffold][8] x 16 bit beside them.
 //   Then per node the winner over the dimensions, the scaffold sides, the children's sizes: one small read-back per level.
 #include "abw_sep_common.h"
 #include <string.h>
@@ -35,6 +39,11 @@ namespace {
 constexpr int TILE_S = 2048;     // scaffolds per tile (256 threads x 8)
 constexpr int TILE_P = 2048;     // sorted positions per tile (256 threads x 8 consecutive)
 constexpr uint32_t PACK_ESCAPE = 0xFFFFFFFFu;
+constexpr int TILE_A = 1024;     // scaffolds per tile of the accumulation (256 threads x 4)
+constexpr int GRP_BINS = 2048;   // LDS bins of one group of narrow dimensions (a narrow dimension has at most 1024)
+
+// a group of narrow dimensions (consecutive in the order of Tr.narrow): their bins lie side by side in LDS and in a node's slice
+struct NGroup { int32_t cnt, total; int32_t loff[8]; int64_t goff; };
 
 struct NodeDev {
     int32_t scaf_begin, scaf_end;       // its scaffolds in `order`
@@ -63,8 +72,11 @@ struct TreeDev {
     const int32_t* narrow; int32_t n_narrow; const int64_t* toffn; int64_t TBn;       // narrow dims, their offsets inside a node's slice
     const int32_t* wide; int32_t n_wide;
     const int32_t* dp2scaf;
-    const int32_t* dim_slot;            // [D]: index among the narrow dimensions, or -(index among the wide ones) - 1
-    const uint16_t* ts16;               // [n_narrow][S]
+    const int32_t* dim_slot;            // [D]: narrow: group * 8 + lane in the group; wide: -(index among the wide ones) - 1
+    const NGroup* groups; int32_t n_groups;
+    const uint4* nk16;                  // [n_groups][N]: 8 x 16 bit per dp: value | (value > t_s) << 15
+    const uint4* ts8;                   // [n_groups][S]: 8 x 16 bit per scaffold: t_s
+    const int4* srec;                   // [S]: first dp, dps, length (lo, hi)
     const uint4* wext;                  // [n_wide][S]: x = dps below t_s, y = dps, z = min(length, 500000), w = bin of t_s
     const uint32_t* wpack;              // [n_wide][S]: x | y << 6 | z << 13 where y <= 127 (4 MB per million scaffolds: L2), else PACK_ESCAPE
     int32_t D, S;
@@ -119,12 +131,14 @@ __global__ void tree_scg_reset_kernel(int32_t* __restrict__ lo, int32_t* __restr
 }
 
 // ---- the static tables (once per loaded table) ------------------------------------------------------------------------
-// flip value of every scaffold in every narrow dimension.  grid (ceil(S / 256), narrow dimensions)
-__global__ __launch_bounds__(256) void tree_static_narrow_kernel(SepDev P, const int32_t* __restrict__ narrow, int32_t S, uint16_t* __restrict__ ts16)
+// flip value of every scaffold in every narrow dimension, into its group's [scaffold][8] table (nslot = group * 8 + lane).
+// grid (ceil(S / 256), narrow dimensions)
+__global__ __launch_bounds__(256) void tree_static_narrow_kernel(SepDev P, const int32_t* __restrict__ narrow, const int32_t* __restrict__ nslot,
+                                                                int32_t S, uint16_t* __restrict__ ts8)
 {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= S) return;
-    const int d = narrow[blockIdx.y];
+    const int d = narrow[blockIdx.y], slot = nslot[blockIdx.y];
     const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
     const int f = P.scaf_first[s], n = P.scaf_ndps[s], k = n >> 1;
     int ts;
@@ -135,7 +149,37 @@ __global__ __launch_bounds__(256) void tree_static_narrow_kernel(SepDev P, const
         ABW_SORT8(x);
         ts = (k == 1) ? x[1] : (k == 2) ? x[2] : (k == 3) ? x[3] : x[4];
     } else ts = select_kth_mem(col + f, n, k, P.T[d]);
-    ts16[(int64_t)blockIdx.y * S + s] = (uint16_t)ts;
+    ts8[((int64_t)(slot >> 3) * S + s) * 8 + (slot & 7)] = (uint16_t)ts;
+}
+
+// the re-coded narrow columns.  grid (ceil(N / 256), groups)
+__global__ __launch_bounds__(256) void tree_static_codes_kernel(SepDev P, const int32_t* __restrict__ narrow, const NGroup* __restrict__ groups,
+                                                               const int32_t* __restrict__ gfirst, const int32_t* __restrict__ dp2scaf, int32_t S,
+                                                               const uint4* __restrict__ ts8, uint4* __restrict__ nk16)
+{
+    const int64_t dp = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (dp >= P.N) return;
+    const int j = blockIdx.y, cnt = groups[j].cnt, first = gfirst[j];
+    const uint4 t = ts8[(int64_t)j * S + dp2scaf[dp]];
+    const uint32_t tw[4] = {t.x, t.y, t.z, t.w};
+    uint32_t cw[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        if (q < cnt) {
+            const uint32_t v = (uint32_t)P.bins[(int64_t)narrow[first + q] * P.N + dp];
+            const uint32_t ts = (tw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+            cw[q >> 1] |= (v | (v > ts ? 0x8000u : 0u)) << (16 * (q & 1));
+        }
+    }
+    nk16[(int64_t)j * P.N + dp] = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+}
+
+__global__ void tree_static_srec_kernel(SepDev P, int32_t S, int4* __restrict__ srec)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const long long len = P.scaf_len[s];
+    srec[s] = make_int4(P.scaf_first[s], P.scaf_ndps[s], (int)(uint32_t)(unsigned long long)len, (int)(uint32_t)((unsigned long long)len >> 32));
 }
 
 // wide dimensions: flip value (as a bin), dps below it, one byte per dp (bit 0: v >= t_s; bit 1: the first dp of the
@@ -196,70 +240,68 @@ __global__ void tree_static_words_kernel(const int32_t* __restrict__ sdp, const 
 }
 
 // ---- narrow dimensions ----------------------------------------------------------------------------------------------
-// Histograms of one tile of scaffolds in one narrow dimension with the static flip values: per dp size[v] += 1 and
-// tp1[max(v, t_s)] += 1 (the dps at or below t_s are credited to bin t_s in one add), per scaffold tot[t_s] += n and
-// bp[t_s] += len -- LDS-private (several copies, see sep_accum_kernel in abw_sep.hip), flushed with one atomic per
-// non-empty bin into the slice of the tile's node.  grid (tiles to accumulate, narrow dimensions)
+// Histograms of one tile of scaffolds in one GROUP of narrow dimensions: per dp and dimension size[v] += 1 and, above the
+// flip value, tp1[v] += 1; per scaffold and dimension tp1[t_s] += its dps at or below t_s (they count from threshold t_s
+// on), tot[t_s] += n and bp[t_s] += len -- in LDS, flushed with one atomic per non-empty bin into the slice of the tile's
+// node.  grid (tiles to accumulate, groups)
 __global__ __launch_bounds__(256) void tree_accum_kernel(TreeDev Tr, const Tile* __restrict__ tiles, const int32_t* __restrict__ order,
                                                         unsigned long long* __restrict__ h_st, unsigned long long* __restrict__ h_bp,
                                                         uint32_t* __restrict__ h_tot)
 {
-    __shared__ uint32_t s_size[ACC_LDS_WORDS];
-    __shared__ uint32_t s_tp1[ACC_LDS_WORDS];
-    __shared__ uint32_t s_tot[ACC_LDS_WORDS];
-    __shared__ unsigned long long s_bp[ACC_LDS_WORDS];
+    __shared__ uint32_t s_size[GRP_BINS];
+    __shared__ uint32_t s_tp1[GRP_BINS];
+    __shared__ uint32_t s_tot[GRP_BINS];
+    __shared__ unsigned long long s_bp[GRP_BINS];
     const Tile t = tiles[blockIdx.x];
-    const int dn = blockIdx.y;
-    const int d = Tr.narrow[dn];
-    const int T = Tr.P.T[d];
-    const int32_t* __restrict__ col = Tr.P.bins + (int64_t)d * Tr.P.N;
-    const uint16_t* __restrict__ tsd = Tr.ts16 + (int64_t)dn * Tr.S;
-    const int Tp = T | 1;
-    int copies = 1;
-    while (copies < 32 && 2 * copies * Tp <= ACC_LDS_WORDS) copies <<= 1;
-    for (int i = threadIdx.x; i < copies * Tp; i += 256) { s_size[i] = 0; s_tp1[i] = 0; s_tot[i] = 0; s_bp[i] = 0; }
+    const int j = blockIdx.y;
+    const NGroup G = Tr.groups[j];
+    for (int i = threadIdx.x; i < G.total; i += 256) { s_size[i] = 0; s_tp1[i] = 0; s_tot[i] = 0; s_bp[i] = 0; }
     __syncthreads();
-    const int mine = (threadIdx.x & (copies - 1)) * Tp;
-    uint32_t* my_size = s_size + mine;
-    uint32_t* my_tp1 = s_tp1 + mine;
+    const uint4* __restrict__ codes = Tr.nk16 + (int64_t)j * Tr.P.N;
+    const uint4* __restrict__ tsv = Tr.ts8 + (int64_t)j * Tr.S;
     for (int ls = t.begin + threadIdx.x; ls < t.end; ls += 256) {
         const int s = order[ls];
-        const int f = Tr.P.scaf_first[s], n = Tr.P.scaf_ndps[s];
-        const int ts = tsd[s];
-        uint32_t tp_ts = 0;
-        if (n <= 8) {
-            int v[8];
+        const int4 rec = Tr.srec[s];
+        const uint4 t8 = tsv[s];
+        const int f = rec.x, n = rec.y;
+        uint32_t le[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i0 = 0; i0 < n; i0 += 4) {
+            uint4 c[4];
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = (i < n) ? col[f + i] : 0;
+            for (int i = 0; i < 4; i++) c[i] = (i0 + i < n) ? codes[f + i0 + i] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (i < n) {
-                    atomicAdd(&my_size[v[i]], 1u);
-                    if (v[i] > ts) atomicAdd(&my_tp1[v[i]], 1u); else tp_ts++;
+            for (int i = 0; i < 4; i++) {
+                if (i0 + i < n) {
+                    const uint32_t cw[4] = {c[i].x, c[i].y, c[i].z, c[i].w};
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        if (q < G.cnt) {
+                            const uint32_t code = (cw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                            const int at = G.loff[q] + (int)(code & 0x7FFFu);
+                            atomicAdd(&s_size[at], 1u);
+                            if (code & 0x8000u) atomicAdd(&s_tp1[at], 1u); else le[q]++;
+                        }
+                    }
                 }
             }
-        } else {
-            for (int i = 0; i < n; i++) {
-                const int v = col[f + i];
-                atomicAdd(&my_size[v], 1u);
-                if (v > ts) atomicAdd(&my_tp1[v], 1u); else tp_ts++;
+        }
+        const uint32_t tw[4] = {t8.x, t8.y, t8.z, t8.w};
+        const unsigned long long len = (unsigned long long)(uint32_t)rec.z | ((unsigned long long)(uint32_t)rec.w << 32);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (q < G.cnt) {
+                const int at = G.loff[q] + (int)((tw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu);
+                atomicAdd(&s_tp1[at], le[q]);
+                atomicAdd(&s_tot[at], (uint32_t)n);
+                atomicAdd(&s_bp[at], len);
             }
         }
-        atomicAdd(&my_tp1[ts], tp_ts);
-        atomicAdd(&s_tot[mine + ts], (uint32_t)n);
-        atomicAdd(&s_bp[mine + ts], (unsigned long long)Tr.P.scaf_len[s]);
     }
     __syncthreads();
-    const int64_t at = (int64_t)t.node * Tr.TBn + Tr.toffn[dn];
-    for (int b = threadIdx.x; b < T; b += 256) {
-        unsigned long long a = 0, e = 0;
-        uint32_t c3 = 0;
-        for (int c = 0; c < copies; c++) {
-            const int i = c * Tp + b;
-            a += (unsigned long long)s_size[i] | ((unsigned long long)s_tp1[i] << 32);
-            c3 += s_tot[i];
-            e += s_bp[i];
-        }
+    const int64_t at = (int64_t)t.node * Tr.TBn + G.goff;
+    for (int b = threadIdx.x; b < G.total; b += 256) {
+        const unsigned long long a = (unsigned long long)s_size[b] | ((unsigned long long)s_tp1[b] << 32), e = s_bp[b];
+        const uint32_t c3 = s_tot[b];
         if (a) atomicAdd(&h_st[at + b], a);
         if (c3) atomicAdd(&h_tot[at + b], c3);
         if (e) atomicAdd(&h_bp[at + b], e);
@@ -304,7 +346,8 @@ __global__ __launch_bounds__(256) void tree_scg_kernel(TreeDev Tr, const int32_t
     const int k = scaf_slot[s];
     if (k < 0 || k >= K) return;                              // no node, or a node the cut work list does not reach
     const int slot = Tr.dim_slot[d];
-    const int ts = slot >= 0 ? (int)Tr.ts16[(int64_t)slot * Tr.S + s] : (int)Tr.wext[(int64_t)(-slot - 1) * Tr.S + s].w;
+    const int ts = slot >= 0 ? (int)reinterpret_cast<const uint16_t*>(Tr.ts8)[((int64_t)(slot >> 3) * Tr.S + s) * 8 + (slot & 7)]
+                             : (int)Tr.wext[(int64_t)(-slot - 1) * Tr.S + s].w;
     const int64_t sg = ((int64_t)k * Tr.D + d) * Tr.P.n_scg;
     for (int e = Tr.P.scg_off[s]; e < Tr.P.scg_off[s + 1]; e++) {
         const int g = Tr.P.scg_ids[e];
@@ -317,13 +360,22 @@ __global__ __launch_bounds__(256) void tree_scg_kernel(TreeDev Tr, const int32_t
 // reference's doubles, the SCG / size gate (ref ...Specificity.cpp:146-161, ClusterQuality.cpp:96-136).
 __device__ __forceinline__ void eval_threshold(long long size1, long long tp1, long long tot1, unsigned long long bp1, long long n,
                                                unsigned long long bp_total, int32_t min_ndps, int bin, int ng, const int32_t* s_lo,
-                                               const int32_t* s_hi, Cand& best)
+                                               const int32_t* s_hi, Cand& best, double bar = 0.0)
 {
     const long long size2 = n - size1, tot2 = n - tot1;
     const long long tp2 = n - (size1 + tot1 - tp1);
     if (size1 < min_ndps || size2 < min_ndps) return;              // ref :151
     const bool small1 = size1 < size2;                             // ref :155 (tie -> cluster2)
     const long long TP = small1 ? tp1 : tp2, TOT = small1 ? tot1 : tot2, SZ = small1 ? size1 : size2;
+    {
+        // Most thresholds lose by far against what is already known (this thread's best; `bar`: a product some other dimension
+        // of the node has reached, which the node's winner must reach as well).  TP^2 / (TOT SZ) below that by more than
+        // the rounding of the three products and of the reference's two divisions and product (< 1e-15 relative each) cannot
+        // win and cannot tie: skipped without the two fp64 divisions.  Anything closer goes through the exact path.
+        const double need = best.found ? (best.prod > bar ? best.prod : bar) : bar;
+        const double tp = (double)TP;
+        if (tp * tp < need * ((double)TOT * (double)SZ) * (1.0 - 1e-9)) return;
+    }
     const double sens = (double)(int)TP / (double)(int)TOT;        // ref .h:75 (int fields)
     const double spec = (double)(int)TP / (double)(int)SZ;         // ref .h:74
     const double prod = sens * spec;
@@ -413,6 +465,20 @@ __global__ __launch_bounds__(256) void tree_eval_narrow_kernel(TreeDev Tr, const
     if (threadIdx.x == 0) cand[(int64_t)k * Tr.D + d] = b;
 }
 
+// the best product the narrow dimensions of every node have reached: the bar for the wide ones (see eval_threshold).
+// grid (nodes), one wave
+__global__ __launch_bounds__(64) void tree_bar_kernel(TreeDev Tr, const Cand* __restrict__ cand, double* __restrict__ bar)
+{
+    double b = 0.0;
+    for (int i = threadIdx.x; i < Tr.n_narrow; i += 64) {
+        const Cand c = cand[(int64_t)blockIdx.x * Tr.D + Tr.narrow[i]];
+        if (c.found && c.prod > b) b = c.prod;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(b, o, 64); if (y > b) b = y; }
+    if (threadIdx.x == 0) bar[blockIdx.x] = b;
+}
+
 // ---- wide dimensions ------------------------------------------------------------------------------------------------
 // what the dp at a sorted position adds to the prefix sums of its node (all static: see tree_static_wide_kernel)
 __device__ __forceinline__ WSums position_terms(const TreeDev& Tr, int w, uint32_t word)
@@ -476,7 +542,7 @@ __global__ __launch_bounds__(256) void tree_wide_eval_kernel(TreeDev Tr, const T
                                                             int32_t K, int32_t min_ndps, const int32_t* __restrict__ wbin, const uint32_t* __restrict__ wword,
                                                             int64_t wstride, const WSums* __restrict__ tile_carry, const WSums* __restrict__ node_total,
                                                             const int32_t* __restrict__ scg_lo, const int32_t* __restrict__ scg_hi,
-                                                            Cand* __restrict__ tile_best)
+                                                            const double* __restrict__ bar, Cand* __restrict__ tile_best)
 {
     __shared__ unsigned long long sh[3][5];
     __shared__ int32_t s_lo[MAX_SCG], s_hi[MAX_SCG];
@@ -492,6 +558,7 @@ __global__ __launch_bounds__(256) void tree_wide_eval_kernel(TreeDev Tr, const T
     const int32_t* __restrict__ bins = wbin + (int64_t)w * wstride;
     const uint32_t* __restrict__ words = wword + (int64_t)w * wstride;
     const unsigned long long bp_total = node_total[(int64_t)w * K + t.node].bp;
+    const double node_bar = bar[t.node];
     const int i0 = (t.begin & ~(TILE_P - 1)) + 8 * threadIdx.x;
     int b[9];
     uint32_t wd[8];
@@ -519,7 +586,7 @@ __global__ __launch_bounds__(256) void tree_wide_eval_kernel(TreeDev Tr, const T
         if (i0 + i >= t.begin && i0 + i < t.end) {
             tp1 += (long long)r[i].tp1; tot1 += (long long)r[i].tot; bp1 += r[i].bp;
             if (b[i + 1] != b[i])                                                       // a run end: threshold = this bin
-                eval_threshold((long long)(i0 + i - nd.dp_begin + 1), tp1, tot1, bp1, n, bp_total, min_ndps, b[i], ng, s_lo, s_hi, best);
+                eval_threshold((long long)(i0 + i - nd.dp_begin + 1), tp1, tot1, bp1, n, bp_total, min_ndps, b[i], ng, s_lo, s_hi, best, node_bar);
         }
     }
     const Cand bb = block_best(best, wbest);
@@ -715,21 +782,33 @@ size_t pack(std::vector<uint8_t>& blob, const std::vector<T>& v)
 }
 
 // The static tables of the loaded table (once; kept with the table until abw_sep_load / abw_ctx_destroy frees them).
-int tree_static_build(abw_ctx* ctx, SepHost& H, const SepDev& P, const int32_t* d_dp2scaf)
+int tree_static_build(abw_ctx* ctx, SepHost& H, const SepDev& P, const int32_t* d_dp2scaf, const int32_t* d_narrow, const int32_t* d_nslot,
+                      const NGroup* d_groups, const int32_t* d_gfirst, int32_t n_groups)
 {
     abw_sep_state& s = ctx->sep;
     hipStream_t st = ctx->stream;
     const int32_t S = s.S, n_narrow = (int32_t)H.narrow_dims.size(), n_wide = (int32_t)H.wide_dims.size();
     const int64_t N = s.N;
     // a build that failed half-way may have left some of them behind
-    if (H.d_ts16) { (void)hipFree(H.d_ts16); H.d_ts16 = nullptr; }
+    if (H.d_ts8) { (void)hipFree(H.d_ts8); H.d_ts8 = nullptr; }
+    if (H.d_nk16) { (void)hipFree(H.d_nk16); H.d_nk16 = nullptr; }
+    if (H.d_srec) { (void)hipFree(H.d_srec); H.d_srec = nullptr; }
     if (H.d_wword) { (void)hipFree(H.d_wword); H.d_wword = nullptr; }
     if (H.d_wext) { (void)hipFree(H.d_wext); H.d_wext = nullptr; }
     if (H.d_wpack) { (void)hipFree(H.d_wpack); H.d_wpack = nullptr; }
     if (H.d_carriers) { (void)hipFree(H.d_carriers); H.d_carriers = nullptr; }
     if (n_narrow) {
-        ABW_HIP(ctx, hipMalloc((void**)&H.d_ts16, (size_t)n_narrow * S * 2));
-        hipLaunchKernelGGL(tree_static_narrow_kernel, dim3((unsigned)((S + 255) / 256), (unsigned)n_narrow), dim3(256), 0, st, P, H.d_narrow, S, H.d_ts16);
+        ABW_HIP(ctx, hipMalloc((void**)&H.d_ts8, (size_t)n_groups * S * 16));
+        ABW_HIP(ctx, hipMalloc((void**)&H.d_nk16, (size_t)n_groups * N * 16));
+        ABW_HIP(ctx, hipMalloc((void**)&H.d_srec, (size_t)S * 16));
+        ABW_HIP(ctx, hipMemsetAsync(H.d_ts8, 0, (size_t)n_groups * S * 16, st));           // the unused lanes of a group
+        hipLaunchKernelGGL(tree_static_narrow_kernel, dim3((unsigned)((S + 255) / 256), (unsigned)n_narrow), dim3(256), 0, st, P, d_narrow, d_nslot, S,
+                           (uint16_t*)H.d_ts8);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(tree_static_codes_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)n_groups), dim3(256), 0, st, P, d_narrow, d_groups, d_gfirst,
+                           d_dp2scaf, S, (const uint4*)H.d_ts8, (uint4*)H.d_nk16);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(tree_static_srec_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, P, S, (int4*)H.d_srec);
         ABW_LAUNCH_CHECK(ctx);
     }
     if (n_wide) {
@@ -779,9 +858,29 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
     const int64_t N = s.N, Np = (N + 7) & ~(int64_t)7, Sp = ((int64_t)S + 7) & ~(int64_t)7;      // strides of the position / scaffold arrays
     if (S > (int32_t)W_SC) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree: more than 2^30 scaffolds");
 
-    // narrow dimensions' offsets inside one node's histogram slice
+    // narrow dimensions by ascending number of bins, cut into groups of at most 8 dimensions and GRP_BINS bins; their offsets
+    // inside one node's histogram slice (a function of the table alone: the static tables follow the same grouping)
+    std::vector<int32_t> nsort(H.narrow_dims.begin(), H.narrow_dims.end()), nslot((size_t)n_narrow), gfirst;
+    std::stable_sort(nsort.begin(), nsort.end(), [&](int32_t a, int32_t b) { return s.h_T[a] < s.h_T[b]; });
     std::vector<int64_t> toffn((size_t)n_narrow + 1, 0);
-    for (int i = 0; i < n_narrow; i++) toffn[i + 1] = toffn[i] + s.h_T[H.narrow_dims[i]];
+    std::vector<NGroup> groups;
+    for (int i = 0; i < n_narrow; i++) {
+        const int32_t T = s.h_T[nsort[i]];
+        if (T > GRP_BINS) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_tree: narrow dimension %d has %d bins", nsort[i], T);
+        if (groups.empty() || groups.back().cnt == 8 || groups.back().total + T > GRP_BINS) {
+            NGroup g;
+            memset(&g, 0, sizeof(g));
+            g.goff = toffn[i];
+            groups.push_back(g);
+            gfirst.push_back(i);
+        }
+        NGroup& g = groups.back();
+        g.loff[g.cnt] = g.total;
+        nslot[i] = (int32_t)(groups.size() - 1) * 8 + g.cnt;
+        g.cnt++; g.total += T;
+        toffn[i + 1] = toffn[i] + T;
+    }
+    const int32_t n_groups = (int32_t)groups.size();
     const int64_t TBn = std::max<int64_t>(1, toffn[n_narrow]);
 
     // buffers of the call (grow-only scratch of the context: scratch is free between entry points)
@@ -796,15 +895,23 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
         if ((rc = abw_reserve(ctx, b_wword, (size_t)2 * n_wide * Np * 4))) return rc;
     }
     std::vector<int32_t> slot_h((size_t)D, 0);
-    for (int i = 0; i < n_narrow; i++) slot_h[H.narrow_dims[i]] = i;
+    for (int i = 0; i < n_narrow; i++) slot_h[nsort[i]] = nslot[i];
     for (int i = 0; i < n_wide; i++) slot_h[H.wide_dims[i]] = -i - 1;
-    const size_t m_toff = (toffn.size() * 8 + 63) & ~(size_t)63, m_slot = ((size_t)D * 4 + 63) & ~(size_t)63;
-    if ((rc = abw_reserve(ctx, b_misc, m_toff + m_slot + (size_t)N * 4 + 64))) return rc;
-    int64_t* d_toffn = (int64_t*)b_misc.p;
-    int32_t* d_slot = (int32_t*)((uint8_t*)b_misc.p + m_toff);
-    int32_t* d_dp2scaf = (int32_t*)((uint8_t*)b_misc.p + m_toff + m_slot);
-    ABW_HIP(ctx, hipMemcpyAsync(d_toffn, toffn.data(), toffn.size() * 8, hipMemcpyHostToDevice, st));
-    ABW_HIP(ctx, hipMemcpyAsync(d_slot, slot_h.data(), (size_t)D * 4, hipMemcpyHostToDevice, st));
+    std::vector<uint8_t> mblob;
+    const size_t o_toffn = pack(mblob, toffn), o_slot = pack(mblob, slot_h), o_nsort = pack(mblob, nsort), o_nslot = pack(mblob, nslot),
+                 o_groups = pack(mblob, groups), o_gfirst = pack(mblob, gfirst);
+    const size_t m_bytes = (mblob.size() + 63) & ~(size_t)63;
+    if ((rc = abw_reserve(ctx, b_misc, m_bytes + (size_t)N * 4 + 64))) return rc;
+    uint8_t* dm = (uint8_t*)b_misc.p;
+    const int64_t* d_toffn = (const int64_t*)(dm + o_toffn);
+    const int32_t* d_slot = (const int32_t*)(dm + o_slot);
+    const int32_t* d_nsort = (const int32_t*)(dm + o_nsort);
+    const int32_t* d_nslot = (const int32_t*)(dm + o_nslot);
+    const NGroup* d_groups = (const NGroup*)(dm + o_groups);
+    const int32_t* d_gfirst = (const int32_t*)(dm + o_gfirst);
+    int32_t* d_dp2scaf = (int32_t*)(dm + m_bytes);
+    ABW_HIP(ctx, hipMemcpyAsync(dm, mblob.data(), mblob.size(), hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));                                     // mblob is pageable and goes out of use below
 
     TreeDev Tr;
     Tr.P.bins = s.d_bins ? s.d_bins : s.d_keys; Tr.P.N = N;
@@ -812,17 +919,18 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
     Tr.P.scg_off = s.d_scg_off; Tr.P.scg_ids = s.d_scg_ids; Tr.P.n_scg = s.n_scg;
     Tr.P.T = s.d_T; Tr.P.Toff = s.d_Toff;
     Tr.P.h_st = nullptr; Tr.P.h_tot = nullptr; Tr.P.h_bp = nullptr; Tr.P.scg_lo = nullptr; Tr.P.scg_hi = nullptr; Tr.P.range = nullptr;
-    if ((n_narrow && !H.d_ts16) || (n_wide && !(H.d_wword && H.d_wpack)) || (s.n_scg > 0 && !H.d_carriers)) {
+    if ((n_narrow && !(H.d_ts8 && H.d_nk16 && H.d_srec)) || (n_wide && !(H.d_wword && H.d_wpack)) || (s.n_scg > 0 && !H.d_carriers)) {
         // dp -> scaffold (only the static build needs it)
         std::vector<int32_t> d2s((size_t)N);
         for (int32_t sc = 0; sc < S; sc++) std::fill(d2s.begin() + s.h_scaf_first[sc], d2s.begin() + s.h_scaf_first[sc] + s.h_scaf_ndps[sc], sc);
         ABW_HIP(ctx, hipMemcpyAsync(d_dp2scaf, d2s.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
         ABW_HIP(ctx, hipStreamSynchronize(st));
-        if ((rc = tree_static_build(ctx, H, Tr.P, d_dp2scaf))) return rc;
+        if ((rc = tree_static_build(ctx, H, Tr.P, d_dp2scaf, d_nsort, d_nslot, d_groups, d_gfirst, n_groups))) return rc;
     }
-    Tr.narrow = H.d_narrow; Tr.n_narrow = n_narrow; Tr.toffn = d_toffn; Tr.TBn = TBn;
+    Tr.narrow = d_nsort; Tr.n_narrow = n_narrow; Tr.toffn = d_toffn; Tr.TBn = TBn;
+    Tr.groups = d_groups; Tr.n_groups = n_groups; Tr.nk16 = (const uint4*)H.d_nk16; Tr.ts8 = (const uint4*)H.d_ts8; Tr.srec = (const int4*)H.d_srec;
     Tr.wide = H.d_wide; Tr.n_wide = n_wide; Tr.dp2scaf = d_dp2scaf; Tr.dim_slot = d_slot;
-    Tr.ts16 = H.d_ts16; Tr.wext = (const uint4*)H.d_wext; Tr.wpack = H.d_wpack; Tr.D = D; Tr.S = S;
+    Tr.wext = (const uint4*)H.d_wext; Tr.wpack = H.d_wpack; Tr.D = D; Tr.S = S;
 
     uint32_t* order[2] = {(uint32_t*)b_order.p, (uint32_t*)b_order.p + Sp};
     int32_t* wbin[2] = {(int32_t*)b_wbin.p, n_wide ? (int32_t*)b_wbin.p + (int64_t)n_wide * Np : nullptr};
@@ -874,7 +982,7 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
             else {
                 zero_slots.push_back(k);
                 int32_t tb, te;
-                make_tiles(atiles, k, nd[k].scaf_begin, nd[k].scaf_end, TILE_S, tb, te);
+                make_tiles(atiles, k, nd[k].scaf_begin, nd[k].scaf_end, TILE_A, tb, te);
             }
         }
         const int32_t n_st = (int32_t)stiles.size(), n_pt = (int32_t)ptiles.size(), n_at = (int32_t)atiles.size();
@@ -907,8 +1015,8 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
                      t_best = ((size_t)std::max(1, n_wide) * n_pt * sizeof(Cand) + 63) & ~(size_t)63,
                      t_tot = ((size_t)std::max(1, n_wide) * K * sizeof(WSums) + 63) & ~(size_t)63,
                      t_cnt = ((size_t)(std::max(1, n_wide) * (size_t)n_pt + n_st) * 4 + 63) & ~(size_t)63,
-                     t_mask = ((size_t)std::max(1, n_wide) * n_pt + n_st) * 256;
-        if ((rc = abw_reserve(ctx, b_tile, t_cand + t_sums + t_best + t_tot + t_cnt + t_mask))) return rc;
+                     t_mask = (((size_t)std::max(1, n_wide) * n_pt + n_st) * 256 + 63) & ~(size_t)63;
+        if ((rc = abw_reserve(ctx, b_tile, t_cand + t_sums + t_best + t_tot + t_cnt + t_mask + (size_t)K * 8))) return rc;
         Cand* d_cand = (Cand*)b_tile.p;
         WSums* d_tsums = (WSums*)((uint8_t*)b_tile.p + t_cand);
         Cand* d_tbest = (Cand*)((uint8_t*)b_tile.p + t_cand + t_sums);
@@ -917,6 +1025,7 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
         uint32_t* d_scnt = d_pcnt + (size_t)std::max(1, n_wide) * n_pt;
         uint8_t* d_pmask = (uint8_t*)b_tile.p + t_cand + t_sums + t_best + t_tot + t_cnt;
         uint8_t* d_smask = d_pmask + (size_t)std::max(1, n_wide) * n_pt * 256;
+        double* d_bar = (double*)(d_pmask + t_mask);
         if (scg_n > 0) {
             hipLaunchKernelGGL(tree_scg_reset_kernel, dim3((unsigned)std::min<int64_t>((scg_n + 255) / 256, ctx->num_cu * 8)), dim3(256), 0, st, d_scg_lo, d_scg_hi, scg_n);
             ABW_LAUNCH_CHECK(ctx);
@@ -946,7 +1055,7 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
                 ABW_LAUNCH_CHECK(ctx);
             }
             if (n_at) {
-                hipLaunchKernelGGL(tree_accum_kernel, dim3((unsigned)n_at, (unsigned)n_narrow), dim3(256), 0, st, Tr, d_atiles, (const int32_t*)order[cur], c_st, c_bp, c_tot);
+                hipLaunchKernelGGL(tree_accum_kernel, dim3((unsigned)n_at, (unsigned)n_groups), dim3(256), 0, st, Tr, d_atiles, (const int32_t*)order[cur], c_st, c_bp, c_tot);
                 ABW_LAUNCH_CHECK(ctx);
             }
             if (!subs.empty()) {
@@ -960,12 +1069,14 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
         // ---- wide dimensions: prefix sums along every node's sorted segment
         if (n_wide) {
             ABW_PROF(ctx, "sep_wide");
+            hipLaunchKernelGGL(tree_bar_kernel, dim3((unsigned)K), dim3(64), 0, st, Tr, d_cand, d_bar);
+            ABW_LAUNCH_CHECK(ctx);
             hipLaunchKernelGGL(tree_wide_sums_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, wword[cur], Np, d_tsums);
             ABW_LAUNCH_CHECK(ctx);
             hipLaunchKernelGGL(tree_wide_scan_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, d_nodes, n_pt, d_tsums, d_ntot, K);
             ABW_LAUNCH_CHECK(ctx);
             hipLaunchKernelGGL(tree_wide_eval_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, d_nodes, K, min_ndps,
-                               wbin[cur], wword[cur], Np, d_tsums, d_ntot, d_scg_lo, d_scg_hi, d_tbest);
+                               wbin[cur], wword[cur], Np, d_tsums, d_ntot, d_scg_lo, d_scg_hi, d_bar, d_tbest);
             ABW_LAUNCH_CHECK(ctx);
             hipLaunchKernelGGL(tree_wide_best_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, Tr, d_nodes, n_pt, d_tbest, d_cand);
             ABW_LAUNCH_CHECK(ctx);
