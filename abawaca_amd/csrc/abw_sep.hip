@@ -33,27 +33,77 @@ namespace {
 
 
 
-// Narrow dimensions (keys in [0, NARROW_T): every signature column).  One thread per (scaffold, dimension):
-// the flip value by a sorting network, then per dp size[v] += 1 and tp1[max(v, t_s)] += 1 (the dps at or below
-// the flip value are credited to bin t_s in one add), per scaffold tot[t_s] += n and bp[t_s] += len -- all
-// in a histogram private to the workgroup (LDS, 32-bit atomics), flushed to the node's histogram at the end.
-// Same-bin contention: a signature column uses few bins (a 4-mer frequency is about 0.004: thousandths 0..15), so the 64
-// lanes of an LDS atomic mostly hit the same handful of words and serialise.  The histograms are therefore kept in as many
-// LDS COPIES as fit into the space one full-range column needs (T <= 1024 bins): copies = 1024 / T rounded down to a power
-// of two, at most 32; a lane uses copy (lane mod copies); the copies lie T|1 words apart -- an odd stride, so that one bin
-// of different copies falls into different banks.  Zeroing and flushing touch copies * T <= 1056 words whatever T is.
-// (Measured r01 with a fixed 4 copies of 1024 bins: slower, the zero / flush passes grew 4x; here they do not grow.)
-__global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const int32_t* __restrict__ dimlist,
+// Narrow dimensions (keys in [0, NARROW_T): every signature column), in groups of up to 8 (NGroup, abw_sep_common.h).
+// ---- the static tables of the groups, built once per loaded table ------------------------------------------------------
+// flip value of every scaffold in every narrow dimension, into its group's [scaffold][8] table (nslot = group * 8 + lane).
+// grid (ceil(S / 256), narrow dimensions in nsort order)
+__global__ __launch_bounds__(256) void sep_static_ts_kernel(SepDev P, const int32_t* __restrict__ nsort, const int32_t* __restrict__ nslot,
+                                                           int32_t S, uint16_t* __restrict__ ts8)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    const int d = nsort[blockIdx.y], slot = nslot[blockIdx.y];
+    const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
+    const int f = P.scaf_first[s], n = P.scaf_ndps[s], k = n >> 1;      // 0-based index of the flip value
+    int ts;
+    if (n <= 8) {
+        int x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = (i < n) ? col[f + i] : INT_MAX;
+        ABW_SORT8(x);
+        ts = (k == 1) ? x[1] : (k == 2) ? x[2] : (k == 3) ? x[3] : x[4];
+    } else ts = select_kth_mem(col + f, n, k, P.T[d]);
+    ts8[((int64_t)(slot >> 3) * S + s) * 8 + (slot & 7)] = (uint16_t)ts;
+}
+
+// the re-coded narrow columns.  grid (ceil(N / 256), groups)
+__global__ __launch_bounds__(256) void sep_static_codes_kernel(SepDev P, const NGroup* __restrict__ groups, const int32_t* __restrict__ dp2scaf,
+                                                              int32_t S, const uint4* __restrict__ ts8, uint4* __restrict__ nk16)
+{
+    const int64_t dp = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (dp >= P.N) return;
+    const int j = blockIdx.y;
+    const NGroup G = groups[j];
+    const uint4 t = ts8[(int64_t)j * S + dp2scaf[dp]];
+    const uint32_t tw[4] = {t.x, t.y, t.z, t.w};
+    uint32_t cw[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        if (q < G.cnt) {
+            const uint32_t v = (uint32_t)P.bins[(int64_t)G.dim[q] * P.N + dp];
+            const uint32_t ts = (tw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+            cw[q >> 1] |= (v | (v > ts ? 0x8000u : 0u)) << (16 * (q & 1));
+        }
+    }
+    nk16[(int64_t)j * P.N + dp] = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+}
+
+__global__ void sep_static_srec_kernel(SepDev P, int32_t S, int4* __restrict__ srec)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const unsigned long long len = (unsigned long long)P.scaf_len[s];
+    srec[s] = make_int4(P.scaf_first[s], P.scaf_ndps[s], (int)(uint32_t)len, (int)(uint32_t)(len >> 32));
+}
+
+// ---- the node's histograms of the narrow dimensions.  grid (ceil(m / TILE_A), groups) ----------------------------------
+__global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const NGroup* __restrict__ groups, const uint4* __restrict__ nk16,
+                                                       const uint4* __restrict__ ts8, const int4* __restrict__ srec, int32_t S,
                                                        const int32_t* __restrict__ node_scaf, int32_t m)
 {
-    __shared__ uint32_t s_size[ACC_LDS_WORDS];            // LDS atomics: 32-bit ones are the fast ones
-    __shared__ uint32_t s_tp1[ACC_LDS_WORDS];
-    __shared__ uint32_t s_tot[ACC_LDS_WORDS];
-    __shared__ unsigned long long s_bp[ACC_LDS_WORDS];
-    const int d = dimlist[blockIdx.y];
-    const int ls_begin = blockIdx.x * ACC_SPB;
-    accum_tile(P, d, node_scaf, ls_begin, min(m, ls_begin + ACC_SPB), P.h_st + P.Toff[d], P.h_tot + P.Toff[d], P.h_bp + P.Toff[d],
-               P.scg_lo + (int64_t)d * P.n_scg, P.scg_hi + (int64_t)d * P.n_scg, s_size, s_tp1, s_tot, s_bp);
+    const int j = blockIdx.y;
+    const NGroup G = groups[j];
+    const int begin = blockIdx.x * TILE_A;
+    accum_group_tile(G, nk16 + (int64_t)j * P.N, ts8 + (int64_t)j * S, srec, node_scaf, begin, min(m, begin + TILE_A), P, P.scg_lo, P.scg_hi,
+                     [&](int b, unsigned long long a, uint32_t c3, unsigned long long e) {
+                         int q = 0;
+#pragma unroll
+                         for (int i = 1; i < 8; i++) q += (i < G.cnt && b >= G.loff[i]);
+                         const int64_t at = P.Toff[G.dim[q]] + (b - G.loff[q]);
+                         if (a) atomicAdd(&P.h_st[at], a);
+                         if (c3) atomicAdd(&P.h_tot[at], c3);
+                         if (e) atomicAdd(&P.h_bp[at], e);
+                     });
 }
 
 // ---- wide dimensions (coverage: about as many distinct keys as dps) -----------------------------------
@@ -592,7 +642,7 @@ extern "C" void abw_sep_free(abw_ctx* ctx)
     if (e) {
         void* q[] = {e->h.d_narrow, e->h.d_wide, e->h.d_dim_first_chunk, e->h.d_dim_nchunks, e->h.d_chunks,
                      e->h.d_chunk_sums, e->h.d_dim_total, e->h.d_chunk_best, e->h.d_sscaf, e->h.d_sbin, e->h.d_sdp,
-                     e->h.d_wts, e->h.d_wbelow, e->h.d_range, e->h.d_ts8, e->h.d_nk16, e->h.d_srec, e->h.d_wword, e->h.d_wext, e->h.d_wpack, e->h.d_carriers};
+                     e->h.d_wts, e->h.d_wbelow, e->h.d_range, e->h.d_groups, e->h.d_nsort, e->h.d_toffn, e->h.d_dim_slot, e->h.d_ts8, e->h.d_nk16, e->h.d_srec, e->h.d_wword, e->h.d_wext, e->h.d_wpack, e->h.d_carriers};
         for (void* p : q) if (p) (void)hipFree(p);
         delete e;
     }
@@ -609,7 +659,7 @@ static int upload(abw_ctx* ctx, T** dst, const T* src, size_t n)
 }
 
 static int sep_load_upload(abw_ctx* ctx, std::vector<int32_t>& st_first, std::vector<int32_t>& st_ndps, std::vector<int32_t>& st_T,
-                           std::vector<int64_t>& st_Toff, std::vector<int64_t>& st_binval_off, std::vector<std::vector<int32_t>>& uniq,
+                           std::vector<int32_t>& st_span, std::vector<int64_t>& st_Toff, std::vector<int64_t>& st_binval_off, std::vector<std::vector<int32_t>>& uniq,
                            std::vector<int32_t>& bins, std::vector<char>& is_wide, const int32_t* keys, int32_t D, int64_t N,
                            const int32_t* dp2scaf, const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
                            int32_t n_scg, bool sharded);
@@ -641,7 +691,7 @@ static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int
     ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // Everything that can reject the input is checked BEFORE the resident table is touched: a refused reload leaves
     // the previous table usable.  The new layout is built in locals and moved in once it is known to be good.
-    struct Staged { std::vector<int32_t> h_scaf_first, h_scaf_ndps, h_T; std::vector<int64_t> h_Toff, h_binval_off; } s;
+    struct Staged { std::vector<int32_t> h_scaf_first, h_scaf_ndps, h_T, h_span; std::vector<int64_t> h_Toff, h_binval_off; } s;
 
     // scaffold layout (ref: ScafDpData.cpp:91-99 numbers dps scaffold by scaffold)
     s.h_scaf_first.assign(S, 0);
@@ -669,6 +719,7 @@ static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int
 
     // bins: narrow dimensions use the key as bin; wide ones the rank among the column's distinct keys
     s.h_T.assign(D, 0);
+    s.h_span.assign(D, 0);                               // narrow dimensions: largest key of THIS table + 1 (<= T)
     s.h_Toff.assign(D + 1, 0);
     s.h_binval_off.assign(D, -1);
     std::vector<std::vector<int32_t>> uniq(D);
@@ -686,6 +737,7 @@ static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int
                     if (dict_off[d + 1] == dict_off[d]) {
                         if (mn < 0 || mx >= NARROW_T) bad_dim[d] = 1;
                         s.h_T[d] = NARROW_T;
+                        s.h_span[d] = std::max(1, std::min(mx, NARROW_T - 1) + 1);
                     } else {
                         is_wide[d] = 1;
                         uniq[d].assign(dict_vals + dict_off[d], dict_vals + dict_off[d + 1]);
@@ -693,7 +745,7 @@ static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int
                     }
                     continue;
                 }
-                if (mn >= 0 && mx < NARROW_T) { s.h_T[d] = mx + 1; continue; }
+                if (mn >= 0 && mx < NARROW_T) { s.h_T[d] = mx + 1; s.h_span[d] = mx + 1; continue; }
                 is_wide[d] = 1;
                 std::vector<int32_t>& u = uniq[d];
                 u.assign(col, col + N);
@@ -733,13 +785,77 @@ static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int
     // the input is good: drop the previous table, move the staged layout in
     abw_sep_free(ctx);
     Staged staged = std::move(s);
-    return sep_load_upload(ctx, staged.h_scaf_first, staged.h_scaf_ndps, staged.h_T, staged.h_Toff, staged.h_binval_off, uniq, bins, is_wide,
+    return sep_load_upload(ctx, staged.h_scaf_first, staged.h_scaf_ndps, staged.h_T, staged.h_span, staged.h_Toff, staged.h_binval_off, uniq, bins, is_wide,
                            keys, D, N, dp2scaf, scaf_len, S, scg_off, scg_ids, n_scg, dict_off != nullptr);
+}
+
+static SepDev sep_params(abw_sep_state& s, SepHost& H);
+
+// The groups of narrow dimensions and their static tables (NGroup, abw_sep_common.h).  span[d]: largest key of dimension d
+// in this table + 1 (the LDS layout follows the table; the histogram layout T may be wider when shards share it).
+static int sep_build_narrow(abw_ctx* ctx, const std::vector<int32_t>& span, const int32_t* dp2scaf)
+{
+    abw_sep_state& s = ctx->sep;
+    SepHost& H = g_extra_of(ctx)->h;
+    const int32_t n_narrow = (int32_t)H.narrow_dims.size(), D = s.D, S = s.S;
+    const int64_t N = s.N;
+    H.nsort.assign(H.narrow_dims.begin(), H.narrow_dims.end());
+    std::stable_sort(H.nsort.begin(), H.nsort.end(), [&](int32_t a, int32_t b) { return span[a] < span[b]; });
+    H.nslot.assign((size_t)n_narrow, 0);
+    H.toffn.assign((size_t)n_narrow + 1, 0);
+    H.groups.clear();
+    for (int32_t i = 0; i < n_narrow; i++) {
+        const int32_t d = H.nsort[i], w = span[d];
+        if (H.groups.empty() || H.groups.back().cnt == 8 || H.groups.back().total + w > GRP_BINS) {
+            NGroup g;
+            memset(&g, 0, sizeof(g));
+            g.goff = H.toffn[i];
+            H.groups.push_back(g);
+        }
+        NGroup& g = H.groups.back();
+        g.loff[g.cnt] = g.total;
+        g.dim[g.cnt] = d;
+        H.nslot[i] = (int32_t)(H.groups.size() - 1) * 8 + g.cnt;
+        g.cnt++; g.total += w;
+        H.toffn[i + 1] = H.toffn[i] + s.h_T[d];
+    }
+    std::vector<int32_t> slot((size_t)D, 0);
+    for (int32_t i = 0; i < n_narrow; i++) slot[H.nsort[i]] = H.nslot[i];
+    for (size_t w = 0; w < H.wide_dims.size(); w++) slot[H.wide_dims[w]] = -(int32_t)w - 1;
+    int rc;
+    if ((rc = upload(ctx, &H.d_dim_slot, slot.data(), (size_t)D))) return rc;
+    if (n_narrow == 0) return ABW_OK;
+    const size_t n_groups = H.groups.size();
+    int32_t *d_nslot = nullptr, *d_dp2scaf = nullptr;
+    if ((rc = upload(ctx, &H.d_groups, H.groups.data(), n_groups))) return rc;
+    if ((rc = upload(ctx, &H.d_nsort, H.nsort.data(), (size_t)n_narrow))) return rc;
+    if ((rc = upload(ctx, &H.d_toffn, H.toffn.data(), (size_t)n_narrow + 1))) return rc;
+    ABW_HIP(ctx, hipMalloc(&H.d_ts8, n_groups * (size_t)S * 16));
+    ABW_HIP(ctx, hipMalloc(&H.d_nk16, n_groups * (size_t)N * 16));
+    ABW_HIP(ctx, hipMalloc(&H.d_srec, (size_t)S * 16));
+    rc = upload(ctx, &d_nslot, H.nslot.data(), (size_t)n_narrow);
+    if (!rc) rc = upload(ctx, &d_dp2scaf, dp2scaf, (size_t)N);
+    if (!rc) {
+        hipStream_t st = ctx->stream;
+        SepDev P = sep_params(s, H);
+        hipError_t e = hipMemsetAsync(H.d_ts8, 0, n_groups * (size_t)S * 16, st);               // the unused lanes of a group
+        hipLaunchKernelGGL(sep_static_ts_kernel, dim3((unsigned)((S + 255) / 256), (unsigned)n_narrow), dim3(256), 0, st, P, H.d_nsort, d_nslot, S,
+                           (uint16_t*)H.d_ts8);
+        hipLaunchKernelGGL(sep_static_codes_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)n_groups), dim3(256), 0, st, P, H.d_groups, d_dp2scaf, S,
+                           (const uint4*)H.d_ts8, (uint4*)H.d_nk16);
+        hipLaunchKernelGGL(sep_static_srec_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, P, S, (int4*)H.d_srec);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = abw_fail(ctx, ABW_ERR_HIP, "abw_sep_load: building the grouped narrow columns: %s", hipGetErrorString(e));
+    }
+    if (d_nslot) (void)hipFree(d_nslot);
+    if (d_dp2scaf) (void)hipFree(d_dp2scaf);
+    return rc;
 }
 
 // second half of sep_load_impl: builds the chunk tables and uploads.  On any failure the half-built table is freed.
 static int sep_load_upload_impl(abw_ctx* ctx, std::vector<int32_t>& st_first, std::vector<int32_t>& st_ndps, std::vector<int32_t>& st_T,
-                                std::vector<int64_t>& st_Toff, std::vector<int64_t>& st_binval_off, std::vector<std::vector<int32_t>>& uniq,
+                                std::vector<int32_t>& st_span, std::vector<int64_t>& st_Toff, std::vector<int64_t>& st_binval_off, std::vector<std::vector<int32_t>>& uniq,
                                 std::vector<int32_t>& bins, std::vector<char>& is_wide, const int32_t* keys, int32_t D, int64_t N,
                                 const int32_t* dp2scaf, const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
                                 int32_t n_scg, bool sharded)
@@ -827,6 +943,7 @@ static int sep_load_upload_impl(abw_ctx* ctx, std::vector<int32_t>& st_first, st
         if ((rc = upload(ctx, &H.d_range, none.data(), none.size()))) return rc;
     }
     H.sharded = sharded;
+    if ((rc = sep_build_narrow(ctx, st_span, dp2scaf))) return rc;
     if ((rc = abw_reserve(ctx, s.scg_lohi, (size_t)std::max<int64_t>(1, (int64_t)D * n_scg) * 8))) return rc;
     if ((rc = abw_reserve(ctx, s.dimbest, (size_t)D * sizeof(DimBestDev) + sizeof(GlobalRes)))) return rc;
     s.loaded = true;
@@ -835,12 +952,12 @@ static int sep_load_upload_impl(abw_ctx* ctx, std::vector<int32_t>& st_first, st
 }
 
 static int sep_load_upload(abw_ctx* ctx, std::vector<int32_t>& st_first, std::vector<int32_t>& st_ndps, std::vector<int32_t>& st_T,
-                           std::vector<int64_t>& st_Toff, std::vector<int64_t>& st_binval_off, std::vector<std::vector<int32_t>>& uniq,
+                           std::vector<int32_t>& st_span, std::vector<int64_t>& st_Toff, std::vector<int64_t>& st_binval_off, std::vector<std::vector<int32_t>>& uniq,
                            std::vector<int32_t>& bins, std::vector<char>& is_wide, const int32_t* keys, int32_t D, int64_t N,
                            const int32_t* dp2scaf, const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
                            int32_t n_scg, bool sharded)
 {
-    const int rc = sep_load_upload_impl(ctx, st_first, st_ndps, st_T, st_Toff, st_binval_off, uniq, bins, is_wide, keys, D, N, dp2scaf,
+    const int rc = sep_load_upload_impl(ctx, st_first, st_ndps, st_T, st_span, st_Toff, st_binval_off, uniq, bins, is_wide, keys, D, N, dp2scaf,
                                         scaf_len, S, scg_off, scg_ids, n_scg, sharded);
     if (rc) { const std::string msg = ctx->err; abw_sep_free(ctx); ctx->err = msg; }      // no half-populated table behind an error
     return rc;
@@ -905,10 +1022,11 @@ static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_
     hipLaunchKernelGGL(sep_range_reset_kernel, dim3((s.D + 63) / 64), dim3(64), 0, st, P, s.D, H.d_wide, (int32_t)H.wide_dims.size(), scatter ? 0 : 1);
     ABW_LAUNCH_CHECK(ctx);
     if (m > 0) {
-        const unsigned gx = (unsigned)((m + ACC_SPB - 1) / ACC_SPB);
+        const unsigned gx = (unsigned)((m + TILE_A - 1) / TILE_A);
         ABW_PROF(ctx, "sep_accum");
         if (!H.narrow_dims.empty()) {
-            hipLaunchKernelGGL(sep_accum_kernel, dim3(gx, (unsigned)H.narrow_dims.size()), dim3(256), 0, st, P, H.d_narrow, d_node_scaf, m);
+            hipLaunchKernelGGL(sep_accum_kernel, dim3(gx, (unsigned)H.groups.size()), dim3(256), 0, st, P, H.d_groups, (const uint4*)H.d_nk16,
+                               (const uint4*)H.d_ts8, (const int4*)H.d_srec, s.S, d_node_scaf, m);
             ABW_LAUNCH_CHECK(ctx);
         }
         if (!H.wide_dims.empty()) {

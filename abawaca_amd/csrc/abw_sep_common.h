@@ -7,11 +7,20 @@
 
 constexpr int NARROW_T = 1024;      // dimensions with keys in [0, NARROW_T) use the key itself as bin
 constexpr int SCAN_CH = 2048;       // bins per scan chunk
-#ifndef ABW_ACC_SPB
-#define ABW_ACC_SPB 2048
-#endif
-constexpr int ACC_SPB = ABW_ACC_SPB;       // scaffolds per workgroup in sep_accum
+constexpr int TILE_A = 1024;        // scaffolds per workgroup of the narrow accumulation (256 threads x 4)
+constexpr int GRP_BINS = 2048;      // LDS bins of one group of narrow dimensions (a narrow dimension has at most NARROW_T)
 constexpr int MAX_SCG = 4096;
+
+// A group of up to 8 narrow dimensions whose values travel together: the narrow columns are kept a second time as
+// [group][dp][8] x 16 bit (value | (value > t_s) << 15, t_s = the flip value of the dp's scaffold in that dimension) with the
+// flip values beside them as [group][scaffold][8] x 16 bit.  A node is a set of whole scaffolds, so t_s -- the
+// (n_s / 2 + 1)-th smallest of the scaffold's own values -- is the same in every node: both tables are built once per
+// loaded table.  One 16-byte load brings a dp's values in 8 dimensions, and the dps of a scaffold are contiguous: the
+// scattered scaffolds of a node deep in the recursion cost 64 useful bytes per cache line instead of 16 (in the
+// [dimension][dp] layout every (scaffold, dimension) is a cache line of its own).
+// The dimensions of a group are consecutive in SepHost::nsort (ascending number of bins); their bins lie side by side in
+// LDS (loff: offsets by the values the table really holds, `total` <= GRP_BINS in all).
+struct NGroup { int32_t cnt, total; int32_t loff[8]; int32_t dim[8]; int64_t goff; };     // goff: offset in a slice laid out in nsort order
 
 struct DimBestDev { int32_t found; int32_t bin; double sens; double spec; double prod; long long size1; long long n; };
 
@@ -84,11 +93,18 @@ struct SepHost {
     // wide dimensions: dps sorted by bin (static) and the per-node flip-value records
     int32_t *d_sscaf = nullptr, *d_sbin = nullptr, *d_sdp = nullptr, *d_wts = nullptr, *d_wbelow = nullptr;
     int32_t* d_range = nullptr;        // [D][2] bins touched by the current node
-    // abw_sep_tree's static tables, built at its first call on this table (abw_tree.hip): a scaffold's flip value in a
-    // dimension depends on the scaffold's own dps only, so it is the same in every node of the recursion
-    void* d_ts8 = nullptr;             // abw_sep_tree's static tables (abw_tree.hip): [groups][S][8] x 16 bit flip values,
-    void* d_nk16 = nullptr;            //   [groups][N][8] x 16 bit re-coded narrow columns,
-    void* d_srec = nullptr;            //   [S] x 16 bytes: first dp, dps, length
+    // narrow dimensions in groups (see NGroup), built by abw_sep_load
+    std::vector<int32_t> nsort, nslot; // narrow dimensions by ascending number of bins; group * 8 + lane of each
+    std::vector<int64_t> toffn;        // [n_narrow + 1] offsets of the dimensions, in nsort order, in a slice of narrow histograms only
+    std::vector<NGroup> groups;
+    NGroup* d_groups = nullptr;
+    int32_t* d_nsort = nullptr;
+    int64_t* d_toffn = nullptr;
+    int32_t* d_dim_slot = nullptr;     // [D] narrow: group * 8 + lane; wide: -(index among the wide dimensions) - 1
+    void* d_ts8 = nullptr;             // [groups][S][8] x 16 bit flip values
+    void* d_nk16 = nullptr;            // [groups][N][8] x 16 bit re-coded narrow columns
+    void* d_srec = nullptr;            // [S] x 16 bytes: first dp, dps, length (lo, hi)
+    // abw_sep_tree's static tables of the wide dimensions, built at its first call on this table (abw_tree.hip)
     uint32_t* d_wword = nullptr;       // [n_wide][N] per sorted position: scaffold | (v >= t_s) << 31 | (owner) << 30
     uint32_t* d_wext = nullptr;        // [n_wide][S][4] per scaffold: dps below t_s, dps, min(length, 500000), bin of t_s
     uint32_t* d_wpack = nullptr;       // [n_wide][S] the first three of d_wext in one word (scaffolds of <= 127 dps), else all ones
@@ -113,107 +129,91 @@ SepHost& abw_sep_host(abw_ctx* ctx);     // abw_sep.hip
         ABW_CX8(x, 1, 2) ABW_CX8(x, 3, 4) ABW_CX8(x, 5, 6)                         \
     } while (0)
 
-// ---- narrow dimensions: histograms of one tile of scaffolds in one dimension --------------------------------------
-constexpr int ACC_LDS_WORDS = NARROW_T + 32;     // copies * (T | 1) <= ACC_LDS_WORDS
-
-// One thread per scaffold of the tile [ls_begin, ls_end) (positions in node_scaf, or scaffold ids themselves when it is
-// NULL), 256 threads striding over it: the flip value by a sorting network, then per dp size[v] += 1 and
-// tp1[max(v, t_s)] += 1 (the dps at or below the flip value are credited to bin t_s in one add), per scaffold
-// tot[t_s] += n and bp[t_s] += len -- all into workgroup-private LDS histograms (several copies, see sep_accum_kernel),
-// flushed with one atomic per non-empty bin to g_st / g_tot / g_bp (the dimension's slice of the node's histogram).
-// scg_lo / scg_hi: the dimension's [n_scg] slice of the node's per-SCG min / max flip values.
-static __device__ __forceinline__ void accum_tile(const SepDev& P, int d, const int32_t* __restrict__ node_scaf, int ls_begin, int ls_end,
-                                                  unsigned long long* __restrict__ g_st, uint32_t* __restrict__ g_tot,
-                                                  unsigned long long* __restrict__ g_bp, int32_t* __restrict__ scg_lo, int32_t* __restrict__ scg_hi,
-                                                  uint32_t* s_size, uint32_t* s_tp1, uint32_t* s_tot, unsigned long long* s_bp)
+// ---- narrow dimensions: histograms of one tile of scaffolds in one group of dimensions -------------------------------
+// One thread per scaffold of the tile [begin, end) (positions in `list`, or the scaffold ids themselves when it is NULL),
+// 256 threads striding over it.  Per dp and dimension size[v] += 1 and, above the flip value, tp1[v] += 1; per scaffold
+// and dimension tp1[t_s] += its dps at or below t_s (they count from threshold t_s on), tot[t_s] += n and bp[t_s] += len
+// -- into workgroup-private LDS histograms, handed bin by bin to flush(b, size | tp1 << 32, tot, bp) at the end (b: bin
+// in the group's LDS layout; only non-empty bins).  scg_lo / scg_hi (NULL: none): [D][n_scg] min / max flip value over
+// the scaffolds that carry each SCG.
+template <typename Flush>
+static __device__ __forceinline__ void accum_group_tile(const NGroup& G, const uint4* __restrict__ codes, const uint4* __restrict__ tsv,
+                                                        const int4* __restrict__ srec, const int32_t* __restrict__ list, int begin, int end,
+                                                        const SepDev& P, int32_t* __restrict__ scg_lo, int32_t* __restrict__ scg_hi, Flush flush)
 {
-    const int T = P.T[d];
-    const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
-    const int Tp = T | 1;
-    int copies = 1;
-    while (copies < 32 && 2 * copies * Tp <= ACC_LDS_WORDS) copies <<= 1;
-    for (int t = threadIdx.x; t < copies * Tp; t += 256) { s_size[t] = 0; s_tp1[t] = 0; s_tot[t] = 0; s_bp[t] = 0; }
+    __shared__ uint32_t s_size[GRP_BINS];                  // LDS atomics: 32-bit ones are the fast ones
+    __shared__ uint32_t s_tp1[GRP_BINS];
+    __shared__ uint32_t s_tot[GRP_BINS];
+    __shared__ unsigned long long s_bp[GRP_BINS];
+    // k-mer frequencies crowd into a handful of bins, and LDS atomics of one instruction on one word are served one after
+    // the other: the histograms are kept in as many copies as fit (a power of two, at most 16), BIN-major -- bin b of copy
+    // c at b * copies + c, the copy of a lane = lane mod copies -- so that lanes of different copies never share a bank.
+    int lg = 0;
+    while (lg < 4 && (G.total << (lg + 1)) <= GRP_BINS) lg++;
+    const int copies = 1 << lg, mine = threadIdx.x & (copies - 1);
+    for (int i = threadIdx.x; i < (G.total << lg); i += 256) { s_size[i] = 0; s_tp1[i] = 0; s_tot[i] = 0; s_bp[i] = 0; }
     __syncthreads();
-    const int mine = (threadIdx.x & (copies - 1)) * Tp;
-    uint32_t* my_size = s_size + mine;
-    uint32_t* my_tp1 = s_tp1 + mine;
-    uint32_t* my_tot = s_tot + mine;
-    unsigned long long* my_bp = s_bp + mine;
-
-    // The loads of a scaffold are a dependent chain (list -> scaffold table -> column values); the next scaffold's are
-    // issued before this one is processed.
-    struct Item { int s, f, n; long long len; int v[8]; };
-    auto fetch = [&](int ls, Item& it) {
-        it.s = node_scaf ? node_scaf[ls] : ls;
-        it.f = P.scaf_first[it.s];
-        it.n = P.scaf_ndps[it.s];
-        it.len = P.scaf_len[it.s];
+    for (int ls = begin + threadIdx.x; ls < end; ls += 256) {
+        const int s = list ? list[ls] : ls;
+        const int4 rec = srec[s];
+        const uint4 t8 = tsv[s];
+        const int f = rec.x, n = rec.y;
+        uint32_t le[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i0 = 0; i0 < n; i0 += 4) {
+            uint4 c[4];
 #pragma unroll
-        for (int i = 0; i < 8; i++) it.v[i] = (i < it.n) ? col[it.f + i] : INT_MAX;      // the first 8 values (all, for n <= 8)
-    };
-    Item cur, nxt;
-    int ls = ls_begin + threadIdx.x;
-    if (ls < ls_end) fetch(ls, cur);
-    for (; ls < ls_end; ls += 256) {
-        if (ls + 256 < ls_end) fetch(ls + 256, nxt);
-        const int s = cur.s, f = cur.f, n = cur.n;
-        const long long slen = cur.len;
-        const int k = n >> 1;                              // 0-based index of the flip value
-        int ts;
-        uint32_t tp_ts = 0;                                // dps at or below the flip value: tp1 credits bin t_s
-        if (n <= 8) {
-            int w[8];
+            for (int i = 0; i < 4; i++) c[i] = (i0 + i < n) ? codes[f + i0 + i] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 8; i++) w[i] = cur.v[i];
-            ABW_SORT8(w);                                  // the tail is padded with INT_MAX
-            ts = (k == 1) ? w[1] : (k == 2) ? w[2] : (k == 3) ? w[3] : w[4];
-            // one LDS atomic per DISTINCT value of the scaffold (its segments often share a 3-decimal value): runs of the
-            // sorted copy; the padding (INT_MAX) ends the last run
-            uint32_t run = 0;
+            for (int i = 0; i < 4; i++) {
+                if (i0 + i < n) {
+                    const uint32_t cw[4] = {c[i].x, c[i].y, c[i].z, c[i].w};
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (i < n) {
-                    run++;
-                    const int nextv = (i < 7) ? w[i + 1] : INT_MAX;
-                    if (nextv != w[i]) {
-                        atomicAdd(&my_size[w[i]], run);
-                        if (w[i] > ts) atomicAdd(&my_tp1[w[i]], run); else tp_ts += run;
-                        run = 0;
+                    for (int q = 0; q < 8; q++) {
+                        if (q < G.cnt) {
+                            const uint32_t code = (cw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                            const int at = ((G.loff[q] + (int)(code & 0x7FFFu)) << lg) + mine;
+                            atomicAdd(&s_size[at], 1u);
+                            if (code & 0x8000u) atomicAdd(&s_tp1[at], 1u); else le[q]++;
+                        }
                     }
                 }
             }
-        } else {
-            ts = select_kth_mem(col + f, n, k, T);
-            for (int i = 0; i < n; i++) {
-                const int v = col[f + i];
-                atomicAdd(&my_size[v], 1u);
-                if (v > ts) atomicAdd(&my_tp1[v], 1u); else tp_ts++;
+        }
+        const uint32_t tw[4] = {t8.x, t8.y, t8.z, t8.w};
+        const unsigned long long len = (unsigned long long)(uint32_t)rec.z | ((unsigned long long)(uint32_t)rec.w << 32);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (q < G.cnt) {
+                const int at = ((G.loff[q] + (int)((tw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu)) << lg) + mine;
+                atomicAdd(&s_tp1[at], le[q]);
+                atomicAdd(&s_tot[at], (uint32_t)n);
+                atomicAdd(&s_bp[at], len);
             }
         }
-        atomicAdd(&my_tp1[ts], tp_ts);
-        atomicAdd(&my_tot[ts], (uint32_t)n);
-        atomicAdd(&my_bp[ts], (unsigned long long)slen);
-        if (P.n_scg > 0) {
+        if (scg_lo && P.n_scg > 0) {
             for (int e = P.scg_off[s]; e < P.scg_off[s + 1]; e++) {
                 const int g = P.scg_ids[e];
-                atomicMin(&scg_lo[g], ts);
-                atomicMax(&scg_hi[g], ts);
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    if (q < G.cnt) {
+                        const int ts = (int)((tw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu);
+                        atomicMin(&scg_lo[(int64_t)G.dim[q] * P.n_scg + g], ts);
+                        atomicMax(&scg_hi[(int64_t)G.dim[q] * P.n_scg + g], ts);
+                    }
+                }
             }
         }
-        cur = nxt;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 256) {
+    for (int b = threadIdx.x; b < G.total; b += 256) {
         unsigned long long a = 0, e = 0;
         uint32_t c3 = 0;
         for (int c = 0; c < copies; c++) {
-            const int at = c * Tp + t;
-            a += (unsigned long long)s_size[at] | ((unsigned long long)s_tp1[at] << 32);
-            c3 += s_tot[at];
-            e += s_bp[at];
+            const int i = (b << lg) + ((c + b) & (copies - 1));          // rotated: the lanes of a wave read different banks
+            a += (unsigned long long)s_size[i] | ((unsigned long long)s_tp1[i] << 32);
+            c3 += s_tot[i];
+            e += s_bp[i];
         }
-        if (a) atomicAdd(&g_st[t], a);
-        if (c3) atomicAdd(&g_tot[t], c3);
-        if (e) atomicAdd(&g_bp[t], e);
+        if (a | c3 | e) flush(b, a, c3, e);
     }
 }

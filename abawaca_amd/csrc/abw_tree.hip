@@ -39,11 +39,6 @@ namespace {
 constexpr int TILE_S = 2048;     // scaffolds per tile (256 threads x 8)
 constexpr int TILE_P = 2048;     // sorted positions per tile (256 threads x 8 consecutive)
 constexpr uint32_t PACK_ESCAPE = 0xFFFFFFFFu;
-constexpr int TILE_A = 1024;     // scaffolds per tile of the accumulation (256 threads x 4)
-constexpr int GRP_BINS = 2048;   // LDS bins of one group of narrow dimensions (a narrow dimension has at most 1024)
-
-// a group of narrow dimensions (consecutive in the order of Tr.narrow): their bins lie side by side in LDS and in a node's slice
-struct NGroup { int32_t cnt, total; int32_t loff[8]; int64_t goff; };
 
 struct NodeDev {
     int32_t scaf_begin, scaf_end;       // its scaffolds in `order`
@@ -131,57 +126,6 @@ __global__ void tree_scg_reset_kernel(int32_t* __restrict__ lo, int32_t* __restr
 }
 
 // ---- the static tables (once per loaded table) ------------------------------------------------------------------------
-// flip value of every scaffold in every narrow dimension, into its group's [scaffold][8] table (nslot = group * 8 + lane).
-// grid (ceil(S / 256), narrow dimensions)
-__global__ __launch_bounds__(256) void tree_static_narrow_kernel(SepDev P, const int32_t* __restrict__ narrow, const int32_t* __restrict__ nslot,
-                                                                int32_t S, uint16_t* __restrict__ ts8)
-{
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= S) return;
-    const int d = narrow[blockIdx.y], slot = nslot[blockIdx.y];
-    const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
-    const int f = P.scaf_first[s], n = P.scaf_ndps[s], k = n >> 1;
-    int ts;
-    if (n <= 8) {
-        int x[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = (i < n) ? col[f + i] : INT_MAX;
-        ABW_SORT8(x);
-        ts = (k == 1) ? x[1] : (k == 2) ? x[2] : (k == 3) ? x[3] : x[4];
-    } else ts = select_kth_mem(col + f, n, k, P.T[d]);
-    ts8[((int64_t)(slot >> 3) * S + s) * 8 + (slot & 7)] = (uint16_t)ts;
-}
-
-// the re-coded narrow columns.  grid (ceil(N / 256), groups)
-__global__ __launch_bounds__(256) void tree_static_codes_kernel(SepDev P, const int32_t* __restrict__ narrow, const NGroup* __restrict__ groups,
-                                                               const int32_t* __restrict__ gfirst, const int32_t* __restrict__ dp2scaf, int32_t S,
-                                                               const uint4* __restrict__ ts8, uint4* __restrict__ nk16)
-{
-    const int64_t dp = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (dp >= P.N) return;
-    const int j = blockIdx.y, cnt = groups[j].cnt, first = gfirst[j];
-    const uint4 t = ts8[(int64_t)j * S + dp2scaf[dp]];
-    const uint32_t tw[4] = {t.x, t.y, t.z, t.w};
-    uint32_t cw[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        if (q < cnt) {
-            const uint32_t v = (uint32_t)P.bins[(int64_t)narrow[first + q] * P.N + dp];
-            const uint32_t ts = (tw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
-            cw[q >> 1] |= (v | (v > ts ? 0x8000u : 0u)) << (16 * (q & 1));
-        }
-    }
-    nk16[(int64_t)j * P.N + dp] = make_uint4(cw[0], cw[1], cw[2], cw[3]);
-}
-
-__global__ void tree_static_srec_kernel(SepDev P, int32_t S, int4* __restrict__ srec)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    const long long len = P.scaf_len[s];
-    srec[s] = make_int4(P.scaf_first[s], P.scaf_ndps[s], (int)(uint32_t)(unsigned long long)len, (int)(uint32_t)((unsigned long long)len >> 32));
-}
-
 // wide dimensions: flip value (as a bin), dps below it, one byte per dp (bit 0: v >= t_s; bit 1: the first dp of the
 // scaffold on bin t_s).  grid (ceil(S / 256), wide dimensions)
 __global__ __launch_bounds__(256) void tree_static_wide_kernel(SepDev P, const int32_t* __restrict__ wide, int32_t S, uint8_t* __restrict__ flags,
@@ -240,72 +184,22 @@ __global__ void tree_static_words_kernel(const int32_t* __restrict__ sdp, const 
 }
 
 // ---- narrow dimensions ----------------------------------------------------------------------------------------------
-// Histograms of one tile of scaffolds in one GROUP of narrow dimensions: per dp and dimension size[v] += 1 and, above the
-// flip value, tp1[v] += 1; per scaffold and dimension tp1[t_s] += its dps at or below t_s (they count from threshold t_s
-// on), tot[t_s] += n and bp[t_s] += len -- in LDS, flushed with one atomic per non-empty bin into the slice of the tile's
-// node.  grid (tiles to accumulate, groups)
+// Histograms of one tile of scaffolds in one GROUP of narrow dimensions (accum_group_tile, abw_sep_common.h), flushed with
+// one atomic per non-empty bin into the slice of the tile's node.  grid (tiles to accumulate, groups)
 __global__ __launch_bounds__(256) void tree_accum_kernel(TreeDev Tr, const Tile* __restrict__ tiles, const int32_t* __restrict__ order,
                                                         unsigned long long* __restrict__ h_st, unsigned long long* __restrict__ h_bp,
                                                         uint32_t* __restrict__ h_tot)
 {
-    __shared__ uint32_t s_size[GRP_BINS];
-    __shared__ uint32_t s_tp1[GRP_BINS];
-    __shared__ uint32_t s_tot[GRP_BINS];
-    __shared__ unsigned long long s_bp[GRP_BINS];
     const Tile t = tiles[blockIdx.x];
     const int j = blockIdx.y;
     const NGroup G = Tr.groups[j];
-    for (int i = threadIdx.x; i < G.total; i += 256) { s_size[i] = 0; s_tp1[i] = 0; s_tot[i] = 0; s_bp[i] = 0; }
-    __syncthreads();
-    const uint4* __restrict__ codes = Tr.nk16 + (int64_t)j * Tr.P.N;
-    const uint4* __restrict__ tsv = Tr.ts8 + (int64_t)j * Tr.S;
-    for (int ls = t.begin + threadIdx.x; ls < t.end; ls += 256) {
-        const int s = order[ls];
-        const int4 rec = Tr.srec[s];
-        const uint4 t8 = tsv[s];
-        const int f = rec.x, n = rec.y;
-        uint32_t le[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i0 = 0; i0 < n; i0 += 4) {
-            uint4 c[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) c[i] = (i0 + i < n) ? codes[f + i0 + i] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (i0 + i < n) {
-                    const uint32_t cw[4] = {c[i].x, c[i].y, c[i].z, c[i].w};
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        if (q < G.cnt) {
-                            const uint32_t code = (cw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
-                            const int at = G.loff[q] + (int)(code & 0x7FFFu);
-                            atomicAdd(&s_size[at], 1u);
-                            if (code & 0x8000u) atomicAdd(&s_tp1[at], 1u); else le[q]++;
-                        }
-                    }
-                }
-            }
-        }
-        const uint32_t tw[4] = {t8.x, t8.y, t8.z, t8.w};
-        const unsigned long long len = (unsigned long long)(uint32_t)rec.z | ((unsigned long long)(uint32_t)rec.w << 32);
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            if (q < G.cnt) {
-                const int at = G.loff[q] + (int)((tw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu);
-                atomicAdd(&s_tp1[at], le[q]);
-                atomicAdd(&s_tot[at], (uint32_t)n);
-                atomicAdd(&s_bp[at], len);
-            }
-        }
-    }
-    __syncthreads();
     const int64_t at = (int64_t)t.node * Tr.TBn + G.goff;
-    for (int b = threadIdx.x; b < G.total; b += 256) {
-        const unsigned long long a = (unsigned long long)s_size[b] | ((unsigned long long)s_tp1[b] << 32), e = s_bp[b];
-        const uint32_t c3 = s_tot[b];
-        if (a) atomicAdd(&h_st[at + b], a);
-        if (c3) atomicAdd(&h_tot[at + b], c3);
-        if (e) atomicAdd(&h_bp[at + b], e);
-    }
+    accum_group_tile(G, Tr.nk16 + (int64_t)j * Tr.P.N, Tr.ts8 + (int64_t)j * Tr.S, Tr.srec, order, t.begin, t.end, Tr.P, nullptr, nullptr,
+                     [&](int b, unsigned long long a, uint32_t c3, unsigned long long e) {
+                         if (a) atomicAdd(&h_st[at + b], a);
+                         if (c3) atomicAdd(&h_tot[at + b], c3);
+                         if (e) atomicAdd(&h_bp[at + b], e);
+                     });
 }
 
 // slices of the nodes that are accumulated start at zero.  grid (nodes to zero, ceil(TBn / 1024))
@@ -782,35 +676,17 @@ size_t pack(std::vector<uint8_t>& blob, const std::vector<T>& v)
 }
 
 // The static tables of the loaded table (once; kept with the table until abw_sep_load / abw_ctx_destroy frees them).
-int tree_static_build(abw_ctx* ctx, SepHost& H, const SepDev& P, const int32_t* d_dp2scaf, const int32_t* d_narrow, const int32_t* d_nslot,
-                      const NGroup* d_groups, const int32_t* d_gfirst, int32_t n_groups)
+int tree_static_build(abw_ctx* ctx, SepHost& H, const SepDev& P, const int32_t* d_dp2scaf)
 {
     abw_sep_state& s = ctx->sep;
     hipStream_t st = ctx->stream;
-    const int32_t S = s.S, n_narrow = (int32_t)H.narrow_dims.size(), n_wide = (int32_t)H.wide_dims.size();
+    const int32_t S = s.S, n_wide = (int32_t)H.wide_dims.size();
     const int64_t N = s.N;
     // a build that failed half-way may have left some of them behind
-    if (H.d_ts8) { (void)hipFree(H.d_ts8); H.d_ts8 = nullptr; }
-    if (H.d_nk16) { (void)hipFree(H.d_nk16); H.d_nk16 = nullptr; }
-    if (H.d_srec) { (void)hipFree(H.d_srec); H.d_srec = nullptr; }
     if (H.d_wword) { (void)hipFree(H.d_wword); H.d_wword = nullptr; }
     if (H.d_wext) { (void)hipFree(H.d_wext); H.d_wext = nullptr; }
     if (H.d_wpack) { (void)hipFree(H.d_wpack); H.d_wpack = nullptr; }
     if (H.d_carriers) { (void)hipFree(H.d_carriers); H.d_carriers = nullptr; }
-    if (n_narrow) {
-        ABW_HIP(ctx, hipMalloc((void**)&H.d_ts8, (size_t)n_groups * S * 16));
-        ABW_HIP(ctx, hipMalloc((void**)&H.d_nk16, (size_t)n_groups * N * 16));
-        ABW_HIP(ctx, hipMalloc((void**)&H.d_srec, (size_t)S * 16));
-        ABW_HIP(ctx, hipMemsetAsync(H.d_ts8, 0, (size_t)n_groups * S * 16, st));           // the unused lanes of a group
-        hipLaunchKernelGGL(tree_static_narrow_kernel, dim3((unsigned)((S + 255) / 256), (unsigned)n_narrow), dim3(256), 0, st, P, d_narrow, d_nslot, S,
-                           (uint16_t*)H.d_ts8);
-        ABW_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(tree_static_codes_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)n_groups), dim3(256), 0, st, P, d_narrow, d_groups, d_gfirst,
-                           d_dp2scaf, S, (const uint4*)H.d_ts8, (uint4*)H.d_nk16);
-        ABW_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(tree_static_srec_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, P, S, (int4*)H.d_srec);
-        ABW_LAUNCH_CHECK(ctx);
-    }
     if (n_wide) {
         const int64_t Np = (N + 7) & ~(int64_t)7;
         ABW_HIP(ctx, hipMalloc((void**)&H.d_wword, (size_t)n_wide * Np * 4));
@@ -858,30 +734,8 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
     const int64_t N = s.N, Np = (N + 7) & ~(int64_t)7, Sp = ((int64_t)S + 7) & ~(int64_t)7;      // strides of the position / scaffold arrays
     if (S > (int32_t)W_SC) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree: more than 2^30 scaffolds");
 
-    // narrow dimensions by ascending number of bins, cut into groups of at most 8 dimensions and GRP_BINS bins; their offsets
-    // inside one node's histogram slice (a function of the table alone: the static tables follow the same grouping)
-    std::vector<int32_t> nsort(H.narrow_dims.begin(), H.narrow_dims.end()), nslot((size_t)n_narrow), gfirst;
-    std::stable_sort(nsort.begin(), nsort.end(), [&](int32_t a, int32_t b) { return s.h_T[a] < s.h_T[b]; });
-    std::vector<int64_t> toffn((size_t)n_narrow + 1, 0);
-    std::vector<NGroup> groups;
-    for (int i = 0; i < n_narrow; i++) {
-        const int32_t T = s.h_T[nsort[i]];
-        if (T > GRP_BINS) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_tree: narrow dimension %d has %d bins", nsort[i], T);
-        if (groups.empty() || groups.back().cnt == 8 || groups.back().total + T > GRP_BINS) {
-            NGroup g;
-            memset(&g, 0, sizeof(g));
-            g.goff = toffn[i];
-            groups.push_back(g);
-            gfirst.push_back(i);
-        }
-        NGroup& g = groups.back();
-        g.loff[g.cnt] = g.total;
-        nslot[i] = (int32_t)(groups.size() - 1) * 8 + g.cnt;
-        g.cnt++; g.total += T;
-        toffn[i + 1] = toffn[i] + T;
-    }
-    const int32_t n_groups = (int32_t)groups.size();
-    const int64_t TBn = std::max<int64_t>(1, toffn[n_narrow]);
+    const int32_t n_groups = (int32_t)H.groups.size();
+    const int64_t TBn = std::max<int64_t>(1, n_narrow ? H.toffn[n_narrow] : 0);      // a node's slice: the narrow dimensions in H.nsort order
 
     // buffers of the call (grow-only scratch of the context: scratch is free between entry points)
     abw_devbuf &b_order = ctx->scratch[0], &b_wbin = ctx->scratch[1], &b_wword = ctx->scratch[2], &b_side = ctx->scratch[4],
@@ -894,24 +748,8 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
         if ((rc = abw_reserve(ctx, b_wbin, (size_t)2 * n_wide * Np * 4))) return rc;
         if ((rc = abw_reserve(ctx, b_wword, (size_t)2 * n_wide * Np * 4))) return rc;
     }
-    std::vector<int32_t> slot_h((size_t)D, 0);
-    for (int i = 0; i < n_narrow; i++) slot_h[nsort[i]] = nslot[i];
-    for (int i = 0; i < n_wide; i++) slot_h[H.wide_dims[i]] = -i - 1;
-    std::vector<uint8_t> mblob;
-    const size_t o_toffn = pack(mblob, toffn), o_slot = pack(mblob, slot_h), o_nsort = pack(mblob, nsort), o_nslot = pack(mblob, nslot),
-                 o_groups = pack(mblob, groups), o_gfirst = pack(mblob, gfirst);
-    const size_t m_bytes = (mblob.size() + 63) & ~(size_t)63;
-    if ((rc = abw_reserve(ctx, b_misc, m_bytes + (size_t)N * 4 + 64))) return rc;
-    uint8_t* dm = (uint8_t*)b_misc.p;
-    const int64_t* d_toffn = (const int64_t*)(dm + o_toffn);
-    const int32_t* d_slot = (const int32_t*)(dm + o_slot);
-    const int32_t* d_nsort = (const int32_t*)(dm + o_nsort);
-    const int32_t* d_nslot = (const int32_t*)(dm + o_nslot);
-    const NGroup* d_groups = (const NGroup*)(dm + o_groups);
-    const int32_t* d_gfirst = (const int32_t*)(dm + o_gfirst);
-    int32_t* d_dp2scaf = (int32_t*)(dm + m_bytes);
-    ABW_HIP(ctx, hipMemcpyAsync(dm, mblob.data(), mblob.size(), hipMemcpyHostToDevice, st));
-    ABW_HIP(ctx, hipStreamSynchronize(st));                                     // mblob is pageable and goes out of use below
+    if ((rc = abw_reserve(ctx, b_misc, (size_t)N * 4 + 64))) return rc;
+    int32_t* d_dp2scaf = (int32_t*)b_misc.p;
 
     TreeDev Tr;
     Tr.P.bins = s.d_bins ? s.d_bins : s.d_keys; Tr.P.N = N;
@@ -919,17 +757,17 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
     Tr.P.scg_off = s.d_scg_off; Tr.P.scg_ids = s.d_scg_ids; Tr.P.n_scg = s.n_scg;
     Tr.P.T = s.d_T; Tr.P.Toff = s.d_Toff;
     Tr.P.h_st = nullptr; Tr.P.h_tot = nullptr; Tr.P.h_bp = nullptr; Tr.P.scg_lo = nullptr; Tr.P.scg_hi = nullptr; Tr.P.range = nullptr;
-    if ((n_narrow && !(H.d_ts8 && H.d_nk16 && H.d_srec)) || (n_wide && !(H.d_wword && H.d_wpack)) || (s.n_scg > 0 && !H.d_carriers)) {
+    if ((n_wide && !(H.d_wword && H.d_wpack)) || (s.n_scg > 0 && !H.d_carriers)) {
         // dp -> scaffold (only the static build needs it)
         std::vector<int32_t> d2s((size_t)N);
         for (int32_t sc = 0; sc < S; sc++) std::fill(d2s.begin() + s.h_scaf_first[sc], d2s.begin() + s.h_scaf_first[sc] + s.h_scaf_ndps[sc], sc);
         ABW_HIP(ctx, hipMemcpyAsync(d_dp2scaf, d2s.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
         ABW_HIP(ctx, hipStreamSynchronize(st));
-        if ((rc = tree_static_build(ctx, H, Tr.P, d_dp2scaf, d_nsort, d_nslot, d_groups, d_gfirst, n_groups))) return rc;
+        if ((rc = tree_static_build(ctx, H, Tr.P, d_dp2scaf))) return rc;
     }
-    Tr.narrow = d_nsort; Tr.n_narrow = n_narrow; Tr.toffn = d_toffn; Tr.TBn = TBn;
-    Tr.groups = d_groups; Tr.n_groups = n_groups; Tr.nk16 = (const uint4*)H.d_nk16; Tr.ts8 = (const uint4*)H.d_ts8; Tr.srec = (const int4*)H.d_srec;
-    Tr.wide = H.d_wide; Tr.n_wide = n_wide; Tr.dp2scaf = d_dp2scaf; Tr.dim_slot = d_slot;
+    Tr.narrow = H.d_nsort; Tr.n_narrow = n_narrow; Tr.toffn = H.d_toffn; Tr.TBn = TBn;
+    Tr.groups = H.d_groups; Tr.n_groups = n_groups; Tr.nk16 = (const uint4*)H.d_nk16; Tr.ts8 = (const uint4*)H.d_ts8; Tr.srec = (const int4*)H.d_srec;
+    Tr.wide = H.d_wide; Tr.n_wide = n_wide; Tr.dp2scaf = d_dp2scaf; Tr.dim_slot = H.d_dim_slot;
     Tr.wext = (const uint4*)H.d_wext; Tr.wpack = H.d_wpack; Tr.D = D; Tr.S = S;
 
     uint32_t* order[2] = {(uint32_t*)b_order.p, (uint32_t*)b_order.p + Sp};

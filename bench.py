@@ -622,6 +622,18 @@ def separator_leg(ctx, keys_host, dp2scaf, scaf_len, genome, G, seed, label, tra
                             ms_per_node=round(rec_s / len(nodes_all) * 1e3, 3), planted_genomes=int(G),
                             scaffolds_in_their_bins_majority_genome=round(agree / len(lab), 4),
                             note="whole recursive binning of the table, GPU separator + Python work-list loop")
+    # ... and the same recursion in ONE call: abw_sep_tree evaluates the nodes of a level together (static flip values,
+    # smaller child accumulated / bigger child by subtraction, scan-based coverage dimensions)
+    separator.binning_tree(store, max_nodes=3)                      # builds the static tables of the loaded table
+    tree_s = None
+    for _ in range(3):
+        rows_t, s2c_t, dt = separator.binning_tree(store)
+        tree_s = dt if tree_s is None else min(tree_s, dt)
+    key = lambda r: (r["id"], r["ndps"], r["split"], r["dim"], r["key"], r["spec"], r["sens"], r["c1"], r["n1"], r["c2"], r["n2"])
+    res["recursion"]["one_call"] = dict(entry_point="abw_sep_tree", ms=round(tree_s * 1e3, 3), ms_per_node=round(tree_s / len(rows_t) * 1e3, 4),
+                                        identical_to_node_by_node=bool([key(r) for r in rows_t] == [key(r) for r in nodes_all]
+                                                                       and np.array_equal(s2c_t, s2c_all)),
+                                        speedup_over_node_by_node_c_abi=round(res["recursion"]["c_abi_s"] / tree_s, 2))
     del store
     return res
 
