@@ -96,10 +96,10 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const NGroup* 
     const int begin = blockIdx.x * TILE_A;
     accum_group_tile(G, nk16 + (int64_t)j * P.N, ts8 + (int64_t)j * S, srec, node_scaf, begin, min(m, begin + TILE_A), P, P.scg_lo, P.scg_hi,
                      [&](int b, unsigned long long a, uint32_t c3, unsigned long long e) {
-                         int q = 0;
+                         int dim = G.dim[0], lo = 0;                    // the bin's dimension: selects, no indexed copy of G
 #pragma unroll
-                         for (int i = 1; i < 8; i++) q += (i < G.cnt && b >= G.loff[i]);
-                         const int64_t at = P.Toff[G.dim[q]] + (b - G.loff[q]);
+                         for (int i = 1; i < 8; i++) if (i < G.cnt && b >= G.loff[i]) { dim = G.dim[i]; lo = G.loff[i]; }
+                         const int64_t at = P.Toff[dim] + (b - lo);
                          if (a) atomicAdd(&P.h_st[at], a);
                          if (c3) atomicAdd(&P.h_tot[at], c3);
                          if (e) atomicAdd(&P.h_bp[at], e);

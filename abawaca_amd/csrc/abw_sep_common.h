@@ -8,7 +8,7 @@
 constexpr int NARROW_T = 1024;      // dimensions with keys in [0, NARROW_T) use the key itself as bin
 constexpr int SCAN_CH = 2048;       // bins per scan chunk
 constexpr int TILE_A = 1024;        // scaffolds per workgroup of the narrow accumulation (256 threads x 4)
-constexpr int GRP_BINS = 2048;      // LDS bins of one group of narrow dimensions (a narrow dimension has at most NARROW_T)
+constexpr int GRP_BINS = 1024;      // LDS bins of one group of narrow dimensions (a narrow dimension has at most NARROW_T)
 constexpr int MAX_SCG = 4096;
 
 // A group of up to 8 narrow dimensions whose values travel together: the narrow columns are kept a second time as

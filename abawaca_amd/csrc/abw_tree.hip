@@ -250,11 +250,14 @@ __global__ __launch_bounds__(256) void tree_scg_kernel(TreeDev Tr, const int32_t
     }
 }
 
+constexpr int SCG_LDS = 256;
+struct ScgView { const int32_t* lo; const int32_t* hi; int n; bool compact; };
+
 // One threshold of a (node, dimension): size check, small side, sensitivity x specificity in fp64 exactly as the
 // reference's doubles, the SCG / size gate (ref ...Specificity.cpp:146-161, ClusterQuality.cpp:96-136).
 __device__ __forceinline__ void eval_threshold(long long size1, long long tp1, long long tot1, unsigned long long bp1, long long n,
-                                               unsigned long long bp_total, int32_t min_ndps, int bin, int ng, const int32_t* s_lo,
-                                               const int32_t* s_hi, Cand& best, double bar = 0.0)
+                                               unsigned long long bp_total, int32_t min_ndps, int bin, const ScgView& scg, Cand& best,
+                                               double bar = 0.0)
 {
     const long long size2 = n - size1, tot2 = n - tot1;
     const long long tp2 = n - (size1 + tot1 - tp1);
@@ -276,8 +279,13 @@ __device__ __forceinline__ void eval_threshold(long long size1, long long tp1, l
     if (!(prod == prod)) return;                                   // NaN is never better (ref .h:28)
     const Cand cnd = {prod, bin, 1, sens, spec, size1};
     if (!cand_better(cnd, best)) return;
-    int cl = 0, chh = 0;
-    for (int g = 0; g < ng; g++) { cl += s_lo[g] <= bin; chh += s_hi[g] <= bin; }
+    int cl = 0, chh = 0, ng = scg.n;
+    if (scg.compact) {
+        for (int g = 0; g < scg.n; g++) { cl += scg.lo[g] <= bin; chh += scg.hi[g] <= bin; }
+    } else {
+        ng = 0;
+        for (int g = 0; g < scg.n; g++) { const int l = scg.lo[g]; if (l != INT_MAX) { ng++; cl += l <= bin; chh += scg.hi[g] <= bin; } }
+    }
     const int G1 = cl, G2 = ng - chh, both = cl - chh;
     bool pass;
     if (G1 == 0 || G2 == 0) pass = (bp1 >= 500000ull) && (bp_total - bp1 >= 500000ull);
@@ -285,9 +293,11 @@ __device__ __forceinline__ void eval_threshold(long long size1, long long tp1, l
     if (pass) best = cnd;
 }
 
-// SCGs present in the (node, dimension): lo != INT_MAX, compacted into LDS.  Call by all threads; returns their number.
-__device__ __forceinline__ int compact_scgs(const int32_t* __restrict__ lo, const int32_t* __restrict__ hi, int n_scg, int32_t* s_lo, int32_t* s_hi, int* s_ng)
+// SCGs present in the (node, dimension): lo != INT_MAX.  Up to SCG_LDS SCGs are compacted into LDS (the gate of a candidate
+// then walks the present ones only); a table with more is read in place.  Call by all threads.
+__device__ __forceinline__ ScgView stage_scgs(const int32_t* __restrict__ lo, const int32_t* __restrict__ hi, int n_scg, int32_t* s_lo, int32_t* s_hi, int* s_ng)
 {
+    if (n_scg > SCG_LDS) return ScgView{lo, hi, n_scg, false};
     if (threadIdx.x == 0) *s_ng = 0;
     __syncthreads();
     for (int g = threadIdx.x; g < n_scg; g += blockDim.x) {
@@ -295,7 +305,7 @@ __device__ __forceinline__ int compact_scgs(const int32_t* __restrict__ lo, cons
         if (l != INT_MAX) { const int slot = atomicAdd(s_ng, 1); s_lo[slot] = l; s_hi[slot] = hi[g]; }
     }
     __syncthreads();
-    return *s_ng;
+    return ScgView{s_lo, s_hi, *s_ng, true};
 }
 
 __device__ __forceinline__ Cand block_best(Cand best, Cand* wbest)
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(256) void tree_eval_narrow_kernel(TreeDev Tr, const
                                                               const int32_t* __restrict__ scg_hi, Cand* __restrict__ cand)
 {
     __shared__ unsigned long long sh[3][5];
-    __shared__ int32_t s_lo[MAX_SCG], s_hi[MAX_SCG];
+    __shared__ int32_t s_lo[SCG_LDS], s_hi[SCG_LDS];
     __shared__ int s_ng;
     __shared__ Cand wbest[4];
     const int k = blockIdx.x, dn = blockIdx.y;
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(256) void tree_eval_narrow_kernel(TreeDev Tr, const
     const long long n = nd.dp_end - nd.dp_begin;
     const int64_t at = (int64_t)k * Tr.TBn + Tr.toffn[dn];
     const int64_t sg = ((int64_t)k * Tr.D + d) * Tr.P.n_scg;
-    const int ng = compact_scgs(scg_lo + sg, scg_hi + sg, Tr.P.n_scg, s_lo, s_hi, &s_ng);
+    const ScgView scg = stage_scgs(scg_lo + sg, scg_hi + sg, Tr.P.n_scg, s_lo, s_hi, &s_ng);
     unsigned long long st[4], bp[4];
     uint32_t tot[4];
     unsigned long long a_size = 0, a_tp1 = 0, a_tot = 0, a_bp = 0;
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(256) void tree_eval_narrow_kernel(TreeDev Tr, const
     for (int i = 0; i < 4; i++) {
         const uint32_t here = (uint32_t)st[i];
         size1 += here; tp1 += (long long)(st[i] >> 32); tot1 += tot[i]; bp1 += bp[i];
-        if (here) eval_threshold(size1, tp1, tot1, bp1, n, tot_bp, min_ndps, 4 * threadIdx.x + i, ng, s_lo, s_hi, best);
+        if (here) eval_threshold(size1, tp1, tot1, bp1, n, tot_bp, min_ndps, 4 * threadIdx.x + i, scg, best);
     }
     const Cand b = block_best(best, wbest);
     if (threadIdx.x == 0) cand[(int64_t)k * Tr.D + d] = b;
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(256) void tree_wide_eval_kernel(TreeDev Tr, const T
                                                             const double* __restrict__ bar, Cand* __restrict__ tile_best)
 {
     __shared__ unsigned long long sh[3][5];
-    __shared__ int32_t s_lo[MAX_SCG], s_hi[MAX_SCG];
+    __shared__ int32_t s_lo[SCG_LDS], s_hi[SCG_LDS];
     __shared__ int s_ng;
     __shared__ Cand wbest[4];
     const Tile t = tiles[blockIdx.x];
@@ -448,7 +458,7 @@ __global__ __launch_bounds__(256) void tree_wide_eval_kernel(TreeDev Tr, const T
     const NodeDev nd = nodes[t.node];
     const long long n = nd.dp_end - nd.dp_begin;
     const int64_t sg = ((int64_t)t.node * Tr.D + d) * Tr.P.n_scg;
-    const int ng = compact_scgs(scg_lo + sg, scg_hi + sg, Tr.P.n_scg, s_lo, s_hi, &s_ng);
+    const ScgView scg = stage_scgs(scg_lo + sg, scg_hi + sg, Tr.P.n_scg, s_lo, s_hi, &s_ng);
     const int32_t* __restrict__ bins = wbin + (int64_t)w * wstride;
     const uint32_t* __restrict__ words = wword + (int64_t)w * wstride;
     const unsigned long long bp_total = node_total[(int64_t)w * K + t.node].bp;
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(256) void tree_wide_eval_kernel(TreeDev Tr, const T
     const int i0 = (t.begin & ~(TILE_P - 1)) + 8 * threadIdx.x;
     int b[9];
     uint32_t wd[8];
-    WSums r[8];
+    uint32_t r_tp[8], r_tot[8], r_bp[8];                 // one position's terms fit 32 bits each (dps of a scaffold; a clamped length)
     WSums a = {0, 0, 0};
     {
         int b8[8];
@@ -467,7 +477,11 @@ __global__ __launch_bounds__(256) void tree_wide_eval_kernel(TreeDev Tr, const T
     }
     load8(words, i0, t.begin, t.end, wd, 0u);
 #pragma unroll
-    for (int i = 0; i < 8; i++) { r[i] = position_terms(Tr, w, wd[i]); a.tp1 += r[i].tp1; a.tot += r[i].tot; a.bp += r[i].bp; }
+    for (int i = 0; i < 8; i++) {
+        const WSums r = position_terms(Tr, w, wd[i]);
+        r_tp[i] = (uint32_t)r.tp1; r_tot[i] = (uint32_t)r.tot; r_bp[i] = (uint32_t)r.bp;
+        a.tp1 += r.tp1; a.tot += r.tot; a.bp += r.bp;
+    }
     const WSums carry = tile_carry[(int64_t)w * n_tiles + blockIdx.x];
     const unsigned long long o1 = block_excl_scan_u64(a.tp1, sh[0], nullptr);
     const unsigned long long o3 = block_excl_scan_u64(a.tot, sh[2], nullptr);
@@ -478,9 +492,9 @@ __global__ __launch_bounds__(256) void tree_wide_eval_kernel(TreeDev Tr, const T
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         if (i0 + i >= t.begin && i0 + i < t.end) {
-            tp1 += (long long)r[i].tp1; tot1 += (long long)r[i].tot; bp1 += r[i].bp;
+            tp1 += (long long)r_tp[i]; tot1 += (long long)r_tot[i]; bp1 += r_bp[i];
             if (b[i + 1] != b[i])                                                       // a run end: threshold = this bin
-                eval_threshold((long long)(i0 + i - nd.dp_begin + 1), tp1, tot1, bp1, n, bp_total, min_ndps, b[i], ng, s_lo, s_hi, best, node_bar);
+                eval_threshold((long long)(i0 + i - nd.dp_begin + 1), tp1, tot1, bp1, n, bp_total, min_ndps, b[i], scg, best, node_bar);
         }
     }
     const Cand bb = block_best(best, wbest);

@@ -94,3 +94,12 @@ def test_tree_on_degenerate_columns_and_without_scgs(ctx):
     # only narrow columns / only wide columns
     _same_as_node_by_node(separator.ColumnStore(ctx, keys[:160], f["dp2scaf"], f["scaf_len"], off, ids, f["n_scg"]))
     _same_as_node_by_node(separator.ColumnStore(ctx, keys[179:], f["dp2scaf"], f["scaf_len"], off, ids, f["n_scg"]))
+
+
+def test_tree_with_more_scgs_than_the_lds_stage_holds(ctx):
+    """above 256 SCGs the gate reads the lo / hi lists in place instead of a compacted copy in LDS"""
+    f = synth.make_features(11, 4000, 6, 3, n_scg=300)
+    off, ids = separator.scg_csr(f["scg_scaf"], f["scg_id"], 4000)
+    assert f["n_scg"] == 300
+    got = _same_as_node_by_node(separator.ColumnStore(ctx, f["milli"], f["dp2scaf"], f["scaf_len"], off, ids, f["n_scg"]))
+    assert sum(r["split"] for r in got) >= 3
