@@ -111,6 +111,15 @@ int abw_prof_read(abw_ctx* ctx, const char* name, uint64_t* launches, double* to
 
 int abw_abi_version(void) { return ABW_ABI_VERSION; }
 
+int abw_device_count(int32_t* n)
+{
+    if (!n) return ABW_ERR_ARG;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) { *n = 0; return ABW_ERR_HIP; }
+    *n = c;
+    return ABW_OK;
+}
+
 int abw_ctx_create(int device, abw_ctx** out)
 {
     if (!out) return ABW_ERR_ARG;

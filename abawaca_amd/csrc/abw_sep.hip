@@ -561,6 +561,17 @@ __global__ __launch_bounds__(64) void sep_global_kernel(const DimBestDev* __rest
     *out = r;
 }
 
+// dst (+)= src over the three exchange buffers of the scaffold-sharded separator (abw_sep_shard_combine)
+__global__ __launch_bounds__(256) void sep_combine_kernel(int64_t* __restrict__ h, const int64_t* __restrict__ sh, uint64_t nh, int32_t* __restrict__ lo,
+                                                         const int32_t* __restrict__ slo, int32_t* __restrict__ hi, const int32_t* __restrict__ shi,
+                                                         uint64_t ng)
+{
+    const uint64_t step = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nh; i += step) h[i] += sh[i];
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < ng; i += step) { lo[i] = min(lo[i], slo[i]); hi[i] = max(hi[i], shi[i]); }
+}
+
+
 // ref ClusterSeparator.cpp:35-53,87-122 on the device, one thread per scaffold of the node: the dps with bin <= t in
 // the winning dimension are the raw "<=" side; cluster1 is the raw side with fewer dps (tie: the "<=" side); a scaffold
 // goes to cluster1 iff at least half of its dps are there; raw flags are written as 1 / 2.
@@ -1199,6 +1210,85 @@ int abw_sep_shard_accum(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, a
     ex->d_scg_lo = (int32_t*)s.scg_lohi.p;
     ex->d_scg_hi = ex->d_scg_lo + (int64_t)s.D * s.n_scg;
     ex->scg_count = (uint64_t)s.D * (uint64_t)s.n_scg;
+    return ABW_OK;
+}
+
+// All-reduce of the exchange buffers over the contexts of ONE process (a context per device of the node, or several on
+// one device): direct reduce-scatter + all-gather with peer copies.  Context k owns the k-th slice of every buffer: it
+// pulls that slice from every other context into a staging block and folds it in (integer sum / min / max: any order
+// gives the same bits), then every context pulls the finished slices from their owners.  Each owner works on its own
+// stream, so on an xGMI mesh all links carry traffic at once.
+int abw_sep_shard_combine(abw_ctx* const* ctxs, int32_t n_ctx)
+{
+    if (!ctxs || n_ctx <= 0) return ABW_ERR_ARG;
+    for (int32_t k = 0; k < n_ctx; k++) if (!ctxs[k]) return ABW_ERR_ARG;
+    abw_ctx* c0 = ctxs[0];
+    for (int32_t k = 0; k < n_ctx; k++) {
+        const abw_sep_state& s = ctxs[k]->sep;
+        if (!s.loaded || !s.node_open) return abw_fail(ctxs[k], ABW_ERR_STATE, "abw_sep_shard_combine: context %d has no node accumulated (abw_sep_shard_accum)", k);
+        if (s.TB != c0->sep.TB || s.D != c0->sep.D || s.n_scg != c0->sep.n_scg)
+            return abw_fail(ctxs[k], ABW_ERR_ARG, "abw_sep_shard_combine: context %d was loaded with another bin layout", k);
+        for (int32_t j = 0; j < k; j++) if (ctxs[j] == ctxs[k]) return abw_fail(ctxs[k], ABW_ERR_ARG, "abw_sep_shard_combine: context %d listed twice", k);
+    }
+    if (n_ctx == 1) return ABW_OK;
+    const uint64_t H = ((uint64_t)c0->sep.TB * 20 + 7) / 8, C = (uint64_t)c0->sep.D * (uint64_t)c0->sep.n_scg;
+    auto cut = [&](uint64_t total, int32_t k) { return total * (uint64_t)k / (uint64_t)n_ctx; };
+    auto peer_copy = [&](abw_ctx* to, void* dst, abw_ctx* from, const void* src, size_t bytes, hipStream_t st) -> hipError_t {
+        if (bytes == 0) return hipSuccess;
+        if (to->device == from->device) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+        return hipMemcpyPeerAsync(dst, to->device, src, from->device, bytes, st);
+    };
+    for (int32_t k = 0; k < n_ctx; k++) {                     // the accumulations have finished
+        abw_device_guard g(ctxs[k]->device);
+        ABW_HIP(ctxs[k], hipStreamSynchronize(ctxs[k]->stream));
+    }
+    for (int32_t k = 0; k < n_ctx; k++) {                     // reduce-scatter
+        abw_ctx* ck = ctxs[k];
+        abw_device_guard g(ck->device);
+        const uint64_t h0 = cut(H, k), h1 = cut(H, k + 1), g0 = cut(C, k), g1 = cut(C, k + 1);
+        const size_t hb = (size_t)(h1 - h0) * 8, gb = (size_t)(g1 - g0) * 4, hb_pad = (hb + 63) & ~(size_t)63, gb_pad = (gb + 63) & ~(size_t)63;
+        int rc;
+        if ((rc = abw_reserve(ck, ck->scratch[0], hb_pad + 2 * gb_pad + 64))) return rc;
+        int64_t* st_h = (int64_t*)ck->scratch[0].p;
+        int32_t* st_lo = (int32_t*)((uint8_t*)ck->scratch[0].p + hb_pad);
+        int32_t* st_hi = (int32_t*)((uint8_t*)ck->scratch[0].p + hb_pad + gb_pad);
+        int64_t* my_h = (int64_t*)ck->sep.hist.p + h0;
+        int32_t* my_lo = (int32_t*)ck->sep.scg_lohi.p + g0;
+        int32_t* my_hi = (int32_t*)ck->sep.scg_lohi.p + C + g0;
+        for (int32_t i = 0; i < n_ctx; i++) {
+            if (i == k) continue;
+            abw_ctx* ci = ctxs[i];
+            ABW_HIP(ck, peer_copy(ck, st_h, ci, (const int64_t*)ci->sep.hist.p + h0, hb, ck->stream));
+            ABW_HIP(ck, peer_copy(ck, st_lo, ci, (const int32_t*)ci->sep.scg_lohi.p + g0, gb, ck->stream));
+            ABW_HIP(ck, peer_copy(ck, st_hi, ci, (const int32_t*)ci->sep.scg_lohi.p + C + g0, gb, ck->stream));
+            const uint64_t work = std::max<uint64_t>(h1 - h0, g1 - g0);
+            if (work > 0) {
+                hipLaunchKernelGGL(sep_combine_kernel, dim3((unsigned)std::min<uint64_t>((work + 255) / 256, (uint64_t)ck->num_cu * 8)), dim3(256), 0, ck->stream,
+                                   my_h, (const int64_t*)st_h, h1 - h0, my_lo, (const int32_t*)st_lo, my_hi, (const int32_t*)st_hi, g1 - g0);
+                ABW_LAUNCH_CHECK(ck);
+            }
+        }
+    }
+    for (int32_t k = 0; k < n_ctx; k++) {
+        abw_device_guard g(ctxs[k]->device);
+        ABW_HIP(ctxs[k], hipStreamSynchronize(ctxs[k]->stream));
+    }
+    for (int32_t k = 0; k < n_ctx; k++) {                     // all-gather: everybody takes slice k from its owner
+        abw_ctx* ck = ctxs[k];
+        abw_device_guard g(ck->device);
+        const uint64_t h0 = cut(H, k), h1 = cut(H, k + 1), g0 = cut(C, k), g1 = cut(C, k + 1);
+        for (int32_t i = 0; i < n_ctx; i++) {
+            if (i == k) continue;
+            abw_ctx* ci = ctxs[i];
+            ABW_HIP(ck, peer_copy(ci, (int64_t*)ci->sep.hist.p + h0, ck, (const int64_t*)ck->sep.hist.p + h0, (size_t)(h1 - h0) * 8, ck->stream));
+            ABW_HIP(ck, peer_copy(ci, (int32_t*)ci->sep.scg_lohi.p + g0, ck, (const int32_t*)ck->sep.scg_lohi.p + g0, (size_t)(g1 - g0) * 4, ck->stream));
+            ABW_HIP(ck, peer_copy(ci, (int32_t*)ci->sep.scg_lohi.p + C + g0, ck, (const int32_t*)ck->sep.scg_lohi.p + C + g0, (size_t)(g1 - g0) * 4, ck->stream));
+        }
+    }
+    for (int32_t k = 0; k < n_ctx; k++) {
+        abw_device_guard g(ctxs[k]->device);
+        ABW_HIP(ctxs[k], hipStreamSynchronize(ctxs[k]->stream));
+    }
     return ABW_OK;
 }
 

@@ -268,22 +268,29 @@ def separate_sharded(store: ShardedColumnStore, local_ids, dist=None, device=Non
     return node
 
 
-def separate_shards_local(stores, ids_list):
-    """The same node played by several shards of ONE process (tests; stores may share a GPU): the
-    combination is done with plain tensor arithmetic."""
+def separate_shards_local(stores, ids_list, combine: str = "library"):
+    """The same node played by several shards of ONE process (stores may share a GPU).  combine = "library": the exchange
+    is abw_sep_shard_combine (peer copies + add kernel, what integration/ClusterSeparatorHipSharded uses); "torch": plain
+    tensor arithmetic (an independent check of it in the tests)."""
     import torch
     nodes = [ShardNode(st, ids) for st, ids in zip(stores, ids_list)]
-    for nd in nodes:
-        nd.store.ctx.synchronize()
-    hist = torch.stack([nd.hist for nd in nodes]).sum(0)
-    for nd in nodes:
-        nd.hist.copy_(hist)
-    if nodes[0].scg_lo is not None:
-        lo = torch.stack([nd.scg_lo for nd in nodes]).amin(0)
-        hi = torch.stack([nd.scg_hi for nd in nodes]).amax(0)
+    if combine == "library":
+        arr = (C.c_void_p * len(nodes))(*[nd.store.ctx.handle for nd in nodes])
+        rc = lib().abw_sep_shard_combine(arr, len(nodes))
         for nd in nodes:
-            nd.scg_lo.copy_(lo)
-            nd.scg_hi.copy_(hi)
+            nd.store.ctx.check(rc)
+    else:
+        for nd in nodes:
+            nd.store.ctx.synchronize()
+        hist = torch.stack([nd.hist for nd in nodes]).sum(0)
+        for nd in nodes:
+            nd.hist.copy_(hist)
+        if nodes[0].scg_lo is not None:
+            lo = torch.stack([nd.scg_lo for nd in nodes]).amin(0)
+            hi = torch.stack([nd.scg_hi for nd in nodes]).amax(0)
+            for nd in nodes:
+                nd.scg_lo.copy_(lo)
+                nd.scg_hi.copy_(hi)
     torch.cuda.synchronize()
     parts = [nd.eval() for nd in nodes]
     n1, n2 = sum(p[0] for p in parts), sum(p[1] for p in parts)
@@ -338,7 +345,7 @@ def carve_shard(keys, dp2scaf, scaf_len, scaf_ids, scg_scaf=(), scg_id=()):
                 scg_id=np.asarray(scg_id)[keep] if len(scg_scaf) else np.asarray(scg_id), dps=dps)
 
 
-def binning_shards_local(stores, max_nodes: int = 1 << 30):
+def binning_shards_local(stores, max_nodes: int = 1 << 30, combine: str = "library"):
     """binning_sharded for several shards driven in lock-step from one process (tests)."""
     k = len(stores)
     work = {1: [None] * k}
@@ -348,7 +355,7 @@ def binning_shards_local(stores, max_nodes: int = 1 << 30):
     while work and len(rows) < max_nodes:
         nid = min(work)
         ids = work.pop(nid)
-        nodes = separate_shards_local(stores, ids)
+        nodes = separate_shards_local(stores, ids, combine)
         o = nodes[0].out
         for nd in nodes[1:]:                                   # every shard reached the same verdict
             p = nd.out

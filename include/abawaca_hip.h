@@ -38,6 +38,8 @@ typedef struct abw_ctx abw_ctx;
 
 /* ---- context ------------------------------------------------------------------------------ */
 /* device: HIP device ordinal.  Creates a stream owned by the context. */
+/* number of HIP devices this process sees (for a caller that spreads contexts over them without including HIP itself) */
+int  abw_device_count(int32_t* n);
 int  abw_ctx_create(int device, abw_ctx** out);
 void abw_ctx_destroy(abw_ctx* ctx);
 /* Run on a caller-owned hipStream_t instead (NULL restores the context's own stream). */
@@ -237,6 +239,13 @@ int abw_sep_shard_accum(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, a
 int abw_sep_shard_eval(abw_ctx* ctx, int32_t min_ndps, abw_split* out, abw_dimbest* per_dim,
                        uint8_t* scaf_side, uint8_t* dp_raw_side);
 int abw_sep_shard_decide(abw_split* out, int64_t ndps1_total, int64_t ndps2_total, int32_t min_ndps);
+/* The exchange between accum and eval for a caller that holds ALL shards in one process (the reference's driver is one
+ * process: one context per GPU of the node, or several contexts on one GPU): the three buffers of every context become
+ * their SUM / MIN / MAX over the contexts, by peer copies and an add kernel (direct reduce-scatter + all-gather; every
+ * owner on its own stream).  What ncclAllReduce does between processes; the reference has no
+ * counterpart (it is single-threaded per dimension, ref: src/ClusterSeparator.cpp:70-78).  Every context must have an
+ * accumulated node (abw_sep_shard_accum) under the same bin layout.  Returns when all contexts hold the result. */
+int abw_sep_shard_combine(abw_ctx* const* ctxs, int32_t n_ctx);
 
 /* Device pointer to the resident column store [D][N] int32 (for abw_km_features_from_keys). */
 const int32_t* abw_sep_dev_keys(const abw_ctx* ctx);

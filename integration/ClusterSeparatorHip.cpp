@@ -30,11 +30,9 @@ void fail(const std::string& what)
 	throw std::runtime_error(msg);
 }
 
-void load_store(const ScafDpData& scaf_db, const SCGdb& scg_db, const ClusterData& root)
+// the library's view of the root table, through public interfaces of the reference only
+void build_table(const ScafDpData& scaf_db, const SCGdb& scg_db, const ClusterData& root, HipStore& st, ClusterSeparatorHip::Table& t)
 {
-	HipStore& st = g_store;
-	if(!st.ctx && abw_ctx_create(0, &st.ctx) != ABW_OK)
-		throw std::runtime_error("ClusterSeparatorHip: no MI355X / HIP device available");
 	const size_t N = scaf_db.ndps(), D = root.ndimensions(), S = scaf_db.nscafs();
 	if(root.ndps() != N)
 		throw std::invalid_argument("ClusterSeparatorHip: the first node must hold every datapoint (root of the recursion)");
@@ -42,10 +40,11 @@ void load_store(const ScafDpData& scaf_db, const SCGdb& scg_db, const ClusterDat
 	st.values.assign(D, std::vector<double>());
 	st.dim_names.assign(D, "");
 	st.raw_of.assign(N + 1, 0);
+	t.owner = &scaf_db; t.N = N; t.D = D; t.S = S;
 
 	// keys: rank of every value among the column's distinct values (order-preserving, exact for any
 	// .lrn; for abawaca-build's 3-decimal output the table has <= 1001 entries per signature column)
-	std::vector<int32_t> keys(D * N);
+	t.keys.assign(D * N, 0);
 	for(size_t d = 0; d < D; d++) {
 		const Dimension& dim = root.get_dimension(d + 1);
 		st.dim_names[d] = dim.get_dimension_name();
@@ -53,30 +52,28 @@ void load_store(const ScafDpData& scaf_db, const SCGdb& scg_db, const ClusterDat
 		u.assign(dim.get_values().begin(), dim.get_values().end());	// std::set<double>: sorted, distinct
 		for(auto it = dim.begin(); it != dim.end(); it++) {
 			const size_t key = std::lower_bound(u.begin(), u.end(), it->value) - u.begin();
-			keys[d * N + (it->dp - 1)] = (int32_t)key;
+			t.keys[d * N + (it->dp - 1)] = (int32_t)key;
 		}
 	}
-	std::vector<int32_t> dp2scaf(N);
-	for(size_t dp = 1; dp <= N; dp++) dp2scaf[dp - 1] = (int32_t)scaf_db.dp2scaf(dp) - 1;
-	std::vector<int64_t> scaf_len(S);
-	for(size_t s = 1; s <= S; s++) scaf_len[s - 1] = (int64_t)scaf_db.get_scaf(s)->get_seq_size();
+	t.dp2scaf.resize(N);
+	for(size_t dp = 1; dp <= N; dp++) t.dp2scaf[dp - 1] = (int32_t)scaf_db.dp2scaf(dp) - 1;
+	t.scaf_len.resize(S);
+	for(size_t s = 1; s <= S; s++) t.scaf_len[s - 1] = (int64_t)scaf_db.get_scaf(s)->get_seq_size();
 	// scaffold -> SCG ids through SCGdb's public interface
 	std::map<std::string, int32_t> scg_id;
-	std::vector<int32_t> scg_off(S + 1, 0), scg_ids;
+	t.scg_off.assign(S + 1, 0);
+	t.scg_ids.clear();
 	for(size_t s = 1; s <= S; s++) {
 		std::set<size_t> one; one.insert(s);
 		std::map<std::string, size_t> found;
 		scg_db.get_scg2count(one, found);
 		for(auto it = found.begin(); it != found.end(); it++) {
 			auto ins = scg_id.insert(std::pair<std::string, int32_t>(it->first, (int32_t)scg_id.size()));
-			scg_ids.push_back(ins.first->second);
+			t.scg_ids.push_back(ins.first->second);
 		}
-		scg_off[s] = (int32_t)scg_ids.size();
+		t.scg_off[s] = (int32_t)t.scg_ids.size();
 	}
-	const int32_t n_scg = (int32_t)scg_id.size();
-	if(abw_sep_load(st.ctx, keys.data(), (int32_t)D, (int64_t)N, dp2scaf.data(), scaf_len.data(), (int32_t)S,
-			n_scg ? scg_off.data() : NULL, n_scg ? scg_ids.data() : NULL, n_scg) != ABW_OK)
-		fail("ClusterSeparatorHip: abw_sep_load failed");
+	t.n_scg = (int32_t)scg_id.size();
 }
 
 }	// namespace
@@ -85,6 +82,37 @@ void load_store(const ScafDpData& scaf_db, const SCGdb& scg_db, const ClusterDat
 ClusterSeparatorHip::ClusterSeparatorHip(const ScafDpData& scaf_db, const SCGdb& scg_db, const ClusterData& clustering_db, Semaphore& threads_semaphore) :
 	ClusterSeparator(scaf_db, scg_db, clustering_db, threads_semaphore, new Result())
 {}
+
+//////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
+bool ClusterSeparatorHip::loaded_for(const ScafDpData* db) const
+{
+	return g_store.ctx != NULL && g_store.scaf_db == db;
+}
+
+//////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
+// One resident column store on device 0 (reference src/abawaca.cpp:86 loads the table once, too)
+void ClusterSeparatorHip::load_table(const Table& t)
+{
+	HipStore& st = g_store;
+	if(!st.ctx && abw_ctx_create(0, &st.ctx) != ABW_OK)
+		throw std::runtime_error("ClusterSeparatorHip: no MI355X / HIP device available");
+	if(abw_sep_load(st.ctx, t.keys.data(), (int32_t)t.D, (int64_t)t.N, t.dp2scaf.data(), t.scaf_len.data(), (int32_t)t.S,
+			t.n_scg ? t.scg_off.data() : NULL, t.n_scg ? t.scg_ids.data() : NULL, t.n_scg) != ABW_OK)
+		fail("ClusterSeparatorHip: abw_sep_load failed");
+}
+
+//////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
+void ClusterSeparatorHip::run_node(const std::vector<int32_t>& scaf_ids, size_t n_dps, NodeResult& r)
+{
+	abw_split out;
+	r.side.assign(scaf_ids.size(), 0);
+	r.raw.assign(n_dps, 0);
+	if(abw_sep_node(g_store.ctx, scaf_ids.data(), (int32_t)scaf_ids.size(), (int32_t)this->cluster_ndps_threshold, &out, NULL,
+			r.side.data(), r.raw.data()) != ABW_OK)
+		fail("ClusterSeparatorHip: abw_sep_node failed");
+	r.dimension = out.dimension; r.key = out.key; r.legal = out.legal; r.split = out.split;
+	r.sensitivity = out.sensitivity; r.specificity = out.specificity;
+}
 
 //////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
 void ClusterSeparatorHip::shutdown()
@@ -116,9 +144,12 @@ bool ClusterSeparatorHip::separate()
 	this->raw_dps_cluster1.clear();
 	this->raw_dps_cluster2.clear();
 
-	if(g_store.ctx == NULL || g_store.scaf_db != &scaf_db)
-		load_store(scaf_db, scg_db, clustering_db);
 	HipStore& st = g_store;
+	if(!loaded_for(&scaf_db) || st.scaf_db != &scaf_db) {
+		Table t;
+		build_table(scaf_db, scg_db, clustering_db, st, t);
+		load_table(t);
+	}
 
 	// the node as a list of whole scaffolds (separate() always hands whole scaffolds to its children,
 	// reference src/ClusterSeparator.cpp:94-122)
@@ -132,10 +163,10 @@ bool ClusterSeparatorHip::separate()
 		scaf_ids.push_back((int32_t)it->first - 1);
 	}
 	const int32_t m = (int32_t)scaf_ids.size();
-	abw_split out;
-	std::vector<uint8_t> side(m), raw(dps.size());
-	if(abw_sep_node(st.ctx, scaf_ids.data(), m, (int32_t)this->cluster_ndps_threshold, &out, NULL, side.data(), raw.data()) != ABW_OK)
-		fail("ClusterSeparatorHip: abw_sep_node failed");
+	NodeResult out;
+	run_node(scaf_ids, dps.size(), out);
+	const std::vector<uint8_t>& side = out.side;
+	const std::vector<uint8_t>& raw = out.raw;
 
 	Result* best = static_cast<Result*>(best_separation);
 	if(out.dimension > 0)

@@ -10,6 +10,8 @@
 #define CLUSTERSEPARATORHIP_H
 
 #include "ClusterSeparator.h"
+#include <stdint.h>
+#include <vector>
 
 class ClusterSeparatorHip : public ClusterSeparator {
 protected:
@@ -34,8 +36,30 @@ public:
 	friend ostream&	operator << (ostream& os, ClusterSeparatorHip& cs);
 	// Releases the GPU context and the resident column store (optional; call once at program end).
 	static void	shutdown();
+	// The two places where the table meets the GPU; ClusterSeparatorHipSharded spreads them over several contexts.
+	// Everything is in the numbering of the library: scaffold ids and datapoint positions 0-based, datapoints scaffold by
+	// scaffold.  The table itself (keys, scaffold layout, SCGs) is built once from the root node's ClusterData.
+	struct Table {
+		const ScafDpData*		owner;		// the ScafDpData the table describes
+		size_t				N, D, S;
+		std::vector<int32_t>		keys;		// [D][N] rank of every value among its column's distinct values
+		std::vector<int32_t>		dp2scaf;	// [N]
+		std::vector<int64_t>		scaf_len;	// [S]
+		std::vector<int32_t>		scg_off, scg_ids;	// CSR scaffold -> SCG ids
+		int32_t				n_scg;
+	};
+	struct NodeResult {					// what abw_sep_node returns (include/abawaca_hip.h)
+		int		dimension, key, legal, split;
+		double		sensitivity, specificity;
+		std::vector<uint8_t> side;			// [m] 1 / 2 per scaffold of the node, in the order of scaf_ids
+		std::vector<uint8_t> raw;			// [n] raw side per datapoint, scaffold by scaffold, ascending datapoint id
+	};
 protected:
 	void		separate_dimension(size_t) override	{}	// separate() is replaced as a whole
+	// hooks of separate(): the resident table, one node
+	virtual void	load_table(const Table& t);
+	virtual void	run_node(const std::vector<int32_t>& scaf_ids, size_t n_dps, NodeResult& r);
+	virtual bool	loaded_for(const ScafDpData* db) const;
 };
 
 ostream& operator << (ostream& os, ClusterSeparatorHip& cs);

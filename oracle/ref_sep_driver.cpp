@@ -28,7 +28,11 @@
 #include "ScafDpData.h"
 #include "ClusterData.h"
 #include "ClusterSeparatorBySensitivitySpecificity.h"
-#if defined(ABW_USE_HIP_SEPARATOR)	// same driver, separator swapped for the GPU drop-in (integration/ClusterSeparatorHip.h)
+#if defined(ABW_USE_HIP_SHARDED_SEPARATOR)	// ... with the table spread over ABW_SHARDS contexts (integration/ClusterSeparatorHipSharded.h)
+#include "ClusterSeparatorHipSharded.h"
+#define SEPARATOR_CLASS ClusterSeparatorHipSharded
+#define ABW_USE_HIP_SEPARATOR
+#elif defined(ABW_USE_HIP_SEPARATOR)	// same driver, separator swapped for the GPU drop-in (integration/ClusterSeparatorHip.h)
 #include "ClusterSeparatorHip.h"
 #define SEPARATOR_CLASS ClusterSeparatorHip
 #elif defined(ABW_USE_KMEANS_SEPARATOR)	// ... or for the k-means extension (integration/ClusterSeparatorKMeans.h)

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref", "ref_sep_driver")
 HIP = os.path.join(ROOT, "oracle", "_ref", "hip_sep_driver")
+HIP_SHARDED = os.path.join(ROOT, "oracle", "_ref", "hip_sharded_sep_driver")
 
 
 def _run(exe, files, prefix, env=None):
@@ -73,3 +74,28 @@ def test_cluster_files_written_by_the_gpu_writer_are_the_reference_files(golden_
         w_ref = open(os.path.join(wd, "ref.writer.tsv")).read().split()
         w_hip = open(os.path.join(wd, "hip.writer.tsv")).read().split()
         assert w_ref[1] == w_hip[1] == str(len(names) // 3)
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HIP_SHARDED)), reason="oracle/_ref drivers not built")
+@pytest.mark.parametrize("case", ["sep_g4tight", "sep_g3noscg", "sep_g6"])
+def test_reference_main_loop_with_the_sharded_hip_separator(golden_dir, case):
+    """The single-process multi-GPU path: integration/ClusterSeparatorHipSharded keeps the table in
+    ABW_SHARDS contexts (here all on the one device), accumulates every node on all of them, combines the histograms with
+    abw_sep_shard_combine and lets every shard assign its own scaffolds.  Same text as the reference's separator, for 1, 2
+    and 4 shards; the cluster files too."""
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    with tempfile.TemporaryDirectory(prefix="abwshard_") as wd:
+        files = synth.write_build_dir(wd, g["milli"], g["dp2scaf"], g["scaf_len"], g["scg_scaf"], g["scg_id"], int(g["n_scg"]))
+        ref_dir = os.path.join(wd, "clusters_ref")
+        os.makedirs(ref_dir)
+        ref = _run(REF, files, os.path.join(wd, "ref"), dict(os.environ, ABW_CLUSTER_DIR=ref_dir))
+        for shards in (1, 2, 4):
+            out_dir = os.path.join(wd, f"clusters_{shards}")
+            os.makedirs(out_dir)
+            got = _run(HIP_SHARDED, files, os.path.join(wd, f"sh{shards}"), dict(os.environ, ABW_SHARDS=str(shards), ABW_CLUSTER_DIR=out_dir))
+            assert got[0] == ref[0], shards
+            assert got[1] == ref[1] and got[2] == ref[2], shards
+            names = sorted(os.listdir(ref_dir))
+            assert names == sorted(os.listdir(out_dir))
+            for nm in names:
+                assert open(os.path.join(ref_dir, nm), "rb").read() == open(os.path.join(out_dir, nm), "rb").read(), (shards, nm)

@@ -57,6 +57,9 @@ def _check_against_whole(keys, dp2scaf, scaf_len, scg_scaf, scg_id, n_scg, group
         for g, a in zip(groups, s2c_parts):
             got[np.asarray(g)] = a
         assert np.array_equal(got, s2c)
+        # the exchange above was the library's (abw_sep_shard_combine); plain tensor arithmetic in its place gives the same
+        rows_t, s2c_t = separator.binning_shards_local(stores, max_nodes=max_nodes, combine="torch")
+        assert [key(a) for a in rows_t] == [key(b) for b in want] and all(np.array_equal(a, b) for a, b in zip(s2c_t, s2c_parts))
         return rows, sep
     finally:
         for c in ctxs + [ctx]:
@@ -105,5 +108,8 @@ def test_shard_load_rejects_bad_dictionaries():
             st = separator.ShardedColumnStore(c, keys, dp2scaf, slen, ok_v, ok_o)
             out = _lib.Split()
             c.check(_lib.lib().abw_sep_shard_eval(c.handle, 100, out, None, None, None))
+        with pytest.raises(_lib.AbwError):               # combine without accum
+            import ctypes as C
+            c.check(_lib.lib().abw_sep_shard_combine((C.c_void_p * 1)(c.handle), 1))
     finally:
         c.close()
