@@ -17,9 +17,14 @@
 //   lrn_nlcount   newlines per 1 KiB block                          -> scan -> line numbers
 //   lrn_lines     start offset of every line
 //   lrn_classify  one thread per line: chomp, data line or not      -> scan -> row numbers
-//   lrn_rows      one wave per data line: the line goes through LDS in 1 KiB pieces; a lane owns 16 bytes, knows the
-//                 field number of its first byte from a wave prefix sum of tab counts, and converts every field that
-//                 STARTS in its bytes (a field may run on into the next lanes' bytes; the LDS copy has a 32-byte halo)
+//   lrn_blocks    one wave per 1 KiB BLOCK of text, whatever lines it holds: a lane owns 16 bytes and knows the line and
+//                 the field number of its first byte -- the line from the newline prefix sums, the field from a segmented
+//                 wave scan of tab counts (restarting at every newline) plus the tabs between the start of the block's
+//                 first line and the block (per-block tails, walked back to the last block with a newline) -- and
+//                 converts every field that STARTS in its bytes (a field may run on into the next lanes' bytes; the LDS
+//                 copy has a 32-byte halo).  Every lane has work whatever the line length is.  Handles the lines whose
+//                 last field is followed directly by the newline (all of abawaca-build's output);
+//   lrn_rows      one wave per data line, for the others (trailing white space, which the reference chomps)
 #include "abw_internal.h"
 #include <string.h>
 #include <stdlib.h>
@@ -59,14 +64,25 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x, int lane)
     return x;
 }
 
-__global__ __launch_bounds__(256) void lrn_nlcount_kernel(const uint8_t* __restrict__ text, uint64_t len, uint32_t* __restrict__ blk_nl, uint64_t nblk)
+// per block: newlines, and the tabs after its last newline (all its tabs when it has none)
+__global__ __launch_bounds__(256) void lrn_nlcount_kernel(const uint8_t* __restrict__ text, uint64_t len, uint32_t* __restrict__ blk_nl,
+                                                         uint32_t* __restrict__ blk_tail, uint64_t nblk)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
     for (uint64_t b = wave; b < nblk; b += nwaves) {
-        const uint32_t c = __popc(eq_mask16(text, b * LBLK + (uint64_t)lane * 16, len, 0x0A0A0A0Au));
+        const uint64_t A = b * LBLK + (uint64_t)lane * 16;
+        const uint32_t nl = eq_mask16(text, A, len, 0x0A0A0A0Au), tb = eq_mask16(text, A, len, 0x09090909u);
+        const uint32_t c = __popc(nl);
         const uint32_t x = wave_incl_scan_u32(c, lane);
-        if (lane == 63) blk_nl[b] = x;
+        const unsigned long long with_nl = __ballot(nl != 0);
+        const int last = with_nl ? 63 - __builtin_clzll(with_nl) : -1;      // the last lane that holds a newline
+        uint32_t t = 0;
+        if (lane > last) t = __popc(tb);
+        else if (lane == last) t = __popc(tb >> (32 - __builtin_clz(nl)));   // tabs above its highest newline bit
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (lane == 63) { blk_nl[b] = x; blk_tail[b] = t; }
     }
 }
 
@@ -89,7 +105,7 @@ struct LineInfo { uint64_t begin, end; };     // [begin, end) after the chomp
 
 __global__ __launch_bounds__(256) void lrn_classify_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ line_start,
                                                           uint64_t n_lines, LineInfo* __restrict__ info, uint32_t* __restrict__ is_row,
-                                                          unsigned long long* __restrict__ err)
+                                                          uint8_t* __restrict__ kind, unsigned long long* __restrict__ err)
 {
     const uint64_t l = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (l >= n_lines) return;
@@ -101,12 +117,127 @@ __global__ __launch_bounds__(256) void lrn_classify_kernel(const uint8_t* __rest
         if (c == ' ' || (c >= 9 && c <= 13)) e--; else break;
     }
     info[l].begin = b; info[l].end = e;
-    is_row[l] = (l >= 4 && e > b && text[b] != '%') ? 1u : 0u;           // ref :123; the first four lines are the header
+    const bool row = l >= 4 && e > b && text[b] != '%';                  // ref :123; the first four lines are the header
+    is_row[l] = row ? 1u : 0u;
+    kind[l] = !row ? 0 : (e == line_start[l + 1] - 1 ? 1 : 2);           // 1: nothing chomped (lrn_blocks), 2: lrn_rows
 }
 
 // error codes in the low byte of err (smallest line wins): 1 line too long, 2 field count, 3 number format, 4 key overflow
+// One field, [-]digits[.digits] up to its terminator (a tab; `term2`: what else may end it), to the key table.  Returns the
+// terminator found.
+__device__ __forceinline__ uint8_t convert_field(const uint8_t* p, uint8_t term2, uint32_t f, uint64_t l, uint64_t row, int32_t ncols, int64_t stride,
+                                                 int32_t* __restrict__ dp_names, int32_t* __restrict__ keys, unsigned long long* __restrict__ err)
+{
+    int j = 0;
+    bool neg = false, bad = false;
+    long long ip = 0;
+    int frac = 0, nd = 0, nfr = 0;
+    if (p[0] == '-') { neg = true; j = 1; }
+    for (; j < MAX_FIELD && p[j] >= '0' && p[j] <= '9'; j++) { ip = ip * 10 + (p[j] - '0'); nd++; if (ip > 4000000000ll) bad = true; }
+    if (f > 0 && p[j] == '.') {
+        j++;
+        for (; j < MAX_FIELD && p[j] >= '0' && p[j] <= '9'; j++) {
+            if (nfr < 3) frac = frac * 10 + (p[j] - '0'); else if (p[j] != '0') bad = true;
+            nfr++;
+        }
+    }
+    if (p[j] != '\t' && p[j] != term2) bad = true;                      // anything else inside the field (or a field too long)
+    if (nd + nfr == 0 && j > 0) bad = true;                              // "-" or "." alone; an empty field is atof("") = 0
+    for (; nfr < 3; nfr++) frac *= 10;
+    const long long key = (neg ? -1 : 1) * (ip * 1000 + frac);
+    if (bad) atomicMin(err, (unsigned long long)(l + 1) << 8 | 3);
+    else if (f == 0 ? (ip > 2147483647ll || neg) : (key > 2147483647ll || key < -2147483647ll)) atomicMin(err, (unsigned long long)(l + 1) << 8 | 4);
+    else if (f == 0) dp_names[row] = (int32_t)ip;                        // ref :146 atoi
+    else if (f < (uint32_t)ncols) keys[(int64_t)(f - 1) * stride + (int64_t)row] = (int32_t)key;
+    return p[j];
+}
+
+// One wave per 1 KiB block of the text (see the head of the file).  kind[l] == 1: the lines this kernel converts.
+__global__ __launch_bounds__(256) void lrn_blocks_kernel(const uint8_t* __restrict__ text, uint64_t len, const uint64_t* __restrict__ blk_prefix,
+                                                        const uint32_t* __restrict__ blk_nl, const uint32_t* __restrict__ blk_tail, uint64_t nblk,
+                                                        const uint8_t* __restrict__ kind, const uint64_t* __restrict__ row_of, uint64_t n_lines,
+                                                        int32_t ncols, int64_t stride, int32_t* __restrict__ dp_names, int32_t* __restrict__ keys,
+                                                        unsigned long long* __restrict__ err)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t buf[4][LBLK + 48];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint8_t* lb = buf[wid];
+    // Which wave takes which block decides how the key table is written: a column of the table holds consecutive rows, a
+    // 128-byte line of it 32 rows = about 32 lines of text, and workgroup i runs on XCD i mod 8, each XCD with an L2 of its own.
+    // Blocks dealt out one by one would have every line of the table written in pieces from all eight L2s (each piece a
+    // partial write-back).  So the text goes to the XCDs in runs of 64 blocks (64 KiB, ~56 rows): the k-th block of XCD x
+    // is block ((k / 64) * 8 + x) * 64 + k % 64, and the waves of the XCD take k = slot, slot + waves, ...
+    const uint64_t xcd = blockIdx.x & 7, slot = (uint64_t)(blockIdx.x >> 3) * 4 + wid, slots = (uint64_t)(gridDim.x >> 3) * 4;
+    for (uint64_t k = slot;; k += slots) {
+        const uint64_t b = ((k >> 6) * 8 + xcd) * 64 + (k & 63);
+        if ((k >> 6) * 8 * 64 >= nblk) break;                            // past the last run of every XCD
+        const uint64_t base = b * LBLK;
+        if (b >= nblk || base >= len) continue;
+        // the block + 32 bytes of halo into LDS; bytes past the end of the text read as newline
+        for (int o = lane * 16; o < LBLK + 32; o += 1024) {
+            const uint64_t at = base + o;
+            uint4 v;
+            if (at + 16 <= len) memcpy(&v, text + at, 16);
+            else {
+                uint8_t t[16];
+                for (int i = 0; i < 16; i++) t[i] = (at + i < len) ? text[at + i] : (uint8_t)'\n';
+                memcpy(&v, t, 16);
+            }
+            *reinterpret_cast<uint4*>(lb + o) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint4 mine = *reinterpret_cast<const uint4*>(lb + lane * 16);
+        const uint64_t A = base + (uint64_t)lane * 16;
+        const int live = (A >= len) ? 0 : (len - A >= 16 ? 16 : (int)(len - A));
+        const uint32_t lm = (1u << live) - 1u;
+        const uint32_t tabs = (eq_mask4(mine.x, 0x09090909u) | (eq_mask4(mine.y, 0x09090909u) << 4) | (eq_mask4(mine.z, 0x09090909u) << 8) |
+                               (eq_mask4(mine.w, 0x09090909u) << 12)) & lm;
+        const uint32_t nls = (eq_mask4(mine.x, 0x0A0A0A0Au) | (eq_mask4(mine.y, 0x0A0A0A0Au) << 4) | (eq_mask4(mine.z, 0x0A0A0A0Au) << 8) |
+                              (eq_mask4(mine.w, 0x0A0A0A0Au) << 12)) & lm;
+        // line of this lane's first byte
+        const uint32_t cn = __popc(nls);
+        const uint64_t line0 = blk_prefix[b] + wave_incl_scan_u32(cn, lane) - cn;
+        // field of this lane's first byte: tabs since the last newline -- a segmented exclusive scan over the lanes ...
+        uint32_t seg_t = nls ? __popc(tabs >> (32 - __builtin_clz(nls))) : __popc(tabs);     // this lane's tabs after its last newline
+        uint32_t seg_f = nls ? 1u : 0u;                                                      // ... which restart the count
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(seg_t, o, 64), f = __shfl_up(seg_f, o, 64);
+            if (lane >= o) { if (!seg_f) seg_t += t; seg_f |= f; }
+        }
+        uint32_t in_t = __shfl_up(seg_t, 1, 64), in_f = __shfl_up(seg_f, 1, 64);
+        if (lane == 0) { in_t = 0; in_f = 0; }
+        // ... plus, while no newline of this block lies before the lane, the tabs between the start of the line and the block
+        uint32_t carry = 0;
+        for (uint64_t j = b; j-- > 0;) { carry += blk_tail[j]; if (blk_nl[j]) break; }      // wave-uniform; a line spans at most 9 blocks
+        const uint32_t field0 = in_t + (in_f ? 0u : carry);
+        // a field starts at the first byte of the text and after every tab or newline
+        uint32_t prev_sep;
+        if (lane == 0) prev_sep = (A == 0) ? 1u : (uint32_t)(text[A - 1] == '\t' || text[A - 1] == '\n');
+        else { const uint8_t c = lb[lane * 16 - 1]; prev_sep = (uint32_t)(c == '\t' || c == '\n'); }
+        uint32_t starts = (((tabs | nls) << 1) | prev_sep) & lm;
+        uint64_t cur_line = ~0ull, row = 0;
+        uint8_t cur_kind = 0;
+        while (starts) {
+            const int i = __ffs(starts) - 1;
+            starts &= starts - 1;
+            const uint32_t below = (1u << i) - 1u;
+            const uint32_t nl_below = nls & below;
+            const uint64_t l = line0 + __popc(nl_below);
+            const uint32_t f = nl_below ? (uint32_t)__popc((tabs & below) >> (32 - __builtin_clz(nl_below))) : field0 + __popc(tabs & below);
+            if (l != cur_line) { cur_line = l; cur_kind = (l < n_lines) ? kind[l] : 0; row = (cur_kind == 1) ? row_of[l] : 0; }
+            if (cur_kind != 1) continue;
+            const uint8_t term = convert_field(lb + lane * 16 + i, '\n', f, l, row, ncols, stride, dp_names, keys, err);
+            if (term == '\n' && f + 1 != (uint32_t)ncols) atomicMin(err, (unsigned long long)(l + 1) << 8 | 2);   // ref :135-140
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ __launch_bounds__(256) void lrn_rows_kernel(const uint8_t* __restrict__ text, const LineInfo* __restrict__ info,
-                                                      const uint32_t* __restrict__ is_row, const uint64_t* __restrict__ row_of,
+                                                      const uint8_t* __restrict__ kind, const uint64_t* __restrict__ row_of,
                                                       uint64_t n_lines, int32_t ncols, int64_t stride,
                                                       int32_t* __restrict__ dp_names, int32_t* __restrict__ keys,
                                                       unsigned long long* __restrict__ err)
@@ -116,7 +247,7 @@ __global__ __launch_bounds__(256) void lrn_rows_kernel(const uint8_t* __restrict
     uint8_t* lb = buf[wid];
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
     for (uint64_t l = (uint64_t)blockIdx.x * 4 + wid; l < n_lines; l += nwaves) {
-        if (!is_row[l]) continue;                                        // wave-uniform
+        if (kind[l] != 2) continue;                                      // wave-uniform
         const uint64_t row = row_of[l];
         const uint64_t b = info[l].begin, e = info[l].end;
         uint32_t carry = 0;                                              // tabs of the line before this piece
@@ -153,29 +284,7 @@ __global__ __launch_bounds__(256) void lrn_rows_kernel(const uint8_t* __restrict
                 const int i = __ffs(starts) - 1;
                 starts &= starts - 1;
                 const uint32_t f = field + __popc(tabs & ((1u << i) - 1u));
-                const uint8_t* p = lb + lane * 16 + i;
-                // [-]digits[.digits]
-                int j = 0;
-                bool neg = false, bad = false;
-                long long ip = 0;
-                int frac = 0, nd = 0, nfr = 0;
-                if (p[0] == '-') { neg = true; j = 1; }
-                for (; j < MAX_FIELD && p[j] >= '0' && p[j] <= '9'; j++) { ip = ip * 10 + (p[j] - '0'); nd++; if (ip > 4000000000ll) bad = true; }
-                if (f > 0 && p[j] == '.') {
-                    j++;
-                    for (; j < MAX_FIELD && p[j] >= '0' && p[j] <= '9'; j++) {
-                        if (nfr < 3) frac = frac * 10 + (p[j] - '0'); else if (p[j] != '0') bad = true;
-                        nfr++;
-                    }
-                }
-                if (p[j] != '\t') bad = true;                            // anything else inside the field (or a field too long)
-                if (nd + nfr == 0 && j > 0) bad = true;                  // "-" or "." alone; an empty field is atof("") = 0
-                for (; nfr < 3; nfr++) frac *= 10;
-                const long long key = (neg ? -1 : 1) * (ip * 1000 + frac);
-                if (bad) atomicMin(err, (unsigned long long)(l + 1) << 8 | 3);
-                else if (f == 0 ? (ip > 2147483647ll || neg) : (key > 2147483647ll || key < -2147483647ll)) atomicMin(err, (unsigned long long)(l + 1) << 8 | 4);
-                else if (f == 0) dp_names[row] = (int32_t)ip;            // ref :146 atoi
-                else if (f < (uint32_t)ncols) keys[(int64_t)(f - 1) * stride + (int64_t)row] = (int32_t)key;
+                convert_field(lb + lane * 16 + i, '\t', f, l, row, ncols, stride, dp_names, keys, err);
             }
             carry += __shfl(incl, 63, 64);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -453,15 +562,16 @@ int abw_lrn_parse(abw_ctx* ctx, const uint8_t* text, uint64_t len, int64_t ndps,
     // scratch[0]: text | scratch[1]: blk_nl u32 + blk_prefix u64 | scratch[2]: line_start u64 | scratch[3]: LineInfo
     // scratch[4]: is_row u32 + row_of u64 | scratch[6]: keys + dp_names + err
     if ((rc = abw_reserve(ctx, ctx->scratch[0], len + 64))) return rc;
-    if ((rc = abw_reserve(ctx, ctx->scratch[1], nblk * 4 + 8 + (nblk + 1) * 8))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[1], 2 * (nblk * 4 + 8) + (nblk + 1) * 8))) return rc;
     uint8_t* d_text = (uint8_t*)ctx->scratch[0].p;
     uint32_t* blk_nl = (uint32_t*)ctx->scratch[1].p;
-    uint64_t* blk_prefix = (uint64_t*)((uint8_t*)blk_nl + ((nblk * 4 + 7) & ~(uint64_t)7));
+    uint32_t* blk_tail = (uint32_t*)((uint8_t*)blk_nl + ((nblk * 4 + 7) & ~(uint64_t)7));
+    uint64_t* blk_prefix = (uint64_t*)((uint8_t*)blk_tail + ((nblk * 4 + 7) & ~(uint64_t)7));
     ABW_HIP(ctx, hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, st));
     const int grid = ctx->num_cu * 8;
     {
         ABW_PROF(ctx, "lrn_parse");                                      // kernels only; the copies are the caller's PCIe cost
-        hipLaunchKernelGGL(lrn_nlcount_kernel, dim3(grid), dim3(256), 0, st, d_text, len, blk_nl, nblk);
+        hipLaunchKernelGGL(lrn_nlcount_kernel, dim3(grid), dim3(256), 0, st, d_text, len, blk_nl, blk_tail, nblk);
         ABW_LAUNCH_CHECK(ctx);
         if ((rc = abw_device_scan_u32(ctx, blk_nl, nblk, blk_prefix))) return rc;
     }
@@ -471,13 +581,14 @@ int abw_lrn_parse(abw_ctx* ctx, const uint8_t* text, uint64_t len, int64_t ndps,
     const uint64_t n_lines = n_nl + ((len > 0 && text[len - 1] != '\n') ? 1 : 0);
     if ((rc = abw_reserve(ctx, ctx->scratch[2], (n_lines + 2) * 8))) return rc;
     if ((rc = abw_reserve(ctx, ctx->scratch[3], (n_lines + 1) * sizeof(LineInfo)))) return rc;
-    if ((rc = abw_reserve(ctx, ctx->scratch[4], ((n_lines * 4 + 15) & ~(uint64_t)7) + (n_lines + 2) * 8))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[4], ((n_lines * 4 + 15) & ~(uint64_t)7) + (n_lines + 2) * 8 + n_lines + 16))) return rc;
     const size_t kb = (size_t)ndims * (size_t)std::max<int64_t>(ndps, 1) * 4, nb = (size_t)std::max<int64_t>(ndps, 1) * 4;
     if ((rc = abw_reserve(ctx, ctx->scratch[6], kb + nb + 64))) return rc;
     uint64_t* line_start = (uint64_t*)ctx->scratch[2].p;
     LineInfo* info = (LineInfo*)ctx->scratch[3].p;
     uint32_t* is_row = (uint32_t*)ctx->scratch[4].p;
     uint64_t* row_of = (uint64_t*)((uint8_t*)is_row + ((n_lines * 4 + 15) & ~(uint64_t)7));
+    uint8_t* kind = (uint8_t*)(row_of + n_lines + 2);
     int32_t* d_keys = (int32_t*)ctx->scratch[6].p;
     int32_t* d_names = (int32_t*)((uint8_t*)d_keys + kb);
     unsigned long long* d_err = (unsigned long long*)((uint8_t*)d_names + ((nb + 7) & ~(size_t)7));
@@ -489,7 +600,7 @@ int abw_lrn_parse(abw_ctx* ctx, const uint8_t* text, uint64_t len, int64_t ndps,
         ABW_PROF(ctx, "lrn_parse");
         hipLaunchKernelGGL(lrn_lines_kernel, dim3(grid), dim3(256), 0, st, d_text, len, blk_prefix, nblk, line_start);
         ABW_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(lrn_classify_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, d_text, line_start, n_lines, info, is_row, d_err);
+        hipLaunchKernelGGL(lrn_classify_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, d_text, line_start, n_lines, info, is_row, kind, d_err);
         ABW_LAUNCH_CHECK(ctx);
         if ((rc = abw_device_scan_u32(ctx, is_row, n_lines, row_of))) return rc;
     }
@@ -500,7 +611,10 @@ int abw_lrn_parse(abw_ctx* ctx, const uint8_t* text, uint64_t len, int64_t ndps,
         return abw_fail(ctx, ABW_ERR_FORMAT, "abw_lrn_parse: %llu datapoint lines, the header says %lld", (unsigned long long)n_rows, (long long)ndps);
     if (n_rows > 0) {
         ABW_PROF(ctx, "lrn_parse");
-        hipLaunchKernelGGL(lrn_rows_kernel, dim3(grid), dim3(256), 0, st, d_text, info, is_row, row_of, n_lines, h.ncols, (int64_t)ndps, d_names, d_keys, d_err);
+        hipLaunchKernelGGL(lrn_blocks_kernel, dim3(grid), dim3(256), 0, st, d_text, len, blk_prefix, blk_nl, blk_tail, nblk, kind, row_of, n_lines,
+                           h.ncols, (int64_t)ndps, d_names, d_keys, d_err);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(lrn_rows_kernel, dim3(grid), dim3(256), 0, st, d_text, info, kind, row_of, n_lines, h.ncols, (int64_t)ndps, d_names, d_keys, d_err);
         ABW_LAUNCH_CHECK(ctx);
     }
     unsigned long long err = 0;

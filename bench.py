@@ -271,7 +271,7 @@ def lrn_bench(ctx, with_cpu):
     res = dict(value=len(text) / k_s / 1e9, unit="GB/s of text (kernels, text resident)", rows=N, columns=D, text_mb=round(len(text) / 1e6, 1),
                ms_kernels=round(k_s * 1e3, 3), ms_with_pcie_both_ways=round(wall * 1e3, 2), fields_per_s=round(N * (D + 1) / k_s / 1e9, 2),
                note="row N4 (next), loader side; fields_per_s in G fields/s; wall includes H2D of the text and D2H of the keys from pageable memory",
-               roofline=dict(kernel="lrn_rows_kernel (+ line scan)", bound="hbm", achieved=round(alg / k_s / 1e9, 1), peak=HBM_PEAK_GBS,
+               roofline=dict(kernel="lrn_blocks_kernel (+ line scan)", bound="hbm", achieved=round(alg / k_s / 1e9, 1), peak=HBM_PEAK_GBS,
                              unit="GB/s", frac=round(alg / k_s / 1e9 / HBM_PEAK_GBS, 4), traffic=None))
     # writer side: the same table back to text (reference src/abawaca-build.cpp:595-607), checked by parsing it again
     rows_m = np.ascontiguousarray(np.concatenate([sig, cov], axis=1).astype(np.int32))
