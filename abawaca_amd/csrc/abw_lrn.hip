@@ -34,7 +34,8 @@ int abw_device_scan_u32(abw_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* 
 
 namespace {
 
-constexpr int LBLK = 1024;
+constexpr int LBLK = 1008;             // bytes of text per block: 63 lanes x 16 (lane 63 of a wave holds the 16 bytes behind its block)
+constexpr int RPIECE = 1024;           // lrn_rows: bytes of a line per pass
 constexpr int MAX_FIELD = 24;          // longest field converted (a 3-decimal int32 key has at most 12 characters)
 constexpr int REF_LINE = 8191;         // the reference reads lines in pieces of this many bytes (char line[8192])
 
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(256) void lrn_nlcount_kernel(const uint8_t* __restr
     const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
     for (uint64_t b = wave; b < nblk; b += nwaves) {
         const uint64_t A = b * LBLK + (uint64_t)lane * 16;
-        const uint32_t nl = eq_mask16(text, A, len, 0x0A0A0A0Au), tb = eq_mask16(text, A, len, 0x09090909u);
+        const uint64_t lim = (lane < 63) ? len : 0;                      // lane 63's bytes belong to the next block
+        const uint32_t nl = eq_mask16(text, A, lim, 0x0A0A0A0Au), tb = eq_mask16(text, A, lim, 0x09090909u);
         const uint32_t c = __popc(nl);
         const uint32_t x = wave_incl_scan_u32(c, lane);
         const unsigned long long with_nl = __ballot(nl != 0);
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void lrn_lines_kernel(const uint8_t* __restric
     const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
     for (uint64_t b = wave; b < nblk; b += nwaves) {
         const uint64_t A = b * LBLK + (uint64_t)lane * 16;
-        uint32_t m = eq_mask16(text, A, len, 0x0A0A0A0Au);
+        uint32_t m = eq_mask16(text, A, (lane < 63) ? len : 0, 0x0A0A0A0Au);
         const uint32_t c = __popc(m);
         uint64_t k = blk_prefix[b] + wave_incl_scan_u32(c, lane) - c;
         while (m) { const int i = __ffs(m) - 1; m &= m - 1; line_start[++k] = A + i + 1; }
@@ -152,49 +154,88 @@ __device__ __forceinline__ uint8_t convert_field(const uint8_t* p, uint8_t term2
     return p[j];
 }
 
-// One wave per 1 KiB block of the text (see the head of the file).  kind[l] == 1: the lines this kernel converts.
+// bit i set iff byte i of x is an ASCII digit
+__device__ __forceinline__ uint32_t digit_mask4(uint32_t x)
+{
+    const uint32_t t = x ^ 0x30303030u;                                   // '0'..'9' -> 0..9
+    const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x76767676u) | t) & 0x80808080u;
+    return __builtin_amdgcn_udot4(z, 0x08040201u, 0u, false) >> 7;
+}
+__device__ __forceinline__ uint32_t digit_mask16(const uint4& v) { return digit_mask4(v.x) | (digit_mask4(v.y) << 4) | (digit_mask4(v.z) << 8) | (digit_mask4(v.w) << 12); }
+__device__ __forceinline__ uint32_t eq_mask16r(const uint4& v, uint32_t pat) { return eq_mask4(v.x, pat) | (eq_mask4(v.y, pat) << 4) | (eq_mask4(v.z, pat) << 8) | (eq_mask4(v.w, pat) << 12); }
+__device__ __forceinline__ uint32_t sel4(int q, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return q == 0 ? a : q == 1 ? b : q == 2 ? c : d; }
+// four ASCII-masked digits (first = most significant in the lowest byte; bytes hold 0..9) -> their number
+__device__ __forceinline__ uint32_t four_digits(uint32_t w)
+{
+    const uint32_t t = w * 10u + (w >> 8);                                // byte 0: d0 d1, byte 2: d2 d3 (no carries: 99 at most)
+    return (t & 0xFFu) * 100u + ((t >> 16) & 0xFFu);
+}
+
+// One wave per block of LBLK = 1008 bytes of the text (see the head of the file): lanes 0..62 own 16 bytes each, lane 63
+// holds the 16 bytes behind the block (the tail of a field that starts in lane 62).  kind[l] == 1: the lines this kernel
+// converts.  A field of the usual shape -- [-] up to 8 digits [. up to 3 digits], at most 12 bytes, ended by a tab or a
+// newline within the 32 bytes the lane sees -- is converted without a loop over its bytes: its parts are found from the
+// lane's character-class masks, the digits taken from a byte-aligned window and multiplied out in parallel.  Everything
+// else (and everything that is an error) goes through convert_field, the byte-by-byte form.
 __global__ __launch_bounds__(256) void lrn_blocks_kernel(const uint8_t* __restrict__ text, uint64_t len, const uint64_t* __restrict__ blk_prefix,
                                                         const uint32_t* __restrict__ blk_nl, const uint32_t* __restrict__ blk_tail, uint64_t nblk,
                                                         const uint8_t* __restrict__ kind, const uint64_t* __restrict__ row_of, uint64_t n_lines,
                                                         int32_t ncols, int64_t stride, int32_t* __restrict__ dp_names, int32_t* __restrict__ keys,
                                                         unsigned long long* __restrict__ err)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t buf[4][LBLK + 48];
+    __shared__ __attribute__((aligned(16))) uint8_t buf[4][1024 + 48];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint8_t* lb = buf[wid];
     // Which wave takes which block decides how the key table is written: a column of the table holds consecutive rows, a
     // 128-byte line of it 32 rows = about 32 lines of text, and workgroup i runs on XCD i mod 8, each XCD with an L2 of its own.
     // Blocks dealt out one by one would have every line of the table written in pieces from all eight L2s (each piece a
-    // partial write-back).  So the text goes to the XCDs in runs of 64 blocks (64 KiB, ~56 rows): the k-th block of XCD x
+    // partial write-back).  So the text goes to the XCDs in runs of 64 blocks (~56 rows): the k-th block of XCD x
     // is block ((k / 64) * 8 + x) * 64 + k % 64, and the waves of the XCD take k = slot, slot + waves, ...
     const uint64_t xcd = blockIdx.x & 7, slot = (uint64_t)(blockIdx.x >> 3) * 4 + wid, slots = (uint64_t)(gridDim.x >> 3) * 4;
+    // 16 bytes of the text at `at`; past its end: newlines
+    auto fetch = [&](uint64_t at) -> uint4 {
+        uint4 v;
+        if (at + 16 <= len) memcpy(&v, text + at, 16);
+        else {
+            uint8_t t[16];
+            for (int i = 0; i < 16; i++) t[i] = (at + i < len) ? text[at + i] : (uint8_t)'\n';
+            memcpy(&v, t, 16);
+        }
+        return v;
+    };
+    auto block_of = [&](uint64_t k) { return ((k >> 6) * 8 + xcd) * 64 + (k & 63); };
+    // the text of the wave's next block is on its way while this one is converted
+    uint4 nxt_mine = fetch(block_of(slot) * LBLK + (uint64_t)lane * 16), nxt_halo = make_uint4(0, 0, 0, 0);
+    if (lane < 2) nxt_halo = fetch(block_of(slot) * LBLK + 1024 + (uint64_t)lane * 16);
     for (uint64_t k = slot;; k += slots) {
-        const uint64_t b = ((k >> 6) * 8 + xcd) * 64 + (k & 63);
+        const uint64_t b = block_of(k);
         if ((k >> 6) * 8 * 64 >= nblk) break;                            // past the last run of every XCD
         const uint64_t base = b * LBLK;
-        if (b >= nblk || base >= len) continue;
-        // the block + 32 bytes of halo into LDS; bytes past the end of the text read as newline
-        for (int o = lane * 16; o < LBLK + 32; o += 1024) {
-            const uint64_t at = base + o;
-            uint4 v;
-            if (at + 16 <= len) memcpy(&v, text + at, 16);
-            else {
-                uint8_t t[16];
-                for (int i = 0; i < 16; i++) t[i] = (at + i < len) ? text[at + i] : (uint8_t)'\n';
-                memcpy(&v, t, 16);
-            }
-            *reinterpret_cast<uint4*>(lb + o) = v;
+        const uint4 mine = nxt_mine, halo = nxt_halo;
+        {
+            const uint64_t nb = block_of(k + slots) * LBLK;
+            nxt_mine = fetch(nb + (uint64_t)lane * 16);
+            if (lane < 2) nxt_halo = fetch(nb + 1024 + (uint64_t)lane * 16);
         }
+        if (b >= nblk || base >= len) continue;
+        // the block, lane 63's 16 bytes and 32 bytes of halo into LDS (the byte-by-byte form reads there)
+        *reinterpret_cast<uint4*>(lb + lane * 16) = mine;
+        if (lane < 2) *reinterpret_cast<uint4*>(lb + 1024 + lane * 16) = halo;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint4 mine = *reinterpret_cast<const uint4*>(lb + lane * 16);
         const uint64_t A = base + (uint64_t)lane * 16;
-        const int live = (A >= len) ? 0 : (len - A >= 16 ? 16 : (int)(len - A));
+        // character classes of this lane's 16 bytes (bit i = byte i); the 16 bytes behind them are the next lane's
+        const uint32_t tab16 = eq_mask16r(mine, 0x09090909u), nl16 = eq_mask16r(mine, 0x0A0A0A0Au);
+        const uint32_t dig16 = digit_mask16(mine), dot16 = eq_mask16r(mine, 0x2E2E2E2Eu), min16 = eq_mask16r(mine, 0x2D2D2D2Du);
+        const uint32_t sep32 = (tab16 | nl16) | (__shfl_down(tab16 | nl16, 1, 64) << 16);
+        const uint32_t nl32 = nl16 | (__shfl_down(nl16, 1, 64) << 16);
+        const uint32_t dig32 = dig16 | (__shfl_down(dig16, 1, 64) << 16);
+        const uint32_t dot32 = dot16 | (__shfl_down(dot16, 1, 64) << 16);
+        const uint32_t W0 = mine.x, W1 = mine.y, W2 = mine.z, W3 = mine.w;
+        const uint32_t W4 = __shfl_down(mine.x, 1, 64), W5 = __shfl_down(mine.y, 1, 64), W6 = __shfl_down(mine.z, 1, 64);
+        const int live = (lane == 63 || A >= len) ? 0 : (len - A >= 16 ? 16 : (int)(len - A));
         const uint32_t lm = (1u << live) - 1u;
-        const uint32_t tabs = (eq_mask4(mine.x, 0x09090909u) | (eq_mask4(mine.y, 0x09090909u) << 4) | (eq_mask4(mine.z, 0x09090909u) << 8) |
-                               (eq_mask4(mine.w, 0x09090909u) << 12)) & lm;
-        const uint32_t nls = (eq_mask4(mine.x, 0x0A0A0A0Au) | (eq_mask4(mine.y, 0x0A0A0A0Au) << 4) | (eq_mask4(mine.z, 0x0A0A0A0Au) << 8) |
-                              (eq_mask4(mine.w, 0x0A0A0A0Au) << 12)) & lm;
+        const uint32_t tabs = tab16 & lm, nls = nl16 & lm;
         // line of this lane's first byte
         const uint32_t cn = __popc(nls);
         const uint64_t line0 = blk_prefix[b] + wave_incl_scan_u32(cn, lane) - cn;
@@ -213,9 +254,8 @@ __global__ __launch_bounds__(256) void lrn_blocks_kernel(const uint8_t* __restri
         for (uint64_t j = b; j-- > 0;) { carry += blk_tail[j]; if (blk_nl[j]) break; }      // wave-uniform; a line spans at most 9 blocks
         const uint32_t field0 = in_t + (in_f ? 0u : carry);
         // a field starts at the first byte of the text and after every tab or newline
-        uint32_t prev_sep;
+        uint32_t prev_sep = (__shfl_up(tab16 | nl16, 1, 64) >> 15) & 1u;                     // (all lanes take part in the shuffle)
         if (lane == 0) prev_sep = (A == 0) ? 1u : (uint32_t)(text[A - 1] == '\t' || text[A - 1] == '\n');
-        else { const uint8_t c = lb[lane * 16 - 1]; prev_sep = (uint32_t)(c == '\t' || c == '\n'); }
         uint32_t starts = (((tabs | nls) << 1) | prev_sep) & lm;
         uint64_t cur_line = ~0ull, row = 0;
         uint8_t cur_kind = 0;
@@ -228,8 +268,48 @@ __global__ __launch_bounds__(256) void lrn_blocks_kernel(const uint8_t* __restri
             const uint32_t f = nl_below ? (uint32_t)__popc((tabs & below) >> (32 - __builtin_clz(nl_below))) : field0 + __popc(tabs & below);
             if (l != cur_line) { cur_line = l; cur_kind = (l < n_lines) ? kind[l] : 0; row = (cur_kind == 1) ? row_of[l] : 0; }
             if (cur_kind != 1) continue;
-            const uint8_t term = convert_field(lb + lane * 16 + i, '\n', f, l, row, ncols, stride, dp_names, keys, err);
-            if (term == '\n' && f + 1 != (uint32_t)ncols) atomicMin(err, (unsigned long long)(l + 1) << 8 | 2);   // ref :135-140
+            // the parts of the field from the masks: length L up to its separator, '-', the point, the digits
+            const uint32_t sepw = sep32 >> i;
+            const int L = sepw ? __ffs(sepw) - 1 : 32;
+            const uint32_t Lm = (L >= 32) ? 0xFFFFFFFFu : (1u << L) - 1u;
+            const uint32_t neg = (min16 >> i) & 1u;
+            const uint32_t dotin = (dot32 >> i) & Lm;
+            const int dp = dotin ? __ffs(dotin) - 1 : L;
+            const int nint = dp - (int)neg, nfr = dotin ? L - dp - 1 : 0;
+            const uint32_t need = Lm & ~neg & ~(dotin ? (1u << dp) : 0u);              // where digits must be
+            const bool usual = L <= 12 && ((dig32 >> i) & need) == need && (dotin & (dotin - 1u)) == 0 && nint >= 0 && nint <= 8 && nfr <= 3 &&
+                               (need != 0 || L == 0) && !(f == 0 && (dotin | neg));
+            bool done = false;
+            bool ends_line = false;
+            if (usual) {
+                // the 12 bytes from the field's first one: a0 a1 a2
+                const int q = i >> 2, sh = i & 3;
+                const uint32_t x0 = sel4(q, W0, W1, W2, W3), x1 = sel4(q, W1, W2, W3, W4), x2 = sel4(q, W2, W3, W4, W5), x3 = sel4(q, W3, W4, W5, W6);
+                const uint32_t a0 = __builtin_amdgcn_alignbyte(x1, x0, sh), a1 = __builtin_amdgcn_alignbyte(x2, x1, sh), a2 = __builtin_amdgcn_alignbyte(x3, x2, sh);
+                // the 8 bytes that end at the point (or at the end of the field): its integer digits, right-aligned; bytes before the
+                // first digit read as 0.  Z = 8 zero bytes, then a0 a1 a2: bytes [dp, dp + 8) of Z
+                const int qd = dp >> 2, shd = dp & 3;
+                const uint32_t y0 = sel4(qd, 0u, 0u, a0, a1), y1 = sel4(qd, 0u, a0, a1, a2), y2 = sel4(qd, a0, a1, a2, 0u);
+                uint32_t lo = __builtin_amdgcn_alignbyte(y1, y0, shd), hi = __builtin_amdgcn_alignbyte(y2, y1, shd);
+                const int drop = 8 - nint;                                            // leading bytes that are not digits of this field
+                const uint32_t mlo = drop >= 4 ? 0u : (0xFFFFFFFFu << (8 * drop)), mhi = drop >= 8 ? 0u : (drop > 4 ? (0xFFFFFFFFu << (8 * (drop - 4))) : 0xFFFFFFFFu);
+                lo &= 0x0F0F0F0Fu & mlo; hi &= 0x0F0F0F0Fu & mhi;
+                const uint32_t ip = four_digits(lo) * 10000u + four_digits(hi);
+                // the 3 bytes behind the point: bytes [dp + 9, dp + 12) of Z (zero bytes behind a2)
+                const int of = dp + 9, qf = (of >> 2) - 2, shf = of & 3;
+                const uint32_t g0 = sel4(qf, a0, a1, a2, 0u), g1 = sel4(qf, a1, a2, 0u, 0u);
+                const uint32_t fr = __builtin_amdgcn_alignbyte(g1, g0, shf) & 0x000F0F0Fu & ((1u << (8 * nfr)) - 1u);
+                const uint32_t frac = (fr & 0xFFu) * 100u + ((fr >> 8) & 0xFFu) * 10u + ((fr >> 16) & 0xFFu);
+                if (f == 0) { dp_names[row] = (int32_t)ip; done = true; }
+                else if (ip < 2147483u) {
+                    const int32_t key = (int32_t)(ip * 1000u + frac);
+                    if (f < (uint32_t)ncols) keys[(int64_t)(f - 1) * stride + (int64_t)row] = neg ? -key : key;
+                    done = true;
+                }
+                ends_line = (nl32 >> (i + L)) & 1u;
+            }
+            if (!done) ends_line = convert_field(lb + lane * 16 + i, '\n', f, l, row, ncols, stride, dp_names, keys, err) == '\n';
+            if (ends_line && f + 1 != (uint32_t)ncols) atomicMin(err, (unsigned long long)(l + 1) << 8 | 2);   // ref :135-140
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -242,7 +322,7 @@ __global__ __launch_bounds__(256) void lrn_rows_kernel(const uint8_t* __restrict
                                                       int32_t* __restrict__ dp_names, int32_t* __restrict__ keys,
                                                       unsigned long long* __restrict__ err)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t buf[4][LBLK + 48];
+    __shared__ __attribute__((aligned(16))) uint8_t buf[4][RPIECE + 48];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint8_t* lb = buf[wid];
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
@@ -251,9 +331,9 @@ __global__ __launch_bounds__(256) void lrn_rows_kernel(const uint8_t* __restrict
         const uint64_t row = row_of[l];
         const uint64_t b = info[l].begin, e = info[l].end;
         uint32_t carry = 0;                                              // tabs of the line before this piece
-        for (uint64_t base = b; base < e; base += LBLK) {
+        for (uint64_t base = b; base < e; base += RPIECE) {
             // piece [base, base + 1024) + 32 bytes of halo into LDS; bytes past the end of the line read as tab
-            for (int o = lane * 16; o < LBLK + 32; o += 1024) {
+            for (int o = lane * 16; o < RPIECE + 32; o += 1024) {
                 const uint64_t at = base + o;
                 uint4 v;
                 if (at + 16 <= e) memcpy(&v, text + at, 16);
