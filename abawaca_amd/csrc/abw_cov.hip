@@ -8,14 +8,19 @@
 //     double(min(e, end) - max(s, start) + 1) / double(end - start + 1)
 // added to its fp64 accumulator IN THE ORDER OF THE SAM FILE.  fp64 addition does not commute in the
 // last bit and abawaca.lrn prints int(1000 * x), so the order is part of the result: contributions are
-// emitted in read order, brought together per segment by a stable radix sort on the segment index
-// (rocPRIM; a library sort, not a hot kernel), and added by one thread per segment in that order
-// (cov_runs marks where every segment's run begins and ends).
+// emitted in read order, brought together per segment WITHOUT changing the order inside a segment, and added by
+// one thread per segment in that order (cov_runs marks where every segment's run begins and ends).
+// Bringing together: a coordinate-sorted SAM file (the usual input) emits its pairs already grouped by segment --
+// detected by one pass over the keys, nothing is moved then.  Otherwise a stable least-significant-digit radix
+// sort on the segment index, up to 10 bits per pass (two passes up to a million segments), written for wave64: a wave owns a
+// tile of 4096 consecutive pairs and takes them 64 at a time in order; the lanes that hold the same digit find each other
+// with one ballot per digit bit, their rank among
+// themselves is a population count below the lane, and a per-wave table of running destinations (LDS, started from
+// the scanned per-tile digit counts) gives every pair its place -- no atomics on the way, so equal keys keep their order.
 // The filter (unmapped / > 15 SNPs / secondary, ref :546) stays with the caller's SAM parser.
 #include "abw_internal.h"
 #include <string.h>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
@@ -83,7 +88,80 @@ __global__ __launch_bounds__(256) void cov_pairs_kernel(const uint64_t* __restri
     }
 }
 
-// after the stable sort: where the run of every segment begins and ends
+// ---- the stable radix sort (see the head of the file) ------------------------------------------------------------------
+constexpr int SORT_ROUNDS = 128, SORT_TILE = 64 * SORT_ROUNDS;         // pairs per wave
+constexpr int SORT_MAX_DB = 9, SORT_MAX_BINS = 1 << SORT_MAX_DB;      // digit bits per pass
+
+// descents[0] = number of keys smaller than their predecessor (0: the pairs are grouped already)
+__global__ __launch_bounds__(256) void cov_sorted_kernel(const uint32_t* __restrict__ key, uint64_t n, unsigned long long* __restrict__ descents)
+{
+    unsigned long long c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i + 1 < n; i += (uint64_t)gridDim.x * 256) c += key[i + 1] < key[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (c && (threadIdx.x & 63) == 0) atomicAdd(descents, c);           // one per wave of a fixed grid
+}
+
+// digit counts of every tile, digit-major: tile_hist[digit * n_tiles + tile]
+__global__ __launch_bounds__(256) void cov_digit_hist_kernel(const uint32_t* __restrict__ key, uint64_t n, int shift, int db, uint32_t* __restrict__ tile_hist,
+                                                            uint64_t n_tiles)
+{
+    __shared__ uint32_t h[4][SORT_MAX_BINS];
+    const int bins = 1 << db;
+    const uint32_t dmask = (uint32_t)bins - 1u;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint64_t tile = (uint64_t)blockIdx.x * 4 + wid;
+    if (tile >= n_tiles) return;                                        // whole waves leave; nothing below synchronises the workgroup
+    for (int d = lane; d < bins; d += 64) h[wid][d] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int r = 0; r < SORT_ROUNDS; r++) {
+        const uint64_t i = tile * SORT_TILE + (uint64_t)r * 64 + lane;
+        if (i < n) atomicAdd(&h[wid][(key[i] >> shift) & dmask], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int d = lane; d < bins; d += 64) tile_hist[(uint64_t)d * n_tiles + tile] = h[wid][d];
+}
+
+// every pair to its place: tile_off = exclusive scan of tile_hist (the first destination of every (digit, tile))
+__global__ __launch_bounds__(256) void cov_digit_scatter_kernel(const uint32_t* __restrict__ key_in, const double* __restrict__ val_in, uint64_t n, int shift,
+                                                               int db, const uint64_t* __restrict__ tile_off, uint64_t n_tiles,
+                                                               uint32_t* __restrict__ key_out, double* __restrict__ val_out)
+{
+    __shared__ uint64_t next[4][SORT_MAX_BINS];                         // running destination of every digit in this wave's tile
+    const int bins = 1 << db;
+    const uint32_t dmask = (uint32_t)bins - 1u;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint64_t tile = (uint64_t)blockIdx.x * 4 + wid;
+    if (tile >= n_tiles) return;
+    for (int d = lane; d < bins; d += 64) next[wid][d] = tile_off[(uint64_t)d * n_tiles + tile];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int r = 0; r < SORT_ROUNDS; r++) {
+        const uint64_t i = tile * SORT_TILE + (uint64_t)r * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t k = valid ? key_in[i] : 0u;
+        const double v = valid ? val_in[i] : 0.0;
+        const uint32_t d = (k >> shift) & dmask;
+        unsigned long long peers = __ballot(valid);                     // the lanes of this round with my digit
+        for (int b = 0; b < db; b++) {
+            const unsigned long long has = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? has : ~has;
+        }
+        const uint64_t base = next[wid][d];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();                                // everybody has read before the leaders write
+        const int rank = __popcll(peers & below);
+        if (valid && rank == 0) next[wid][d] = base + (uint64_t)__popcll(peers);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (valid) { key_out[base + rank] = k; val_out[base + rank] = v; }
+    }
+}
+
+// where the run of every segment begins and ends in the grouped pairs
 __global__ __launch_bounds__(256) void cov_runs_kernel(const uint32_t* __restrict__ key, uint64_t n_pairs, uint64_t* __restrict__ run_start,
                                                       uint64_t* __restrict__ run_end)
 {
@@ -145,22 +223,51 @@ extern "C" int abw_cov_accumulate_dev(abw_ctx* ctx, const uint32_t* d_seg_scaf, 
     ABW_HIP(ctx, hipMemcpyAsync(&n_pairs, offset + n_reads, 8, hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));
     if (n_pairs == 0) return ABW_OK;
-    // scratch[11]: key_in | key_out (u32) | val_in | val_out (f64) | rocPRIM temporary storage
+    // scratch[11]: key_in | key_out (u32) | val_in | val_out (f64) | tile_hist u32 + tile_off u64 [256][tiles] | flag
     int bits = 1;
     while (((uint64_t)1 << bits) < n_seg) bits++;
-    size_t tmp_bytes = 0;
-    ABW_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (double*)nullptr, (double*)nullptr,
-                                           (size_t)n_pairs, 0u, (unsigned)bits, st));
-    const size_t b_key = (n_pairs * 4 + 7) & ~(size_t)7, b_val = n_pairs * 8;
-    if ((rc = abw_reserve(ctx, ctx->scratch[11], 2 * b_key + 2 * b_val + tmp_bytes + 256))) return rc;
+    const uint64_t n_tiles = (n_pairs + SORT_TILE - 1) / SORT_TILE;
+    const uint64_t bins_max = (uint64_t)SORT_MAX_BINS;
+    const size_t b_key = (n_pairs * 4 + 7) & ~(size_t)7, b_val = n_pairs * 8, b_hist = (bins_max * n_tiles * 4 + 7) & ~(size_t)7, b_toff = (bins_max * n_tiles + 1) * 8;
+    if ((rc = abw_reserve(ctx, ctx->scratch[11], 2 * b_key + 2 * b_val + b_hist + b_toff + 256))) return rc;
     uint8_t* base = (uint8_t*)ctx->scratch[11].p;
-    uint32_t* key_in = (uint32_t*)base; uint32_t* key_out = (uint32_t*)(base + b_key);
-    double* val_in = (double*)(base + 2 * b_key); double* val_out = (double*)(base + 2 * b_key + b_val);
-    void* tmp = base + 2 * b_key + 2 * b_val;
+    uint32_t* key_a = (uint32_t*)base; uint32_t* key_b = (uint32_t*)(base + b_key);
+    double* val_a = (double*)(base + 2 * b_key); double* val_b = (double*)(base + 2 * b_key + b_val);
+    uint32_t* tile_hist = (uint32_t*)(base + 2 * b_key + 2 * b_val);
+    uint64_t* tile_off = (uint64_t*)((uint8_t*)tile_hist + b_hist);
+    unsigned long long* d_flag = (unsigned long long*)((uint8_t*)tile_off + b_toff);
+    ABW_HIP(ctx, hipMemsetAsync(d_flag, 0, 8, st));
     hipLaunchKernelGGL(cov_pairs_kernel, dim3(gr), dim3(256), 0, st, d_read_pos, d_read_len, n_reads, d_seg_start, d_seg_end, count, first,
-                       offset, key_in, val_in);
+                       offset, key_a, val_a);
     ABW_LAUNCH_CHECK(ctx);
-    ABW_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, key_in, key_out, val_in, val_out, (size_t)n_pairs, 0u, (unsigned)bits, st));
+    hipLaunchKernelGGL(cov_sorted_kernel, dim3((unsigned)std::min<uint64_t>((n_pairs + 255) / 256, (uint64_t)ctx->num_cu * 8)), dim3(256), 0, st, (const uint32_t*)key_a, n_pairs, d_flag);
+    ABW_LAUNCH_CHECK(ctx);
+    unsigned long long unsorted = 0;
+    ABW_HIP(ctx, hipMemcpyAsync(&unsorted, d_flag, 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t* key_out = key_a;
+    const double* val_out = val_a;
+    if (unsorted) {
+        // Nearly grouped pairs (a coordinate-sorted file whose reads straddle segment borders) stay near their places: few wide
+        // passes.  Pairs in no order scatter over the whole array, and a (tile, digit) run of a few pairs wastes most of every
+        // cache line it is written to: more passes of fewer digits, longer runs.
+        const int max_db = (unsorted * 8 > n_pairs) ? 6 : SORT_MAX_DB;
+        const int passes = (bits + max_db - 1) / max_db, db = (bits + passes - 1) / passes;      // e.g. 18 bits: 2 passes of 9, or 3 of 6
+        const uint64_t bins = (uint64_t)1 << db;
+        const unsigned gt = (unsigned)((n_tiles + 3) / 4);
+        for (int shift = 0; shift < bits; shift += db) {
+            hipLaunchKernelGGL(cov_digit_hist_kernel, dim3(gt), dim3(256), 0, st, (const uint32_t*)key_a, n_pairs, shift, db, tile_hist, n_tiles);
+            ABW_LAUNCH_CHECK(ctx);
+            if ((rc = abw_device_scan_u32(ctx, tile_hist, bins * n_tiles, tile_off))) return rc;
+            hipLaunchKernelGGL(cov_digit_scatter_kernel, dim3(gt), dim3(256), 0, st, (const uint32_t*)key_a, (const double*)val_a, n_pairs, shift, db,
+                               (const uint64_t*)tile_off, n_tiles, key_b, val_b);
+            ABW_LAUNCH_CHECK(ctx);
+            std::swap(key_a, key_b);
+            std::swap(val_a, val_b);
+        }
+        key_out = key_a;
+        val_out = val_a;
+    }
     ABW_HIP(ctx, hipMemsetAsync(run_start, 0, 2 * b_run, st));                      // start = end = 0: no contributions
     hipLaunchKernelGGL(cov_runs_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, key_out, n_pairs, run_start, run_end);
     ABW_LAUNCH_CHECK(ctx);

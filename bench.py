@@ -1018,8 +1018,9 @@ def main():
         alg_cov = 16.0 * n_reads + 8.0 * 2 * n_seg
         out["coverage"] = dict(value=n_reads / cov_s / 1e6, unit="M reads/s", reads=n_reads, segments=int(n_seg), ms_per_sample=cov_s * 1e3,
                                note="row N1 (next): per-segment overlap sums in SAM order, fp64; reads and segments resident; "
-                                    "includes a stable radix sort (rocPRIM) that brings each segment's contributions together in read order",
-                               roofline=dict(kernel="cov_accumulate (4 kernels + sort)", bound="hbm", achieved=round(alg_cov / (mscv / ncv * 1e-3) / 1e9, 1),
+                                    "includes the stable radix sort (hand-written, wave64 ballots) that brings each segment's contributions together in read order; "
+                                    "reads here are in NO order (the worst case; a coordinate-sorted file takes about half the time)",
+                               roofline=dict(kernel="cov_accumulate (span, pairs, radix passes, sum)", bound="hbm", achieved=round(alg_cov / (mscv / ncv * 1e-3) / 1e9, 1),
                                              peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg_cov / (mscv / ncv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                              traffic=None, ms_per_launch=round(mscv / ncv, 4)))
         if world == 1 and not args.no_cpu:
