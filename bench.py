@@ -630,7 +630,19 @@ def separator_leg(ctx, keys_host, dp2scaf, scaf_len, genome, G, seed, label, tra
         rows_t, s2c_t, dt = separator.binning_tree(store)
         tree_s = dt if tree_s is None else min(tree_s, dt)
     key = lambda r: (r["id"], r["ndps"], r["split"], r["dim"], r["key"], r["spec"], r["sens"], r["c1"], r["n1"], r["c2"], r["n2"])
+    # per kernel family (HIP-event brackets inside the call) and against the bytes the recursion reads when every node reads
+    # its own part of the table once, 4 bytes per (datapoint, dimension) -- SURVEY section 8(d)'s unit, summed over the nodes
+    ctx.prof_reset(); ctx.prof_enable(True)
+    separator.binning_tree(store)
+    fam = {k: ctx.prof_read(k)[1] for k in ("sep_accum", "sep_wide", "sep_eval", "sep_partition")}
+    ctx.prof_enable(False)
+    node_bytes = 4.0 * D * sum(r["ndps"] for r in rows_t)
     res["recursion"]["one_call"] = dict(entry_point="abw_sep_tree", ms=round(tree_s * 1e3, 3), ms_per_node=round(tree_s / len(rows_t) * 1e3, 4),
+                                        ms_by_family=dict(narrow_accumulate_and_eval=round(fam["sep_accum"], 3), wide_scans=round(fam["sep_wide"], 3),
+                                                          winner_and_sides=round(fam["sep_eval"], 3), partition=round(fam["sep_partition"], 3)),
+                                        roofline=dict(kernels="tree_* (all of the call)", bound="hbm", achieved=round(node_bytes / tree_s / 1e9, 1), peak=HBM_PEAK_GBS,
+                                                      unit="GB/s", frac=round(node_bytes / tree_s / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
+                                                      algorithmic_bytes="4 B x dimensions x datapoints of every node, summed over the nodes"),
                                         identical_to_node_by_node=bool([key(r) for r in rows_t] == [key(r) for r in nodes_all]
                                                                        and np.array_equal(s2c_t, s2c_all)),
                                         speedup_over_node_by_node_c_abi=round(res["recursion"]["c_abi_s"] / tree_s, 2))
