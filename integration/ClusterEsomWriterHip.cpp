@@ -1,6 +1,9 @@
 // See ClusterEsomWriterHip.h.
 #include "ClusterEsomWriterHip.h"
 #include "abawaca_hip.h"
+#include <stdlib.h>
+// the GPU this process works on: ABW_DEVICE in the environment (default 0)
+static inline int abw_env_device() { const char* e = getenv("ABW_DEVICE"); return e ? atoi(e) : 0; }
 #include <stdexcept>
 #include <stdio.h>
 #include <stdlib.h>
@@ -19,7 +22,7 @@ WriterStore g_writer;
 void load_table(const ScafDpData& scaf_db, const ClusterData& root)
 {
 	WriterStore& st = g_writer;
-	if(!st.ctx && abw_ctx_create(0, &st.ctx) != ABW_OK)
+	if(!st.ctx && abw_ctx_create(abw_env_device(), &st.ctx) != ABW_OK)
 		throw std::runtime_error("ClusterEsomWriterHip: no MI355X / HIP device available");
 	const size_t N = scaf_db.ndps(), D = root.ndimensions();
 	std::vector<double> values(D * N, 0.0);				// [D][N], column dp-1 = datapoint dp

@@ -2,6 +2,9 @@
 // ClusterData, SCGdb, Cluster) and the C ABI of libabawaca_hip.so (include/abawaca_hip.h).
 #include "ClusterSeparatorHip.h"
 #include "abawaca_hip.h"
+#include <stdlib.h>
+// the GPU this process works on: ABW_DEVICE in the environment (default 0)
+static inline int abw_env_device() { const char* e = getenv("ABW_DEVICE"); return e ? atoi(e) : 0; }
 #include <algorithm>
 #include <map>
 #include <set>
@@ -94,7 +97,7 @@ bool ClusterSeparatorHip::loaded_for(const ScafDpData* db) const
 void ClusterSeparatorHip::load_table(const Table& t)
 {
 	HipStore& st = g_store;
-	if(!st.ctx && abw_ctx_create(0, &st.ctx) != ABW_OK)
+	if(!st.ctx && abw_ctx_create(abw_env_device(), &st.ctx) != ABW_OK)
 		throw std::runtime_error("ClusterSeparatorHip: no MI355X / HIP device available");
 	if(abw_sep_load(st.ctx, t.keys.data(), (int32_t)t.D, (int64_t)t.N, t.dp2scaf.data(), t.scaf_len.data(), (int32_t)t.S,
 			t.n_scg ? t.scg_off.data() : NULL, t.n_scg ? t.scg_ids.data() : NULL, t.n_scg) != ABW_OK)

@@ -3,6 +3,9 @@
 // every node of the recursion then sends only its scaffold list.
 #include "ClusterSeparatorKMeans.h"
 #include "abawaca_hip.h"
+#include <stdlib.h>
+// the GPU this process works on: ABW_DEVICE in the environment (default 0)
+static inline int abw_env_device() { const char* e = getenv("ABW_DEVICE"); return e ? atoi(e) : 0; }
 #include <algorithm>
 #include <cmath>
 #include <map>
@@ -49,7 +52,7 @@ void km_fail(const std::string& what)
 void km_load(const ScafDpData& scaf_db, const ClusterData& root)
 {
 	KmStore& st = g_km;
-	if(!st.ctx && abw_ctx_create(0, &st.ctx) != ABW_OK)
+	if(!st.ctx && abw_ctx_create(abw_env_device(), &st.ctx) != ABW_OK)
 		throw std::runtime_error("ClusterSeparatorKMeans: no MI355X / HIP device available");
 	const size_t N = scaf_db.ndps(), D = root.ndimensions();
 	if(root.ndps() != N)

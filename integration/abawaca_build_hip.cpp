@@ -36,6 +36,9 @@
 #include "String.h"
 #include "common.h"
 #include "abawaca_hip.h"
+#include <stdlib.h>
+// the GPU this process works on: ABW_DEVICE in the environment (default 0)
+static inline int abw_env_device() { const char* e = getenv("ABW_DEVICE"); return e ? atoi(e) : 0; }
 
 using namespace std;
 
@@ -80,7 +83,7 @@ int main(int argc, const char* argv[])
 	}
 
 	abw_ctx* ctx = NULL;
-	if(abw_ctx_create(0, &ctx) != ABW_OK) {
+	if(abw_ctx_create(abw_env_device(), &ctx) != ABW_OK) {
 		cerr << "abawaca-build (hip): no MI355X / HIP device available" << endl;
 		return -1;
 	}
