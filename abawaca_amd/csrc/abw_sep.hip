@@ -45,15 +45,20 @@ __global__ __launch_bounds__(256) void sep_static_ts_kernel(SepDev P, const int3
     const int d = nsort[blockIdx.y], slot = nslot[blockIdx.y];
     const int32_t* __restrict__ col = P.bins + (int64_t)d * P.N;
     const int f = P.scaf_first[s], n = P.scaf_ndps[s], k = n >> 1;      // 0-based index of the flip value
-    int ts;
+    int ts, gt = 0;                                      // gt: its dps above the flip value
     if (n <= 8) {
         int x[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) x[i] = (i < n) ? col[f + i] : INT_MAX;
         ABW_SORT8(x);
         ts = (k == 1) ? x[1] : (k == 2) ? x[2] : (k == 3) ? x[3] : x[4];
-    } else ts = select_kth_mem(col + f, n, k, P.T[d]);
-    ts8[((int64_t)(slot >> 3) * S + s) * 8 + (slot & 7)] = (uint16_t)ts;
+#pragma unroll
+        for (int i = 0; i < 8; i++) gt += (i < n && x[i] > ts);
+    } else {
+        ts = select_kth_mem(col + f, n, k, P.T[d]);
+        for (int i = 0; i < n; i++) gt += col[f + i] > ts;
+    }
+    ts8[((int64_t)(slot >> 3) * S + s) * 8 + (slot & 7)] = (uint16_t)(ts | (min(gt, 63) << 10));
 }
 
 // the re-coded narrow columns.  grid (ceil(N / 256), groups)
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(256) void sep_static_codes_kernel(SepDev P, const N
     for (int q = 0; q < 8; q++) {
         if (q < G.cnt) {
             const uint32_t v = (uint32_t)P.bins[(int64_t)G.dim[q] * P.N + dp];
-            const uint32_t ts = (tw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+            const uint32_t ts = (tw[q >> 1] >> (16 * (q & 1))) & 0x3FFu;
             cw[q >> 1] |= (v | (v > ts ? 0x8000u : 0u)) << (16 * (q & 1));
         }
     }

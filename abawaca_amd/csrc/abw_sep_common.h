@@ -13,7 +13,8 @@ constexpr int MAX_SCG = 4096;
 
 // A group of up to 8 narrow dimensions whose values travel together: the narrow columns are kept a second time as
 // [group][dp][8] x 16 bit (value | (value > t_s) << 15, t_s = the flip value of the dp's scaffold in that dimension) with the
-// flip values beside them as [group][scaffold][8] x 16 bit.  A node is a set of whole scaffolds, so t_s -- the
+// flip values beside them as [group][scaffold][8] x 16 bit (t_s in the low 10 bits; above them the number of the scaffold's
+// dps with a value > t_s, 63 standing for "63 or more: count them").  A node is a set of whole scaffolds, so t_s -- the
 // (n_s / 2 + 1)-th smallest of the scaffold's own values -- is the same in every node: both tables are built once per
 // loaded table.  One 16-byte load brings a dp's values in 8 dimensions, and the dps of a scaffold are contiguous: the
 // scattered scaffolds of a node deep in the recursion cost 64 useful bytes per cache line instead of 16 (in the
@@ -153,8 +154,61 @@ static __device__ __forceinline__ void accum_group_tile(const NGroup& G, const u
     const int copies = 1 << lg, mine = threadIdx.x & (copies - 1);
     for (int i = threadIdx.x; i < (G.total << lg); i += 256) { s_size[i] = 0; s_tp1[i] = 0; s_tot[i] = 0; s_bp[i] = 0; }
     __syncthreads();
+    if (!list) {
+        // The tile is a RANGE of scaffold ids: its dps are one contiguous run, and with the flags and the counts above the flip
+        // value precomputed nothing a dp needs depends on its scaffold.  Two loops without a dependent load: a thread per dp
+        // (16-byte loads side by side), then a thread per scaffold for what lands on bin t_s.
+        const int4 r0 = srec[begin], r1 = srec[end - 1];
+        for (int dp = r0.x + (int)threadIdx.x; dp < r1.x + r1.y; dp += 256) {
+            const uint4 c = codes[dp];
+            const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (q < G.cnt) {
+                    const uint32_t code = (cw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                    const int at = ((G.loff[q] + (int)(code & 0x7FFFu)) << lg) + mine;
+                    atomicAdd(&s_size[at], 1u);
+                    if (code & 0x8000u) atomicAdd(&s_tp1[at], 1u);
+                }
+            }
+        }
+        for (int s = begin + (int)threadIdx.x; s < end; s += 256) {
+            const int4 rec = srec[s];
+            const uint4 t8 = tsv[s];
+            const int f = rec.x, n = rec.y;
+            const uint32_t tw[4] = {t8.x, t8.y, t8.z, t8.w};
+            const unsigned long long len = (unsigned long long)(uint32_t)rec.z | ((unsigned long long)(uint32_t)rec.w << 32);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (q < G.cnt) {
+                    const uint32_t e = (tw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                    const int ts = (int)(e & 0x3FFu);
+                    uint32_t gt = e >> 10;
+                    if (gt == 63u) {                                     // a long scaffold: count
+                        gt = 0;
+                        for (int i = 0; i < n; i++) {
+                            const uint4 c = codes[f + i];
+                            const uint32_t w = (q >> 1) == 0 ? c.x : (q >> 1) == 1 ? c.y : (q >> 1) == 2 ? c.z : c.w;
+                            gt += (w >> (16 * (q & 1) + 15)) & 1u;
+                        }
+                    }
+                    const int at = ((G.loff[q] + ts) << lg) + mine;
+                    atomicAdd(&s_tp1[at], (uint32_t)n - gt);
+                    atomicAdd(&s_tot[at], (uint32_t)n);
+                    atomicAdd(&s_bp[at], len);
+                    if (scg_lo && P.n_scg > 0) {
+                        for (int k = P.scg_off[s]; k < P.scg_off[s + 1]; k++) {
+                            const int g = P.scg_ids[k];
+                            atomicMin(&scg_lo[(int64_t)G.dim[q] * P.n_scg + g], ts);
+                            atomicMax(&scg_hi[(int64_t)G.dim[q] * P.n_scg + g], ts);
+                        }
+                    }
+                }
+            }
+        }
+    } else
     for (int ls = begin + threadIdx.x; ls < end; ls += 256) {
-        const int s = list ? list[ls] : ls;
+        const int s = list[ls];
         const int4 rec = srec[s];
         const uint4 t8 = tsv[s];
         const int f = rec.x, n = rec.y;
@@ -184,7 +238,7 @@ static __device__ __forceinline__ void accum_group_tile(const NGroup& G, const u
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             if (q < G.cnt) {
-                const int at = ((G.loff[q] + (int)((tw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu)) << lg) + mine;
+                const int at = ((G.loff[q] + (int)((tw[q >> 1] >> (16 * (q & 1))) & 0x3FFu)) << lg) + mine;
                 atomicAdd(&s_tp1[at], le[q]);
                 atomicAdd(&s_tot[at], (uint32_t)n);
                 atomicAdd(&s_bp[at], len);
@@ -196,7 +250,7 @@ static __device__ __forceinline__ void accum_group_tile(const NGroup& G, const u
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     if (q < G.cnt) {
-                        const int ts = (int)((tw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu);
+                        const int ts = (int)((tw[q >> 1] >> (16 * (q & 1))) & 0x3FFu);
                         atomicMin(&scg_lo[(int64_t)G.dim[q] * P.n_scg + g], ts);
                         atomicMax(&scg_hi[(int64_t)G.dim[q] * P.n_scg + g], ts);
                     }

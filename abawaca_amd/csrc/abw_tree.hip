@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void tree_scg_kernel(TreeDev Tr, const int32_t
     const int k = scaf_slot[s];
     if (k < 0 || k >= K) return;                              // no node, or a node the cut work list does not reach
     const int slot = Tr.dim_slot[d];
-    const int ts = slot >= 0 ? (int)reinterpret_cast<const uint16_t*>(Tr.ts8)[((int64_t)(slot >> 3) * Tr.S + s) * 8 + (slot & 7)]
+    const int ts = slot >= 0 ? (int)(reinterpret_cast<const uint16_t*>(Tr.ts8)[((int64_t)(slot >> 3) * Tr.S + s) * 8 + (slot & 7)] & 0x3FFu)
                              : (int)Tr.wext[(int64_t)(-slot - 1) * Tr.S + s].w;
     const int64_t sg = ((int64_t)k * Tr.D + d) * Tr.P.n_scg;
     for (int e = Tr.P.scg_off[s]; e < Tr.P.scg_off[s + 1]; e++) {
@@ -907,7 +907,10 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
                 ABW_LAUNCH_CHECK(ctx);
             }
             if (n_at) {
-                hipLaunchKernelGGL(tree_accum_kernel, dim3((unsigned)n_at, (unsigned)n_groups), dim3(256), 0, st, Tr, d_atiles, (const int32_t*)order[cur], c_st, c_bp, c_tot);
+                // level 0 holds all scaffolds in id order: no list (accum_group_tile then takes its tiles as ranges of ids)
+                const bool identity = (K == 1 && level[0].parent < 0);
+                hipLaunchKernelGGL(tree_accum_kernel, dim3((unsigned)n_at, (unsigned)n_groups), dim3(256), 0, st, Tr, d_atiles,
+                                   identity ? (const int32_t*)nullptr : (const int32_t*)order[cur], c_st, c_bp, c_tot);
                 ABW_LAUNCH_CHECK(ctx);
             }
             if (!subs.empty()) {

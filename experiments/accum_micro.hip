@@ -87,19 +87,20 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const dim3 grid((m + tile - 1) / tile, ng);
     const char* names[4] = {"full", "no LDS atomics (loads only)", "no flush", "loads only"};
+    for (int use_list = (stride == 1 ? 0 : 1); use_list < 2; use_list++)
     for (int mode : {0, 2, 3}) {
         float best = 1e9f;
         for (int rep = 0; rep < 6; rep++) {
             CK(hipEventRecord(e0));
-            if (mode == 0) hipLaunchKernelGGL(k_accum<0>, grid, dim3(256), 0, 0, d_groups, d_nk, d_ts, d_srec, S, N, stride == 1 ? nullptr : d_list, m, tile, d_st, d_bp, d_tot, goff, d_sink);
-            if (mode == 2) hipLaunchKernelGGL(k_accum<2>, grid, dim3(256), 0, 0, d_groups, d_nk, d_ts, d_srec, S, N, stride == 1 ? nullptr : d_list, m, tile, d_st, d_bp, d_tot, goff, d_sink);
-            if (mode == 3) hipLaunchKernelGGL(k_accum<3>, grid, dim3(256), 0, 0, d_groups, d_nk, d_ts, d_srec, S, N, stride == 1 ? nullptr : d_list, m, tile, d_st, d_bp, d_tot, goff, d_sink);
+            if (mode == 0) hipLaunchKernelGGL(k_accum<0>, grid, dim3(256), 0, 0, d_groups, d_nk, d_ts, d_srec, S, N, (use_list ? d_list : nullptr), m, tile, d_st, d_bp, d_tot, goff, d_sink);
+            if (mode == 2) hipLaunchKernelGGL(k_accum<2>, grid, dim3(256), 0, 0, d_groups, d_nk, d_ts, d_srec, S, N, (use_list ? d_list : nullptr), m, tile, d_st, d_bp, d_tot, goff, d_sink);
+            if (mode == 3) hipLaunchKernelGGL(k_accum<3>, grid, dim3(256), 0, 0, d_groups, d_nk, d_ts, d_srec, S, N, (use_list ? d_list : nullptr), m, tile, d_st, d_bp, d_tot, goff, d_sink);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) best = std::min(best, ms);
         }
         int64_t dps = 0; for (int s : list) dps += srec[s].y;
-        printf("tile %4d %-30s %8.1f us   (%d scaffolds of %d, %lld dps, %d groups, %.2f TB/s of 16-byte codes)\n", tile, names[mode], best * 1e3, m, S, (long long)dps, ng,
+        printf("%s tile %4d %-30s %8.1f us   (%d scaffolds of %d, %lld dps, %d groups, %.2f TB/s of 16-byte codes)\n", use_list ? "list " : "range", tile, names[mode], best * 1e3, m, S, (long long)dps, ng,
                dps * 16.0 * ng / (best * 1e-3) / 1e12);
     }
     return 0;
