@@ -24,6 +24,7 @@ EXPORTS = [
     "abw_km_features_from_keys", "abw_km_tinymt_selftest", "abw_km_auto_chunk",
     "abw_cov_accumulate", "abw_cov_accumulate_dev", "abw_km_load", "abw_km_node", "abw_lrn_header", "abw_lrn_parse", "abw_lrn_emit", "abw_lrn_emit_rows", "abw_lrn_emit_rows_dev", "abw_lrn_table_load",
     "abw_sep_shard_load", "abw_sep_shard_accum", "abw_sep_shard_eval", "abw_sep_shard_decide", "abw_sep_shard_combine", "abw_device_count",
+    "abw_sep_tree_begin", "abw_sep_tree_eval", "abw_sep_tree_assign", "abw_sep_tree_advance", "abw_sep_tree_result", "abw_sep_tree_merge",
     "abw_km_shard_begin", "abw_km_shard_ready", "abw_km_shard_step", "abw_km_shard_update", "abw_km_shard_finish",
 ]
 
@@ -95,6 +96,12 @@ def lib():
     L.abw_sep_shard_decide.argtypes = [C.POINTER(Split), i64, i64, i32]
     L.abw_sep_shard_combine.argtypes = [C.POINTER(vp), i32]
     L.abw_device_count.argtypes = [C.POINTER(i32)]
+    L.abw_sep_tree_begin.argtypes = [vp, i32, i64]
+    L.abw_sep_tree_eval.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    L.abw_sep_tree_assign.argtypes = [vp, vp, i64, C.POINTER(vp), C.POINTER(i64)]
+    L.abw_sep_tree_advance.argtypes = [vp]
+    L.abw_sep_tree_result.argtypes = [vp, vp, i64, C.POINTER(i64), vp]
+    L.abw_sep_tree_merge.argtypes = [vp, i32, i64, vp, vp]
     L.abw_sep_dev_keys.restype = vp
     L.abw_km_run_dev.argtypes = [vp, vp, i64, i32, i32, u32, i32, i32, vp, vp, vp]
     L.abw_km_run.argtypes = [vp, vp, i64, i32, i32, u32, i32, i32, vp, vp, vp]

@@ -660,6 +660,7 @@ extern "C" void abw_sep_free(abw_ctx* ctx)
                      e->h.d_chunk_sums, e->h.d_dim_total, e->h.d_chunk_best, e->h.d_sscaf, e->h.d_sbin, e->h.d_sdp,
                      e->h.d_wts, e->h.d_wbelow, e->h.d_range, e->h.d_groups, e->h.d_nsort, e->h.d_toffn, e->h.d_dim_slot, e->h.d_ts8, e->h.d_nk16, e->h.d_srec, e->h.d_wword, e->h.d_wext, e->h.d_wpack, e->h.d_carriers};
         for (void* p : q) if (p) (void)hipFree(p);
+        abw_tree_run_free(e->h.tree_run);
         delete e;
     }
 }

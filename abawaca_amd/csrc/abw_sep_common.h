@@ -111,12 +111,14 @@ struct SepHost {
     uint32_t* d_wpack = nullptr;       // [n_wide][S] the first three of d_wext in one word (scaffolds of <= 127 dps), else all ones
     int32_t* d_carriers = nullptr;     // scaffolds that carry at least one SCG
     int32_t n_carriers = 0;
+    void* tree_run = nullptr;          // the recursion in progress (abw_sep_tree_begin .. abw_sep_tree_result; abw_tree.hip)
     bool sharded = false;              // table loaded with a shared bin layout (abw_sep_shard_load)
 };
 
 
 struct abw_sep_extra { SepHost h; };
 SepHost& abw_sep_host(abw_ctx* ctx);     // abw_sep.hip
+void abw_tree_run_free(void* run);       // abw_tree.hip
 
 // sorts the 8 ints x[0..8) ascending in place (Batcher's 19-comparator network; unused slots padded with INT_MAX)
 #define ABW_CX8(x, a, b) { const int lo_ = min(x[a], x[b]), hi_ = max(x[a], x[b]); x[a] = lo_; x[b] = hi_; }

@@ -545,16 +545,14 @@ __global__ __launch_bounds__(64) void tree_winner_kernel(TreeDev Tr, const NodeD
 }
 
 // ---- scaffold sides (ref ClusterSeparator.cpp:35-53,94-122): cluster1 = the raw side with fewer dps (tie: the "<=" side), a
-// scaffold goes to cluster1 iff at least half of its dps are there.  grid (scaffold tiles)
+// scaffold goes to cluster1 iff at least half of its dps are there.  Only the nodes whose winner is THIS context's
+// (res.win.legal set by the host: a legal winner in one of its dimensions) are assigned here.  grid (scaffold tiles)
 __global__ __launch_bounds__(256) void tree_assign_kernel(TreeDev Tr, const Tile* __restrict__ tiles, const int32_t* __restrict__ order,
-                                                         NodeRes* __restrict__ res, uint8_t* __restrict__ scaf_side)
+                                                         const NodeRes* __restrict__ res, uint8_t* __restrict__ scaf_side)
 {
-    __shared__ unsigned long long b[4];
     const Tile t = tiles[blockIdx.x];
     const GlobalRes win = res[t.node].win;
-    if (!win.legal) return;                                   // uniform for the tile: nothing to reconstruct (ref :27-28)
-    if (threadIdx.x < 4) b[threadIdx.x] = 0;
-    __syncthreads();
+    if (!win.legal) return;                                   // uniform for the tile: nothing to reconstruct (ref :27-28), or not mine
     const bool swap = win.n - win.size1 < win.size1;
     const int32_t* __restrict__ col = Tr.P.bins + (int64_t)win.dim * Tr.P.N;
     for (int ls = t.begin + threadIdx.x; ls < t.end; ls += 256) {
@@ -563,11 +561,28 @@ __global__ __launch_bounds__(256) void tree_assign_kernel(TreeDev Tr, const Tile
         int c = 0;
         for (int i = 0; i < tot; i++) c += col[f + i] <= win.bin;
         const int c1 = swap ? tot - c : c;
-        const bool to1 = c1 > 0 && 2 * (long long)c1 >= tot;
-        scaf_side[s] = to1 ? 1 : 2;
-        atomicAdd(&b[to1 ? 0 : 1], (unsigned long long)tot);
-        atomicAdd(&b[to1 ? 2 : 3], 1ull);
+        scaf_side[s] = (c1 > 0 && 2 * (long long)c1 >= tot) ? 1 : 2;
     }
+}
+
+// the children's sizes from the (combined) sides: dps and scaffolds sent to cluster1 / cluster2.  grid (scaffold tiles)
+__global__ __launch_bounds__(256) void tree_count_kernel(TreeDev Tr, const Tile* __restrict__ tiles, const int32_t* __restrict__ order,
+                                                        const uint8_t* __restrict__ scaf_side, NodeRes* __restrict__ res)
+{
+    __shared__ unsigned long long b[4];
+    const Tile t = tiles[blockIdx.x];
+    if (threadIdx.x < 4) b[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long n1 = 0, n2 = 0, m1 = 0, m2 = 0;
+    for (int ls = t.begin + threadIdx.x; ls < t.end; ls += 256) {
+        const int s = order[ls];
+        const uint8_t sd = scaf_side[s];
+        const unsigned long long tot = (unsigned long long)Tr.P.scaf_ndps[s];
+        if (sd == 1) { n1 += tot; m1++; } else if (sd == 2) { n2 += tot; m2++; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { n1 += __shfl_xor(n1, o, 64); n2 += __shfl_xor(n2, o, 64); m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&b[0], n1); atomicAdd(&b[1], n2); atomicAdd(&b[2], m1); atomicAdd(&b[3], m2); }
     __syncthreads();
     if (threadIdx.x == 0) {
         if (b[0]) atomicAdd(&res[t.node].n1, b[0]);
@@ -728,33 +743,68 @@ int tree_static_build(abw_ctx* ctx, SepHost& H, const SepDev& P, const int32_t* 
     return ABW_OK;
 }
 
-}  // namespace
+// ---- the recursion as a sequence of levels that a caller can interleave with an exchange ------------------------------
+// node of a level: id, size, and where its histogram comes from
+struct HostNode { int32_t id; int32_t m; int64_t n; int32_t parent; };      // parent: its slot in the previous level (-1: the root)
 
-extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, abw_tree_node* nodes_out, int64_t node_cap,
-                            int64_t* n_nodes, int32_t* scaf2cluster)
+struct TreeRun {
+    abw_ctx* ctx = nullptr;
+    int32_t min_ndps = 0;
+    int64_t max_nodes = 0, visited = 0;
+    int32_t next_id = 2;
+    int cur = 0;
+    int phase = 0;                       // 0: a level waits for eval, 1: for assign, 2: for advance, 3: the recursion is over
+    std::vector<HostNode> level;
+    std::vector<abw_tree_node> nodes;
+    std::vector<abw_tree_winner> final_winners;
+    TreeDev Tr;
+    // sizes and strides
+    int32_t D = 0, S = 0, n_narrow = 0, n_wide = 0, n_groups = 0;
+    int64_t N = 0, Np = 0, Sp = 0, TBn = 1;
+    // whole-call device arrays
+    uint32_t* order[2] = {nullptr, nullptr};
+    int32_t* wbin[2] = {nullptr, nullptr};
+    uint32_t* wword[2] = {nullptr, nullptr};
+    uint8_t* d_scaf_side = nullptr;
+    int32_t* d_scaf_slot = nullptr;
+    // the level in flight
+    int32_t K = 0, n_st = 0, n_pt = 0;
+    size_t o_res = 0, o_part = 0;
+    const NodeDev* d_nodes = nullptr;
+    const Tile *d_stiles = nullptr, *d_ptiles = nullptr;
+    NodeRes* d_res = nullptr;
+    NodePart* d_part = nullptr;
+    uint32_t *d_pcnt = nullptr, *d_scnt = nullptr;
+    uint8_t *d_pmask = nullptr, *d_smask = nullptr;
+
+    int32_t key_of(int32_t d, int32_t bin) const
+    {
+        const abw_sep_state& s = ctx->sep;
+        return s.h_binval_off[d] < 0 ? bin : s.h_binval[(size_t)s.h_binval_off[d] + bin];
+    }
+    int begin(int32_t min_ndps_, int64_t max_nodes_);
+    int eval(abw_tree_winner* best, int64_t cap, int64_t* n_level);
+    int assign(const abw_tree_winner* winners, int64_t n);
+    int advance();
+};
+
+int TreeRun::begin(int32_t min_ndps_, int64_t max_nodes_)
 {
-    if (!ctx) return ABW_ERR_ARG;
     abw_sep_state& s = ctx->sep;
-    if (!s.loaded) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_tree: call abw_sep_load first");
-    if (!n_nodes || (node_cap > 0 && !nodes_out) || min_ndps < 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree: bad argument");
     SepHost& H = abw_sep_host(ctx);
-    if (H.sharded) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_tree: the table is one shard of a sharded problem (abw_sep_shard_load); use abw_sep_shard_*");
-    abw_device_guard g(ctx->device);
     hipStream_t st = ctx->stream;
-    *n_nodes = 0;
-    if (max_nodes <= 0) max_nodes = INT64_MAX;
+    min_ndps = min_ndps_;
+    max_nodes = max_nodes_ <= 0 ? INT64_MAX : max_nodes_;
     int rc;
-    const int32_t D = s.D, S = s.S, n_narrow = (int32_t)H.narrow_dims.size(), n_wide = (int32_t)H.wide_dims.size();
-    const int64_t N = s.N, Np = (N + 7) & ~(int64_t)7, Sp = ((int64_t)S + 7) & ~(int64_t)7;      // strides of the position / scaffold arrays
+    D = s.D; S = s.S; n_narrow = (int32_t)H.narrow_dims.size(); n_wide = (int32_t)H.wide_dims.size();
+    N = s.N; Np = (N + 7) & ~(int64_t)7; Sp = ((int64_t)S + 7) & ~(int64_t)7;      // strides of the position / scaffold arrays
     if (S > (int32_t)W_SC) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree: more than 2^30 scaffolds");
+    n_groups = (int32_t)H.groups.size();
+    TBn = std::max<int64_t>(1, n_narrow ? H.toffn[n_narrow] : 0);      // a node's slice: the narrow dimensions in H.nsort order
 
-    const int32_t n_groups = (int32_t)H.groups.size();
-    const int64_t TBn = std::max<int64_t>(1, n_narrow ? H.toffn[n_narrow] : 0);      // a node's slice: the narrow dimensions in H.nsort order
-
-    // buffers of the call (grow-only scratch of the context: scratch is free between entry points)
+    // buffers of the run (grow-only scratch of the context: no other entry point may run on the context until the run is over)
     abw_devbuf &b_order = ctx->scratch[0], &b_wbin = ctx->scratch[1], &b_wword = ctx->scratch[2], &b_side = ctx->scratch[4],
-               &b_scg = ctx->scratch[5], &b_lvl = ctx->scratch[6], &b_tile = ctx->scratch[7], &b_misc = ctx->scratch[8], &b_s2c = ctx->scratch[9];
-    abw_devbuf* b_hist[2] = {&ctx->scratch[10], &ctx->scratch[11]};
+               &b_misc = ctx->scratch[8], &b_s2c = ctx->scratch[9];
     if ((rc = abw_reserve(ctx, b_order, (size_t)2 * Sp * 4))) return rc;
     if ((rc = abw_reserve(ctx, b_side, (size_t)S + 64 + (size_t)S * 4))) return rc;
     if ((rc = abw_reserve(ctx, b_s2c, (size_t)S * 4))) return rc;
@@ -765,7 +815,6 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
     if ((rc = abw_reserve(ctx, b_misc, (size_t)N * 4 + 64))) return rc;
     int32_t* d_dp2scaf = (int32_t*)b_misc.p;
 
-    TreeDev Tr;
     Tr.P.bins = s.d_bins ? s.d_bins : s.d_keys; Tr.P.N = N;
     Tr.P.scaf_first = s.d_scaf_first; Tr.P.scaf_ndps = s.d_scaf_ndps; Tr.P.scaf_len = s.d_scaf_len;
     Tr.P.scg_off = s.d_scg_off; Tr.P.scg_ids = s.d_scg_ids; Tr.P.n_scg = s.n_scg;
@@ -784,11 +833,11 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
     Tr.wide = H.d_wide; Tr.n_wide = n_wide; Tr.dp2scaf = d_dp2scaf; Tr.dim_slot = H.d_dim_slot;
     Tr.wext = (const uint4*)H.d_wext; Tr.wpack = H.d_wpack; Tr.D = D; Tr.S = S;
 
-    uint32_t* order[2] = {(uint32_t*)b_order.p, (uint32_t*)b_order.p + Sp};
-    int32_t* wbin[2] = {(int32_t*)b_wbin.p, n_wide ? (int32_t*)b_wbin.p + (int64_t)n_wide * Np : nullptr};
-    uint32_t* wword[2] = {(uint32_t*)b_wword.p, n_wide ? (uint32_t*)b_wword.p + (int64_t)n_wide * Np : nullptr};
-    uint8_t* d_scaf_side = (uint8_t*)b_side.p;
-    int32_t* d_scaf_slot = (int32_t*)((uint8_t*)b_side.p + (((size_t)S + 63) & ~(size_t)63));
+    order[0] = (uint32_t*)b_order.p; order[1] = (uint32_t*)b_order.p + Sp;
+    wbin[0] = (int32_t*)b_wbin.p; wbin[1] = n_wide ? (int32_t*)b_wbin.p + (int64_t)n_wide * Np : nullptr;
+    wword[0] = (uint32_t*)b_wword.p; wword[1] = n_wide ? (uint32_t*)b_wword.p + (int64_t)n_wide * Np : nullptr;
+    d_scaf_side = (uint8_t*)b_side.p;
+    d_scaf_slot = (int32_t*)((uint8_t*)b_side.p + (((size_t)S + 63) & ~(size_t)63));
     hipLaunchKernelGGL(tree_iota_kernel, dim3(ctx->num_cu * 4), dim3(256), 0, st, order[0], S);
     ABW_LAUNCH_CHECK(ctx);
     ABW_HIP(ctx, hipMemsetAsync(d_scaf_slot, 0, (size_t)S * 4, st));          // every scaffold starts in node slot 0 (the root)
@@ -797,222 +846,411 @@ extern "C" int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, a
         ABW_HIP(ctx, hipMemcpy2DAsync(wbin[0], (size_t)Np * 4, H.d_sbin, (size_t)N * 4, (size_t)N * 4, (size_t)n_wide, hipMemcpyDeviceToDevice, st));
         ABW_HIP(ctx, hipMemcpyAsync(wword[0], H.d_wword, (size_t)n_wide * Np * 4, hipMemcpyDeviceToDevice, st));
     }
-
-    // node of a level: id, size, and where its histogram comes from
-    struct HostNode { int32_t id; int32_t m; int64_t n; int32_t parent; };      // parent: its slot in the previous level (-1: the root)
-    std::vector<HostNode> level{{1, S, N, -1}};
-    int32_t next_id = 2;
-    int64_t visited = 0;
-    int cur = 0;
-    auto key_of = [&](int32_t d, int32_t bin) -> int32_t {
-        return s.h_binval_off[d] < 0 ? bin : s.h_binval[(size_t)s.h_binval_off[d] + bin];
-    };
-
-    while (!level.empty() && visited < max_nodes) {
-        if ((int64_t)level.size() > max_nodes - visited) level.resize((size_t)(max_nodes - visited));   // the work list is cut in id order
-        const int32_t K = (int32_t)level.size();
-        // ---- node table, tiles, and the plan for the histograms of this level
-        std::vector<NodeDev> nd((size_t)K);
-        std::vector<Tile> stiles, ptiles, atiles;
-        std::vector<int32_t> zero_slots;
-        std::vector<SubJob> subs;
-        int32_t sb = 0, pb = 0;
-        for (int32_t k = 0; k < K; k++) {
-            nd[k].scaf_begin = sb; nd[k].scaf_end = sb + level[k].m;
-            nd[k].dp_begin = pb; nd[k].dp_end = pb + (int32_t)level[k].n;
-            make_tiles(stiles, k, nd[k].scaf_begin, nd[k].scaf_end, TILE_S, nd[k].stile_begin, nd[k].stile_end);
-            make_tiles(ptiles, k, nd[k].dp_begin, nd[k].dp_end, TILE_P, nd[k].ptile_begin, nd[k].ptile_end);
-            sb += level[k].m; pb += (int32_t)level[k].n;
-        }
-        // children come in pairs (2j, 2j + 1) of one parent: the smaller is accumulated, the bigger subtracted; a node without
-        // its sibling in this (cut) level, and the root, are accumulated
-        for (int32_t k = 0; k < K; k++) {
-            const int32_t sib = (level[k].parent >= 0) ? (k ^ 1) : -1;
-            const bool has_sib = sib >= 0 && sib < K && level[sib].parent == level[k].parent;
-            const bool bigger = has_sib && (level[k].n > level[sib].n || (level[k].n == level[sib].n && k > sib));
-            if (bigger) subs.push_back(SubJob{k, level[k].parent, sib});
-            else {
-                zero_slots.push_back(k);
-                int32_t tb, te;
-                make_tiles(atiles, k, nd[k].scaf_begin, nd[k].scaf_end, TILE_A, tb, te);
-            }
-        }
-        const int32_t n_st = (int32_t)stiles.size(), n_pt = (int32_t)ptiles.size(), n_at = (int32_t)atiles.size();
-        std::vector<uint8_t> blob;
-        const size_t o_nodes = pack(blob, nd), o_st = pack(blob, stiles), o_pt = pack(blob, ptiles), o_at = pack(blob, atiles),
-                     o_zero = pack(blob, zero_slots), o_sub = pack(blob, subs);
-        const size_t lvl_bytes = (blob.size() + 63) & ~(size_t)63;
-        const size_t o_res = lvl_bytes, o_part = o_res + (((size_t)K * sizeof(NodeRes) + 63) & ~(size_t)63), all_bytes = o_part + (size_t)K * sizeof(NodePart) + 64;
-        if ((rc = abw_reserve(ctx, b_lvl, all_bytes))) return rc;
-        if ((rc = abw_reserve_pinned(ctx, all_bytes))) return rc;
-        uint8_t* hp = (uint8_t*)ctx->pinned;
-        memcpy(hp, blob.data(), blob.size());
-        ABW_HIP(ctx, hipMemcpyAsync(b_lvl.p, hp, lvl_bytes, hipMemcpyHostToDevice, st));
-        uint8_t* dl = (uint8_t*)b_lvl.p;
-        const NodeDev* d_nodes = (const NodeDev*)(dl + o_nodes);
-        const Tile* d_stiles = (const Tile*)(dl + o_st);
-        const Tile* d_ptiles = (const Tile*)(dl + o_pt);
-        const Tile* d_atiles = (const Tile*)(dl + o_at);
-        const int32_t* d_zero = (const int32_t*)(dl + o_zero);
-        const SubJob* d_subs = (const SubJob*)(dl + o_sub);
-        NodeRes* d_res = (NodeRes*)(dl + o_res);
-        NodePart* d_part = (NodePart*)(dl + o_part);
-
-        // per-level buffers: SCG lo / hi, candidates, tile sums / bests / counts
-        const int64_t scg_n = (int64_t)K * D * s.n_scg;
-        if ((rc = abw_reserve(ctx, b_scg, (size_t)std::max<int64_t>(1, scg_n) * 8))) return rc;
-        int32_t* d_scg_lo = (int32_t*)b_scg.p; int32_t* d_scg_hi = d_scg_lo + scg_n;
-        const size_t t_cand = ((size_t)K * D * sizeof(Cand) + 63) & ~(size_t)63,
-                     t_sums = ((size_t)std::max(1, n_wide) * n_pt * sizeof(WSums) + 63) & ~(size_t)63,
-                     t_best = ((size_t)std::max(1, n_wide) * n_pt * sizeof(Cand) + 63) & ~(size_t)63,
-                     t_tot = ((size_t)std::max(1, n_wide) * K * sizeof(WSums) + 63) & ~(size_t)63,
-                     t_cnt = ((size_t)(std::max(1, n_wide) * (size_t)n_pt + n_st) * 4 + 63) & ~(size_t)63,
-                     t_mask = (((size_t)std::max(1, n_wide) * n_pt + n_st) * 256 + 63) & ~(size_t)63;
-        if ((rc = abw_reserve(ctx, b_tile, t_cand + t_sums + t_best + t_tot + t_cnt + t_mask + (size_t)K * 8))) return rc;
-        Cand* d_cand = (Cand*)b_tile.p;
-        WSums* d_tsums = (WSums*)((uint8_t*)b_tile.p + t_cand);
-        Cand* d_tbest = (Cand*)((uint8_t*)b_tile.p + t_cand + t_sums);
-        WSums* d_ntot = (WSums*)((uint8_t*)b_tile.p + t_cand + t_sums + t_best);
-        uint32_t* d_pcnt = (uint32_t*)((uint8_t*)b_tile.p + t_cand + t_sums + t_best + t_tot);
-        uint32_t* d_scnt = d_pcnt + (size_t)std::max(1, n_wide) * n_pt;
-        uint8_t* d_pmask = (uint8_t*)b_tile.p + t_cand + t_sums + t_best + t_tot + t_cnt;
-        uint8_t* d_smask = d_pmask + (size_t)std::max(1, n_wide) * n_pt * 256;
-        double* d_bar = (double*)(d_pmask + t_mask);
-        if (scg_n > 0) {
-            hipLaunchKernelGGL(tree_scg_reset_kernel, dim3((unsigned)std::min<int64_t>((scg_n + 255) / 256, ctx->num_cu * 8)), dim3(256), 0, st, d_scg_lo, d_scg_hi, scg_n);
-            ABW_LAUNCH_CHECK(ctx);
-            if (H.n_carriers > 0) {
-                const int64_t work = (int64_t)H.n_carriers * D;
-                hipLaunchKernelGGL(tree_scg_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, Tr, H.d_carriers, H.n_carriers, d_scaf_slot, K, d_scg_lo, d_scg_hi);
-                ABW_LAUNCH_CHECK(ctx);
-            }
-        }
-
-        // ---- narrow dimensions: this level's slices (pool cur) from the table or from the parents' slices (pool cur ^ 1)
-        if (n_narrow) {
-            const size_t slice = (size_t)TBn * 20;
-            if ((size_t)K * slice > ((size_t)48 << 30)) return abw_fail(ctx, ABW_ERR_NOMEM, "abw_sep_tree: %d nodes in one level need %zu bytes of histograms", K, (size_t)K * slice);
-            if ((rc = abw_reserve(ctx, *b_hist[cur], (size_t)K * slice + 64))) return rc;
-            const int64_t capc = (int64_t)((b_hist[cur]->cap - 64) / slice), capp = b_hist[cur ^ 1]->cap > 64 ? (int64_t)((b_hist[cur ^ 1]->cap - 64) / slice) : 0;
-            unsigned long long* c_st = (unsigned long long*)b_hist[cur]->p;
-            unsigned long long* c_bp = c_st + capc * TBn;
-            uint32_t* c_tot = (uint32_t*)(c_bp + capc * TBn);
-            const unsigned long long* p_st = (const unsigned long long*)b_hist[cur ^ 1]->p;
-            const unsigned long long* p_bp = p_st ? p_st + capp * TBn : nullptr;
-            const uint32_t* p_tot = p_st ? (const uint32_t*)(p_bp + capp * TBn) : nullptr;
-            const unsigned gy = (unsigned)((TBn + 1023) / 1024);
-            ABW_PROF(ctx, "sep_accum");
-            if (!zero_slots.empty()) {
-                hipLaunchKernelGGL(tree_zero_kernel, dim3((unsigned)zero_slots.size(), gy), dim3(256), 0, st, d_zero, TBn, c_st, c_bp, c_tot);
-                ABW_LAUNCH_CHECK(ctx);
-            }
-            if (n_at) {
-                // level 0 holds all scaffolds in id order: no list (accum_group_tile then takes its tiles as ranges of ids)
-                const bool identity = (K == 1 && level[0].parent < 0);
-                hipLaunchKernelGGL(tree_accum_kernel, dim3((unsigned)n_at, (unsigned)n_groups), dim3(256), 0, st, Tr, d_atiles,
-                                   identity ? (const int32_t*)nullptr : (const int32_t*)order[cur], c_st, c_bp, c_tot);
-                ABW_LAUNCH_CHECK(ctx);
-            }
-            if (!subs.empty()) {
-                hipLaunchKernelGGL(tree_sub_kernel, dim3((unsigned)subs.size(), gy), dim3(256), 0, st, d_subs, TBn, c_st, c_bp, c_tot, p_st, p_bp, p_tot);
-                ABW_LAUNCH_CHECK(ctx);
-            }
-            hipLaunchKernelGGL(tree_eval_narrow_kernel, dim3((unsigned)K, (unsigned)n_narrow), dim3(256), 0, st, Tr, d_nodes, min_ndps,
-                               (const unsigned long long*)c_st, (const unsigned long long*)c_bp, (const uint32_t*)c_tot, d_scg_lo, d_scg_hi, d_cand);
-            ABW_LAUNCH_CHECK(ctx);
-        }
-        // ---- wide dimensions: prefix sums along every node's sorted segment
-        if (n_wide) {
-            ABW_PROF(ctx, "sep_wide");
-            hipLaunchKernelGGL(tree_bar_kernel, dim3((unsigned)K), dim3(64), 0, st, Tr, d_cand, d_bar);
-            ABW_LAUNCH_CHECK(ctx);
-            hipLaunchKernelGGL(tree_wide_sums_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, wword[cur], Np, d_tsums);
-            ABW_LAUNCH_CHECK(ctx);
-            hipLaunchKernelGGL(tree_wide_scan_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, d_nodes, n_pt, d_tsums, d_ntot, K);
-            ABW_LAUNCH_CHECK(ctx);
-            hipLaunchKernelGGL(tree_wide_eval_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, d_nodes, K, min_ndps,
-                               wbin[cur], wword[cur], Np, d_tsums, d_ntot, d_scg_lo, d_scg_hi, d_bar, d_tbest);
-            ABW_LAUNCH_CHECK(ctx);
-            hipLaunchKernelGGL(tree_wide_best_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, Tr, d_nodes, n_pt, d_tbest, d_cand);
-            ABW_LAUNCH_CHECK(ctx);
-        }
-        // ---- winners, sides, read-back
-        {
-            ABW_PROF(ctx, "sep_eval");
-            hipLaunchKernelGGL(tree_winner_kernel, dim3((unsigned)K), dim3(64), 0, st, Tr, d_nodes, d_cand, d_res);
-            ABW_LAUNCH_CHECK(ctx);
-            hipLaunchKernelGGL(tree_assign_kernel, dim3((unsigned)n_st), dim3(256), 0, st, Tr, d_stiles, (const int32_t*)order[cur], d_res, d_scaf_side);
-            ABW_LAUNCH_CHECK(ctx);
-        }
-        NodeRes* h_res = (NodeRes*)(hp + o_res);
-        ABW_HIP(ctx, hipMemcpyAsync(h_res, d_res, (size_t)K * sizeof(NodeRes), hipMemcpyDeviceToHost, st));
-        ABW_HIP(ctx, hipStreamSynchronize(st));
-
-        // ---- the level's verdicts (ref ClusterSeparator.cpp:125-132) and the next level
-        std::vector<HostNode> next;
-        NodePart* h_part = (NodePart*)(hp + o_part);
-        int32_t nsb = 0, npb = 0;
-        for (int32_t k = 0; k < K; k++) {
-            const NodeRes& r = h_res[k];
-            abw_tree_node o;
-            memset(&o, 0, sizeof(o));
-            o.id = level[k].id; o.ndps = level[k].n; o.n_scaf = level[k].m; o.dimension = -1; o.key = -1;
-            bool split = false;
-            if (r.win.found) {
-                o.dimension = r.win.dim + 1; o.key = key_of(r.win.dim, r.win.bin);
-                o.sensitivity = r.win.sens; o.specificity = r.win.spec; o.legal = r.win.legal;
-                if (r.win.legal) {
-                    split = (int64_t)r.n1 >= min_ndps && (int64_t)r.n2 >= min_ndps;
-                    if (!split) { o.dimension = -1; o.key = -1; o.sensitivity = 0; o.specificity = 0; }      // best_separation->reset(), ref :130
-                }
-            }
-            NodePart& np = h_part[k];
-            memset(&np, 0, sizeof(np));
-            np.split = split; np.id = o.id; np.slot1 = np.slot2 = -1;
-            if (split) {
-                o.split = 1; o.child1 = next_id; o.child2 = next_id + 1; o.ndps1 = (int64_t)r.n1; o.ndps2 = (int64_t)r.n2;
-                next_id += 2;
-                np.scaf_base1 = nsb; np.scaf_base2 = nsb + (int32_t)r.m1;
-                np.dp_base1 = npb; np.dp_base2 = npb + (int32_t)r.n1;
-                np.slot1 = (int32_t)next.size(); np.slot2 = np.slot1 + 1;
-                nsb += (int32_t)(r.m1 + r.m2); npb += (int32_t)(r.n1 + r.n2);
-                next.push_back(HostNode{o.child1, (int32_t)r.m1, (int64_t)r.n1, k});
-                next.push_back(HostNode{o.child2, (int32_t)r.m2, (int64_t)r.n2, k});
-            }
-            if (visited < node_cap) nodes_out[visited] = o;
-            visited++;
-        }
-        // ---- partition into the next level's order (terminal nodes' scaffolds get their cluster id)
-        ABW_HIP(ctx, hipMemcpyAsync(d_part, h_part, (size_t)K * sizeof(NodePart), hipMemcpyHostToDevice, st));
-        {
-            ABW_PROF(ctx, "sep_partition");
-            hipLaunchKernelGGL(tree_part_count_kernel, dim3((unsigned)n_st, 1), dim3(256), 0, st, d_stiles, n_st, d_part, (const uint32_t*)order[cur], (int64_t)0, d_scaf_side, d_scnt, d_smask);
-            ABW_LAUNCH_CHECK(ctx);
-            hipLaunchKernelGGL(tree_part_scan_kernel, dim3((unsigned)K, 1), dim3(64), 0, st, d_nodes, d_part, n_st, d_scnt, 1);
-            ABW_LAUNCH_CHECK(ctx);
-            hipLaunchKernelGGL(tree_part_scatter_kernel, dim3((unsigned)n_st, 1), dim3(256), 0, st, d_stiles, n_st, d_nodes, d_part, (const uint32_t*)order[cur],
-                               (const int32_t*)nullptr, (int64_t)0, d_smask, d_scnt, order[cur ^ 1], (int32_t*)nullptr, 1, (int32_t*)b_s2c.p, d_scaf_slot);
-            ABW_LAUNCH_CHECK(ctx);
-            if (n_wide && !next.empty()) {
-                hipLaunchKernelGGL(tree_part_count_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, d_ptiles, n_pt, d_part, (const uint32_t*)wword[cur], Np, d_scaf_side, d_pcnt, d_pmask);
-                ABW_LAUNCH_CHECK(ctx);
-                hipLaunchKernelGGL(tree_part_scan_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, d_nodes, d_part, n_pt, d_pcnt, 0);
-                ABW_LAUNCH_CHECK(ctx);
-                hipLaunchKernelGGL(tree_part_scatter_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, d_ptiles, n_pt, d_nodes, d_part, (const uint32_t*)wword[cur],
-                                   (const int32_t*)wbin[cur], Np, d_pmask, d_pcnt, wword[cur ^ 1], wbin[cur ^ 1], 0, (int32_t*)nullptr, (int32_t*)nullptr);
-                ABW_LAUNCH_CHECK(ctx);
-            }
-        }
-        // the level's pinned block is re-used by the next level's upload: the copy of h_part must have left it
-        ABW_HIP(ctx, hipStreamSynchronize(st));
-        cur ^= 1;
-        level.swap(next);
-    }
-    *n_nodes = visited;
-    if (scaf2cluster) {
-        ABW_HIP(ctx, hipMemcpyAsync(scaf2cluster, b_s2c.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
-        ABW_HIP(ctx, hipStreamSynchronize(st));
-    }
-    if (visited > node_cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_sep_tree: %lld nodes, capacity %lld", (long long)visited, (long long)node_cap);
+    level.assign(1, HostNode{1, S, N, -1});
+    nodes.clear();
+    next_id = 2; visited = 0; cur = 0; phase = 0;
     return ABW_OK;
 }
+
+// One level up to this context's best threshold of every node.  *n_level = 0: the recursion is over.
+int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
+{
+    abw_sep_state& s = ctx->sep;
+    SepHost& H = abw_sep_host(ctx);
+    hipStream_t st = ctx->stream;
+    int rc;
+    if (phase == 3 || level.empty() || visited >= max_nodes) { phase = 3; *n_level = 0; return ABW_OK; }
+    if (phase != 0) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_tree_eval: the level in flight waits for %s", phase == 1 ? "abw_sep_tree_assign" : "abw_sep_tree_advance");
+    if ((int64_t)level.size() > max_nodes - visited) level.resize((size_t)(max_nodes - visited));   // the work list is cut in id order
+    K = (int32_t)level.size();
+    *n_level = K;
+    if (cap < K || !best) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_sep_tree_eval: %d nodes in the level, capacity %lld", K, (long long)cap);
+    abw_devbuf &b_scg = ctx->scratch[5], &b_lvl = ctx->scratch[6], &b_tile = ctx->scratch[7];
+    abw_devbuf* b_hist[2] = {&ctx->scratch[10], &ctx->scratch[11]};
+    // ---- node table, tiles, and the plan for the histograms of this level
+    std::vector<NodeDev> nd((size_t)K);
+    std::vector<Tile> stiles, ptiles, atiles;
+    std::vector<int32_t> zero_slots;
+    std::vector<SubJob> subs;
+    int32_t sb = 0, pb = 0;
+    for (int32_t k = 0; k < K; k++) {
+        nd[k].scaf_begin = sb; nd[k].scaf_end = sb + level[k].m;
+        nd[k].dp_begin = pb; nd[k].dp_end = pb + (int32_t)level[k].n;
+        make_tiles(stiles, k, nd[k].scaf_begin, nd[k].scaf_end, TILE_S, nd[k].stile_begin, nd[k].stile_end);
+        make_tiles(ptiles, k, nd[k].dp_begin, nd[k].dp_end, TILE_P, nd[k].ptile_begin, nd[k].ptile_end);
+        sb += level[k].m; pb += (int32_t)level[k].n;
+    }
+    // children come in pairs (2j, 2j + 1) of one parent: the smaller is accumulated, the bigger subtracted; a node without
+    // its sibling in this (cut) level, and the root, are accumulated
+    for (int32_t k = 0; k < K; k++) {
+        const int32_t sib = (level[k].parent >= 0) ? (k ^ 1) : -1;
+        const bool has_sib = sib >= 0 && sib < K && level[sib].parent == level[k].parent;
+        const bool bigger = has_sib && (level[k].n > level[sib].n || (level[k].n == level[sib].n && k > sib));
+        if (bigger) subs.push_back(SubJob{k, level[k].parent, sib});
+        else {
+            zero_slots.push_back(k);
+            int32_t tb, te;
+            make_tiles(atiles, k, nd[k].scaf_begin, nd[k].scaf_end, TILE_A, tb, te);
+        }
+    }
+    n_st = (int32_t)stiles.size(); n_pt = (int32_t)ptiles.size();
+    const int32_t n_at = (int32_t)atiles.size();
+    std::vector<uint8_t> blob;
+    const size_t o_nodes = pack(blob, nd), o_st = pack(blob, stiles), o_pt = pack(blob, ptiles), o_at = pack(blob, atiles),
+                 o_zero = pack(blob, zero_slots), o_sub = pack(blob, subs);
+    const size_t lvl_bytes = (blob.size() + 63) & ~(size_t)63;
+    o_res = lvl_bytes; o_part = o_res + (((size_t)K * sizeof(NodeRes) + 63) & ~(size_t)63);
+    const size_t all_bytes = o_part + (size_t)K * sizeof(NodePart) + 64;
+    if ((rc = abw_reserve(ctx, b_lvl, all_bytes))) return rc;
+    if ((rc = abw_reserve_pinned(ctx, all_bytes))) return rc;
+    uint8_t* hp = (uint8_t*)ctx->pinned;
+    memcpy(hp, blob.data(), blob.size());
+    ABW_HIP(ctx, hipMemcpyAsync(b_lvl.p, hp, lvl_bytes, hipMemcpyHostToDevice, st));
+    uint8_t* dl = (uint8_t*)b_lvl.p;
+    d_nodes = (const NodeDev*)(dl + o_nodes);
+    d_stiles = (const Tile*)(dl + o_st);
+    d_ptiles = (const Tile*)(dl + o_pt);
+    const Tile* d_atiles = (const Tile*)(dl + o_at);
+    const int32_t* d_zero = (const int32_t*)(dl + o_zero);
+    const SubJob* d_subs = (const SubJob*)(dl + o_sub);
+    d_res = (NodeRes*)(dl + o_res);
+    d_part = (NodePart*)(dl + o_part);
+
+    // per-level buffers: SCG lo / hi, candidates, tile sums / bests / counts
+    const int64_t scg_n = (int64_t)K * D * s.n_scg;
+    if ((rc = abw_reserve(ctx, b_scg, (size_t)std::max<int64_t>(1, scg_n) * 8))) return rc;
+    int32_t* d_scg_lo = (int32_t*)b_scg.p; int32_t* d_scg_hi = d_scg_lo + scg_n;
+    const size_t t_cand = ((size_t)K * D * sizeof(Cand) + 63) & ~(size_t)63,
+                 t_sums = ((size_t)std::max(1, n_wide) * n_pt * sizeof(WSums) + 63) & ~(size_t)63,
+                 t_best = ((size_t)std::max(1, n_wide) * n_pt * sizeof(Cand) + 63) & ~(size_t)63,
+                 t_tot = ((size_t)std::max(1, n_wide) * K * sizeof(WSums) + 63) & ~(size_t)63,
+                 t_cnt = ((size_t)(std::max(1, n_wide) * (size_t)n_pt + n_st) * 4 + 63) & ~(size_t)63,
+                 t_mask = (((size_t)std::max(1, n_wide) * n_pt + n_st) * 256 + 63) & ~(size_t)63;
+    if ((rc = abw_reserve(ctx, b_tile, t_cand + t_sums + t_best + t_tot + t_cnt + t_mask + (size_t)K * 8))) return rc;
+    Cand* d_cand = (Cand*)b_tile.p;
+    WSums* d_tsums = (WSums*)((uint8_t*)b_tile.p + t_cand);
+    Cand* d_tbest = (Cand*)((uint8_t*)b_tile.p + t_cand + t_sums);
+    WSums* d_ntot = (WSums*)((uint8_t*)b_tile.p + t_cand + t_sums + t_best);
+    d_pcnt = (uint32_t*)((uint8_t*)b_tile.p + t_cand + t_sums + t_best + t_tot);
+    d_scnt = d_pcnt + (size_t)std::max(1, n_wide) * n_pt;
+    d_pmask = (uint8_t*)b_tile.p + t_cand + t_sums + t_best + t_tot + t_cnt;
+    d_smask = d_pmask + (size_t)std::max(1, n_wide) * n_pt * 256;
+    double* d_bar = (double*)(d_pmask + t_mask);
+    if (scg_n > 0) {
+        hipLaunchKernelGGL(tree_scg_reset_kernel, dim3((unsigned)std::min<int64_t>((scg_n + 255) / 256, ctx->num_cu * 8)), dim3(256), 0, st, d_scg_lo, d_scg_hi, scg_n);
+        ABW_LAUNCH_CHECK(ctx);
+        if (H.n_carriers > 0) {
+            const int64_t work = (int64_t)H.n_carriers * D;
+            hipLaunchKernelGGL(tree_scg_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, Tr, H.d_carriers, H.n_carriers, d_scaf_slot, K, d_scg_lo, d_scg_hi);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+    }
+
+    // ---- narrow dimensions: this level's slices (pool cur) from the table or from the parents' slices (pool cur ^ 1)
+    if (n_narrow) {
+        const size_t slice = (size_t)TBn * 20;
+        if ((size_t)K * slice > ((size_t)48 << 30)) return abw_fail(ctx, ABW_ERR_NOMEM, "abw_sep_tree: %d nodes in one level need %zu bytes of histograms", K, (size_t)K * slice);
+        if ((rc = abw_reserve(ctx, *b_hist[cur], (size_t)K * slice + 64))) return rc;
+        const int64_t capc = (int64_t)((b_hist[cur]->cap - 64) / slice), capp = b_hist[cur ^ 1]->cap > 64 ? (int64_t)((b_hist[cur ^ 1]->cap - 64) / slice) : 0;
+        unsigned long long* c_st = (unsigned long long*)b_hist[cur]->p;
+        unsigned long long* c_bp = c_st + capc * TBn;
+        uint32_t* c_tot = (uint32_t*)(c_bp + capc * TBn);
+        const unsigned long long* p_st = (const unsigned long long*)b_hist[cur ^ 1]->p;
+        const unsigned long long* p_bp = p_st ? p_st + capp * TBn : nullptr;
+        const uint32_t* p_tot = p_st ? (const uint32_t*)(p_bp + capp * TBn) : nullptr;
+        const unsigned gy = (unsigned)((TBn + 1023) / 1024);
+        ABW_PROF(ctx, "sep_accum");
+        if (!zero_slots.empty()) {
+            hipLaunchKernelGGL(tree_zero_kernel, dim3((unsigned)zero_slots.size(), gy), dim3(256), 0, st, d_zero, TBn, c_st, c_bp, c_tot);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        if (n_at) {
+            // level 0 holds all scaffolds in id order: no list (accum_group_tile then takes its tiles as ranges of ids)
+            const bool identity = (K == 1 && level[0].parent < 0);
+            hipLaunchKernelGGL(tree_accum_kernel, dim3((unsigned)n_at, (unsigned)n_groups), dim3(256), 0, st, Tr, d_atiles,
+                               identity ? (const int32_t*)nullptr : (const int32_t*)order[cur], c_st, c_bp, c_tot);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        if (!subs.empty()) {
+            hipLaunchKernelGGL(tree_sub_kernel, dim3((unsigned)subs.size(), gy), dim3(256), 0, st, d_subs, TBn, c_st, c_bp, c_tot, p_st, p_bp, p_tot);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        hipLaunchKernelGGL(tree_eval_narrow_kernel, dim3((unsigned)K, (unsigned)n_narrow), dim3(256), 0, st, Tr, d_nodes, min_ndps,
+                           (const unsigned long long*)c_st, (const unsigned long long*)c_bp, (const uint32_t*)c_tot, d_scg_lo, d_scg_hi, d_cand);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    // ---- wide dimensions: prefix sums along every node's sorted segment
+    if (n_wide) {
+        ABW_PROF(ctx, "sep_wide");
+        hipLaunchKernelGGL(tree_bar_kernel, dim3((unsigned)K), dim3(64), 0, st, Tr, d_cand, d_bar);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(tree_wide_sums_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, wword[cur], Np, d_tsums);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(tree_wide_scan_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, d_nodes, n_pt, d_tsums, d_ntot, K);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(tree_wide_eval_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, d_nodes, K, min_ndps,
+                           wbin[cur], wword[cur], Np, d_tsums, d_ntot, d_scg_lo, d_scg_hi, d_bar, d_tbest);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(tree_wide_best_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, Tr, d_nodes, n_pt, d_tbest, d_cand);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    // ---- this context's winner of every node
+    {
+        ABW_PROF(ctx, "sep_eval");
+        hipLaunchKernelGGL(tree_winner_kernel, dim3((unsigned)K), dim3(64), 0, st, Tr, d_nodes, d_cand, d_res);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    NodeRes* h_res = (NodeRes*)(hp + o_res);
+    ABW_HIP(ctx, hipMemcpyAsync(h_res, d_res, (size_t)K * sizeof(NodeRes), hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    for (int32_t k = 0; k < K; k++) {
+        const GlobalRes& w = h_res[k].win;
+        abw_tree_winner& b = best[k];
+        memset(&b, 0, sizeof(b));
+        b.found = w.found; b.dimension = w.found ? w.dim : -1; b.key = w.found ? key_of(w.dim, w.bin) : -1;
+        b.legal = w.legal; b.sensitivity = w.sens; b.specificity = w.spec;
+        b.global_dimension = w.found ? w.dim + 1 : -1;
+    }
+    phase = 1;
+    return ABW_OK;
+}
+
+// winners[k]: the node's winner over ALL contexts; dimension >= 0 when it is this context's own best (as eval returned it).
+// The scaffolds of those nodes get their sides; every other entry of the level's side array stays 0.  Asynchronous.
+int TreeRun::assign(const abw_tree_winner* winners, int64_t n)
+{
+    hipStream_t st = ctx->stream;
+    if (phase != 1) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_tree_assign: no evaluated level (abw_sep_tree_eval)");
+    if (n != K || !winners) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree_assign: %lld winners for a level of %d nodes", (long long)n, K);
+    NodeRes* h_res = (NodeRes*)((uint8_t*)ctx->pinned + o_res);
+    final_winners.assign(winners, winners + K);
+    for (int32_t k = 0; k < K; k++) {
+        const abw_tree_winner& w = winners[k];
+        GlobalRes& mine = h_res[k].win;
+        const bool is_mine = w.found && w.dimension >= 0 && mine.found && w.dimension == mine.dim && w.key == key_of(mine.dim, mine.bin);
+        if (w.found && w.dimension >= 0 && !is_mine)
+            return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree_assign: node %d: the winner named as this context's is not the one abw_sep_tree_eval returned", k);
+        if (!(is_mine && w.legal)) mine.legal = 0;              // nothing to assign here (illegal winner, or another context's)
+        h_res[k].n1 = h_res[k].n2 = 0; h_res[k].m1 = h_res[k].m2 = 0;
+    }
+    ABW_HIP(ctx, hipMemcpyAsync(d_res, h_res, (size_t)K * sizeof(NodeRes), hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemsetAsync(d_scaf_side, 0, (size_t)S, st));
+    {
+        ABW_PROF(ctx, "sep_eval");
+        hipLaunchKernelGGL(tree_assign_kernel, dim3((unsigned)n_st), dim3(256), 0, st, Tr, d_stiles, (const int32_t*)order[cur], (const NodeRes*)d_res, d_scaf_side);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    phase = 2;
+    return ABW_OK;
+}
+
+// After the side array holds the sides decided by all contexts: children sizes, the verdicts of ref ClusterSeparator.cpp:125-132,
+// the next level, the partition.
+int TreeRun::advance()
+{
+    hipStream_t st = ctx->stream;
+    if (phase != 2) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_tree_advance: no assigned level (abw_sep_tree_assign)");
+    uint8_t* hp = (uint8_t*)ctx->pinned;
+    NodeRes* h_res = (NodeRes*)(hp + o_res);
+    {
+        ABW_PROF(ctx, "sep_eval");
+        hipLaunchKernelGGL(tree_count_kernel, dim3((unsigned)n_st), dim3(256), 0, st, Tr, d_stiles, (const int32_t*)order[cur], (const uint8_t*)d_scaf_side, d_res);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    ABW_HIP(ctx, hipMemcpyAsync(h_res, d_res, (size_t)K * sizeof(NodeRes), hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    std::vector<HostNode> next;
+    NodePart* h_part = (NodePart*)(hp + o_part);
+    int32_t nsb = 0, npb = 0;
+    for (int32_t k = 0; k < K; k++) {
+        const NodeRes& r = h_res[k];
+        const abw_tree_winner& w = final_winners[k];
+        abw_tree_node o;
+        memset(&o, 0, sizeof(o));
+        o.id = level[k].id; o.ndps = level[k].n; o.n_scaf = level[k].m; o.dimension = -1; o.key = -1;
+        bool split = false;
+        if (w.found) {
+            o.dimension = w.global_dimension; o.key = w.key;
+            o.sensitivity = w.sensitivity; o.specificity = w.specificity; o.legal = w.legal;
+            if (w.legal) {
+                split = (int64_t)r.n1 >= min_ndps && (int64_t)r.n2 >= min_ndps;
+                if (!split) { o.dimension = -1; o.key = -1; o.sensitivity = 0; o.specificity = 0; }      // best_separation->reset(), ref :130
+            }
+        }
+        NodePart& np = h_part[k];
+        memset(&np, 0, sizeof(np));
+        np.split = split; np.id = o.id; np.slot1 = np.slot2 = -1;
+        if (split) {
+            o.split = 1; o.child1 = next_id; o.child2 = next_id + 1; o.ndps1 = (int64_t)r.n1; o.ndps2 = (int64_t)r.n2;
+            next_id += 2;
+            np.scaf_base1 = nsb; np.scaf_base2 = nsb + (int32_t)r.m1;
+            np.dp_base1 = npb; np.dp_base2 = npb + (int32_t)r.n1;
+            np.slot1 = (int32_t)next.size(); np.slot2 = np.slot1 + 1;
+            nsb += (int32_t)(r.m1 + r.m2); npb += (int32_t)(r.n1 + r.n2);
+            next.push_back(HostNode{o.child1, (int32_t)r.m1, (int64_t)r.n1, k});
+            next.push_back(HostNode{o.child2, (int32_t)r.m2, (int64_t)r.n2, k});
+        }
+        nodes.push_back(o);
+        visited++;
+    }
+    // ---- partition into the next level's order (terminal nodes' scaffolds get their cluster id)
+    ABW_HIP(ctx, hipMemcpyAsync(d_part, h_part, (size_t)K * sizeof(NodePart), hipMemcpyHostToDevice, st));
+    {
+        ABW_PROF(ctx, "sep_partition");
+        hipLaunchKernelGGL(tree_part_count_kernel, dim3((unsigned)n_st, 1), dim3(256), 0, st, d_stiles, n_st, d_part, (const uint32_t*)order[cur], (int64_t)0, d_scaf_side, d_scnt, d_smask);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(tree_part_scan_kernel, dim3((unsigned)K, 1), dim3(64), 0, st, d_nodes, d_part, n_st, d_scnt, 1);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(tree_part_scatter_kernel, dim3((unsigned)n_st, 1), dim3(256), 0, st, d_stiles, n_st, d_nodes, d_part, (const uint32_t*)order[cur],
+                           (const int32_t*)nullptr, (int64_t)0, d_smask, d_scnt, order[cur ^ 1], (int32_t*)nullptr, 1, (int32_t*)ctx->scratch[9].p, d_scaf_slot);
+        ABW_LAUNCH_CHECK(ctx);
+        if (n_wide && !next.empty()) {
+            hipLaunchKernelGGL(tree_part_count_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, d_ptiles, n_pt, d_part, (const uint32_t*)wword[cur], Np, d_scaf_side, d_pcnt, d_pmask);
+            ABW_LAUNCH_CHECK(ctx);
+            hipLaunchKernelGGL(tree_part_scan_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, d_nodes, d_part, n_pt, d_pcnt, 0);
+            ABW_LAUNCH_CHECK(ctx);
+            hipLaunchKernelGGL(tree_part_scatter_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, d_ptiles, n_pt, d_nodes, d_part, (const uint32_t*)wword[cur],
+                               (const int32_t*)wbin[cur], Np, d_pmask, d_pcnt, wword[cur ^ 1], wbin[cur ^ 1], 0, (int32_t*)nullptr, (int32_t*)nullptr);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+    }
+    // the level's pinned block is re-used by the next level's upload: the copy of h_part must have left it
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    cur ^= 1;
+    level.swap(next);
+    phase = (level.empty() || visited >= max_nodes) ? 3 : 0;
+    return ABW_OK;
+}
+
+TreeRun* run_of(abw_ctx* ctx, const char* who, bool create)
+{
+    if (!ctx) return nullptr;
+    if (!ctx->sep.loaded) { abw_fail(ctx, ABW_ERR_STATE, "%s: call abw_sep_load first", who); return nullptr; }
+    SepHost& H = abw_sep_host(ctx);
+    if (H.sharded) { abw_fail(ctx, ABW_ERR_STATE, "%s: the table is one shard of a scaffold-sharded problem (abw_sep_shard_load); use abw_sep_shard_*", who); return nullptr; }
+    if (create) {
+        abw_tree_run_free(H.tree_run);
+        TreeRun* r = new TreeRun();
+        r->ctx = ctx;
+        H.tree_run = r;
+    }
+    if (!H.tree_run) { abw_fail(ctx, ABW_ERR_STATE, "%s: no recursion in progress (abw_sep_tree_begin)", who); return nullptr; }
+    return (TreeRun*)H.tree_run;
+}
+
+}  // namespace
+
+void abw_tree_run_free(void* run) { delete (TreeRun*)run; }
+
+extern "C" {
+
+int abw_sep_tree_begin(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (min_ndps < 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree_begin: bad argument");
+    TreeRun* r = run_of(ctx, "abw_sep_tree_begin", true);
+    if (!r) return ABW_ERR_STATE;
+    abw_device_guard g(ctx->device);
+    return r->begin(min_ndps, max_nodes);
+}
+
+int abw_sep_tree_eval(abw_ctx* ctx, abw_tree_winner* best, int64_t cap, int64_t* n_level)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!n_level) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree_eval: bad argument");
+    TreeRun* r = run_of(ctx, "abw_sep_tree_eval", false);
+    if (!r) return ABW_ERR_STATE;
+    abw_device_guard g(ctx->device);
+    return r->eval(best, cap, n_level);
+}
+
+int abw_sep_tree_assign(abw_ctx* ctx, const abw_tree_winner* winners, int64_t n, uint8_t** d_side, int64_t* side_count)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    TreeRun* r = run_of(ctx, "abw_sep_tree_assign", false);
+    if (!r) return ABW_ERR_STATE;
+    abw_device_guard g(ctx->device);
+    const int rc = r->assign(winners, n);
+    if (!rc && d_side) *d_side = r->d_scaf_side;
+    if (!rc && side_count) *side_count = r->S;
+    return rc;
+}
+
+int abw_sep_tree_advance(abw_ctx* ctx)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    TreeRun* r = run_of(ctx, "abw_sep_tree_advance", false);
+    if (!r) return ABW_ERR_STATE;
+    abw_device_guard g(ctx->device);
+    return r->advance();
+}
+
+int abw_sep_tree_result(abw_ctx* ctx, abw_tree_node* nodes_out, int64_t node_cap, int64_t* n_nodes, int32_t* scaf2cluster)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!n_nodes || (node_cap > 0 && !nodes_out)) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree_result: bad argument");
+    TreeRun* r = run_of(ctx, "abw_sep_tree_result", false);
+    if (!r) return ABW_ERR_STATE;
+    if (r->phase == 1 || r->phase == 2) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_tree_result: a level is in flight");
+    abw_device_guard g(ctx->device);
+    const int64_t n = (int64_t)r->nodes.size();
+    *n_nodes = n;
+    for (int64_t i = 0; i < std::min(n, node_cap); i++) nodes_out[i] = r->nodes[(size_t)i];
+    if (scaf2cluster) {
+        ABW_HIP(ctx, hipMemcpyAsync(scaf2cluster, ctx->scratch[9].p, (size_t)r->S * 4, hipMemcpyDeviceToHost, ctx->stream));
+        ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (n > node_cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_sep_tree: %lld nodes, capacity %lld", (long long)n, (long long)node_cap);
+    return ABW_OK;
+}
+
+// The winner of every node over several contexts' bests: the larger product sensitivity x specificity, on equal products the
+// smaller dimension of the whole table (ref ...Specificity.h:25-30 + ClusterSeparator.cpp:11-16, dimensions in ascending order).
+// all: [n_ctx][n] as abw_sep_tree_eval returned them, global_dimension filled in by the caller.  out[k].dimension is kept
+// from the winning record; the caller hands record k back to context c with dimension = -1 unless c == owner[k].
+int abw_sep_tree_merge(const abw_tree_winner* all, int32_t n_ctx, int64_t n, abw_tree_winner* out, int32_t* owner)
+{
+    if (!all || !out || n_ctx <= 0 || n < 0) return ABW_ERR_ARG;
+    for (int64_t k = 0; k < n; k++) {
+        int32_t best = -1;
+        for (int32_t c = 0; c < n_ctx; c++) {
+            const abw_tree_winner& w = all[(int64_t)c * n + k];
+            if (!w.found) continue;
+            if (best < 0) { best = c; continue; }
+            const abw_tree_winner& b = all[(int64_t)best * n + k];
+            const double pw = w.sensitivity * w.specificity, pb = b.sensitivity * b.specificity;
+            if (pw > pb || (pw == pb && w.global_dimension < b.global_dimension)) best = c;
+        }
+        if (best >= 0) out[k] = all[(int64_t)best * n + k];
+        else { memset(&out[k], 0, sizeof(out[k])); out[k].dimension = -1; out[k].key = -1; out[k].global_dimension = -1; }
+        if (owner) owner[k] = best;
+    }
+    return ABW_OK;
+}
+
+// The whole recursion on one context: the loop over the level calls above.
+int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, abw_tree_node* nodes_out, int64_t node_cap,
+                 int64_t* n_nodes, int32_t* scaf2cluster)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!n_nodes || (node_cap > 0 && !nodes_out) || min_ndps < 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree: bad argument");
+    *n_nodes = 0;
+    int rc;
+    if ((rc = abw_sep_tree_begin(ctx, min_ndps, max_nodes))) return rc;
+    std::vector<abw_tree_winner> best(256);
+    for (;;) {
+        int64_t k = 0;
+        rc = abw_sep_tree_eval(ctx, best.data(), (int64_t)best.size(), &k);
+        if (rc == ABW_ERR_CAPACITY && k > (int64_t)best.size()) {           // the level is wider than the buffer: it has not started
+            best.resize((size_t)k);
+            continue;
+        }
+        if (rc) return rc;
+        if (k == 0) break;
+        if ((rc = abw_sep_tree_assign(ctx, best.data(), k, nullptr, nullptr))) return rc;
+        if ((rc = abw_sep_tree_advance(ctx))) return rc;
+    }
+    return abw_sep_tree_result(ctx, nodes_out, node_cap, n_nodes, scaf2cluster);
+}
+
+}  // extern "C"

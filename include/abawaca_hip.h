@@ -203,6 +203,41 @@ typedef struct {
 int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, abw_tree_node* nodes_out, int64_t node_cap,
                  int64_t* n_nodes, int32_t* scaf2cluster);
 
+/* ---- the same recursion level by level, for a table whose DIMENSIONS are spread over several contexts / processes / GPUs.
+ *      The sweep of a dimension needs nothing from the other dimensions (ref: src/ClusterSeparator.cpp:70-78 runs them as
+ *      independent threads and compares their results afterwards, :11-16), so every context loads ALL scaffolds but only its
+ *      own columns (abw_sep_load with D = its number of columns) and the contexts meet twice per LEVEL with a few bytes:
+ *        eval    : this context's best threshold of every node of the level (best[k]; *n_level = 0: the recursion is over;
+ *                  ABW_ERR_CAPACITY with *n_level set when cap is too small -- call again)
+ *        -- the caller fills best[k].global_dimension (1-based dimension in the whole table), gathers the records of all
+ *           contexts and picks every node's winner as the reference does: larger sensitivity x specificity, then the smaller
+ *           dimension (abw_sep_tree_merge) --
+ *        assign  : winners[k] = the node's winner; .dimension >= 0 only in the record handed back to the context that owns
+ *                  it, -1 elsewhere.  The owner assigns the node's scaffolds: *d_side = device array [*side_count = S] of
+ *                  bytes, 1 / 2 for the scaffolds this context decided, 0 elsewhere.  Asynchronous.
+ *        -- the caller combines the side arrays of all contexts (MAX or SUM: every scaffold is decided by at most one) --
+ *        advance : children sizes, the size check (ref: src/ClusterSeparator.cpp:125-132), next level, partition.
+ *        result  : the nodes and the bins, as abw_sep_tree returns them (dimension = global_dimension).
+ *      Every context walks the same tree.  abw_sep_tree is this loop on one context.  Between begin and result no other entry
+ *      point may run on the context (the run lives in its scratch buffers).  Nothing of this exists in the reference's
+ *      single process; the partition follows its thread-per-dimension loop. */
+typedef struct abw_tree_winner {
+    int32_t found;              /* 0: no threshold passed the gates */
+    int32_t dimension;          /* 0-based column of THIS context's table; -1: not this context's */
+    int32_t key;
+    int32_t legal;
+    double  sensitivity, specificity;
+    int32_t global_dimension;   /* 1-based dimension of the whole table (eval: dimension + 1; the caller translates) */
+    int32_t reserved;
+} abw_tree_winner;
+int abw_sep_tree_begin(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes);
+int abw_sep_tree_eval(abw_ctx* ctx, abw_tree_winner* best, int64_t cap, int64_t* n_level);
+int abw_sep_tree_assign(abw_ctx* ctx, const abw_tree_winner* winners, int64_t n, uint8_t** d_side, int64_t* side_count);
+int abw_sep_tree_advance(abw_ctx* ctx);
+int abw_sep_tree_result(abw_ctx* ctx, abw_tree_node* nodes_out, int64_t node_cap, int64_t* n_nodes, int32_t* scaf2cluster);
+/* host only: all = [n_ctx][n] records of eval (global_dimension filled in); out[k] = the winner, owner[k] = its context (-1: none) */
+int abw_sep_tree_merge(const abw_tree_winner* all, int32_t n_ctx, int64_t n, abw_tree_winner* out, int32_t* owner);
+
 /* ---- the separator with the SCAFFOLDS sharded over several contexts / processes / GPUs (SURVEY §8(e):
  *      "scaffold-sharded" full recursive binning; the reference itself is one process with a thread per
  *      dimension, ref: src/ClusterSeparator.cpp:72-78).  A shard holds whole scaffolds (a node of the
