@@ -374,3 +374,162 @@ def binning_shards_local(stores, max_nodes: int = 1 << 30, combine: str = "libra
                 a[nd.ids] = nid
         rows.append(row)
     return rows, s2c
+
+
+# ---- dimension-sharded recursion (abw_sep_tree_begin / eval / assign / advance) ---------------------------
+# Every rank loads ALL scaffolds but only its own columns; per LEVEL of the recursion the ranks exchange one
+# small record per node (their best thresholds) and one byte per scaffold (the sides the winners' owners decided).
+
+_WIN_DTYPE = np.dtype([("found", "i4"), ("dim", "i4"), ("key", "i4"), ("legal", "i4"), ("sens", "f8"), ("spec", "f8"),
+                       ("gdim", "i4"), ("reserved", "i4")])                                       # = struct abw_tree_winner
+
+
+def dim_partition(keys, world: int):
+    """Columns dealt to `world` ranks: the wide ones (coverage: any key >= 1024, they cost most) round-robin, then the
+    narrow ones round-robin.  -> list of ascending int arrays of global column indices."""
+    keys = np.asarray(keys)
+    wide = np.array([bool(keys[d].max() >= 1024 or keys[d].min() < 0) for d in range(keys.shape[0])])
+    w, n = np.flatnonzero(wide), np.flatnonzero(~wide)
+    return [np.sort(np.concatenate([w[r::world], n[r::world]])).astype(np.int64) for r in range(world)]
+
+
+class DimShardStore(ColumnStore):
+    """All scaffolds, the columns `dims` (global 0-based indices) of the table."""
+
+    def __init__(self, ctx: Context, keys, dims, dp2scaf, scaf_len, scg_off=None, scg_ids=None, n_scg=0):
+        self.dims = np.ascontiguousarray(dims, dtype=np.int64)
+        super().__init__(ctx, np.ascontiguousarray(np.asarray(keys)[self.dims]), dp2scaf, scaf_len, scg_off, scg_ids, n_scg)
+
+
+class DimShardRun:
+    """The level calls of one context."""
+
+    def __init__(self, store: DimShardStore, max_nodes: int = 0):
+        self.store = store
+        self.cap = 256
+        store.ctx.check(lib().abw_sep_tree_begin(store.ctx.handle, ClusterSeparatorHip.cluster_ndps_threshold, int(max_nodes)))
+
+    def eval(self):
+        """-> this context's bests of the level's nodes (global_dimension filled in), or None when the recursion is over"""
+        st = self.store
+        while True:
+            best = np.zeros(self.cap, dtype=_WIN_DTYPE)
+            k = C.c_int64(0)
+            rc = lib().abw_sep_tree_eval(st.ctx.handle, C.c_void_p(best.ctypes.data), self.cap, C.byref(k))
+            if rc == -3 and k.value > self.cap:
+                self.cap = int(k.value)
+                continue
+            st.ctx.check(rc)
+            break
+        if k.value == 0:
+            return None
+        best = best[:int(k.value)].copy()
+        mine = best["found"] != 0
+        best["gdim"][mine] = st.dims[best["dim"][mine]] + 1
+        return best
+
+    def assign(self, winners, owner_is_me):
+        """winners: merged records; owner_is_me: bool per node.  -> torch uint8 view [S] of the side array (device)"""
+        import torch
+        from .kmeans import _DevView
+        st = self.store
+        w = np.ascontiguousarray(winners.copy())
+        w["dim"][~np.asarray(owner_is_me, dtype=bool)] = -1
+        ptr, cnt = C.c_void_p(), C.c_int64(0)
+        st.ctx.check(lib().abw_sep_tree_assign(st.ctx.handle, C.c_void_p(w.ctypes.data), len(w), C.byref(ptr), C.byref(cnt)))
+        return torch.as_tensor(_DevView(ptr.value, cnt.value, "|u1"), device=torch.device("cuda", st.ctx.device))
+
+    def advance(self):
+        self.store.ctx.check(lib().abw_sep_tree_advance(self.store.ctx.handle))
+
+    def result(self):
+        st = self.store
+        cap = 1024
+        while True:
+            arr = np.zeros(cap, dtype=_TREE_DTYPE)
+            s2c = np.zeros(st.S, dtype=np.int32)
+            n = C.c_int64(0)
+            rc = lib().abw_sep_tree_result(st.ctx.handle, C.c_void_p(arr.ctypes.data), cap, C.byref(n), C.c_void_p(s2c.ctypes.data))
+            if rc == -3 and n.value > cap:
+                cap = int(n.value)
+                continue
+            st.ctx.check(rc)
+            break
+        rows = [dict(id=int(r["id"]), ndps=int(r["ndps"]), split=int(r["split"]), dim=int(r["dim"]), key=int(r["key"]), spec=float(r["spec"]),
+                     sens=float(r["sens"]), c1=int(r["c1"]), n1=int(r["n1"]), c2=int(r["c2"]), n2=int(r["n2"]), n_scaf=int(r["n_scaf"]))
+                for r in arr[:int(n.value)]]
+        return rows, s2c
+
+
+def merge_winners(all_best):
+    """all_best: [world][K] records -> (winners [K], owner int32 [K]) by the library's rule (abw_sep_tree_merge)."""
+    a = np.ascontiguousarray(np.stack(all_best))
+    world, K = a.shape
+    out = np.zeros(K, dtype=_WIN_DTYPE)
+    owner = np.zeros(K, dtype=np.int32)
+    rc = lib().abw_sep_tree_merge(C.c_void_p(a.ctypes.data), world, K, C.c_void_p(out.ctypes.data), C.c_void_p(owner.ctypes.data))
+    if rc:
+        raise RuntimeError(f"abw_sep_tree_merge: {rc}")
+    return out, owner
+
+
+def binning_tree_dims_local(stores, max_nodes: int = 0):
+    """The dimension-sharded recursion with all shards driven from one process (tests; the stores may share a GPU)."""
+    import torch
+    runs = [DimShardRun(st, max_nodes) for st in stores]
+    exchanged = 0
+    while True:
+        bests = [r.eval() for r in runs]
+        if bests[0] is None:
+            assert all(b is None for b in bests)
+            break
+        winners, owner = merge_winners(bests)
+        sides = [r.assign(winners, owner == k) for k, r in enumerate(runs)]
+        for st in stores:
+            st.ctx.synchronize()
+        tot = torch.stack(sides).amax(0)
+        for t in sides:
+            t.copy_(tot)
+        torch.cuda.synchronize()
+        exchanged += winners.nbytes + int(tot.numel())
+        for r in runs:
+            r.advance()
+    res = [r.result() for r in runs]
+    return res, exchanged
+
+
+def binning_tree_dims(store: DimShardStore, dist, max_nodes: int = 0):
+    """One rank of the dimension-sharded recursion over torch.distributed (RCCL on GPUs).
+    -> (rows, scaf2cluster, seconds, bytes this rank exchanged per direction)"""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", store.ctx.device) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t0 = time.perf_counter()
+    run = DimShardRun(store, max_nodes)
+    exchanged = 0
+    while True:
+        best = run.eval()
+        k = torch.tensor([0 if best is None else len(best)], dtype=torch.int64, device=dev)
+        ks = [torch.zeros_like(k) for _ in range(world)]
+        dist.all_gather(ks, k)
+        if best is None:
+            assert all(int(x) == 0 for x in ks)
+            break
+        assert all(int(x) == len(best) for x in ks), "the ranks walk different trees"
+        mine = torch.from_numpy(best.view(np.uint8).reshape(-1).copy()).to(dev)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        winners, owner = merge_winners([p.cpu().numpy().view(_WIN_DTYPE) for p in parts])
+        side = run.assign(winners, owner == rank)
+        store.ctx.synchronize()
+        if dev.type == "cpu":
+            h = side.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            side.copy_(h)
+        else:
+            dist.all_reduce(side, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        exchanged += mine.numel() * world + side.numel()
+        run.advance()
+    rows, s2c = run.result()
+    return rows, s2c, time.perf_counter() - t0, exchanged

@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--genomes", type=int, default=0, help="planted genomes; 0 = the configuration's own (100 / 200)")
     ap.add_argument("--sep-scaffolds", type=int, default=2_000_000, help="N > 1: scaffolds of the sharded separator leg in total (configs[4])")
     ap.add_argument("--sep-nodes", type=int, default=127, help="N > 1: nodes of the sharded recursion to run (0 = all)")
+    ap.add_argument("--sep-nodes-dims", type=int, default=0, help="N > 1: nodes of the dimension-sharded recursion to run (0 = all)")
     ap.add_argument("--no-c2", action="store_true", help="N = 1: skip the configs[2] job on the one GPU")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--chunk", type=int, default=0, help="points per fp32 partial sum; 0 = the library's choice (abw_km_auto_chunk)")
@@ -876,6 +877,50 @@ def main():
         sctx.close()
         dist.barrier()
 
+    # ---------------- multi-rank only: the separator with the DIMENSIONS spread over the ranks -------------------------
+    # (configs[4]: ONE table of --sep-scaffolds scaffolds, the same on every rank (same seed); a rank loads all scaffolds but
+    # only its share of the columns and the whole recursion runs level by level (abw_sep_tree_eval / assign / advance): per
+    # level one record per node and one byte per scaffold cross the links.  Strong scaling of one recursion.)
+    sep_dims = None
+    if dist is not None and not args.no_sep_sharded:
+        c4 = CONFIGS[4]
+        keys_d, dp2scaf_d, scaf_len_d, genome_d, G4d = make_points(20244, args.sep_scaffolds, c4["samples"], dev, c4["genomes"])
+        scg_scaf_d, scg_id_d = make_scgs(20244, genome_d, G4d)
+        so_d, si_d = separator.scg_csr(scg_scaf_d, scg_id_d, args.sep_scaffolds)
+        D4, N4 = keys_d.shape
+        colmax = keys_d.amax(dim=1).cpu().numpy()
+        wide_cols, narrow_cols = np.flatnonzero(colmax >= 1024), np.flatnonzero(colmax < 1024)
+        my_dims = np.sort(np.concatenate([wide_cols[rank::world], narrow_cols[rank::world]])).astype(np.int64)
+        keys_mine = keys_d[torch.from_numpy(my_dims).to(dev)].cpu().numpy()
+        del keys_d
+        torch.cuda.empty_cache()
+        dctx = _lib.Context(dev_index)
+        t0 = time.perf_counter()
+        dstore = separator.DimShardStore(dctx, keys_mine, np.arange(len(my_dims)), dp2scaf_d, scaf_len_d, so_d, si_d, 30)
+        dstore.dims = my_dims                                            # global column numbers of the rows loaded
+        load_d = time.perf_counter() - t0
+        del keys_mine
+        separator.binning_tree_dims(dstore, dist, max_nodes=3)           # warm-up: static tables, RCCL channels
+        barrier()
+        best_d = None
+        for _ in range(2):
+            rows_d, s2c_d, dt_d, ex_d = separator.binning_tree_dims(dstore, dist, max_nodes=args.sep_nodes_dims)
+            dt_d = multi.max_elapsed(dt_d, dist, dev)
+            best_d = dt_d if best_d is None else min(best_d, dt_d)
+        chk = torch.tensor([len(rows_d), int(np.asarray(s2c_d, dtype=np.int64).sum() % (1 << 31))], dtype=torch.int64, device=dev)
+        chks = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(chks, chk)
+        sep_dims = dict(value=sum(r["ndps"] for r in rows_d) * D4 / best_d, unit="dimension*points/s (every node's datapoints x all dimensions)",
+                        s=round(best_d, 4), nodes=len(rows_d), bins=int(sum(1 for r in rows_d if not r["split"])),
+                        workload=f"configs[4]: ONE recursion on {args.sep_scaffolds} scaffolds -> {N4} dps x {D4} dims, 30 SCGs x {G4d} genomes",
+                        columns_per_rank=int(len(my_dims)), wide_columns_per_rank=int(len(wide_cols[rank::world])),
+                        exchange_bytes_total=int(ex_d), load_s=round(load_d, 2), scaling="strong",
+                        same_tree_on_all_ranks=bool(all(torch.equal(c, chks[0]) for c in chks)),
+                        collective=f"per level: all-gather of {separator._WIN_DTYPE.itemsize} B per node, all-reduce MAX of 1 B per scaffold, over {args.backend}")
+        del dstore
+        dctx.close()
+        dist.barrier()
+
     # ---------------- multi-rank only: signature build, scaffolds dealt to the ranks (no exchange) ---------------
     sig_sharded = None
     if dist is not None and not args.no_sep_sharded:
@@ -951,6 +996,8 @@ def main():
         out["weak_restarts"] = weak
     if sep_sharded is not None:
         out["separator_sharded"] = sep_sharded
+    if sep_dims is not None:
+        out["separator_dimension_sharded"] = sep_dims
     if sig_sharded is not None:
         out["signature_sharded"] = sig_sharded
 
