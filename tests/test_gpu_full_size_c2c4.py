@@ -8,6 +8,7 @@ prove the same thing).  The CPU oracle would take hours at these sizes: size-ind
         the unsharded run the fp32 partial sums are cut at other places, so the results agree to a stated tolerance and
         (almost) every point keeps its cluster
   configs[4]  2M scaffolds -> ~8.0 M dps x 199 dims, 30 SCGs x 400 genomes, the whole recursion
+      * node by node, in one call (abw_sep_tree), and with the dimensions spread over 2 and 8 contexts: the same nodes and bins
       * unsharded: the tree is well-formed, every scaffold ends in exactly one bin, the root's winner recomputed from the
         definition in numpy gives the returned doubles, the planted genomes come out
       * 2 and 8 scaffold shards: the same nodes (winner dimension, key, sensitivity / specificity bits, children sizes)
@@ -138,8 +139,23 @@ def test_configs4_whole_recursion_unsharded_and_scaffold_sharded():
     try:
         store = separator.ColumnStore(ctx, keys, dp2scaf, scaf_len, so, si, 30)
         nodes, s2c, d2c = separator.binning(store)
+        # the same recursion in one call (abw_sep_tree), and with the DIMENSIONS spread over 2 and 8 contexts
+        rows_t, s2c_t, _dt = separator.binning_tree(store)
+        assert [_tree_key(r) for r in rows_t] == [_tree_key(r) for r in nodes] and np.array_equal(s2c_t, s2c)
     finally:
         ctx.close()
+    for world in (2, 8):
+        ctxs = [_lib.Context(0) for _ in range(world)]
+        try:
+            stores = [separator.DimShardStore(c, keys, p, dp2scaf, scaf_len, so, si, 30) for c, p in zip(ctxs, separator.dim_partition(keys, world))]
+            res, exchanged = separator.binning_tree_dims_local(stores)
+            for rows_k, s2c_k in res:
+                assert [_tree_key(r) for r in rows_k] == [_tree_key(r) for r in nodes] and np.array_equal(s2c_k, s2c)
+            assert exchanged < 100 * (S + 40 * 1024)              # per level a byte per scaffold and a record per node
+            del stores
+        finally:
+            for c in ctxs:
+                c.close()
     by_id = {r["id"]: r for r in nodes}
     assert nodes[0]["ndps"] == N and nodes[0]["split"] == 1
     # root winner from its definition (reference ...Specificity.cpp:6-76, .h:74-75)
