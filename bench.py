@@ -965,11 +965,11 @@ def main():
     flops_per_unit = 4 * (D + 1)
     ms_avg = ms_launch / max(n_launch, 1)
     achieved = kernel_N * kernel_R * flops_per_unit / (ms_avg * 1e-3) / 1e12      # per launch: the points and restarts ONE GPU's launch covers
-    # HBM bytes per launch from the committed PMC passes (profiles/pmc_r01.json; collected on this
+    # HBM bytes per launch from the committed PMC passes (profiles/pmc_r02.json; collected on this
     # workload with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as the microarchitecture guide says)
     pmc_all = {}
     try:
-        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_r01.json")))
+        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_r02.json")))
     except Exception:
         pmc_all = {}
     default_workload = world == 1 and (args.scaffolds, args.samples, R, args.sig_mbp) == (200000, 10, 64, 1000)
