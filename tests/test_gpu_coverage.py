@@ -76,12 +76,51 @@ def test_random_reads_bit_exact_vs_oracle(ctx, seed, n_scaf, n_reads):
     assert np.array_equal(cov2.view(np.uint64), ref2.view(np.uint64))
 
 
+@pytest.mark.parametrize("seed,seg_lo,seg_hi,order", [(11, 90, 200, "none"), (12, 90, 200, "coordinate"), (13, 10, 60, "none"),
+                                                        (14, 10, 60, "coordinate"), (15, 150, 400, "scaffold"), (16, 150, 400, "coordinate"),
+                                                        (17, 100, 130, "coordinate")])
+def test_reads_longer_than_segments(ctx, seed, seg_lo, seg_hi, order):
+    """A read over three or four segments (coordinate-sorted: the grouped path with K = 3, 4) and over many (pairs), reads
+    in no order, coordinate-sorted, and grouped by scaffold only."""
+    rng = np.random.default_rng(seed)
+    n_scaf, n_reads = 300, 120000
+    seg_scaf, seg_start, seg_end, lens = [], [], [], []
+    for s in range(n_scaf):
+        L = int(rng.integers(400, 3000))
+        lens.append(L)
+        pos = 1 + int(rng.integers(0, 30))
+        while pos + seg_lo < L:
+            end = min(L, pos + int(rng.integers(seg_lo, seg_hi)) - 1)
+            seg_scaf.append(s); seg_start.append(pos); seg_end.append(end)
+            pos = end + 1 + (int(rng.integers(0, 25)) if rng.random() < 0.2 else 0)
+    lens = np.array(lens)
+    rs = rng.integers(0, n_scaf + 1, size=n_reads).astype(np.uint32)             # id n_scaf: an unknown name
+    rl = rng.integers(1, 300, size=n_reads).astype(np.uint32)
+    rp = (rng.random(n_reads) * (lens[np.minimum(rs, n_scaf - 1)] + 50)).astype(np.uint64)
+    if order == "coordinate":
+        o = np.lexsort((rp, rs)); rs, rp, rl = rs[o], rp[o], rl[o]
+    elif order == "scaffold":
+        o = np.argsort(rs, kind="stable"); rs, rp, rl = rs[o], rp[o], rl[o]
+    cov = coverage.accumulate(ctx, seg_scaf, seg_start, seg_end, n_scaf, rs, rp, rl)
+    ref = orc.coverage(seg_scaf, seg_start, seg_end, n_scaf, rs, rp, rl)
+    assert np.array_equal(cov.view(np.uint64), ref.view(np.uint64))
+    # a second sample onto the same accumulators
+    cov2 = coverage.accumulate(ctx, seg_scaf, seg_start, seg_end, n_scaf, rs[::-1].copy(), rp[::-1].copy(), rl[::-1].copy(), cov=cov.copy())
+    ref2 = orc.coverage(seg_scaf, seg_start, seg_end, n_scaf, rs[::-1].copy(), rp[::-1].copy(), rl[::-1].copy(), cov=ref.copy())
+    assert np.array_equal(cov2.view(np.uint64), ref2.view(np.uint64))
+
+
 def test_zero_length_reads_as_the_reference_computes_them(ctx):
     seg_scaf, seg_start, seg_end = [0, 0, 1, 1, 1], [1, 2001, 1, 1501, 3001], [2000, 4100, 1500, 3000, 4600]
     rs, rp, rl = [1, 0, 1, 0, 1], [0, 2500, 1500, 100, 0], [0, 0, 0, 150, 7]
     cov = coverage.accumulate(ctx, seg_scaf, seg_start, seg_end, 2, rs, rp, rl)
     ref = orc.coverage(seg_scaf, seg_start, seg_end, 2, rs, rp, rl)
     assert np.array_equal(cov.view(np.uint64), ref.view(np.uint64)) and cov[3] == 1.0 and cov[1] == 0.0
+
+
+def test_a_segment_of_2_to_the_32_bases_is_refused(ctx):
+    with pytest.raises(Exception, match="2\\^32 bases"):
+        coverage.accumulate(ctx, [0, 0], [1, 1 << 33], [1 << 32, 1 << 34], 1, [0], [5], [100])
 
 
 def test_empty_inputs(ctx):
