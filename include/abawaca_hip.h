@@ -293,11 +293,12 @@ const int32_t* abw_sep_dev_keys(const abw_ctx* ctx);
  * src/ReadMapping.cpp:41) with read_len[i] bases, in SAM order.  cov[g] += the read's overlap with
  * segment g divided by the segment's length, added in read order, exactly as the reference's fp64
  * accumulator; call once per chunk of a SAM file (in order) with the same cov to continue the sums, and
- * with a zeroed cov for the next sample.  At most 2^32-2 segments and reads per call. */
+ * with a zeroed cov for the next sample.  At most 2^32-3 segments, scaffolds and reads (and 2^32-2 contributions) per call;
+ * a segment is shorter than 2^32 bases. */
 int abw_cov_accumulate(abw_ctx* ctx, const uint32_t* seg_scaf, const uint64_t* seg_start, const uint64_t* seg_end,
                        uint64_t n_seg, uint64_t n_scaf, const uint32_t* read_scaf, const uint64_t* read_pos,
                        const uint32_t* read_len, uint64_t n_reads, double* cov);
-/* Same with every pointer on the device; asynchronous except for one internal size read-back. */
+/* Same with every pointer on the device; asynchronous except for one or two internal read-backs of a few words. */
 int abw_cov_accumulate_dev(abw_ctx* ctx, const uint32_t* d_seg_scaf, const uint64_t* d_seg_start, const uint64_t* d_seg_end,
                            uint64_t n_seg, uint64_t n_scaf, const uint32_t* d_read_scaf, const uint64_t* d_read_pos,
                            const uint32_t* d_read_len, uint64_t n_reads, double* d_cov);
