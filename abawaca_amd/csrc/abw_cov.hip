@@ -380,18 +380,16 @@ __global__ __launch_bounds__(256) void cov_sum_pairs_kernel(const uint32_t* __re
 // the scan of abw_sig.hip (two-level, scratch[8])
 int abw_device_scan_u32(abw_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out);
 
-namespace {
-
 // keys (n of them, values below 2^bits) grouped stably: *keys_out = the keys in order, *pay_out = their payloads (pay ==
 // NULL: where each came from).  Measured on 20 M keys of 18 bits in no order: 3 passes of 6 bits and 2 of 9 take the same time.
-size_t sort_work_bytes(uint64_t n)
+size_t abw_sort_work_bytes(uint64_t n)
 {
     const uint64_t n_tiles = (n + SORT_TILE - 1) / SORT_TILE;
     return 4 * ((n * 4 + 15) & ~(size_t)15) + (((uint64_t)SORT_MAX_BINS * n_tiles * 4 + 15) & ~(size_t)15) + ((uint64_t)SORT_MAX_BINS * n_tiles + 2) * 8;
 }
 
-int stable_sort_keys(abw_ctx* ctx, const uint32_t* keys, const uint32_t* pay, uint64_t n, int bits, uint8_t* work,
-                     const uint32_t** keys_out, const uint32_t** pay_out)
+int abw_stable_sort_u32(abw_ctx* ctx, const uint32_t* keys, const uint32_t* pay, uint64_t n, int bits, uint8_t* work,
+                        const uint32_t** keys_out, const uint32_t** pay_out)
 {
     hipStream_t st = ctx->stream;
     int rc;
@@ -420,8 +418,6 @@ int stable_sort_keys(abw_ctx* ctx, const uint32_t* keys, const uint32_t* pay, ui
     *pay_out = pin;
     return ABW_OK;
 }
-
-}  // namespace
 
 extern "C" int abw_cov_accumulate_dev(abw_ctx* ctx, const uint32_t* d_seg_scaf, const uint64_t* d_seg_start, const uint64_t* d_seg_end,
                                       uint64_t n_seg, uint64_t n_scaf, const uint32_t* d_read_scaf, const uint64_t* d_read_pos,
@@ -503,7 +499,7 @@ extern "C" int abw_cov_accumulate_dev(abw_ctx* ctx, const uint32_t* d_seg_scaf, 
         n_pairs = h_flags[66];
         if (n_pairs >= 0xFFFFFFFFull) return abw_fail(ctx, ABW_ERR_ARG, "abw_cov_accumulate_dev: more than 2^32-2 contributions per call");
     }
-    const size_t b_key = up16(n_pairs * 4), b_all = b_off + 2 * b_key + sort_work_bytes(n_pairs);
+    const size_t b_key = up16(n_pairs * 4), b_all = b_off + 2 * b_key + abw_sort_work_bytes(n_pairs);
     if (bounded || ctx->scratch[11].cap < b_all) {
         if ((rc = abw_reserve(ctx, ctx->scratch[11], b_all))) return rc;
         if ((rc = abw_device_scan_u32(ctx, count, n_reads, (uint64_t*)ctx->scratch[11].p))) return rc;
@@ -537,7 +533,7 @@ extern "C" int abw_cov_accumulate_dev(abw_ctx* ctx, const uint32_t* d_seg_scaf, 
     if (descents) {
         int bits = 1;
         while (((uint64_t)1 << bits) < n_seg) bits++;                           // key values 0 .. n_seg - 1
-        if ((rc = stable_sort_keys(ctx, pkey, ppay, n_pairs, bits, work, &keys, &pays))) return rc;
+        if ((rc = abw_stable_sort_u32(ctx, pkey, ppay, n_pairs, bits, work, &keys, &pays))) return rc;
     }
     const unsigned gp = (unsigned)((n_pairs + 255) / 256);
     hipLaunchKernelGGL(cov_runs_kernel, dim3(gp), dim3(256), 0, st, keys, n_pairs, run_start, run_end, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);

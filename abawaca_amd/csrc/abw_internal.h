@@ -132,6 +132,14 @@ struct abw_prof_scope {
 #define ABW_CAT(a, b) ABW_CAT2(a, b)
 #define ABW_PROF(ctx, name) abw_prof_scope ABW_CAT(prof_scope_, __LINE__)((ctx), (name))
 
+// abw_cov.hip: stable least-significant-digit radix sort of n 32-bit keys below 2^bits with 32-bit payloads (pay == NULL: the
+// key's own index), on ctx->stream.  work: abw_sort_work_bytes(n) bytes of device memory, 16-byte aligned; the results
+// (*keys_out, *pay_out) lie inside it.  Uses ctx->scratch[8] (the scan's temporary).
+size_t abw_sort_work_bytes(uint64_t n);
+int abw_stable_sort_u32(abw_ctx* ctx, const uint32_t* keys, const uint32_t* pay, uint64_t n, int bits, uint8_t* work,
+                        const uint32_t** keys_out, const uint32_t** pay_out);
+int abw_device_scan_u32(abw_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out);      // abw_sig.hip: exclusive, out[n] = the total
+
 // RAII device guard: every entry point runs with the context's device current.
 struct abw_device_guard {
     int prev = -1;

@@ -681,6 +681,132 @@ static int sep_load_upload(abw_ctx* ctx, std::vector<int32_t>& st_first, std::ve
                            const int32_t* dp2scaf, const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
                            int32_t n_scg, bool sharded);
 
+// ---- the column store built on the device -----------------------------------------------------------------------------
+// What the host build below does with 16 threads (classify every column, sort the wide ones, rank their keys, order their
+// dps by (bin, dp)) as kernels over the keys where they are: 1.9 s -> tens of milliseconds at 4 M datapoints x 199 columns.
+namespace {
+
+// smallest and largest key of every column: mm[2 d], mm[2 d + 1] (start: INT_MAX, INT_MIN); grid (any, D)
+__global__ __launch_bounds__(256) void load_minmax_kernel(const int32_t* __restrict__ keys, int64_t N, int32_t* __restrict__ mm)
+{
+    const int32_t* __restrict__ col = keys + (int64_t)blockIdx.y * N;
+    int32_t mn = INT_MAX, mx = INT_MIN;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) { const int32_t v = col[i]; mn = min(mn, v); mx = max(mx, v); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o, 64)); mx = max(mx, __shfl_xor(mx, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[2 * blockIdx.y], mn); atomicMax(&mm[2 * blockIdx.y + 1], mx); }
+}
+
+// a wide column as unsigned sort keys: key - smallest key
+__global__ __launch_bounds__(256) void load_bias_kernel(const int32_t* __restrict__ col, int64_t N, int32_t mn, uint32_t* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) out[i] = (uint32_t)col[i] - (uint32_t)mn;
+}
+
+__global__ __launch_bounds__(256) void load_heads_kernel(const uint32_t* __restrict__ ks, int64_t N, uint32_t* __restrict__ head)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) head[i] = (i == 0 || ks[i] != ks[i - 1]) ? 1u : 0u;
+}
+
+// sorted position i of a wide column (keys ks ascending, equal keys in dp order; perm = the dp; before = distinct keys in
+// front of it): its bin = rank of its key, the (bin, dp)-ordered tables, the dp's bin, the bin's key
+__global__ __launch_bounds__(256) void load_rank_kernel(const uint32_t* __restrict__ ks, const uint32_t* __restrict__ perm, const uint64_t* __restrict__ before,
+                                                       int64_t N, int32_t mn, const int32_t* __restrict__ dp2scaf, int32_t* __restrict__ sbin,
+                                                       int32_t* __restrict__ sdp, int32_t* __restrict__ sscaf, int32_t* __restrict__ bins_col,
+                                                       int32_t* __restrict__ binval)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const bool head = i == 0 || ks[i] != ks[i - 1];
+    const int32_t rank = (int32_t)(before[i] + (head ? 1u : 0u)) - 1;
+    const uint32_t dp = perm[i];
+    sbin[i] = rank; sdp[i] = (int32_t)dp; sscaf[i] = dp2scaf[dp];
+    bins_col[dp] = rank;
+    if (head) binval[rank] = (int32_t)(ks[i] + (uint32_t)mn);
+}
+
+}  // namespace
+
+// keys: [D][N] on the host or on the device.  Fills T / span / is_wide / uniq (the distinct keys of every wide column) and
+// leaves keys, bins and the sorted tables of the wide columns on the device (ctx->sep.d_keys, d_bins; H.d_sscaf, d_sbin, d_sdp).
+static int sep_device_build(abw_ctx* ctx, const int32_t* keys, bool keys_on_device, int32_t D, int64_t N, const int32_t* dp2scaf,
+                            std::vector<int32_t>& h_T, std::vector<int32_t>& h_span, std::vector<char>& is_wide,
+                            std::vector<std::vector<int32_t>>& uniq)
+{
+    abw_sep_state& s = ctx->sep;
+    SepHost& H = g_extra_of(ctx)->h;
+    hipStream_t st = ctx->stream;
+    int rc;
+    ABW_HIP(ctx, hipMalloc((void**)&s.d_keys, (size_t)D * N * 4));
+    ABW_HIP(ctx, hipMemcpyAsync(s.d_keys, keys, (size_t)D * N * 4, keys_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    if ((rc = abw_reserve(ctx, ctx->scratch[6], (size_t)D * 8))) return rc;
+    int32_t* d_mm = (int32_t*)ctx->scratch[6].p;
+    std::vector<int32_t> mm((size_t)2 * D);
+    for (int32_t d = 0; d < D; d++) { mm[2 * d] = INT_MAX; mm[2 * d + 1] = INT_MIN; }
+    ABW_HIP(ctx, hipMemcpyAsync(d_mm, mm.data(), mm.size() * 4, hipMemcpyHostToDevice, st));
+    const unsigned gx = (unsigned)std::min<int64_t>((N + 255) / 256, std::max(1, ctx->num_cu * 8 / std::max(1, D) + 1));
+    hipLaunchKernelGGL(load_minmax_kernel, dim3(gx, (unsigned)D), dim3(256), 0, st, (const int32_t*)s.d_keys, N, d_mm);
+    ABW_LAUNCH_CHECK(ctx);
+    ABW_HIP(ctx, hipMemcpyAsync(mm.data(), d_mm, mm.size() * 4, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    size_t n_wide = 0;
+    for (int32_t d = 0; d < D; d++) {
+        const int32_t mn = mm[2 * d], mx = mm[2 * d + 1];
+        if (mn >= 0 && mx < NARROW_T) { h_T[d] = mx + 1; h_span[d] = mx + 1; }
+        else { is_wide[d] = 1; n_wide++; }
+    }
+    if (n_wide == 0) return ABW_OK;
+    ABW_HIP(ctx, hipMalloc((void**)&s.d_bins, (size_t)D * N * 4));
+    ABW_HIP(ctx, hipMemcpyAsync(s.d_bins, s.d_keys, (size_t)D * N * 4, hipMemcpyDeviceToDevice, st));    // narrow columns: bin = key
+    ABW_HIP(ctx, hipMalloc((void**)&H.d_sscaf, n_wide * (size_t)N * 4));
+    ABW_HIP(ctx, hipMalloc((void**)&H.d_sbin, n_wide * (size_t)N * 4));
+    ABW_HIP(ctx, hipMalloc((void**)&H.d_sdp, n_wide * (size_t)N * 4));
+    auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t b_n = up16((size_t)N * 4);
+    // scratch[0]: biased keys | heads | bin keys (u32[N] each) | dp2scaf i32[N];  scratch[1]: heads before u64[N + 1];  scratch[2]: the sort's work
+    if ((rc = abw_reserve(ctx, ctx->scratch[0], 4 * b_n))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[1], ((size_t)N + 2) * 8))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[2], abw_sort_work_bytes((uint64_t)N)))) return rc;
+    uint8_t* base = (uint8_t*)ctx->scratch[0].p;
+    uint32_t* d_biased = (uint32_t*)base;
+    uint32_t* d_head = (uint32_t*)(base + b_n);
+    int32_t* d_binval = (int32_t*)(base + 2 * b_n);
+    int32_t* d_dp2scaf = (int32_t*)(base + 3 * b_n);
+    uint64_t* d_before = (uint64_t*)ctx->scratch[1].p;
+    ABW_HIP(ctx, hipMemcpyAsync(d_dp2scaf, dp2scaf, (size_t)N * 4, hipMemcpyHostToDevice, st));
+    const unsigned gn = (unsigned)((N + 255) / 256);
+    size_t w = 0;
+    for (int32_t d = 0; d < D; d++) {
+        if (!is_wide[d]) continue;
+        const int32_t mn = mm[2 * d], mx = mm[2 * d + 1];
+        const uint64_t range = (uint64_t)((int64_t)mx - (int64_t)mn);
+        int bits = 1;
+        while (bits < 32 && (range >> bits) != 0) bits++;
+        const int32_t* col = s.d_keys + (int64_t)d * N;
+        hipLaunchKernelGGL(load_bias_kernel, dim3(gn), dim3(256), 0, st, col, N, mn, d_biased);
+        ABW_LAUNCH_CHECK(ctx);
+        const uint32_t *ks = nullptr, *perm = nullptr;
+        if ((rc = abw_stable_sort_u32(ctx, d_biased, nullptr, (uint64_t)N, bits, (uint8_t*)ctx->scratch[2].p, &ks, &perm))) return rc;
+        hipLaunchKernelGGL(load_heads_kernel, dim3(gn), dim3(256), 0, st, ks, N, d_head);
+        ABW_LAUNCH_CHECK(ctx);
+        if ((rc = abw_device_scan_u32(ctx, d_head, (uint64_t)N, d_before))) return rc;
+        hipLaunchKernelGGL(load_rank_kernel, dim3(gn), dim3(256), 0, st, ks, perm, (const uint64_t*)d_before, N, mn, (const int32_t*)d_dp2scaf,
+                           H.d_sbin + w * (size_t)N, H.d_sdp + w * (size_t)N, H.d_sscaf + w * (size_t)N, s.d_bins + (int64_t)d * N, d_binval);
+        ABW_LAUNCH_CHECK(ctx);
+        uint64_t T = 0;
+        ABW_HIP(ctx, hipMemcpyAsync(&T, d_before + N, 8, hipMemcpyDeviceToHost, st));
+        ABW_HIP(ctx, hipStreamSynchronize(st));
+        if (T == 0 || T > (uint64_t)N) return abw_fail(ctx, ABW_ERR_HIP, "abw_sep_load: %llu distinct keys in dimension %d of %lld datapoints", (unsigned long long)T, d, (long long)N);
+        h_T[d] = (int32_t)T;
+        uniq[d].resize((size_t)T);
+        ABW_HIP(ctx, hipMemcpy(uniq[d].data(), d_binval, (size_t)T * 4, hipMemcpyDeviceToHost));
+        w++;
+    }
+    return ABW_OK;
+}
+
 // dict_off == NULL: the table is the whole problem, the bin layout follows from it (narrow dimension:
 // T = max key + 1; wide: the column's own distinct keys).  dict_off != NULL: the table is ONE SHARD of a
 // scaffold-sharded problem and every shard must lay its histograms out identically: a dimension with an
@@ -688,7 +814,7 @@ static int sep_load_upload(abw_ctx* ctx, std::vector<int32_t>& st_first, std::ve
 // column over ALL shards) is wide with T = its length.
 static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int32_t D, int64_t N, const int32_t* dp2scaf,
                          const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
-                         int32_t n_scg, const int32_t* dict_vals, const int64_t* dict_off)
+                         int32_t n_scg, const int32_t* dict_vals, const int64_t* dict_off, bool keys_on_device = false)
 {
     if (!ctx) return ABW_ERR_ARG;
     if (!keys || !dp2scaf || !scaf_len || D <= 0 || N <= 0 || S <= 0 || N > INT_MAX - 16)
@@ -743,6 +869,25 @@ static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int
     std::vector<int32_t> bins;
     std::vector<char> is_wide(D, 0);
     std::vector<int32_t> bad_dim(D, 0);
+    // A shard's layout comes from the shared dictionaries: built on the host, as is any table when ABW_SEP_LOAD_HOST is set
+    // (the older path, kept as the check of the device build: tests/test_gpu_separator_load.py).
+    const char* force_host = getenv("ABW_SEP_LOAD_HOST");
+    const bool host_build = dict_off != nullptr || (force_host && force_host[0] == '1');
+    std::vector<int32_t> from_device;
+    if (host_build && keys_on_device) {
+        from_device.resize((size_t)D * N);
+        ABW_HIP(ctx, hipMemcpy(from_device.data(), keys, (size_t)D * N * 4, hipMemcpyDeviceToHost));
+        keys = from_device.data();
+        keys_on_device = false;
+    }
+    if (!host_build) {
+        abw_sep_free(ctx);                               // nothing below rejects the input; failures from here on are the device's
+        const int rc = sep_device_build(ctx, keys, keys_on_device, D, N, dp2scaf, s.h_T, s.h_span, is_wide, uniq);
+        if (rc) { const std::string msg = ctx->err; abw_sep_free(ctx); ctx->err = msg; return rc; }
+        Staged staged = std::move(s);
+        return sep_load_upload(ctx, staged.h_scaf_first, staged.h_scaf_ndps, staged.h_T, staged.h_span, staged.h_Toff, staged.h_binval_off, uniq, bins, is_wide,
+                               nullptr, D, N, dp2scaf, scaf_len, S, scg_off, scg_ids, n_scg, false);
+    }
     {
         unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
         auto classify_dim = [&](unsigned t) {
@@ -905,8 +1050,11 @@ static int sep_load_upload_impl(abw_ctx* ctx, std::vector<int32_t>& st_first, st
     s.D = D; s.N = N; s.S = S; s.n_scg = n_scg;
 
     int rc;
-    if ((rc = upload(ctx, &s.d_keys, keys, (size_t)D * N))) return rc;
-    if (!bins.empty()) { if ((rc = upload(ctx, &s.d_bins, bins.data(), (size_t)D * N))) return rc; }
+    const bool built = keys == nullptr;                  // sep_device_build has left keys, bins and the sorted wide tables on the device
+    if (!built) {
+        if ((rc = upload(ctx, &s.d_keys, keys, (size_t)D * N))) return rc;
+        if (!bins.empty()) { if ((rc = upload(ctx, &s.d_bins, bins.data(), (size_t)D * N))) return rc; }
+    }
     if ((rc = upload(ctx, &s.d_scaf_first, s.h_scaf_first.data(), (size_t)S))) return rc;
     if ((rc = upload(ctx, &s.d_scaf_ndps, s.h_scaf_ndps.data(), (size_t)S))) return rc;
     if ((rc = upload(ctx, &s.d_scaf_len, scaf_len, (size_t)S))) return rc;
@@ -924,7 +1072,11 @@ static int sep_load_upload_impl(abw_ctx* ctx, std::vector<int32_t>& st_first, st
     if ((rc = upload<Sums>(ctx, &H.d_chunk_sums, nullptr, H.chunks.size()))) return rc;
     if ((rc = upload<Sums>(ctx, &H.d_dim_total, nullptr, (size_t)D))) return rc;
     if ((rc = upload<Cand>(ctx, &H.d_chunk_best, nullptr, H.chunks.size()))) return rc;
-    if (!H.wide_dims.empty()) {
+    if (!H.wide_dims.empty() && built) {
+        const size_t Dw = H.wide_dims.size();
+        if ((rc = upload<int32_t>(ctx, &H.d_wts, nullptr, Dw * (size_t)S))) return rc;
+        if ((rc = upload<int32_t>(ctx, &H.d_wbelow, nullptr, Dw * (size_t)S))) return rc;
+    } else if (!H.wide_dims.empty()) {
         // dps of every wide dimension in ascending (bin, dp) order: counting sort on the dense ranks
         const size_t Dw = H.wide_dims.size();
         std::vector<int32_t> sscaf(Dw * (size_t)N), sbin(Dw * (size_t)N), sdp(Dw * (size_t)N);
@@ -1157,6 +1309,13 @@ int abw_sep_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const 
                  int32_t n_scg)
 {
     return sep_load_impl(ctx, "abw_sep_load", keys, D, N, dp2scaf, scaf_len, S, scg_off, scg_ids, n_scg, nullptr, nullptr);
+}
+
+int abw_sep_load_dev(abw_ctx* ctx, const int32_t* d_keys, int32_t D, int64_t N, const int32_t* dp2scaf,
+                     const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
+                     int32_t n_scg)
+{
+    return sep_load_impl(ctx, "abw_sep_load_dev", d_keys, D, N, dp2scaf, scaf_len, S, scg_off, scg_ids, n_scg, nullptr, nullptr, true);
 }
 
 int abw_sep_shard_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const int32_t* dp2scaf,

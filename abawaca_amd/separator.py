@@ -31,10 +31,16 @@ _PER_DTYPE = np.dtype([("found", "i4"), ("key", "i4"), ("sens", "f8"), ("spec", 
 class ColumnStore:
     """The resident feature table (ClusterData + ScafDpData + SCGdb as the separator sees them)."""
 
-    def __init__(self, ctx: Context, keys, dp2scaf, scaf_len, scg_off=None, scg_ids=None, n_scg=0):
+    def __init__(self, ctx: Context, keys, dp2scaf, scaf_len, scg_off=None, scg_ids=None, n_scg=0, device_keys=None):
+        """keys: [D, N] int32 on the host -- or None with device_keys = (device address of a [D][N] int32 table, D, N), e.g. a torch
+        tensor's data_ptr(): the table is then built from the keys where they are (abw_sep_load_dev)."""
         self.ctx = ctx
-        self.keys = np.ascontiguousarray(keys, dtype=np.int32)          # [D, N]
-        self.D, self.N = self.keys.shape
+        if device_keys is None:
+            self.keys = np.ascontiguousarray(keys, dtype=np.int32)          # [D, N]
+            self.D, self.N = self.keys.shape
+        else:
+            self.keys = None
+            d_ptr, self.D, self.N = int(device_keys[0]), int(device_keys[1]), int(device_keys[2])
         self.dp2scaf = np.ascontiguousarray(dp2scaf, dtype=np.int32)
         self.scaf_len = np.ascontiguousarray(scaf_len, dtype=np.int64)
         self.S = len(self.scaf_len)
@@ -44,8 +50,12 @@ class ColumnStore:
         so = np.ascontiguousarray(scg_off, dtype=np.int32) if self.n_scg else None
         si = np.ascontiguousarray(scg_ids, dtype=np.int32) if self.n_scg else None
         p = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None
-        ctx.check(lib().abw_sep_load(ctx.handle, p(self.keys), self.D, self.N, p(self.dp2scaf), p(self.scaf_len), self.S,
-                                     p(so), p(si), self.n_scg))
+        if device_keys is None:
+            ctx.check(lib().abw_sep_load(ctx.handle, p(self.keys), self.D, self.N, p(self.dp2scaf), p(self.scaf_len), self.S,
+                                         p(so), p(si), self.n_scg))
+        else:
+            ctx.check(lib().abw_sep_load_dev(ctx.handle, C.c_void_p(d_ptr), self.D, self.N, p(self.dp2scaf), p(self.scaf_len), self.S,
+                                             p(so), p(si), self.n_scg))
 
     def dev_keys_ptr(self):
         return lib().abw_sep_dev_keys(self.ctx.handle)

@@ -162,6 +162,14 @@ typedef struct {
 int abw_sep_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const int32_t* dp2scaf,
                  const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
                  int32_t n_scg);
+/* The same with the keys already on the device (d_keys: [D][N] int32 on ctx's device, e.g. what a loader left there; it is
+ * copied, the caller keeps its buffer); every other argument on the host as above.  Both calls build the table on the
+ * device: the columns are classified, the wide ones (keys outside [0, 1024): the coverage columns of ref
+ * src/abawaca-build.cpp:603) sorted and ranked by kernels.  The same rows of the reference as abw_sep_load replace
+ * (src/ClusterData.cpp:117-163, src/Dimension.cpp). */
+int abw_sep_load_dev(abw_ctx* ctx, const int32_t* d_keys, int32_t D, int64_t N, const int32_t* dp2scaf,
+                     const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
+                     int32_t n_scg);
 
 /* One node.  scaf_ids: host, the node's scaffolds (any order, no duplicates); NULL = all S
  * scaffolds (the root, ref: init_cluster, src/abawaca.cpp:242-251).  min_ndps is
