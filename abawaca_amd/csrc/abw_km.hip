@@ -552,6 +552,15 @@ void launch_step(abw_ctx* ctx, const StepArgs& a)
 
 }  // namespace
 
+__global__ __launch_bounds__(256) void km_sum_ordered_kernel(const double* __restrict__ parts, int32_t n_parts, int64_t n, double* out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double acc = parts[i];
+    for (int32_t p = 1; p < n_parts; p++) acc += parts[(int64_t)p * n + i];
+    out[i] = acc;
+}
+
 extern "C" {
 
 int abw_km_tinymt_selftest(abw_ctx* ctx, uint32_t seed, int32_t n, uint32_t* out)
@@ -710,6 +719,20 @@ int abw_km_shard_update(abw_ctx* ctx, int32_t last)
     hipLaunchKernelGGL(km_update_kernel, dim3(k.Rp), dim3(k.W), upd_lds, ctx->stream, k.single ? k.gsum : k.sums, k.single ? k.ngroups : (int64_t)1,
                        k.moments, k.Rp, k.W, k.d, k.cent, k.dT,
                        last ? 0 : 1, k.col_term);
+    ABW_LAUNCH_CHECK(ctx);
+    return ABW_OK;
+}
+
+// The combine step of the point-sharded run for a caller that holds the shards' buffers side by side on the device
+// (d_parts: [n_parts][n] fp64, e.g. the output of one all-gather): d_out[i] = ((part 0 + part 1) + part 2) + ..., the order
+// abawaca_amd/multi.py adds them in, so every rank holds identical bits.  On the context's stream; d_out may be a part.
+int abw_km_sum_ordered(abw_ctx* ctx, const double* d_parts, int32_t n_parts, int64_t n, double* d_out)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!d_parts || !d_out || n_parts < 1 || n < 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_sum_ordered: bad argument");
+    if (n == 0) return ABW_OK;
+    abw_device_guard g(ctx->device);
+    hipLaunchKernelGGL(km_sum_ordered_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_parts, n_parts, n, d_out);
     ABW_LAUNCH_CHECK(ctx);
     return ABW_OK;
 }

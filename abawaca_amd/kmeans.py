@@ -105,14 +105,14 @@ def kmeans_sharded_dev(ctx: Context, t_x_local, first_point: int, N_total: int, 
             torch.cuda.synchronize(t_x_local.device)
     lib_done()
     multi.combine_int_sum(run.init, dist)
-    multi.combine_ordered_sum(run.moments, dist)
+    multi.combine_ordered_sum(run.moments, dist, ctx)
     torch_done()
     run.ready()
     for it in range(iters + 1):
         last = it == iters
         run.step(t_assign if last else None)
         lib_done()
-        multi.combine_ordered_sum(run.sums, dist)
+        multi.combine_ordered_sum(run.sums, dist, ctx)
         torch_done()
         run.update(last)
     run.finish(t_centroids, t_inertia)

@@ -112,21 +112,48 @@ def combine_int_sum(t, dist=None):
     return t
 
 
-def combine_ordered_sum(t, dist=None):
+_fast_combine_failed = False
+
+
+def combine_ordered_sum(t, dist=None, ctx=None):
     """In-place fp64 sum over the shards, added in shard (rank) order on every rank, so that all ranks
     hold identical bits and the result does not depend on the collective's internal order: all-gather
-    (a few hundred KB per rank, one direct exchange per peer over xGMI) + local adds."""
+    (a few hundred KB per rank, one direct exchange per peer over xGMI) + local adds.  With `ctx` (a Context whose
+    stream is torch's current stream) on RCCL: one all-gather into one buffer and one kernel (abw_km_sum_ordered)."""
+    global _fast_combine_failed
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return t
     import torch
+    world = dist.get_world_size()
+    if ctx is not None and t.is_cuda and dist.get_backend() == "nccl" and ctx.shares_torch_stream and not _fast_combine_failed:
+        try:
+            buf = torch.empty((world, t.numel()), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(buf, t.reshape(-1))
+            sum_ordered(ctx, buf, t)
+            return t
+        except (RuntimeError, AttributeError) as e:       # an older torch / a backend without the flat all-gather: the generic way
+            _fast_combine_failed = True
+            import sys
+            print(f"[abawaca_amd.multi] fast combine unavailable ({e}); using all_gather + adds", file=sys.stderr)
     src = t.cpu() if (t.is_cuda and dist.get_backend() != "nccl") else t
-    parts = [torch.empty_like(src) for _ in range(dist.get_world_size())]
+    parts = [torch.empty_like(src) for _ in range(world)]
     dist.all_gather(parts, src)
     acc = parts[0].clone()
     for p in parts[1:]:
         acc.add_(p)
     t.copy_(acc)
     return t
+
+
+def sum_ordered(ctx, t_parts, t_out):
+    """t_out[i] = ((t_parts[0][i] + t_parts[1][i]) + ...) -- fp64 device tensors, t_parts [n_parts, n] contiguous; one
+    kernel on the context's stream (abw_km_sum_ordered)."""
+    import ctypes as C
+    from ._lib import lib
+    n_parts, n = int(t_parts.shape[0]), int(t_out.numel())
+    assert t_parts.is_contiguous() and t_out.is_contiguous() and t_parts.numel() == n_parts * n
+    ctx.check(lib().abw_km_sum_ordered(ctx.handle, C.c_void_p(t_parts.data_ptr()), n_parts, n, C.c_void_p(t_out.data_ptr())))
+    return t_out
 
 
 # ---- scaffold-sharded separator (SURVEY §8 row e): shard layout, shared bin layout, the exchange ----

@@ -397,6 +397,10 @@ typedef struct abw_km_exchange {
     double*  d_moments;  uint64_t moments_count;
     double*  d_sums;     uint64_t sums_count;
 } abw_km_exchange;
+/* The fp64 "sum in shard order" of the combine steps above as one kernel, for a caller that has the shards' buffers side
+ * by side on its device (d_parts: [n_parts][n], e.g. the output of one RCCL all-gather): d_out[i] = ((part 0 + part 1) +
+ * part 2) + ...  No counterpart in the reference (it is one process). */
+int abw_km_sum_ordered(abw_ctx* ctx, const double* d_parts, int32_t n_parts, int64_t n, double* d_out);
 int abw_km_shard_begin(abw_ctx* ctx, const float* d_x, int64_t N_local, int64_t first_point, int64_t N_total, int32_t d,
                        int32_t R, uint32_t base_seed, int32_t chunk, abw_km_exchange* ex);
 int abw_km_shard_ready(abw_ctx* ctx);

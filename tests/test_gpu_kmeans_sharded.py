@@ -87,3 +87,50 @@ def test_one_shard_over_the_distributed_driver_is_the_plain_run():
         assert np.array_equal(i.cpu().numpy(), oi)
     finally:
         ctx.close()
+
+
+def test_sum_ordered_is_the_rank_ordered_sum():
+    """abw_km_sum_ordered = what multi.combine_ordered_sum does with torch adds: part 0 + part 1 + ... in that order"""
+    ctx = _lib.Context(0)
+    try:
+        g = torch.Generator(device="cuda:0"); g.manual_seed(7)
+        for world, n in ((2, 1), (5, 57344), (8, 114688 + 3)):
+            parts = (torch.rand((world, n), device="cuda:0", generator=g, dtype=torch.float64) - 0.5) * 1e6
+            want = parts[0].clone()
+            for p in parts[1:]:
+                want.add_(p)
+            out = torch.empty(n, dtype=torch.float64, device="cuda:0")
+            torch.cuda.synchronize()
+            multi.sum_ordered(ctx, parts, out)
+            ctx.synchronize()
+            assert torch.equal(out.view(torch.int64), want.view(torch.int64))
+            multi.sum_ordered(ctx, parts, parts[0])                     # in place, onto the first part
+            ctx.synchronize()
+            assert torch.equal(parts[0].view(torch.int64), want.view(torch.int64))
+    finally:
+        ctx.close()
+
+
+def test_fast_combine_over_rccl_with_one_rank():
+    """The RCCL path of multi.combine_ordered_sum (all_gather_into_tensor + one kernel on torch's stream) cannot meet a second
+    GPU here; with a one-rank RCCL group its steps still run for real: the gathered buffer is the tensor itself."""
+    import torch.distributed as dist
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    ctx = _lib.Context(0)
+    try:
+        ctx.use_torch_stream(True)
+        t = torch.arange(1000, dtype=torch.float64, device="cuda:0") * 0.37
+        want = t.clone()
+        buf = torch.empty((1, t.numel()), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(buf, t.reshape(-1))
+        multi.sum_ordered(ctx, buf, t)
+        torch.cuda.synchronize()
+        assert torch.equal(t, want)
+        # and the function itself (one rank: nothing to add, returns the tensor)
+        assert multi.combine_ordered_sum(t, dist, ctx) is t
+    finally:
+        ctx.use_torch_stream(False)
+        ctx.close()
+        dist.destroy_process_group()
