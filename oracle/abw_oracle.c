@@ -435,6 +435,128 @@ int abw_or_coverage(const uint32_t* seg_scaf, const uint64_t* seg_start, const u
 }
 
 /* ---------------------------------------------------------------------------------------- */
+/* Row N1, the reader side: SAM records                                                      */
+/* ---------------------------------------------------------------------------------------- */
+static int plain_number(const uint8_t* p, uint64_t n, uint64_t* v)      /* 1..9 digits */
+{
+    if (n == 0 || n > 9) return 0;
+    uint64_t x = 0;
+    for (uint64_t i = 0; i < n; i++) { if (p[i] < '0' || p[i] > '9') return 0; x = x * 10 + (uint64_t)(p[i] - '0'); }
+    *v = x;
+    return 1;
+}
+
+int abw_or_sam_line(const uint8_t* line, uint64_t len, abw_or_sam_rec* out)
+{
+    /* split('\t', ...), src/common.cpp:95-108: n tabs make n + 1 fields (an empty line makes none) */
+    uint64_t fo[12], fl[12];          /* the first 11 fields; [11]: everything behind the 11th tab */
+    int nf = 0;
+    uint64_t p1 = 0;
+    if (len > 0) {
+        for (uint64_t i = 0; i <= len && nf < 11; i++) {
+            if (i == len || line[i] == '\t') { fo[nf] = p1; fl[nf] = i - p1; nf++; p1 = i + 1; }
+        }
+    }
+    if (nf < 11) return 1;
+    uint64_t v;
+    if (!plain_number(line + fo[1], fl[1], &v)) return 2;              /* FLAG = atoi(fs[1]), ref :39 */
+    out->flag = (uint32_t)v;
+    if (!plain_number(line + fo[3], fl[3], &v)) return 2;              /* POS = atoi(fs[3]) - 1, ref :41 */
+    out->pos0 = v - 1;
+    out->rname_off = fo[2]; out->rname_len = fl[2];                    /* ref :40 */
+    out->seq_len = (uint32_t)fl[9];                                    /* ref :53 */
+    for (uint64_t i = 0; i < fl[9]; i++) if (line[fo[9] + i] == 'n') return 3;      /* src/String.cpp:45-49 */
+    const uint64_t qual_len = fl[10];
+    out->nsnps = 0;
+    /* the MD:Z field, ref :57-69: the first field behind the 11th that holds "MD:Z:" */
+    const uint8_t* md = 0;
+    uint64_t md_len = 0;
+    for (uint64_t a = p1; a <= len && !md; ) {
+        uint64_t b = a;
+        while (b < len && line[b] != '\t') b++;
+        for (uint64_t i = a; i + 5 <= b; i++) {
+            if (line[i] == 'M' && line[i + 1] == 'D' && line[i + 2] == ':' && line[i + 3] == 'Z' && line[i + 4] == ':') {
+                if (i != a) return 4;                                  /* inside a field: refused here */
+                md = line + a; md_len = b - a;
+                break;
+            }
+        }
+        a = b + 1;
+    }
+    if (!md) return 0;                                                 /* ref :80-81 */
+    for (uint64_t i = 0; i < md_len; i++) if (md[i] == ' ') return 4;  /* ref :60-66 keeps the blank, :102-103 throws on it */
+    /* determine_snps, ref :85-128 */
+    uint64_t q = 5, read_pos = 0, nd = 0;
+    while (q < md_len && md[q] >= '0' && md[q] <= '9') { read_pos = read_pos * 10 + (uint64_t)(md[q++] - '0'); if (++nd > 9) return 4; }
+    read_pos--;                                                        /* ref :98 (wraps when the string starts with 0) */
+    uint32_t snps = 0;
+    while (q < md_len) {
+        if (md[q] != '^' && (md[q] < 'A' || md[q] > 'Z')) return 4;   /* ref :102-103 */
+        if (md[q] == '^') {
+            q++;
+            while (q < md_len && (md[q] < '0' || md[q] > '9')) { snps++; q++; }     /* ref :107-111: one per deleted base */
+        } else {
+            read_pos++;
+            if (read_pos >= out->seq_len || read_pos >= qual_len) return 4;          /* ref :115: get() / at() throw */
+            snps++;
+            q++;
+        }
+        if (q >= md_len || md[q] < '0' || md[q] > '9') return 4;       /* ref :120-121 */
+        uint64_t o = 0; nd = 0;
+        while (q < md_len && md[q] >= '0' && md[q] <= '9') { o = o * 10 + (uint64_t)(md[q++] - '0'); if (++nd > 9) return 4; }
+        read_pos += o;
+    }
+    /* the CIGAR string, ref :132-179 */
+    const uint8_t* cg = line + fo[5];
+    const uint64_t cl = fl[5];
+    if (cl == 0) return 5;
+    if (cg[cl - 1] != 'I' && cg[cl - 1] != 'D' && cg[cl - 1] != 'M') return 5;       /* ref :134-137 */
+    uint64_t read_pos2 = 0;
+    for (uint64_t i = 0; i < cl; ) {
+        uint64_t o = 0; nd = 0;
+        while (i < cl && cg[i] >= '0' && cg[i] <= '9') { o = o * 10 + (uint64_t)(cg[i++] - '0'); if (++nd > 9) return 5; }
+        if (o == 0) return 5;                                          /* ref :147-149 */
+        const uint8_t op = cg[i++];                                    /* the last character is a letter: i < cl here */
+        if (op == 'M') read_pos2 += o;
+        else if (op == 'D') { }
+        else if (op == 'I') { read_pos += o; snps++; read_pos2 += o; } /* ref :161-173: one SNP per insertion */
+        else return 5;                                                 /* ref :176-177 */
+    }
+    if (read_pos + 1 != (uint64_t)out->seq_len || read_pos2 != (uint64_t)out->seq_len) return 6;   /* ref :182-183 */
+    out->nsnps = snps;
+    return 0;
+}
+
+int64_t abw_or_sam_parse(const uint8_t* text, uint64_t len, const uint8_t* names, const uint64_t* name_off, uint64_t n_scaf,
+                         uint32_t* scaf, uint64_t* pos0, uint32_t* seq_len, uint32_t* flag, uint32_t* nsnps, uint64_t cap,
+                         int32_t* err_code)
+{
+    int64_t n = 0, line_no = 0;
+    for (uint64_t a = 0; a < len; ) {
+        uint64_t b = a;
+        while (b < len && text[b] != '\n') b++;
+        uint64_t e = b;
+        line_no++;
+        if (text[a] != '@') {                                          /* src/ReadMappingReader.cpp:105-107 */
+            while (e > a && (text[e - 1] == '\r' || text[e - 1] == '\n')) e--;   /* chomp, src/common.cpp:38-49 */
+            abw_or_sam_rec r;
+            const int rc = abw_or_sam_line(text + a, e - a, &r);
+            if (rc) { if (err_code) *err_code = rc; return -line_no; }
+            if ((uint64_t)n < cap) {
+                uint64_t id = n_scaf;                                  /* scafs.find(ref_name()), src/abawaca-build.cpp:549 */
+                for (uint64_t s = 0; s < n_scaf; s++) {
+                    if (name_off[s + 1] - name_off[s] == r.rname_len && memcmp(names + name_off[s], text + a + r.rname_off, r.rname_len) == 0) { id = s; break; }
+                }
+                scaf[n] = (uint32_t)id; pos0[n] = r.pos0; seq_len[n] = r.seq_len; flag[n] = r.flag; nsnps[n] = r.nsnps;
+            }
+            n++;
+        }
+        a = b + 1;
+    }
+    return n;
+}
+
+/* ---------------------------------------------------------------------------------------- */
 /* K-means restarts (extension; semantics fixed in DESIGN.md "K-means")                      */
 /* ---------------------------------------------------------------------------------------- */
 #define KM_GROUP 32   /* chunk partials are first added in groups of 32 consecutive chunks, then the groups */

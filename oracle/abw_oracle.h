@@ -98,6 +98,37 @@ void     abw_or_tinymt_init(abw_or_tinymt* t, uint32_t seed);
 uint32_t abw_or_tinymt_next(abw_or_tinymt* t);
 
 /* ------------------------------------------------------------------------------------------
+ * Row N1, the reader side: one SAM record line as Bio::ReadMapping::ReadMapping(const char*) takes it apart
+ * (reference src/ReadMapping.cpp:23-72) and determine_snps counts its SNPs (:78-185).
+ * line: the record without its end of line (SAMReader::next_mapping chomps "\n" and "\r", src/ReadMappingReader.cpp:113,
+ * src/common.cpp:38-49).  Returns 0, or the code of what the reference would do to the line instead of returning a
+ * mapping (it throws, or indexes a field that is not there), or of what this restatement is stricter about:
+ *   1  fewer than 11 tab-separated fields (:38-54 index fs[0] .. fs[10])
+ *   2  FLAG or POS is not 1..9 digits (atoi would stop at the first other character: refused here)
+ *   3  a lower-case n in SEQ (src/String.cpp:45-49 throws)
+ *   4  the MD:Z string (throws :86-88, :102-103, :120-121; at() :115; a field behind the 11th that holds "MD:Z:" anywhere
+ *      but at its start, or a number of more than 9 digits: refused here)
+ *   5  the CIGAR string of a record with an MD:Z tag (throws :134-137, :147-149, :176-177)
+ *   6  SNP offsets and CIGAR lengths do not add up to the read length (:182-183)
+ * nsnps = num_snps(): one per mismatched and per deleted base of MD:Z, one per I operation of the CIGAR string.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint32_t flag;              /* atoi(fs[1]) */
+    uint64_t pos0;              /* atoi(fs[3]) - 1 as size_t: POS 0 wraps (:41) */
+    uint32_t seq_len;           /* SEQ.size() (:53) */
+    uint32_t nsnps;
+    uint64_t rname_off, rname_len;   /* fs[2] inside the line */
+} abw_or_sam_rec;
+int abw_or_sam_line(const uint8_t* line, uint64_t len, abw_or_sam_rec* out);
+/* A whole SAM text: lines that start with '@' are skipped (src/ReadMappingReader.cpp:105-107), every other line is a record,
+ * in file order; scaf = index of RNAME among the n_scaf names (names: blob, name_off[n_scaf + 1]) or n_scaf when it is none
+ * of them (src/abawaca-build.cpp:549-551).  Returns the number of records (at most cap are written), or -(1-based line
+ * number) with *err_code set when a line is refused. */
+int64_t abw_or_sam_parse(const uint8_t* text, uint64_t len, const uint8_t* names, const uint64_t* name_off, uint64_t n_scaf,
+                         uint32_t* scaf, uint64_t* pos0, uint32_t* seq_len, uint32_t* flag, uint32_t* nsnps, uint64_t cap,
+                         int32_t* err_code);
+
+/* ------------------------------------------------------------------------------------------
  * Row N1: per-segment read coverage (reference src/abawaca-build.cpp:231-244, :177-185).
  * cov[g] += overlap/length for every read, in read order (fp64, the reference's accumulator).
  * Segments grouped by scaffold, ascending; read_pos 0-based (SAM POS - 1).

@@ -31,6 +31,7 @@ def lib():
         _LIB.abw_or_milli.restype = C.c_int32
         _LIB.abw_or_milli.argtypes = [C.c_double]
         _LIB.abw_or_tinymt_next.restype = C.c_uint32
+        _LIB.abw_or_sam_parse.restype = C.c_int64
     return _LIB
 
 
@@ -210,6 +211,31 @@ def coverage(seg_scaf, seg_start, seg_end, n_scaf, read_scaf, read_pos, read_len
     if rc != 0:
         raise RuntimeError("abw_or_coverage failed: %d" % rc)
     return out
+
+
+def names_blob(names):
+    """scaffold names -> (blob u8, name_off u64[n + 1]) as abw_sam_parse / abw_or_sam_parse take them"""
+    enc = [n.encode() if isinstance(n, str) else bytes(n) for n in names]
+    off = np.zeros(len(enc) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(e) for e in enc])
+    return np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8).copy(), off
+
+
+def sam_parse(text: np.ndarray, names):
+    """abw_or_sam_parse -> (scaf u32, pos0 u64, len u32, flag u32, nsnps u32) of every record, or raises
+    ValueError((line number, code)) where the reference would not return a mapping."""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    blob, off = names_blob(names)
+    cap = int((text == 10).sum()) + 1
+    scaf, pos0 = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint64)
+    ln, fl, ns = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint32)
+    code = C.c_int32(0)
+    n = lib().abw_or_sam_parse(_p(text, C.c_uint8), C.c_uint64(len(text)), _p(blob, C.c_uint8), _p(off, C.c_uint64), C.c_uint64(len(names)),
+                               _p(scaf, C.c_uint32), _p(pos0, C.c_uint64), _p(ln, C.c_uint32), _p(fl, C.c_uint32), _p(ns, C.c_uint32),
+                               C.c_uint64(cap), C.byref(code))
+    if n < 0:
+        raise ValueError((int(-n), int(code.value)))
+    return scaf[:n], pos0[:n], ln[:n], fl[:n], ns[:n]
 
 
 def lrn_parse(text: np.ndarray, row_cap: int, ndims_cap: int = 4096):
