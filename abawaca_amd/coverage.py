@@ -72,3 +72,44 @@ def accumulate(ctx: Context, seg_scaf, seg_start, seg_end, n_scaf: int, read_sca
 def milli(cov):
     """the thousandths abawaca.lrn prints (ref src/abawaca-build.cpp:603: int(1000.0 * x))"""
     return (1000.0 * np.asarray(cov, dtype=np.float64)).astype(np.int64)
+
+
+class SamCounts(C.Structure):
+    _fields_ = [("lines", C.c_uint64), ("records", C.c_uint64), ("kept", C.c_uint64)]
+
+
+def names_table(names):
+    """scaffold names -> (blob u8, name_off u64[n + 1]) as abw_sam_parse takes them"""
+    enc = [n.encode() if isinstance(n, str) else bytes(n) for n in names]
+    off = np.zeros(len(enc) + 1, dtype=np.uint64)
+    if enc:
+        off[1:] = np.cumsum([len(e) for e in enc])
+    return np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8).copy(), off
+
+
+def parse_sam(ctx: Context, text, names, max_snps: int = MAX_SNPS, every_record: bool = False):
+    """SAM text (bytes / uint8 array; a whole file or a part cut at line ends) -> (scaf u32, pos0 u64, len u32) of the records
+    the reference accumulates (reference src/ReadMappingReader.cpp:80-116, src/ReadMapping.cpp:23-185,
+    src/abawaca-build.cpp:546-551), in file order, ready for `accumulate`.  every_record: also a dict of the arrays of EVERY
+    record (scaf, pos0, len, flag, nsnps) and the counts.  Raises (ABW_ERR_FORMAT / ABW_ERR_LOWER_N, the line named in the
+    message) where the reference's reader would not return a mapping: fall back to that reader."""
+    text = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
+    blob, off = names_table(names)
+    cap = int(np.count_nonzero(text == 10)) + 1
+    rs, rp, rl = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint32)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    cnt = SamCounts()
+    if every_record:
+        cs, cp, cl = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint32)
+        cf, cn = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint32)
+        extra = [p(cs), p(cp), p(cl), p(cf), p(cn)]
+    else:
+        extra = [None] * 5
+    ctx.check(lib().abw_sam_parse(ctx.handle, p(text), len(text), p(blob), p(off), len(names), int(max_snps), cap, p(rs), p(rp), p(rl),
+                                  *extra, C.byref(cnt)))
+    k = int(cnt.kept)
+    kept = (rs[:k], rp[:k], rl[:k])
+    if not every_record:
+        return kept
+    r = int(cnt.records)
+    return kept, dict(scaf=cs[:r], pos0=cp[:r], len=cl[:r], flag=cf[:r], nsnps=cn[:r], lines=int(cnt.lines), records=r, kept=k)

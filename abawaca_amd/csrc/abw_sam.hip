@@ -1,0 +1,428 @@
+// Row N1, the reader side — SAM text to the arrays abw_cov_accumulate takes.
+//
+// Reference semantics (restated in oracle/abw_oracle.c abw_or_sam_line, pinned to the SAM files of a reference run):
+//   lines     src/ReadMappingReader.cpp:80-116  lines that start with '@' are skipped, every other line is a record;
+//                                               "\n" and "\r" at its end are chomped (src/common.cpp:38-49)
+//   fields    src/ReadMapping.cpp:23-72         split at tabs (src/common.cpp:95-108); FLAG = atoi(fs[1]), RNAME = fs[2],
+//                                               POS = atoi(fs[3]) - 1 as size_t (POS 0 wraps), read length = SEQ.size(),
+//                                               a lower-case n in SEQ throws (src/String.cpp:45-49)
+//   SNPs      src/ReadMapping.cpp:78-185        the first field behind the 11th that holds "MD:Z:"; one SNP per mismatched
+//                                               and per deleted base of it, one per I operation of the CIGAR string; every
+//                                               malformation throws, as does a length that does not add up (:182-183)
+//   filter    src/abawaca-build.cpp:546         unmapped (FLAG & 4), more than max_snps SNPs, secondary (FLAG & 0x100)
+//   lookup    src/abawaca-build.cpp:549-551     RNAME among the scaffold names; unknown names are skipped
+// A line the reference would not survive (it throws, or indexes a field that is not there), and the few things this parser
+// is stricter about (FLAG / POS must be 1..9 digits; "MD:Z:" inside a field), make the call fail with ABW_ERR_FORMAT
+// (ABW_ERR_LOWER_N for the n) and name the line: the caller falls back to the reference's reader, which then does what it
+// does.  The `-c` sample's read-pair links (src/abawaca-build.cpp:531-545) stay with the caller.
+//
+// Kernels: newlines per 4 KiB block -> scan -> start of every line; one thread per line walks it once (fields counted at
+// the tabs, FLAG / POS converted and RNAME hashed on the way, SEQ checked for n), then the MD:Z and CIGAR strings; the
+// scaffold comes from a hash table of the names (FNV-1a, open addressing, built by the host per call; a hit is confirmed
+// by comparing the bytes); two scans compact the records and the records that pass the filter, file order kept.
+#include "abw_internal.h"
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int SAM_BLK = 4096;                       // bytes of text per workgroup of the line kernels (16 per thread)
+constexpr uint64_t FNV_OFFSET = 0xcbf29ce484222325ull, FNV_PRIME = 0x100000001b3ull;
+constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu;
+
+struct SamNames {
+    const uint64_t* slot_hash; const uint32_t* slot_id; uint64_t mask;
+    const uint8_t* blob; const uint64_t* off; uint32_t n_scaf;
+};
+
+__device__ __forceinline__ uint32_t nl_mask16(const uint8_t* __restrict__ text, uint64_t at, uint64_t len)
+{
+    uint32_t m = 0;
+    if (at + 16 <= len) {
+        uint4 v;
+        memcpy(&v, text + at, 16);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) m |= (((w[q] >> (8 * b)) & 0xFFu) == 10u) ? (1u << (4 * q + b)) : 0u;
+    } else {
+        for (int i = 0; i < 16 && at + i < len; i++) m |= (text[at + i] == 10) ? (1u << i) : 0u;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void sam_nlcount_kernel(const uint8_t* __restrict__ text, uint64_t len, uint32_t* __restrict__ blk_nl)
+{
+    __shared__ uint32_t s_c;
+    if (threadIdx.x == 0) s_c = 0;
+    __syncthreads();
+    uint32_t c = __popc(nl_mask16(text, (uint64_t)blockIdx.x * SAM_BLK + (uint64_t)threadIdx.x * 16, len));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor((int)c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_c, c);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_nl[blockIdx.x] = s_c;
+}
+
+// line_start[0] = 0 (written by the host); the line behind the k-th newline of the text starts at its position + 1
+__global__ __launch_bounds__(256) void sam_lines_kernel(const uint8_t* __restrict__ text, uint64_t len, const uint64_t* __restrict__ blk_prefix,
+                                                       uint64_t* __restrict__ line_start)
+{
+    __shared__ uint32_t s_w[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint64_t at = (uint64_t)blockIdx.x * SAM_BLK + (uint64_t)threadIdx.x * 16;
+    uint32_t m = nl_mask16(text, at, len);
+    const uint32_t c = __popc(m);
+    uint32_t incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += y; }
+    if (lane == 63) s_w[wid] = incl;
+    __syncthreads();
+    uint64_t k = blk_prefix[blockIdx.x] + incl - c;
+    for (int w = 0; w < wid; w++) k += s_w[w];
+    while (m) {
+        const int i = __ffs(m) - 1;
+        m &= m - 1;
+        line_start[++k] = at + (uint64_t)i + 1;
+    }
+}
+
+// Returns 0 or the refusal code of oracle/abw_oracle.h (abw_or_sam_line); t[a, e): the line without its end.
+__device__ int sam_line(const uint8_t* __restrict__ t, uint64_t a, uint64_t e, const SamNames& nm, uint32_t& flag, uint64_t& pos0,
+                        uint32_t& seq_len, uint32_t& nsnps, uint32_t& scaf)
+{
+    if (e == a) return 1;                                                // split() of an empty line: no field at all
+    // one walk over the first eleven fields (ref src/ReadMapping.cpp:36-54)
+    int nf = 0;
+    uint64_t fstart = a, vflag = 0, vpos = 0, h = FNV_OFFSET;
+    int dflag = 0, dpos = 0;
+    bool bad_flag = false, bad_pos = false, lower_n = false;
+    uint64_t rn_off = a, rn_len = 0, cg_off = a, cg_len = 0, sq_len = 0, ql_len = 0;
+    uint64_t i = a;
+    for (;;) {
+        const bool at_end = i == e;
+        const uint8_t c = at_end ? (uint8_t)'\t' : t[i];
+        if (c == '\t') {                                                 // field nf is [fstart, i)
+            if (nf == 2) { rn_off = fstart; rn_len = i - fstart; }
+            else if (nf == 5) { cg_off = fstart; cg_len = i - fstart; }
+            else if (nf == 9) sq_len = i - fstart;
+            else if (nf == 10) ql_len = i - fstart;
+            nf++;
+            fstart = i + 1;
+            if (at_end || nf == 11) break;
+        } else if (nf == 1) {
+            if (c < '0' || c > '9') bad_flag = true;
+            vflag = vflag * 10 + (uint64_t)(c - '0'); dflag++;
+        } else if (nf == 2) {
+            h = (h ^ c) * FNV_PRIME;
+        } else if (nf == 3) {
+            if (c < '0' || c > '9') bad_pos = true;
+            vpos = vpos * 10 + (uint64_t)(c - '0'); dpos++;
+        } else if (nf == 9) {
+            lower_n |= c == 'n';
+        }
+        i++;
+    }
+    if (nf < 11) return 1;
+    if (bad_flag || dflag < 1 || dflag > 9) return 2;                    // FLAG = atoi(fs[1]), ref :39
+    if (bad_pos || dpos < 1 || dpos > 9) return 2;                       // POS = atoi(fs[3]) - 1, ref :41
+    if (lower_n) return 3;                                               // src/String.cpp:45-49
+    flag = (uint32_t)vflag;
+    pos0 = vpos - 1;
+    seq_len = (uint32_t)sq_len;
+    nsnps = 0;
+    // the scaffold of RNAME (src/abawaca-build.cpp:549)
+    scaf = nm.n_scaf;
+    for (uint64_t s = h & nm.mask;; s = (s + 1) & nm.mask) {
+        const uint32_t id = nm.slot_id[s];
+        if (id == SLOT_EMPTY) break;
+        if (nm.slot_hash[s] == h && nm.off[id + 1] - nm.off[id] == rn_len) {
+            const uint8_t* __restrict__ name = nm.blob + nm.off[id];
+            bool same = true;
+            for (uint64_t j = 0; j < rn_len; j++) if (name[j] != t[rn_off + j]) { same = false; break; }
+            if (same) { scaf = id; break; }
+        }
+    }
+    // the MD:Z field, ref :57-69: the first field behind the 11th that holds "MD:Z:"
+    uint64_t md = 0, md_end = 0;
+    bool have_md = false;
+    if (i < e) {                                                         // i: the tab that closed the 11th field
+        uint64_t fs = i + 1;
+        for (uint64_t j = fs; j + 5 <= e; j++) {
+            const uint8_t c = t[j];
+            if (c == '\t') { fs = j + 1; continue; }
+            if (c == 'M' && t[j + 1] == 'D' && t[j + 2] == ':' && t[j + 3] == 'Z' && t[j + 4] == ':') {
+                if (j != fs) return 4;                                   // inside a field: refused here
+                md = j; md_end = j + 5;
+                while (md_end < e && t[md_end] != '\t') md_end++;
+                have_md = true;
+                break;
+            }
+        }
+    }
+    if (!have_md) return 0;                                              // ref :80-81
+    for (uint64_t j = md; j < md_end; j++) if (t[j] == ' ') return 4;    // ref :60-66 keeps the blank, :102-103 throws on it
+    // determine_snps, ref :85-128
+    uint64_t q = md + 5, read_pos = 0;
+    int nd = 0;
+    while (q < md_end && t[q] >= '0' && t[q] <= '9') { read_pos = read_pos * 10 + (uint64_t)(t[q++] - '0'); if (++nd > 9) return 4; }
+    read_pos--;                                                          // ref :98
+    uint32_t snps = 0;
+    while (q < md_end) {
+        const uint8_t c = t[q];
+        if (c != '^' && (c < 'A' || c > 'Z')) return 4;                  // ref :102-103
+        if (c == '^') {
+            q++;
+            while (q < md_end && (t[q] < '0' || t[q] > '9')) { snps++; q++; }       // ref :107-111
+        } else {
+            read_pos++;
+            if (read_pos >= sq_len || read_pos >= ql_len) return 4;      // ref :115: get() / at() throw
+            snps++;
+            q++;
+        }
+        if (q >= md_end || t[q] < '0' || t[q] > '9') return 4;           // ref :120-121
+        uint64_t o = 0;
+        nd = 0;
+        while (q < md_end && t[q] >= '0' && t[q] <= '9') { o = o * 10 + (uint64_t)(t[q++] - '0'); if (++nd > 9) return 4; }
+        read_pos += o;
+    }
+    // the CIGAR string, ref :132-179
+    if (cg_len == 0) return 5;
+    const uint8_t last = t[cg_off + cg_len - 1];
+    if (last != 'I' && last != 'D' && last != 'M') return 5;             // ref :134-137
+    uint64_t read_pos2 = 0;
+    for (uint64_t j = cg_off; j < cg_off + cg_len;) {
+        uint64_t o = 0;
+        nd = 0;
+        while (t[j] >= '0' && t[j] <= '9') { o = o * 10 + (uint64_t)(t[j++] - '0'); if (++nd > 9) return 5; }   // the last character is a letter
+        if (o == 0) return 5;                                            // ref :147-149
+        const uint8_t op = t[j++];
+        if (op == 'M') read_pos2 += o;
+        else if (op == 'D') { }
+        else if (op == 'I') { read_pos += o; snps++; read_pos2 += o; }   // ref :161-173
+        else return 5;                                                   // ref :176-177
+    }
+    if (read_pos + 1 != sq_len || read_pos2 != sq_len) return 6;         // ref :182-183
+    nsnps = snps;
+    return 0;
+}
+
+// one thread per line slot (n_slots = newlines + 1; the last one may be empty)
+__global__ __launch_bounds__(256) void sam_parse_kernel(const uint8_t* __restrict__ text, uint64_t len, const uint64_t* __restrict__ line_start,
+                                                       uint64_t n_slots, SamNames nm, uint32_t max_snps,
+                                                       uint32_t* __restrict__ l_scaf, uint64_t* __restrict__ l_pos, uint32_t* __restrict__ l_len,
+                                                       uint32_t* __restrict__ l_flag, uint32_t* __restrict__ l_nsnps,
+                                                       uint32_t* __restrict__ is_rec, uint32_t* __restrict__ keep, unsigned long long* __restrict__ err)
+{
+    const uint64_t l = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= n_slots) return;
+    const uint64_t a = line_start[l];
+    uint64_t e = (l + 1 < n_slots) ? line_start[l + 1] - 1 : len;        // the newline, or the end of the text
+    uint32_t rec = 0, kp = 0;
+    if (a < len && text[a] != '@') {                                     // src/ReadMappingReader.cpp:105-107
+        while (e > a && (text[e - 1] == '\r' || text[e - 1] == '\n')) e--;           // chomp
+        uint32_t flag = 0, seq_len = 0, nsnps = 0, scaf = nm.n_scaf;
+        uint64_t pos0 = 0;
+        const int rc = sam_line(text, a, e, nm, flag, pos0, seq_len, nsnps, scaf);
+        if (rc) atomicMin(err, (unsigned long long)(l + 1) << 8 | (unsigned)rc);     // the first refused line wins
+        rec = 1;
+        kp = (rc == 0 && !(flag & 0x4u) && nsnps <= max_snps && !(flag & 0x100u)) ? 1u : 0u;    // src/abawaca-build.cpp:546
+        l_scaf[l] = scaf; l_pos[l] = pos0; l_len[l] = seq_len; l_flag[l] = flag; l_nsnps[l] = nsnps;
+    }
+    is_rec[l] = rec;
+    keep[l] = kp;
+}
+
+__global__ __launch_bounds__(256) void sam_compact_kernel(uint64_t n_slots, const uint32_t* __restrict__ is_rec, const uint32_t* __restrict__ keep,
+                                                         const uint64_t* __restrict__ rec_at, const uint64_t* __restrict__ keep_at, uint64_t cap,
+                                                         const uint32_t* __restrict__ l_scaf, const uint64_t* __restrict__ l_pos,
+                                                         const uint32_t* __restrict__ l_len, const uint32_t* __restrict__ l_flag,
+                                                         const uint32_t* __restrict__ l_nsnps,
+                                                         uint32_t* __restrict__ read_scaf, uint64_t* __restrict__ read_pos, uint32_t* __restrict__ read_len,
+                                                         uint32_t* __restrict__ rec_scaf, uint64_t* __restrict__ rec_pos, uint32_t* __restrict__ rec_len,
+                                                         uint32_t* __restrict__ rec_flag, uint32_t* __restrict__ rec_nsnps)
+{
+    const uint64_t l = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= n_slots || !is_rec[l]) return;
+    const uint64_t r = rec_at[l];
+    if (r < cap) {
+        if (rec_scaf) rec_scaf[r] = l_scaf[l];
+        if (rec_pos) rec_pos[r] = l_pos[l];
+        if (rec_len) rec_len[r] = l_len[l];
+        if (rec_flag) rec_flag[r] = l_flag[l];
+        if (rec_nsnps) rec_nsnps[r] = l_nsnps[l];
+    }
+    if (keep[l]) {
+        const uint64_t k = keep_at[l];
+        if (k < cap) {
+            if (read_scaf) read_scaf[k] = l_scaf[l];
+            if (read_pos) read_pos[k] = l_pos[l];
+            if (read_len) read_len[k] = l_len[l];
+        }
+    }
+}
+
+uint64_t fnv1a(const uint8_t* p, uint64_t n)
+{
+    uint64_t h = FNV_OFFSET;
+    for (uint64_t i = 0; i < n; i++) h = (h ^ p[i]) * FNV_PRIME;
+    return h;
+}
+
+}  // namespace
+
+extern "C" int abw_sam_parse_dev(abw_ctx* ctx, const uint8_t* d_text, uint64_t len, const uint8_t* names, const uint64_t* name_off,
+                                 uint64_t n_scaf, uint32_t max_snps, uint64_t cap, uint32_t* d_read_scaf, uint64_t* d_read_pos,
+                                 uint32_t* d_read_len, uint32_t* d_rec_scaf, uint64_t* d_rec_pos, uint32_t* d_rec_len, uint32_t* d_rec_flag,
+                                 uint32_t* d_rec_nsnps, abw_sam_counts* counts)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!counts || (len && !d_text) || (n_scaf && (!names || !name_off)) || n_scaf >= 0xFFFFFFFEull)
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_sam_parse: bad argument");
+    counts->lines = counts->records = counts->kept = 0;
+    if (len == 0) return ABW_OK;
+    abw_device_guard g(ctx->device);
+    hipStream_t st = ctx->stream;
+    int rc;
+    // the names: open addressing, at most half full; equal names keep the first (an unordered_map insert does)
+    uint64_t n_slots_tab = 16;
+    while (n_slots_tab < 2 * n_scaf + 2) n_slots_tab <<= 1;
+    std::vector<uint64_t> slot_hash((size_t)n_slots_tab, 0);
+    std::vector<uint32_t> slot_id((size_t)n_slots_tab, SLOT_EMPTY);
+    for (uint64_t s = 0; s < n_scaf; s++) {
+        if (name_off[s + 1] < name_off[s]) return abw_fail(ctx, ABW_ERR_ARG, "abw_sam_parse: name_off not monotone");
+        const uint64_t n = name_off[s + 1] - name_off[s], h = fnv1a(names + name_off[s], n);
+        uint64_t at = h & (n_slots_tab - 1);
+        bool dup = false;
+        while (slot_id[at] != SLOT_EMPTY) {
+            const uint32_t o = slot_id[at];
+            if (slot_hash[at] == h && name_off[o + 1] - name_off[o] == n && memcmp(names + name_off[o], names + name_off[s], n) == 0) { dup = true; break; }
+            at = (at + 1) & (n_slots_tab - 1);
+        }
+        if (!dup) { slot_hash[at] = h; slot_id[at] = (uint32_t)s; }
+    }
+    const uint64_t blob_len = n_scaf ? name_off[n_scaf] : 0;
+    const uint64_t nblk = (len + SAM_BLK - 1) / SAM_BLK;
+    auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    // scratch[0]: slot_hash | name_off | slot_id | blob;  scratch[1]: blk_prefix u64[nblk + 1] | blk_nl u32[nblk] | err u64
+    const size_t b_sh = n_slots_tab * 8, b_no = (n_scaf + 1) * 8, b_si = up16(n_slots_tab * 4), b_bl = up16(blob_len + 1);
+    if ((rc = abw_reserve(ctx, ctx->scratch[0], b_sh + b_no + b_si + b_bl))) return rc;
+    uint8_t* p0 = (uint8_t*)ctx->scratch[0].p;
+    uint64_t* d_slot_hash = (uint64_t*)p0; uint64_t* d_name_off = (uint64_t*)(p0 + b_sh);
+    uint32_t* d_slot_id = (uint32_t*)(p0 + b_sh + b_no); uint8_t* d_blob = p0 + b_sh + b_no + b_si;
+    ABW_HIP(ctx, hipMemcpyAsync(d_slot_hash, slot_hash.data(), b_sh, hipMemcpyHostToDevice, st));
+    const uint64_t zero_off = 0;
+    ABW_HIP(ctx, hipMemcpyAsync(d_name_off, n_scaf ? name_off : &zero_off, b_no, hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemcpyAsync(d_slot_id, slot_id.data(), n_slots_tab * 4, hipMemcpyHostToDevice, st));
+    if (blob_len) ABW_HIP(ctx, hipMemcpyAsync(d_blob, names, blob_len, hipMemcpyHostToDevice, st));
+    const size_t b_bp = (nblk + 2) * 8, b_bn = up16(nblk * 4);
+    if ((rc = abw_reserve(ctx, ctx->scratch[1], b_bp + b_bn + 16))) return rc;
+    uint64_t* blk_prefix = (uint64_t*)ctx->scratch[1].p;
+    uint32_t* blk_nl = (uint32_t*)((uint8_t*)blk_prefix + b_bp);
+    unsigned long long* d_err = (unsigned long long*)((uint8_t*)blk_nl + b_bn);
+    ABW_PROF(ctx, "sam_parse");
+    hipLaunchKernelGGL(sam_nlcount_kernel, dim3((unsigned)nblk), dim3(256), 0, st, d_text, len, blk_nl);
+    ABW_LAUNCH_CHECK(ctx);
+    if ((rc = abw_device_scan_u32(ctx, blk_nl, nblk, blk_prefix))) return rc;
+    if ((rc = abw_reserve_pinned(ctx, 64))) return rc;
+    unsigned long long* h_back = (unsigned long long*)ctx->pinned;       // [0] newlines, [1] last byte, [2] error, [3] records, [4] kept
+    ABW_HIP(ctx, hipMemcpyAsync(h_back, blk_prefix + nblk, 8, hipMemcpyDeviceToHost, st));
+    h_back[1] = 0;
+    ABW_HIP(ctx, hipMemcpyAsync(h_back + 1, d_text + len - 1, 1, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    const uint64_t n_nl = h_back[0], n_slots = n_nl + 1;
+    counts->lines = n_nl + (((uint8_t)h_back[1] != (uint8_t)'\n') ? 1 : 0);
+    // scratch[2]: line_start u64[n_slots] | l_pos u64 | rec_at, keep_at u64[n_slots + 1] | l_scaf, l_len, l_flag, l_nsnps, is_rec, keep u32[n_slots]
+    const size_t b_l8 = n_slots * 8, b_at = (n_slots + 2) * 8, b_l4 = up16(n_slots * 4);
+    if ((rc = abw_reserve(ctx, ctx->scratch[2], 2 * b_l8 + 2 * b_at + 6 * b_l4))) return rc;
+    uint8_t* p2 = (uint8_t*)ctx->scratch[2].p;
+    uint64_t* line_start = (uint64_t*)p2;           p2 += b_l8;
+    uint64_t* l_pos = (uint64_t*)p2;                p2 += b_l8;
+    uint64_t* rec_at = (uint64_t*)p2;               p2 += b_at;
+    uint64_t* keep_at = (uint64_t*)p2;              p2 += b_at;
+    uint32_t* l_scaf = (uint32_t*)p2;               p2 += b_l4;
+    uint32_t* l_len = (uint32_t*)p2;                p2 += b_l4;
+    uint32_t* l_flag = (uint32_t*)p2;               p2 += b_l4;
+    uint32_t* l_nsnps = (uint32_t*)p2;              p2 += b_l4;
+    uint32_t* is_rec = (uint32_t*)p2;               p2 += b_l4;
+    uint32_t* keep = (uint32_t*)p2;
+    ABW_HIP(ctx, hipMemsetAsync(line_start, 0, 8, st));
+    ABW_HIP(ctx, hipMemsetAsync(d_err, 0xFF, 8, st));
+    hipLaunchKernelGGL(sam_lines_kernel, dim3((unsigned)nblk), dim3(256), 0, st, d_text, len, (const uint64_t*)blk_prefix, line_start);
+    ABW_LAUNCH_CHECK(ctx);
+    SamNames nm = {d_slot_hash, d_slot_id, n_slots_tab - 1, d_blob, d_name_off, (uint32_t)n_scaf};
+    const unsigned gl = (unsigned)((n_slots + 255) / 256);
+    hipLaunchKernelGGL(sam_parse_kernel, dim3(gl), dim3(256), 0, st, d_text, len, (const uint64_t*)line_start, n_slots, nm, max_snps,
+                       l_scaf, l_pos, l_len, l_flag, l_nsnps, is_rec, keep, d_err);
+    ABW_LAUNCH_CHECK(ctx);
+    if ((rc = abw_device_scan_u32(ctx, is_rec, n_slots, rec_at))) return rc;
+    if ((rc = abw_device_scan_u32(ctx, keep, n_slots, keep_at))) return rc;
+    hipLaunchKernelGGL(sam_compact_kernel, dim3(gl), dim3(256), 0, st, n_slots, (const uint32_t*)is_rec, (const uint32_t*)keep,
+                       (const uint64_t*)rec_at, (const uint64_t*)keep_at, cap, (const uint32_t*)l_scaf, (const uint64_t*)l_pos,
+                       (const uint32_t*)l_len, (const uint32_t*)l_flag, (const uint32_t*)l_nsnps,
+                       d_read_scaf, d_read_pos, d_read_len, d_rec_scaf, d_rec_pos, d_rec_len, d_rec_flag, d_rec_nsnps);
+    ABW_LAUNCH_CHECK(ctx);
+    ABW_HIP(ctx, hipMemcpyAsync(h_back + 2, d_err, 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipMemcpyAsync(h_back + 3, rec_at + n_slots, 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipMemcpyAsync(h_back + 4, keep_at + n_slots, 8, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    counts->records = h_back[3];
+    counts->kept = h_back[4];
+    if (h_back[2] != ~0ull) {
+        const int code = (int)(h_back[2] & 0xFF);
+        static const char* what[] = {"", "fewer than 11 fields", "FLAG or POS is not a plain number", "a lower-case n in SEQ", "the MD:Z string",
+                                     "the CIGAR string", "SNP offsets and CIGAR lengths do not add up to the read length"};
+        counts->kept = 0;
+        return abw_fail(ctx, code == 3 ? ABW_ERR_LOWER_N : ABW_ERR_FORMAT, "abw_sam_parse: line %llu: %s (code %d): the reference's reader does not survive "
+                        "this line, or this parser is stricter -- use the reference's reader", (unsigned long long)(h_back[2] >> 8),
+                        code >= 1 && code <= 6 ? what[code] : "?", code);
+    }
+    if (counts->records > cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_sam_parse: %llu records, capacity %llu", (unsigned long long)counts->records,
+                                               (unsigned long long)cap);
+    return ABW_OK;
+}
+
+extern "C" int abw_sam_parse(abw_ctx* ctx, const uint8_t* text, uint64_t len, const uint8_t* names, const uint64_t* name_off, uint64_t n_scaf,
+                             uint32_t max_snps, uint64_t cap, uint32_t* read_scaf, uint64_t* read_pos, uint32_t* read_len, uint32_t* rec_scaf,
+                             uint64_t* rec_pos, uint32_t* rec_len, uint32_t* rec_flag, uint32_t* rec_nsnps, abw_sam_counts* counts)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!counts || (len && !text)) return abw_fail(ctx, ABW_ERR_ARG, "abw_sam_parse: bad argument");
+    counts->lines = counts->records = counts->kept = 0;
+    if (len == 0) return ABW_OK;
+    abw_device_guard g(ctx->device);
+    hipStream_t st = ctx->stream;
+    int rc;
+    auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    // scratch[3]: the text | the eight output arrays at capacity
+    const size_t b_text = up16(len + 16), b8 = up16(cap * 8), b4 = up16(cap * 4);
+    if ((rc = abw_reserve(ctx, ctx->scratch[3], b_text + 2 * b8 + 6 * b4))) return rc;
+    uint8_t* p = (uint8_t*)ctx->scratch[3].p;
+    uint8_t* d_text = p;                            p += b_text;
+    uint64_t* d_rpos = (uint64_t*)p;                p += b8;
+    uint64_t* d_cpos = (uint64_t*)p;                p += b8;
+    uint32_t* d_rscaf = (uint32_t*)p;               p += b4;
+    uint32_t* d_rlen = (uint32_t*)p;                p += b4;
+    uint32_t* d_cscaf = (uint32_t*)p;               p += b4;
+    uint32_t* d_clen = (uint32_t*)p;                p += b4;
+    uint32_t* d_cflag = (uint32_t*)p;               p += b4;
+    uint32_t* d_csnps = (uint32_t*)p;
+    ABW_HIP(ctx, hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, st));
+    rc = abw_sam_parse_dev(ctx, d_text, len, names, name_off, n_scaf, max_snps, cap, read_scaf ? d_rscaf : nullptr, read_pos ? d_rpos : nullptr,
+                           read_len ? d_rlen : nullptr, rec_scaf ? d_cscaf : nullptr, rec_pos ? d_cpos : nullptr, rec_len ? d_clen : nullptr,
+                           rec_flag ? d_cflag : nullptr, rec_nsnps ? d_csnps : nullptr, counts);
+    if (rc) return rc;
+    const uint64_t nk = counts->kept, nr = counts->records;
+    if (read_scaf && nk) ABW_HIP(ctx, hipMemcpyAsync(read_scaf, d_rscaf, nk * 4, hipMemcpyDeviceToHost, st));
+    if (read_pos && nk) ABW_HIP(ctx, hipMemcpyAsync(read_pos, d_rpos, nk * 8, hipMemcpyDeviceToHost, st));
+    if (read_len && nk) ABW_HIP(ctx, hipMemcpyAsync(read_len, d_rlen, nk * 4, hipMemcpyDeviceToHost, st));
+    if (rec_scaf && nr) ABW_HIP(ctx, hipMemcpyAsync(rec_scaf, d_cscaf, nr * 4, hipMemcpyDeviceToHost, st));
+    if (rec_pos && nr) ABW_HIP(ctx, hipMemcpyAsync(rec_pos, d_cpos, nr * 8, hipMemcpyDeviceToHost, st));
+    if (rec_len && nr) ABW_HIP(ctx, hipMemcpyAsync(rec_len, d_clen, nr * 4, hipMemcpyDeviceToHost, st));
+    if (rec_flag && nr) ABW_HIP(ctx, hipMemcpyAsync(rec_flag, d_cflag, nr * 4, hipMemcpyDeviceToHost, st));
+    if (rec_nsnps && nr) ABW_HIP(ctx, hipMemcpyAsync(rec_nsnps, d_csnps, nr * 4, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    return ABW_OK;
+}

@@ -311,6 +311,32 @@ int abw_cov_accumulate_dev(abw_ctx* ctx, const uint32_t* d_seg_scaf, const uint6
                            uint64_t n_seg, uint64_t n_scaf, const uint32_t* d_read_scaf, const uint64_t* d_read_pos,
                            const uint32_t* d_read_len, uint64_t n_reads, double* d_cov);
 
+/* ---- next row N1, the reader side: SAM text -> the arrays abw_cov_accumulate takes ------------------------------------
+ * What the reference does per line of a SAM file before Scaf::add_mapped_read sees it: SAMReader::next_mapping (ref
+ * src/ReadMappingReader.cpp:80-116: '@' lines skipped, line ends chomped), ReadMapping's constructor (ref
+ * src/ReadMapping.cpp:23-72: FLAG, RNAME, POS - 1, the read length = SEQ's), determine_snps (ref :78-185: SNPs counted from
+ * the MD:Z and CIGAR strings), the filter of ref src/abawaca-build.cpp:546 (unmapped, more than max_snps SNPs -- the
+ * reference's constant is 15 --, secondary) and the name lookup of ref :549-551.
+ * text: the file, or a part of it cut at line ends.  names / name_off[n_scaf + 1]: the scaffold names, concatenated (host).
+ * Outputs, each of capacity cap or NULL: read_* = the records that pass the filter, in file order -- scaffold index (n_scaf
+ * for a name that is none of the scaffolds; abw_cov_accumulate ignores those), 0-based position (POS 0 wraps as the
+ * reference's size_t does), length -- ready for abw_cov_accumulate[_dev]; rec_* = the same and FLAG and the SNP count of
+ * EVERY record.  counts: lines, records (lines that do not start with '@') and records kept.
+ * A line the reference would not survive (it throws, or indexes a field that is not there), or one of the few things this
+ * parser is stricter about (FLAG and POS must be 1..9 digits; "MD:Z:" inside a field; numbers of more than 9 digits),
+ * fails the call with ABW_ERR_FORMAT (ABW_ERR_LOWER_N for a lower-case n in SEQ) and abw_last_error names the line: fall
+ * back to the reference's reader.  More records than cap: ABW_ERR_CAPACITY with counts filled.  The read-pair links of the
+ * `-c` sample (ref src/abawaca-build.cpp:531-545) are not made here. */
+typedef struct abw_sam_counts { uint64_t lines, records, kept; } abw_sam_counts;
+int abw_sam_parse(abw_ctx* ctx, const uint8_t* text, uint64_t len, const uint8_t* names, const uint64_t* name_off, uint64_t n_scaf,
+                  uint32_t max_snps, uint64_t cap, uint32_t* read_scaf, uint64_t* read_pos, uint32_t* read_len, uint32_t* rec_scaf,
+                  uint64_t* rec_pos, uint32_t* rec_len, uint32_t* rec_flag, uint32_t* rec_nsnps, abw_sam_counts* counts);
+/* The same with the text and every output array on the device (names on the host); one or two internal read-backs. */
+int abw_sam_parse_dev(abw_ctx* ctx, const uint8_t* d_text, uint64_t len, const uint8_t* names, const uint64_t* name_off,
+                      uint64_t n_scaf, uint32_t max_snps, uint64_t cap, uint32_t* d_read_scaf, uint64_t* d_read_pos,
+                      uint32_t* d_read_len, uint32_t* d_rec_scaf, uint64_t* d_rec_pos, uint32_t* d_rec_len, uint32_t* d_rec_flag,
+                      uint32_t* d_rec_nsnps, abw_sam_counts* counts);
+
 /* ---- next row N4: the .lrn feature table, text -> integer keys (loader) and integer keys -> text (writer)
  *      (ref: ClusterData::ClusterData(esom_lrn_file, scaf_db), src/ClusterData.cpp:27-168; the file is written by
  *      src/abawaca-build.cpp:578-607 with every value printed "%.3lf").

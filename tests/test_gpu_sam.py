@@ -1,0 +1,125 @@
+"""abw_sam_parse (row N1, the reader side) against (a) the SAM files a reference run read and the coverage columns it
+printed for them (tests/golden/build_b.npz, cov_b.npz), (b) the oracle's restatement of the reference's reader on
+generated files with every kind of record, (c) the lines the reference does not survive."""
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+from abawaca_amd import _lib, coverage
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _same_as_oracle(ctx, text, names, max_snps=15):
+    (rs, rp, rl), ev = coverage.parse_sam(ctx, text, names, max_snps, every_record=True)
+    scaf, pos0, ln, fl, ns = orc.sam_parse(text, names)
+    assert ev["records"] == len(scaf)
+    assert np.array_equal(ev["scaf"], scaf) and np.array_equal(ev["pos0"], pos0) and np.array_equal(ev["len"], ln)
+    assert np.array_equal(ev["flag"], fl) and np.array_equal(ev["nsnps"], ns)
+    keep = ((fl & 4) == 0) & ((fl & 256) == 0) & (ns <= max_snps)                 # ref src/abawaca-build.cpp:546
+    assert np.array_equal(rs, scaf[keep]) and np.array_equal(rp, pos0[keep]) and np.array_equal(rl, ln[keep])
+    return ev
+
+
+def test_the_files_of_the_reference_run_and_its_coverage_columns(ctx):
+    g, c = np.load(os.path.join(GOLD, "build_b.npz")), np.load(os.path.join(GOLD, "cov_b.npz"))
+    names = [str(n) for n in g["scaf_names"]]
+    ro = g["read_off"]
+    for s in range(3):
+        ev = _same_as_oracle(ctx, g[f"sam{s}"], names)
+        a, b = int(ro[s]), int(ro[s + 1])
+        assert ev["records"] == b - a and np.array_equal(ev["flag"], g["read_flag"][a:b]) and np.array_equal(ev["nsnps"], g["read_nsnps"][a:b])
+        # SAM text -> coverage column, all on this side: what the reference printed
+        rs, rp, rl = coverage.parse_sam(ctx, g[f"sam{s}"], names)
+        cov = coverage.accumulate(ctx, c["seg_scaf"], c["seg_start"], c["seg_end"], int(c["n_scaf"]), rs, rp, rl)
+        assert np.array_equal(coverage.milli(cov), c["cov_milli"][:, s])
+
+
+def _random_sam(seed, n_lines, names, crlf=False):
+    rng = np.random.default_rng(seed)
+    out = [b"@HD\tVN:1.0\tSO:unsorted\n"] + [f"@SQ\tSN:{n}\tLN:100000\n".encode() for n in names[:5]]
+    eol = b"\r\n" if crlf else b"\n"
+    for i in range(n_lines):
+        L = int(rng.integers(30, 260))
+        seq = "".join(rng.choice(list("ACGTN"), size=L, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+        qual = "I" * L
+        flag = int(rng.choice([0, 16, 4, 256, 272, 99, 147, 1024]))
+        name = names[int(rng.integers(0, len(names)))] if rng.random() < 0.9 else ("unknown_%d" % rng.integers(0, 50))
+        pos = int(rng.integers(0, 90000)) if rng.random() < 0.98 else 0
+        kind = rng.integers(0, 6)
+        tags = ["XA:i:0"] if rng.random() < 0.5 else []
+        cigar = f"{L}M"
+        if kind == 1:                                  # mismatches
+            k = int(rng.integers(1, 20))
+            gaps = rng.multinomial(L - k, np.ones(k + 1) / (k + 1)) if L > k else None
+            if gaps is not None:
+                md = str(gaps[0]) + "".join("ACGT"[int(rng.integers(0, 4))] + str(int(x)) for x in gaps[1:])
+                tags.append("MD:Z:" + md)
+        elif kind == 2 and L > 40:                     # an insertion (or two)
+            i1 = int(rng.integers(5, L - 30)); il = int(rng.integers(1, 4))
+            cigar = f"{i1}M{il}I{L - i1 - il}M"
+            tags.append(f"MD:Z:{L - il}")
+        elif kind == 3 and L > 40:                     # a deletion and a mismatch right behind it
+            d1 = int(rng.integers(5, L - 30)); dl = int(rng.integers(1, 18))
+            cigar = f"{d1}M{dl}D{L - d1}M"
+            tags.append("MD:Z:%d^%s0T%d" % (d1, "".join(rng.choice(list("ACGT"), size=dl)), L - d1 - 1))
+        elif kind == 4:
+            tags.append(f"MD:Z:{L}")
+            tags.append("NM:i:0")
+        line = "\t".join([f"read{i}/1", str(flag), name, str(pos), "255", cigar, "=", str(pos + 200), "300", seq, qual] + tags)
+        out.append(line.encode() + eol)
+    return np.frombuffer(b"".join(out), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("seed,n_lines,n_names,crlf", [(1, 3000, 40, False), (2, 60000, 5000, False), (3, 500, 3, True), (4, 1, 1, False)])
+def test_generated_files_against_the_oracle(ctx, seed, n_lines, n_names, crlf):
+    names = ["scaffold_%d" % i for i in range(n_names)] + (["scaffold_1"] if n_names > 2 else [])      # a name twice: the first counts
+    text = _random_sam(seed, n_lines, names, crlf)
+    ev = _same_as_oracle(ctx, text, names)
+    assert ev["records"] == n_lines and ev["lines"] == n_lines + 1 + min(5, len(names))
+    _same_as_oracle(ctx, text[:-1] if not crlf else text[:-2], names)          # the last line without its end
+    _same_as_oracle(ctx, text, names, max_snps=3)
+    if n_lines >= 3000:                                                          # the generator does make every kind
+        assert ev["nsnps"].max() > 15 and (ev["scaf"] == len(names)).any() and (ev["pos0"] == 2 ** 64 - 1).any()
+
+
+SEQ, QUAL = "ACGTN" * 10, "I" * 50
+
+
+@pytest.mark.parametrize("fields,code", [
+    (("r", "0", "s1", "5", "255", "50M", "*", "0", "0", SEQ), 1),
+    (("r", "x0", "s1", "5", "255", "50M", "*", "0", "0", SEQ, QUAL), 2),
+    (("r", "0", "s1", "", "255", "50M", "*", "0", "0", SEQ, QUAL), 2),
+    (("r", "0", "s1", "5", "255", "50M", "*", "0", "0", SEQ[:20] + "n" + SEQ[21:], QUAL), 3),
+    (("r", "0", "s1", "5", "255", "50M", "*", "0", "0", SEQ, QUAL, "MD:Z:20a29"), 4),
+    (("r", "0", "s1", "5", "255", "50M", "*", "0", "0", SEQ, QUAL, "NM:i:1", "XX:Z:MD:Z:50"), 4),
+    (("r", "0", "s1", "5", "255", "50M", "*", "0", "0", SEQ, QUAL[:10], "MD:Z:20A29"), 4),
+    (("r", "0", "s1", "5", "255", "*", "*", "0", "0", SEQ, QUAL, "MD:Z:50"), 5),
+    (("r", "0", "s1", "5", "255", "5S45M", "*", "0", "0", SEQ, QUAL, "MD:Z:45"), 5),
+    (("r", "0", "s1", "5", "255", "49M", "*", "0", "0", SEQ, QUAL, "MD:Z:50"), 6),
+    ((), 1),
+])
+def test_lines_the_reference_does_not_survive(ctx, fields, code):
+    good = ("\t".join(["g", "0", "s1", "5", "255", "50M", "*", "0", "0", SEQ, QUAL]) + "\n").encode()
+    text = np.frombuffer(good * 3 + ("\t".join(fields) + "\n").encode() + good * 200 + b"also bad\n", dtype=np.uint8)
+    with pytest.raises(Exception, match=r"line 4: .*\(code %d\)" % code):
+        coverage.parse_sam(ctx, text, ["s0", "s1"])
+    with pytest.raises(ValueError) as e:
+        orc.sam_parse(text, ["s0", "s1"])
+    assert e.value.args[0] == (4, code)
+
+
+def test_empty_text_and_headers_only(ctx):
+    assert [len(a) for a in coverage.parse_sam(ctx, b"", ["s0"])] == [0, 0, 0]
+    kept, ev = coverage.parse_sam(ctx, b"@HD\tVN:1.0\n@SQ\tSN:s0\tLN:5\n", ["s0"], every_record=True)
+    assert ev["records"] == 0 and ev["lines"] == 2 and len(kept[0]) == 0
