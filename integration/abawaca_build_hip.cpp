@@ -4,11 +4,13 @@
 // host with the reference's OWN classes -- the command line (ref :449-479), the FASTA reader
 // (Bio::SeqIORead_fasta<Bio::DNASequence>, ref src/SeqIORead_fasta.h:51-103, with DNAString's upper-casing and its
 // exception for a lower-case n, ref src/String.cpp:37-51), the SAM reader and record parser (Bio::SAMReader,
-// Bio::ReadMapping: ref src/ReadMappingReader.cpp:80-116, src/ReadMapping.cpp:23-185), the read filter (ref :546), the
+// Bio::ReadMapping: ref src/ReadMappingReader.cpp:80-116, src/ReadMapping.cpp:23-185; only as the fall-back for a file
+// that abw_sam_parse refuses, or with ABW_SAM_READER=reference), the read filter (ref :546), the
 // scaffold order of its std::map (ref :482,596), and the text of abawaca.names / abawaca.info / the abawaca.lrn header
 // (ref :578-599) -- and hands the three data-parallel pieces to the GPU through the C ABI:
 //
 //     Scaf::Scaf + Scaf_segment::Scaf_segment   (ref :103-228)      ->  abw_sig_build       (one call for the assembly)
+//     SAMReader + ReadMapping + the filter      (see above)          ->  abw_sam_parse       (per 64 MiB of a SAM file)
 //     Scaf::add_mapped_read / Scaf_segment::... (ref :231-244,177-185) ->  abw_cov_accumulate  (per chunk of a SAM file)
 //     the row loop of abawaca.lrn               (ref :600-605)      ->  abw_lrn_emit
 //
@@ -27,6 +29,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <iostream>
 #include <map>
 #include <string>
@@ -113,6 +116,13 @@ int main(int argc, const char* argv[])
 		}
 	}
 	const size_t n_scaf = recs.size();
+	vector<uint8_t>		name_blob;				// the scaffold names as abw_sam_parse takes them, in input order
+	vector<uint64_t>	name_off(1, 0);
+	for(size_t sc = 0; sc < n_scaf; sc++) {
+		name_blob.insert(name_blob.end(), recs[sc].name.begin(), recs[sc].name.end());
+		name_off.push_back(name_blob.size());
+	}
+	name_blob.push_back(0);
 
 	// ---- segments + signatures of every scaffold in one call (ref :198-228, :103-174)
 	uint64_t		n_seg = 0, cap = blob.size() / window_size + n_scaf + 16;
@@ -152,6 +162,63 @@ int main(int argc, const char* argv[])
 					die(ctx, "abw_cov_accumulate");
 				r_scaf.clear(); r_pos.clear(); r_len.clear();
 			};
+			// The records through abw_sam_parse (the reference's reader, record parser, filter and name lookup as kernels),
+			// the file in pieces cut at line ends.  A line that parser refuses -- one the reference's reader does not survive
+			// either, or one of the few things it is stricter about -- sends the WHOLE file through the reference's reader
+			// below instead (ABW_SAM_READER=reference in the environment: always).
+			bool parsed = false;
+			const char* which = getenv("ABW_SAM_READER");
+			if(!(which && !strcmp(which, "reference"))) {
+				FILE* fp = fopen(vit->c_str(), "rb");
+				if(fp == NULL) { cerr << "abawaca-build (hip): failed to open SAM file " << *vit << endl; return -1; }
+				const size_t piece = (size_t)64 << 20;
+				vector<uint8_t>	buf;
+				vector<size_t>	nbps_add(dimension == this_sample ? n_scaf : 0, 0);
+				size_t have = 0;
+				bool ok = true, eof = false;
+				while(ok && !(eof && have == 0)) {
+					buf.resize(have + piece);
+					const size_t got = eof ? 0 : fread(buf.data() + have, 1, piece, fp);
+					if(got < piece) eof = true;
+					have += got;
+					size_t cut = have;				// the whole rest at the end of the file, else up to the last line end
+					if(!eof) { while(cut > 0 && buf[cut - 1] != '\n') cut--; if(cut == 0) continue; }
+					size_t cap_r = 1;
+					for(size_t i = 0; i < cut; i++) cap_r += buf[i] == '\n';
+					r_scaf.resize(cap_r); r_pos.resize(cap_r); r_len.resize(cap_r);
+					abw_sam_counts cnt;
+					const int rc = abw_sam_parse(ctx, buf.data(), cut, name_blob.data(), name_off.data(), n_scaf, (uint32_t)max_snps, cap_r,
+					                             r_scaf.data(), r_pos.data(), r_len.data(), NULL, NULL, NULL, NULL, NULL, &cnt);
+					if(rc == ABW_ERR_FORMAT || rc == ABW_ERR_LOWER_N) {
+						cerr << "abawaca-build (hip): " << abw_last_error(ctx) << endl;
+						ok = false;
+						break;
+					}
+					if(rc != ABW_OK) die(ctx, "abw_sam_parse");
+					// names the assembly does not have come back as n_scaf: dropped here as the reference drops them (ref :550-552)
+					size_t k = 0;
+					for(size_t i = 0; i < cnt.kept; i++) {
+						if(r_scaf[i] >= n_scaf) continue;
+						r_scaf[k] = r_scaf[i]; r_pos[k] = r_pos[i]; r_len[k] = r_len[i];
+						if(dimension == this_sample) nbps_add[r_scaf[k]] += r_len[k];		// ref :242-243
+						k++;
+					}
+					r_scaf.resize(k); r_pos.resize(k); r_len.resize(k);
+					flush();
+					memmove(buf.data(), buf.data() + cut, have - cut);
+					have -= cut;
+				}
+				fclose(fp);
+				if(ok) {
+					for(size_t sc = 0; sc < nbps_add.size(); sc++) recs[sc].nbps += nbps_add[sc];
+					parsed = true;
+				} else {
+					std::fill(cov.back().begin(), cov.back().end(), 0.0);
+					r_scaf.clear(); r_pos.clear(); r_len.clear();
+				}
+			}
+			if(parsed)
+				continue;
 			Bio::SAMReader	reader(*vit);
 			while(reader.good()) {
 				Bio::ReadMappingPtr mapping(reader.next_mapping());

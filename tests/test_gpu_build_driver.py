@@ -1,6 +1,7 @@
 """The compiled drop-in for `abawaca-build`: oracle/_ref/hip_build_driver = integration/abawaca_build_hip.cpp (the
-reference's own FASTA reader, SAM reader, record parser and read filter; segmentation + signatures, coverage sums and the
-rows of abawaca.lrn through the C ABI on the GPU) linked with the reference's unmodified objects.  Its abawaca.lrn,
+reference's own FASTA reader; SAM records through abw_sam_parse with the reference's SAM reader, record parser and read
+filter as the fall-back; segmentation + signatures, coverage sums and the rows of abawaca.lrn through the C ABI on the GPU)
+linked with the reference's unmodified objects.  Its abawaca.lrn,
 abawaca.names and abawaca.info must be the bytes the reference's own abawaca-build writes:
 
   * against the committed golden (tests/golden/build_b.npz: the files the reference wrote here, with the FASTA and SAM
@@ -22,10 +23,12 @@ HIP = os.path.join(ROOT, "oracle", "_ref", "hip_build_driver")
 REF = os.path.join(ROOT, "oracle", "_ref", "abawaca-build")
 
 
-def _run(exe, fasta, out, sam_glob, this_sam):
+def _run(exe, fasta, out, sam_glob, this_sam, env=None, stderr_has=None):
     os.makedirs(out, exist_ok=True)
-    p = subprocess.run([exe, "-f", fasta, "-o", out, "-s", sam_glob, "-c", this_sam], capture_output=True, text=True, timeout=300)
+    p = subprocess.run([exe, "-f", fasta, "-o", out, "-s", sam_glob, "-c", this_sam], capture_output=True, text=True, timeout=300,
+                       env=None if env is None else {**os.environ, **env})
     assert p.returncode == 0, p.stderr[-2000:]
+    assert stderr_has is None or stderr_has in p.stderr, p.stderr[-2000:]
     return {k: open(os.path.join(out, "abawaca." + k), "rb").read() for k in ("lrn", "names", "info")}
 
 
@@ -80,5 +83,13 @@ def test_driver_beside_the_reference_program(seed, n_scaf):
                 f.write(f"u5\t16\t{asm.names[2]}\t{len(asm.seqs[2]) - 30}\t255\t150M\t*\t0\t0\t{seq}\t{q}\n")
         ref = _run(REF, fasta, os.path.join(wd, "ref"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"))
         got = _run(HIP, fasta, os.path.join(wd, "hip"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"))
+        old = _run(HIP, fasta, os.path.join(wd, "hip2"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"), env={"ABW_SAM_READER": "reference"})
+        # a record abw_sam_parse refuses and the reference reads (atoi stops at the blank): that file falls back, the result stands
+        with open(os.path.join(wd, "s1.sam"), "a") as f:
+            f.write(f"u6\t0 \t{asm.names[3]}\t7\t255\t150M\t*\t0\t0\t{seq}\t{q}\n")
+        ref3 = _run(REF, fasta, os.path.join(wd, "ref3"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"))
+        got3 = _run(HIP, fasta, os.path.join(wd, "hip3"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"), stderr_has="FLAG or POS is not a plain number")
     assert got["lrn"] == ref["lrn"] and got["names"] == ref["names"] and got["info"] == ref["info"]
+    assert old == got
+    assert got3 == ref3 and got3["lrn"] != got["lrn"]
     assert got["lrn"].count(b"\n") > n_scaf
