@@ -36,21 +36,35 @@ struct SamNames {
     const uint8_t* blob; const uint64_t* off; uint32_t n_scaf;
 };
 
-__device__ __forceinline__ uint32_t nl_mask16(const uint8_t* __restrict__ text, uint64_t at, uint64_t len)
+__device__ __forceinline__ uint32_t eq_mask4(uint32_t x, uint32_t pat)     // bit i set iff byte i of x equals the pattern byte
 {
-    uint32_t m = 0;
-    if (at + 16 <= len) {
-        uint4 v;
-        memcpy(&v, text + at, 16);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) m |= (((w[q] >> (8 * b)) & 0xFFu) == 10u) ? (1u << (4 * q + b)) : 0u;
-    } else {
-        for (int i = 0; i < 16 && at + i < len; i++) m |= (text[at + i] == 10) ? (1u << i) : 0u;
+    const uint32_t t = x ^ pat;
+    const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+    return __builtin_amdgcn_udot4(z, 0x08040201u, 0u, false) >> 7;
+}
+__device__ __forceinline__ uint32_t eq_mask16(const uint4& v, uint32_t pat)
+{
+    return eq_mask4(v.x, pat) | (eq_mask4(v.y, pat) << 4) | (eq_mask4(v.z, pat) << 8) | (eq_mask4(v.w, pat) << 12);
+}
+
+// 0x80 in every byte of x that equals the pattern byte, 0 elsewhere (exact: no borrow between the bytes)
+__device__ __forceinline__ uint32_t eq_bytes4(uint32_t x, uint32_t pat)
+{
+    const uint32_t t = x ^ pat;
+    return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+}
+
+// the 16 bytes of the text at `at` (a multiple of 16; past the end of the text: zeros)
+__device__ __forceinline__ uint4 text16(const uint8_t* __restrict__ text, uint64_t at, uint64_t len)
+{
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (at + 16 <= len) memcpy(&v, text + at, 16);
+    else if (at < len) {
+        uint8_t b[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 16 && at + i < len; i++) b[i] = text[at + i];
+        memcpy(&v, b, 16);
     }
-    return m;
+    return v;
 }
 
 __global__ __launch_bounds__(256) void sam_nlcount_kernel(const uint8_t* __restrict__ text, uint64_t len, uint32_t* __restrict__ blk_nl)
@@ -58,7 +72,9 @@ __global__ __launch_bounds__(256) void sam_nlcount_kernel(const uint8_t* __restr
     __shared__ uint32_t s_c;
     if (threadIdx.x == 0) s_c = 0;
     __syncthreads();
-    uint32_t c = __popc(nl_mask16(text, (uint64_t)blockIdx.x * SAM_BLK + (uint64_t)threadIdx.x * 16, len));
+    const uint4 v = text16(text, (uint64_t)blockIdx.x * SAM_BLK + (uint64_t)threadIdx.x * 16, len);
+    uint32_t c = __popc(eq_bytes4(v.x, 0x0A0A0A0Au)) + __popc(eq_bytes4(v.y, 0x0A0A0A0Au)) + __popc(eq_bytes4(v.z, 0x0A0A0A0Au)) +
+                 __popc(eq_bytes4(v.w, 0x0A0A0A0Au));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor((int)c, o, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_c, c);
@@ -73,62 +89,80 @@ __global__ __launch_bounds__(256) void sam_lines_kernel(const uint8_t* __restric
     __shared__ uint32_t s_w[4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint64_t at = (uint64_t)blockIdx.x * SAM_BLK + (uint64_t)threadIdx.x * 16;
-    uint32_t m = nl_mask16(text, at, len);
-    const uint32_t c = __popc(m);
+    const uint4 v = text16(text, at, len);
+    uint32_t z[4] = {eq_bytes4(v.x, 0x0A0A0A0Au), eq_bytes4(v.y, 0x0A0A0A0Au), eq_bytes4(v.z, 0x0A0A0A0Au), eq_bytes4(v.w, 0x0A0A0A0Au)};
+    const uint32_t c = __popc(z[0]) + __popc(z[1]) + __popc(z[2]) + __popc(z[3]);
     uint32_t incl = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += y; }
     if (lane == 63) s_w[wid] = incl;
     __syncthreads();
+    if (c == 0) return;
     uint64_t k = blk_prefix[blockIdx.x] + incl - c;
     for (int w = 0; w < wid; w++) k += s_w[w];
-    while (m) {
-        const int i = __ffs(m) - 1;
-        m &= m - 1;
-        line_start[++k] = at + (uint64_t)i + 1;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t m = z[q];
+        while (m) {
+            const int i = (__ffs(m) - 1) >> 3;
+            m &= m - 1;
+            line_start[++k] = at + (uint64_t)(4 * q + i) + 1;
+        }
     }
 }
 
 // Returns 0 or the refusal code of oracle/abw_oracle.h (abw_or_sam_line); t[a, e): the line without its end.
+// A thread per line, and the lanes of a wave must do the same KIND of work at the same time or each waits for the others'
+// kind in turn: so the line is taken in phases -- (A) the ends of its first eleven fields, from tab to tab through aligned
+// 16-byte loads and byte-equality masks (nine tenths of a record are QNAME, SEQ and QUAL, of which only the ends matter,
+// and the n of SEQ falls out of a second mask); (B) the three short fields FLAG, RNAME, POS byte by byte; (C) the tags
+// for "MD:Z:"; (D) the MD:Z and CIGAR strings.
 __device__ int sam_line(const uint8_t* __restrict__ t, uint64_t a, uint64_t e, const SamNames& nm, uint32_t& flag, uint64_t& pos0,
                         uint32_t& seq_len, uint32_t& nsnps, uint32_t& scaf)
 {
     if (e == a) return 1;                                                // split() of an empty line: no field at all
-    // one walk over the first eleven fields (ref src/ReadMapping.cpp:36-54)
+    // (A) tp[f]: where field f ends (a tab, or the end of the line), relative to a; ref src/ReadMapping.cpp:36-54
+    uint32_t tp[11];
     int nf = 0;
-    uint64_t fstart = a, vflag = 0, vpos = 0, h = FNV_OFFSET;
-    int dflag = 0, dpos = 0;
-    bool bad_flag = false, bad_pos = false, lower_n = false;
-    uint64_t rn_off = a, rn_len = 0, cg_off = a, cg_len = 0, sq_len = 0, ql_len = 0;
-    uint64_t i = a;
-    for (;;) {
-        const bool at_end = i == e;
-        const uint8_t c = at_end ? (uint8_t)'\t' : t[i];
-        if (c == '\t') {                                                 // field nf is [fstart, i)
-            if (nf == 2) { rn_off = fstart; rn_len = i - fstart; }
-            else if (nf == 5) { cg_off = fstart; cg_len = i - fstart; }
-            else if (nf == 9) sq_len = i - fstart;
-            else if (nf == 10) ql_len = i - fstart;
-            nf++;
-            fstart = i + 1;
-            if (at_end || nf == 11) break;
-        } else if (nf == 1) {
-            if (c < '0' || c > '9') bad_flag = true;
-            vflag = vflag * 10 + (uint64_t)(c - '0'); dflag++;
-        } else if (nf == 2) {
-            h = (h ^ c) * FNV_PRIME;
-        } else if (nf == 3) {
-            if (c < '0' || c > '9') bad_pos = true;
-            vpos = vpos * 10 + (uint64_t)(c - '0'); dpos++;
-        } else if (nf == 9) {
-            lower_n |= c == 'n';
+    bool lower_n = false;
+    for (uint64_t i = a; i < e && nf < 11;) {
+        const uintptr_t addr = (uintptr_t)(t + i);
+        const uint4 v = *reinterpret_cast<const uint4*>(addr & ~(uintptr_t)15);      // the aligned 16 bytes that hold byte i: inside its page
+        int k = (int)(addr & 15);
+        const uint64_t base = i - (uint64_t)k;                           // text index of the chunk's byte 0 (may lie before the line)
+        const int lim = (e - base < 16) ? (int)(e - base) : 16;          // the line's bytes of the chunk: [k, lim)
+        const uint32_t valid = ((1u << lim) - 1u) & ~((1u << k) - 1u);
+        uint32_t tabs = 0;
+        if (eq_bytes4(v.x, 0x09090909u) | eq_bytes4(v.y, 0x09090909u) | eq_bytes4(v.z, 0x09090909u) | eq_bytes4(v.w, 0x09090909u))
+            tabs = eq_mask16(v, 0x09090909u) & valid;                    // most chunks of a record hold no tab
+        const uint32_t ens = (nf == 9 || (nf < 9 && tabs)) ? (eq_mask16(v, 0x6E6E6E6Eu) & valid) : 0u;    // only where SEQ can be
+        while (tabs && nf < 11) {
+            const int p = __ffs(tabs) - 1;
+            tabs &= tabs - 1;
+            if (nf == 9) lower_n |= ((ens >> k) & ((1u << (p - k)) - 1u)) != 0;      // SEQ: src/String.cpp:45-49
+            tp[nf++] = (uint32_t)(base + (uint64_t)p - a);
+            k = p + 1;
         }
-        i++;
+        if (nf == 9 && k < lim) lower_n |= (ens >> k) != 0;
+        i = base + (uint64_t)lim;
     }
+    if (nf < 11) tp[nf++] = (uint32_t)(e - a);                           // the last field ends with the line
     if (nf < 11) return 1;
-    if (bad_flag || dflag < 1 || dflag > 9) return 2;                    // FLAG = atoi(fs[1]), ref :39
-    if (bad_pos || dpos < 1 || dpos > 9) return 2;                       // POS = atoi(fs[3]) - 1, ref :41
-    if (lower_n) return 3;                                               // src/String.cpp:45-49
+    // (B) FLAG = atoi(fs[1]) ref :39, POS = atoi(fs[3]) - 1 ref :41 (1..9 digits, nothing else), RNAME hashed
+    uint64_t vflag = 0, vpos = 0, h = FNV_OFFSET;
+    {
+        const uint32_t f0 = tp[0] + 1, f1 = tp[1];
+        if (f1 - f0 < 1 || f1 - f0 > 9) return 2;
+        for (uint32_t j = f0; j < f1; j++) { const uint8_t c = t[a + j]; if (c < '0' || c > '9') return 2; vflag = vflag * 10 + (uint64_t)(c - '0'); }
+        const uint32_t p0 = tp[2] + 1, p1 = tp[3];
+        if (p1 - p0 < 1 || p1 - p0 > 9) return 2;
+        for (uint32_t j = p0; j < p1; j++) { const uint8_t c = t[a + j]; if (c < '0' || c > '9') return 2; vpos = vpos * 10 + (uint64_t)(c - '0'); }
+    }
+    if (lower_n) return 3;
+    const uint64_t rn_off = a + tp[1] + 1, rn_len = tp[2] - tp[1] - 1;
+    const uint64_t cg_off = a + tp[4] + 1, cg_len = tp[5] - tp[4] - 1;
+    const uint64_t sq_len = tp[9] - tp[8] - 1, ql_len = tp[10] - tp[9] - 1;
+    for (uint64_t j = 0; j < rn_len; j++) h = (h ^ t[rn_off + j]) * FNV_PRIME;
     flag = (uint32_t)vflag;
     pos0 = vpos - 1;
     seq_len = (uint32_t)sq_len;
@@ -145,22 +179,24 @@ __device__ int sam_line(const uint8_t* __restrict__ t, uint64_t a, uint64_t e, c
             if (same) { scaf = id; break; }
         }
     }
-    // the MD:Z field, ref :57-69: the first field behind the 11th that holds "MD:Z:"
+    // (C) the MD:Z field, ref :57-69: the first field behind the 11th that holds "MD:Z:" (a five-state matcher)
     uint64_t md = 0, md_end = 0;
     bool have_md = false;
-    if (i < e) {                                                         // i: the tab that closed the 11th field
-        uint64_t fs = i + 1;
-        for (uint64_t j = fs; j + 5 <= e; j++) {
+    {
+        uint64_t fs = a + tp[10] + 1;
+        int m = 0;
+        for (uint64_t j = fs; j < e; j++) {
             const uint8_t c = t[j];
-            if (c == '\t') { fs = j + 1; continue; }
-            if (c == 'M' && t[j + 1] == 'D' && t[j + 2] == ':' && t[j + 3] == 'Z' && t[j + 4] == ':') {
-                if (j != fs) return 4;                                   // inside a field: refused here
-                md = j; md_end = j + 5;
-                while (md_end < e && t[md_end] != '\t') md_end++;
-                have_md = true;
+            if (c == '\t') { fs = j + 1; m = 0; continue; }
+            const uint8_t want = m == 0 ? 'M' : m == 1 ? 'D' : m == 3 ? 'Z' : ':';
+            m = (c == want) ? m + 1 : (c == 'M' ? 1 : 0);
+            if (m == 5) {
+                if (j - 4 != fs) return 4;                               // inside a field: refused here
+                have_md = true; md = fs;
                 break;
             }
         }
+        if (have_md) { md_end = md + 5; while (md_end < e && t[md_end] != '\t') md_end++; }
     }
     if (!have_md) return 0;                                              // ref :80-81
     for (uint64_t j = md; j < md_end; j++) if (t[j] == ' ') return 4;    // ref :60-66 keeps the blank, :102-103 throws on it

@@ -228,6 +228,70 @@ def cpu_separator_baseline(keys_host, dp2scaf, scaf_len, n_scaf_sample=12000):
                        f"-p {cores}) on the root node of the first {S} scaffolds ({n} dps x {D} dims), {usec / 1e6:.2f} s")
 
 
+def sam_leg(ctx, dev, with_cpu, n_blocks=100, block_lines=20000, n_names=100_000):
+    """Row N1, the reader side: SAM text resident in HBM -> the arrays abw_cov_accumulate takes (abw_sam_parse_dev)."""
+    import subprocess
+    import tempfile
+    import torch
+    from _sam_gen import random_sam
+    from abawaca_amd import _lib, coverage
+    names = ["scaffold_%d" % i for i in range(n_names)]
+    block = random_sam(20248, block_lines, names)
+    head = int(np.flatnonzero(block == 10)[5]) + 1                     # the six header lines once
+    body = block[head:]
+    text = np.concatenate([block[:head], np.tile(body, n_blocks)])
+    n_lines = block_lines * n_blocks
+    t_text = torch.from_numpy(text).to(dev)
+    blob, off = coverage.names_table(names)
+    cap = n_lines + 8
+    t_s, t_p, t_l = (torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int64, device=dev),
+                     torch.empty(cap, dtype=torch.int32, device=dev))
+    cnt = coverage.SamCounts()
+    pv = lambda t: C.c_void_p(t.data_ptr())
+    pn = lambda a: C.c_void_p(a.ctypes.data)
+
+    def step():
+        ctx.check(_lib.lib().abw_sam_parse_dev(ctx.handle, pv(t_text), len(text), pn(blob), pn(off), len(names), 15, cap, pv(t_s), pv(t_p), pv(t_l),
+                                               None, None, None, None, None, C.byref(cnt)))
+    step()
+    ctx.synchronize()
+    ctx.prof_reset(); ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        step()
+    ctx.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    nk, msk = ctx.prof_read("sam_parse")
+    ctx.prof_enable(False)
+    ms = msk / nk
+    alg = float(len(text)) + 16.0 * int(cnt.kept)
+    res = dict(value=len(text) / (ms * 1e-3) / 1e9, unit="GB/s of SAM text (kernels, text resident)", records=int(cnt.records), kept=int(cnt.kept),
+               text_mb=round(len(text) / 1e6, 1), ms_kernels=round(ms, 3), ms_call=round(wall * 1e3, 3), records_per_s=round(int(cnt.records) / (ms * 1e-3) / 1e6, 1),
+               note="row N1 (next), the reader side; records_per_s in M records/s; ms_call includes building and uploading the hash table of the "
+                    f"{n_names} scaffold names; the text is {n_blocks} x the same {block_lines} generated records (every kind the reference's reader tells apart)",
+               roofline=dict(kernel="sam_parse_kernel (+ line index, compaction)", bound="hbm", achieved=round(alg / (ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
+                             unit="GB/s", frac=round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=None))
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_sam_reader")
+    if with_cpu and os.path.exists(exe):
+        sample = np.concatenate([block[:head], np.tile(body, n_blocks)])
+        with tempfile.TemporaryDirectory(prefix="abwsam_") as wd:
+            p = os.path.join(wd, "s.sam")
+            sample.tofile(p)
+            o = subprocess.run([exe, p], capture_output=True, text=True, timeout=600).stdout.split()
+        if len(o) >= 7:
+            # the same sample through the library: the reference's own reader must count the same records
+            c2 = coverage.SamCounts()
+            t_smp = torch.from_numpy(sample).to(dev)
+            ctx.check(_lib.lib().abw_sam_parse_dev(ctx.handle, pv(t_smp), len(sample), pn(blob), pn(off), len(names), 15, cap, pv(t_s), pv(t_p), pv(t_l),
+                                                   None, None, None, None, None, C.byref(c2)))
+            res["cpu_baseline"] = dict(value=round(len(sample) / float(o[6]) / 1e9, 4), unit="GB/s of SAM text", cores=1, kind="reference",
+                                       sample=f"the reference's SAMReader + ReadMapping (oracle/_ref/ref_sam_reader, -O2, single-threaded by design) on "
+                                              f"{int(o[0])} of the records, {float(o[6]):.1f} s",
+                                       same_counts=bool(int(o[0]) == int(c2.records) and int(o[1]) == int(c2.kept)))
+    return res
+
+
 def lrn_bench(ctx, with_cpu):
     """row N4 (next), loader side: the .lrn text of a configs[1]-shaped table (200 000 rows x 189 columns of the
     bench table's widths, fixed-width so that numpy can write it quickly) -> int32 keys."""
@@ -1118,6 +1182,7 @@ def main():
                                                    sample=f"oracle abw_or_coverage (the reference's loops, its SAM text parsing not included), "
                                                           f"first {ns} reads, {dt:.1f} s")
         del t_ascii
+        out["sam"] = sam_leg(ctx, dev, world == 1 and not args.no_cpu)
         out["lrn"] = lrn_bench(ctx, world == 1 and not args.no_cpu)
 
     # ---------------- one GPU: configs[2]'s job and table on this GPU (the base of the N > 1 strong-scaling runs) ------

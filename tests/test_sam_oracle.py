@@ -73,3 +73,23 @@ def test_counts_and_quirks():
     assert scaf.tolist() == [1, 0, 2, 2, 1, 1] and fl.tolist() == [0, 16, 0, 4, 0, 0]
     assert pos0.tolist() == [2 ** 64 - 1, 6, 6, 2 ** 64 - 1, 8, 8] and ln.tolist() == [50, 50, 50, 1, 50, 50]
     assert ns.tolist() == [0, 2, 4, 0, 0, 0]
+
+
+def test_reader_against_the_reference_reader_itself(tmp_path):
+    """oracle/_ref/ref_sam_reader = the reference's own SAMReader / ReadMapping around a counting loop (compiled from the
+    reference's sources): records, records kept by the filter and the sums of the fields over a generated file."""
+    import subprocess
+    from _sam_gen import random_sam
+    exe = os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "ref_sam_reader")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_sam_reader is built where /root/reference exists (make -C oracle ref)")
+    names = ["scaffold_%d" % i for i in range(300)]
+    for seed, crlf in ((21, False), (22, True)):
+        text = random_sam(seed, 20000, names, crlf)
+        p = tmp_path / f"s{seed}.sam"
+        p.write_bytes(text.tobytes())
+        out = subprocess.run([exe, str(p)], capture_output=True, text=True, timeout=120, check=True).stdout.split()
+        scaf, pos0, ln, fl, ns = orc.sam_parse(text, names)
+        keep = ((fl & 4) == 0) & ((fl & 256) == 0) & (ns <= 15)
+        want = [len(scaf), int(keep.sum()), int((fl & 0x104).sum()), int(pos0.sum(dtype=np.uint64)), int(ln.sum()), int(ns.sum())]
+        assert [int(x) for x in out[:6]] == want
