@@ -2,9 +2,9 @@
 replaces (reference src/abawaca-build.cpp:482-490 scaffolds -> segments + signatures, :507-552 SAM records -> coverage
 columns, :578-607 abawaca.lrn / abawaca.names / abawaca.info).  The three GPU pieces are abw_sig_build (signature),
 abw_cov_accumulate (one call per SAM file) and abw_lrn_emit (the rows of the table); this module only orders, formats
-the small per-segment / per-scaffold text and concatenates.  FASTA and SAM text parsing, the links file (:519-557) and
-the SCG prediction (:613-614) stay with the reference's own code: the caller hands over the sequences and the SAM
-records as arrays.
+the small per-segment / per-scaffold text and concatenates.  FASTA parsing, the links file (:519-557) and the SCG
+prediction (:613-614) stay with the reference's own code: the caller hands over the sequences, and the SAM records either
+as arrays or as the text of the file, which then goes through abw_sam_parse (the reference's reader on the GPU).
 """
 from __future__ import annotations
 
@@ -29,7 +29,8 @@ def build_tables(ctx: Context, names: Sequence[str], ascii_blob: np.ndarray, sca
     read_pos1 = SAM POS, read_len, read_flag[, read_nsnps]), in the order of the reference's glob.  read_nsnps =
     coverage.count_snps(CIGAR, MD:Z) per record; this function applies the whole filter of ref :546 (unmapped, more than
     15 SNPs, secondary) before both the coverage sums and the .info coverage.  Without the sixth field no record is taken
-    to carry an MD:Z tag.
+    to carry an MD:Z tag.  Or per SAM file (dimension name, the file's text as bytes / uint8 array): read, filtered and
+    looked up by coverage.parse_sam.
     -> dict(lrn=bytes, names=bytes, info=bytes, milli=int32[n_dps, 179 + n_samples])"""
     blob = np.ascontiguousarray(ascii_blob, dtype=np.uint8)
     off = np.ascontiguousarray(scaf_off, dtype=np.int64)
@@ -40,8 +41,11 @@ def build_tables(ctx: Context, names: Sequence[str], ascii_blob: np.ndarray, sca
     cols = [r["milli"].astype(np.int64)]
     nbps = np.zeros(n_scaf, dtype=np.int64)
     for s, smp in enumerate(samples):
-        _dim, rs, rp1, rl, rf = smp[:5]
-        fs, fp, fl = coverage.filter_reads(rs, rp1, rl, rf, smp[5] if len(smp) > 5 else None)
+        if len(smp) == 2:
+            fs, fp, fl = coverage.parse_sam(ctx, smp[1], names)
+        else:
+            _dim, rs, rp1, rl, rf = smp[:5]
+            fs, fp, fl = coverage.filter_reads(rs, rp1, rl, rf, smp[5] if len(smp) > 5 else None)
         cov = coverage.accumulate(ctx, seg_scaf, seg_start, seg_end, n_scaf, fs, fp, fl)
         cols.append(coverage.milli(cov)[:, None])
         if s == this_sample:                                  # Scaf::nbps, ref :242-243: every accepted read of a known scaffold

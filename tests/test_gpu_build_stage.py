@@ -35,6 +35,14 @@ def test_max_snps_rule_in_the_whole_stage(ctx, golden_dir):
     assert out["lrn"] == bytes(z["lrn"]) and out["names"] == bytes(z["names"]) and out["info"] == bytes(z["info"])
 
 
+def test_from_the_text_of_the_sam_files(ctx, golden_dir):
+    """The same with the SAM files read on the GPU (abw_sam_parse): FASTA bytes + SAM text in, the reference's three files out."""
+    z = np.load(os.path.join(golden_dir, "build_b.npz"))
+    samples = [(str(z["sample_names"][s]), z[f"sam{s}"]) for s in range(3)]
+    out = build.build_tables(ctx, [str(n) for n in z["scaf_names"]], z["ascii"], z["scaf_off"], samples, this_sample=0)
+    assert out["lrn"] == bytes(z["lrn"]) and out["names"] == bytes(z["names"]) and out["info"] == bytes(z["info"])
+
+
 def test_three_files_byte_identical_to_the_reference(ctx, golden_dir):
     z = np.load(os.path.join(golden_dir, "build_a.npz"))
     out = build.build_tables(ctx, [str(n) for n in z["scaf_names"]], z["ascii"], z["scaf_off"], _samples(z), this_sample=0)
