@@ -19,6 +19,8 @@ int abw_fail(abw_ctx* ctx, int code, const char* fmt, ...)
 
 int abw_reserve(abw_ctx* ctx, abw_devbuf& b, size_t bytes)
 {
+    // whoever reserves one of the context's scratch buffers is about to write it (abw_tree.hip: TreeGuard)
+    if (!ctx->scratch_quiet && &b >= &ctx->scratch[0] && &b < &ctx->scratch[12]) ctx->scratch_epoch++;
     if (bytes <= b.cap) return ABW_OK;
     if (b.p) { ABW_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
     size_t want = bytes + bytes / 4 + 256;

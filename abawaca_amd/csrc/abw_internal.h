@@ -90,6 +90,8 @@ struct abw_ctx {
     std::string err;
     abw_sep_state sep;
     abw_devbuf  scratch[12];           // general-purpose grow-only scratch (valid only inside one entry-point call)
+    uint64_t    scratch_epoch = 0;     // counts the reservations of scratch[] made outside a recursion's own phases: the phase
+    bool        scratch_quiet = false; // API of abw_sep_tree keeps its level in scratch[] between calls and checks the count
     abw_devbuf  km_buf[3];             // state of a k-means run in progress (abw_km_shard_*): lives across calls
     int         num_cu = 256;
     void*       pinned = nullptr;      // grow-only pinned host staging (results of a call leave the GPU in one batch)

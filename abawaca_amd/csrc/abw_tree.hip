@@ -754,6 +754,7 @@ struct TreeRun {
     int32_t next_id = 2;
     int cur = 0;
     int phase = 0;                       // 0: a level waits for eval, 1: for assign, 2: for advance, 3: the recursion is over
+    uint64_t scratch_epoch = 0;          // ctx->scratch_epoch when the last phase returned (TreeGuard)
     std::vector<HostNode> level;
     std::vector<abw_tree_node> nodes;
     std::vector<abw_tree_winner> final_winners;
@@ -1142,6 +1143,24 @@ TreeRun* run_of(abw_ctx* ctx, const char* who, bool create)
 
 void abw_tree_run_free(void* run) { delete (TreeRun*)run; }
 
+namespace {
+// The level of a recursion lives in the context's scratch buffers between the calls of the phase API.  Another entry point
+// that reserves one of them in between (it may grow = free it, or simply write it) would leave the run with stale device
+// pointers: every phase checks that nobody did, and its own reservations do not count.
+struct TreeGuard {
+    abw_ctx* ctx; TreeRun* r; bool was_quiet;
+    TreeGuard(abw_ctx* c, TreeRun* run) : ctx(c), r(run), was_quiet(c->scratch_quiet) { ctx->scratch_quiet = true; }
+    ~TreeGuard() { ctx->scratch_quiet = was_quiet; r->scratch_epoch = ctx->scratch_epoch; }
+    int stale(const char* who) const
+    {
+        if (r->scratch_epoch == ctx->scratch_epoch) return ABW_OK;
+        r->phase = 3;
+        return abw_fail(ctx, ABW_ERR_STATE, "%s: another entry point used this context's work buffers since the recursion's last call; "
+                        "start it again (abw_sep_tree_begin), or give the other work a context of its own", who);
+    }
+};
+}  // namespace
+
 extern "C" {
 
 int abw_sep_tree_begin(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes)
@@ -1151,6 +1170,7 @@ int abw_sep_tree_begin(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes)
     TreeRun* r = run_of(ctx, "abw_sep_tree_begin", true);
     if (!r) return ABW_ERR_STATE;
     abw_device_guard g(ctx->device);
+    TreeGuard tg(ctx, r);
     return r->begin(min_ndps, max_nodes);
 }
 
@@ -1161,6 +1181,8 @@ int abw_sep_tree_eval(abw_ctx* ctx, abw_tree_winner* best, int64_t cap, int64_t*
     TreeRun* r = run_of(ctx, "abw_sep_tree_eval", false);
     if (!r) return ABW_ERR_STATE;
     abw_device_guard g(ctx->device);
+    TreeGuard tg(ctx, r);
+    if (int rc = tg.stale("abw_sep_tree_eval")) return rc;
     return r->eval(best, cap, n_level);
 }
 
@@ -1170,6 +1192,8 @@ int abw_sep_tree_assign(abw_ctx* ctx, const abw_tree_winner* winners, int64_t n,
     TreeRun* r = run_of(ctx, "abw_sep_tree_assign", false);
     if (!r) return ABW_ERR_STATE;
     abw_device_guard g(ctx->device);
+    TreeGuard tg(ctx, r);
+    if (int rc0 = tg.stale("abw_sep_tree_assign")) return rc0;
     const int rc = r->assign(winners, n);
     if (!rc && d_side) *d_side = r->d_scaf_side;
     if (!rc && side_count) *side_count = r->S;
@@ -1182,6 +1206,8 @@ int abw_sep_tree_advance(abw_ctx* ctx)
     TreeRun* r = run_of(ctx, "abw_sep_tree_advance", false);
     if (!r) return ABW_ERR_STATE;
     abw_device_guard g(ctx->device);
+    TreeGuard tg(ctx, r);
+    if (int rc = tg.stale("abw_sep_tree_advance")) return rc;
     return r->advance();
 }
 
@@ -1193,6 +1219,8 @@ int abw_sep_tree_result(abw_ctx* ctx, abw_tree_node* nodes_out, int64_t node_cap
     if (!r) return ABW_ERR_STATE;
     if (r->phase == 1 || r->phase == 2) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_tree_result: a level is in flight");
     abw_device_guard g(ctx->device);
+    TreeGuard tg(ctx, r);
+    if (scaf2cluster) { if (int rc = tg.stale("abw_sep_tree_result")) return rc; }
     const int64_t n = (int64_t)r->nodes.size();
     *n_nodes = n;
     for (int64_t i = 0; i < std::min(n, node_cap); i++) nodes_out[i] = r->nodes[(size_t)i];

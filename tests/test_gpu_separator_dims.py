@@ -80,5 +80,20 @@ def test_calls_out_of_order_are_refused():
             run.assign(wrong, np.ones(len(best), bool))          # not the record eval returned
         run.assign(best, np.ones(len(best), bool))
         run.advance()
+        # the level lives in the context's work buffers between the calls: another entry point on the SAME context in between
+        # ends the recursion with an error instead of letting it go on with buffers that may have been freed or overwritten
+        best = run.eval()
+        from abawaca_amd import coverage
+        coverage.accumulate(c, [0], [1], [100], 1, [0], [5], [50])
+        with pytest.raises(_lib.AbwError, match="another entry point"):
+            run.assign(best, np.ones(len(best), bool))
+        with pytest.raises(_lib.AbwError):
+            run.advance()
+        run = separator.DimShardRun(st)                          # begun again: fine
+        best = run.eval()
+        run.assign(best, np.ones(len(best), bool))
+        run.advance()
+        rows, _s2c, _dt = separator.binning_tree(separator.ColumnStore(c, f["milli"], f["dp2scaf"], f["scaf_len"], off, ids, f["n_scg"]))
+        assert len(rows) >= 1
     finally:
         c.close()
