@@ -227,7 +227,8 @@ int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, abw_tree_nod
  *        advance : children sizes, the size check (ref: src/ClusterSeparator.cpp:125-132), next level, partition.
  *        result  : the nodes and the bins, as abw_sep_tree returns them (dimension = global_dimension).
  *      Every context walks the same tree.  abw_sep_tree is this loop on one context.  Between begin and result no other entry
- *      point may run on the context (the run lives in its scratch buffers).  Nothing of this exists in the reference's
+ *      point may run on the context (the run lives in its scratch buffers; one that does is noticed: the next level call returns
+ *      ABW_ERR_STATE and the recursion has to be begun again).  Nothing of this exists in the reference's
  *      single process; the partition follows its thread-per-dimension loop. */
 typedef struct abw_tree_winner {
     int32_t found;              /* 0: no threshold passed the gates */
