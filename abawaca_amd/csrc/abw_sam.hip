@@ -117,52 +117,90 @@ __global__ __launch_bounds__(256) void sam_lines_kernel(const uint8_t* __restric
 // 16-byte loads and byte-equality masks (nine tenths of a record are QNAME, SEQ and QUAL, of which only the ends matter,
 // and the n of SEQ falls out of a second mask); (B) the three short fields FLAG, RNAME, POS byte by byte; (C) the tags
 // for "MD:Z:"; (D) the MD:Z and CIGAR strings.
-__device__ int sam_line(const uint8_t* __restrict__ t, uint64_t a, uint64_t e, const SamNames& nm, uint32_t& flag, uint64_t& pos0,
+// 64 bytes of a line in LDS, one window per thread: dword d of thread x at w[d * 256] (w already points at the thread's
+// column, so the lanes of a wave that read the same dword of their windows hit 64 different banks).  The short fields are
+// read byte by byte; from global memory every byte would be a round trip to the L2 with nothing else in flight.
+struct Window {
+    uint32_t* w;
+    uint64_t base;                                                        // text index of the window's byte 0; ~0: nothing loaded
+    __device__ __forceinline__ void load(const uint8_t* __restrict__ t, uint64_t from, uint64_t e)
+    {
+        const uintptr_t addr = (uintptr_t)(t + from);
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(addr & ~(uintptr_t)15);
+        base = from - (uint64_t)(addr & 15);
+        uint4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = (base + 16 * (uint64_t)j < e) ? src[j] : make_uint4(0, 0, 0, 0);     // chunks that hold a byte of the line
+#pragma unroll
+        for (int j = 0; j < 4; j++) { w[(4 * j) * 256] = v[j].x; w[(4 * j + 1) * 256] = v[j].y; w[(4 * j + 2) * 256] = v[j].z; w[(4 * j + 3) * 256] = v[j].w; }
+    }
+    __device__ __forceinline__ bool holds(uint64_t i) const { return i - base < 64; }
+    __device__ __forceinline__ uint8_t get(uint64_t i) const { const uint32_t o = (uint32_t)(i - base); return (uint8_t)(w[(o >> 2) * 256] >> (8 * (o & 3))); }
+};
+
+__device__ int sam_line(const uint8_t* __restrict__ t, uint64_t a, uint64_t e, const SamNames& nm, uint32_t* lds, uint32_t& flag, uint64_t& pos0,
                         uint32_t& seq_len, uint32_t& nsnps, uint32_t& scaf)
 {
     if (e == a) return 1;                                                // split() of an empty line: no field at all
-    // (A) tp[f]: where field f ends (a tab, or the end of the line), relative to a; ref src/ReadMapping.cpp:36-54
+    // (A) tp[f]: where field f ends (a tab, or the end of the line), relative to a; ref src/ReadMapping.cpp:36-54.
+    // Four chunks are loaded at a time: a thread has nothing else in flight while it waits for one.
     uint32_t tp[11];
     int nf = 0;
     bool lower_n = false;
     for (uint64_t i = a; i < e && nf < 11;) {
         const uintptr_t addr = (uintptr_t)(t + i);
-        const uint4 v = *reinterpret_cast<const uint4*>(addr & ~(uintptr_t)15);      // the aligned 16 bytes that hold byte i: inside its page
-        int k = (int)(addr & 15);
-        const uint64_t base = i - (uint64_t)k;                           // text index of the chunk's byte 0 (may lie before the line)
-        const int lim = (e - base < 16) ? (int)(e - base) : 16;          // the line's bytes of the chunk: [k, lim)
-        const uint32_t valid = ((1u << lim) - 1u) & ~((1u << k) - 1u);
-        uint32_t tabs = 0;
-        if (eq_bytes4(v.x, 0x09090909u) | eq_bytes4(v.y, 0x09090909u) | eq_bytes4(v.z, 0x09090909u) | eq_bytes4(v.w, 0x09090909u))
-            tabs = eq_mask16(v, 0x09090909u) & valid;                    // most chunks of a record hold no tab
-        const uint32_t ens = (nf == 9 || (nf < 9 && tabs)) ? (eq_mask16(v, 0x6E6E6E6Eu) & valid) : 0u;    // only where SEQ can be
-        while (tabs && nf < 11) {
-            const int p = __ffs(tabs) - 1;
-            tabs &= tabs - 1;
-            if (nf == 9) lower_n |= ((ens >> k) & ((1u << (p - k)) - 1u)) != 0;      // SEQ: src/String.cpp:45-49
-            tp[nf++] = (uint32_t)(base + (uint64_t)p - a);
-            k = p + 1;
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(addr & ~(uintptr_t)15);   // the aligned 16 bytes that hold byte i: inside its page
+        const int k0 = (int)(addr & 15);
+        const uint64_t base0 = i - (uint64_t)k0;                         // text index of the first chunk's byte 0 (may lie before the line)
+        uint4 vv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) vv[j] = (base0 + 16 * (uint64_t)j < e) ? src[j] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t base = base0 + 16 * (uint64_t)j;
+            if (base < e && nf < 11) {
+                const uint4 v = vv[j];
+                int k = j == 0 ? k0 : 0;
+                const int lim = (e - base < 16) ? (int)(e - base) : 16;  // the line's bytes of the chunk: [k, lim)
+                const uint32_t valid = ((1u << lim) - 1u) & ~((1u << k) - 1u);
+                uint32_t tabs = 0;
+                if (eq_bytes4(v.x, 0x09090909u) | eq_bytes4(v.y, 0x09090909u) | eq_bytes4(v.z, 0x09090909u) | eq_bytes4(v.w, 0x09090909u))
+                    tabs = eq_mask16(v, 0x09090909u) & valid;            // most chunks of a record hold no tab
+                const uint32_t ens = (nf == 9 || (nf < 9 && tabs)) ? (eq_mask16(v, 0x6E6E6E6Eu) & valid) : 0u;    // only where SEQ can be
+                while (tabs && nf < 11) {
+                    const int p = __ffs(tabs) - 1;
+                    tabs &= tabs - 1;
+                    if (nf == 9) lower_n |= ((ens >> k) & ((1u << (p - k)) - 1u)) != 0;      // SEQ: src/String.cpp:45-49
+                    tp[nf++] = (uint32_t)(base + (uint64_t)p - a);
+                    k = p + 1;
+                }
+                if (nf == 9 && k < lim) lower_n |= (ens >> k) != 0;
+                i = base + (uint64_t)lim;
+            }
         }
-        if (nf == 9 && k < lim) lower_n |= (ens >> k) != 0;
-        i = base + (uint64_t)lim;
     }
     if (nf < 11) tp[nf++] = (uint32_t)(e - a);                           // the last field ends with the line
     if (nf < 11) return 1;
+    // the short fields through two windows: FLAG .. CIGAR (usually all of them), and the tags
+    Window w1 = {lds, 0}, w2 = {lds + 16 * 256, 0};
+    w1.load(t, a + tp[0] + 1, e);
+    if (tp[10] + 1 < e - a) w2.load(t, a + tp[10] + 1, e); else w2.base = ~0ull - 64;
+    auto rd = [&](uint64_t i) -> uint8_t { return w1.holds(i) ? w1.get(i) : w2.holds(i) ? w2.get(i) : t[i]; };
     // (B) FLAG = atoi(fs[1]) ref :39, POS = atoi(fs[3]) - 1 ref :41 (1..9 digits, nothing else), RNAME hashed
     uint64_t vflag = 0, vpos = 0, h = FNV_OFFSET;
     {
         const uint32_t f0 = tp[0] + 1, f1 = tp[1];
         if (f1 - f0 < 1 || f1 - f0 > 9) return 2;
-        for (uint32_t j = f0; j < f1; j++) { const uint8_t c = t[a + j]; if (c < '0' || c > '9') return 2; vflag = vflag * 10 + (uint64_t)(c - '0'); }
+        for (uint32_t j = f0; j < f1; j++) { const uint8_t c = rd(a + j); if (c < '0' || c > '9') return 2; vflag = vflag * 10 + (uint64_t)(c - '0'); }
         const uint32_t p0 = tp[2] + 1, p1 = tp[3];
         if (p1 - p0 < 1 || p1 - p0 > 9) return 2;
-        for (uint32_t j = p0; j < p1; j++) { const uint8_t c = t[a + j]; if (c < '0' || c > '9') return 2; vpos = vpos * 10 + (uint64_t)(c - '0'); }
+        for (uint32_t j = p0; j < p1; j++) { const uint8_t c = rd(a + j); if (c < '0' || c > '9') return 2; vpos = vpos * 10 + (uint64_t)(c - '0'); }
     }
     if (lower_n) return 3;
     const uint64_t rn_off = a + tp[1] + 1, rn_len = tp[2] - tp[1] - 1;
     const uint64_t cg_off = a + tp[4] + 1, cg_len = tp[5] - tp[4] - 1;
     const uint64_t sq_len = tp[9] - tp[8] - 1, ql_len = tp[10] - tp[9] - 1;
-    for (uint64_t j = 0; j < rn_len; j++) h = (h ^ t[rn_off + j]) * FNV_PRIME;
+    for (uint64_t j = 0; j < rn_len; j++) h = (h ^ rd(rn_off + j)) * FNV_PRIME;
     flag = (uint32_t)vflag;
     pos0 = vpos - 1;
     seq_len = (uint32_t)sq_len;
@@ -175,7 +213,7 @@ __device__ int sam_line(const uint8_t* __restrict__ t, uint64_t a, uint64_t e, c
         if (nm.slot_hash[s] == h && nm.off[id + 1] - nm.off[id] == rn_len) {
             const uint8_t* __restrict__ name = nm.blob + nm.off[id];
             bool same = true;
-            for (uint64_t j = 0; j < rn_len; j++) if (name[j] != t[rn_off + j]) { same = false; break; }
+            for (uint64_t j = 0; j < rn_len; j++) if (name[j] != rd(rn_off + j)) { same = false; break; }
             if (same) { scaf = id; break; }
         }
     }
@@ -186,7 +224,7 @@ __device__ int sam_line(const uint8_t* __restrict__ t, uint64_t a, uint64_t e, c
         uint64_t fs = a + tp[10] + 1;
         int m = 0;
         for (uint64_t j = fs; j < e; j++) {
-            const uint8_t c = t[j];
+            const uint8_t c = rd(j);
             if (c == '\t') { fs = j + 1; m = 0; continue; }
             const uint8_t want = m == 0 ? 'M' : m == 1 ? 'D' : m == 3 ? 'Z' : ':';
             m = (c == want) ? m + 1 : (c == 'M' ? 1 : 0);
@@ -196,45 +234,46 @@ __device__ int sam_line(const uint8_t* __restrict__ t, uint64_t a, uint64_t e, c
                 break;
             }
         }
-        if (have_md) { md_end = md + 5; while (md_end < e && t[md_end] != '\t') md_end++; }
+        if (have_md) { md_end = md + 5; while (md_end < e && rd(md_end) != '\t') md_end++; }
     }
     if (!have_md) return 0;                                              // ref :80-81
-    for (uint64_t j = md; j < md_end; j++) if (t[j] == ' ') return 4;    // ref :60-66 keeps the blank, :102-103 throws on it
+    for (uint64_t j = md; j < md_end; j++) if (rd(j) == ' ') return 4;    // ref :60-66 keeps the blank, :102-103 throws on it
     // determine_snps, ref :85-128
     uint64_t q = md + 5, read_pos = 0;
     int nd = 0;
-    while (q < md_end && t[q] >= '0' && t[q] <= '9') { read_pos = read_pos * 10 + (uint64_t)(t[q++] - '0'); if (++nd > 9) return 4; }
+    for (uint8_t c; q < md_end && (c = rd(q)) >= '0' && c <= '9'; q++) { read_pos = read_pos * 10 + (uint64_t)(c - '0'); if (++nd > 9) return 4; }
     read_pos--;                                                          // ref :98
     uint32_t snps = 0;
     while (q < md_end) {
-        const uint8_t c = t[q];
+        const uint8_t c = rd(q);
         if (c != '^' && (c < 'A' || c > 'Z')) return 4;                  // ref :102-103
         if (c == '^') {
             q++;
-            while (q < md_end && (t[q] < '0' || t[q] > '9')) { snps++; q++; }       // ref :107-111
+            for (uint8_t d; q < md_end && ((d = rd(q)) < '0' || d > '9'); q++) snps++;          // ref :107-111
         } else {
             read_pos++;
             if (read_pos >= sq_len || read_pos >= ql_len) return 4;      // ref :115: get() / at() throw
             snps++;
             q++;
         }
-        if (q >= md_end || t[q] < '0' || t[q] > '9') return 4;           // ref :120-121
         uint64_t o = 0;
         nd = 0;
-        while (q < md_end && t[q] >= '0' && t[q] <= '9') { o = o * 10 + (uint64_t)(t[q++] - '0'); if (++nd > 9) return 4; }
+        for (uint8_t d; q < md_end && (d = rd(q)) >= '0' && d <= '9'; q++) { o = o * 10 + (uint64_t)(d - '0'); if (++nd > 9) return 4; }
+        if (nd == 0) return 4;                                           // ref :120-121
         read_pos += o;
     }
     // the CIGAR string, ref :132-179
     if (cg_len == 0) return 5;
-    const uint8_t last = t[cg_off + cg_len - 1];
+    const uint8_t last = rd(cg_off + cg_len - 1);
     if (last != 'I' && last != 'D' && last != 'M') return 5;             // ref :134-137
     uint64_t read_pos2 = 0;
     for (uint64_t j = cg_off; j < cg_off + cg_len;) {
         uint64_t o = 0;
         nd = 0;
-        while (t[j] >= '0' && t[j] <= '9') { o = o * 10 + (uint64_t)(t[j++] - '0'); if (++nd > 9) return 5; }   // the last character is a letter
+        uint8_t op;
+        for (; (op = rd(j)) >= '0' && op <= '9'; j++) { o = o * 10 + (uint64_t)(op - '0'); if (++nd > 9) return 5; }   // the last character is a letter
         if (o == 0) return 5;                                            // ref :147-149
-        const uint8_t op = t[j++];
+        j++;
         if (op == 'M') read_pos2 += o;
         else if (op == 'D') { }
         else if (op == 'I') { read_pos += o; snps++; read_pos2 += o; }   // ref :161-173
@@ -252,6 +291,7 @@ __global__ __launch_bounds__(256) void sam_parse_kernel(const uint8_t* __restric
                                                        uint32_t* __restrict__ l_flag, uint32_t* __restrict__ l_nsnps,
                                                        uint32_t* __restrict__ is_rec, uint32_t* __restrict__ keep, unsigned long long* __restrict__ err)
 {
+    __shared__ uint32_t s_win[2 * 16 * 256];                             // two windows of 64 bytes per thread (struct Window)
     const uint64_t l = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (l >= n_slots) return;
     const uint64_t a = line_start[l];
@@ -261,7 +301,7 @@ __global__ __launch_bounds__(256) void sam_parse_kernel(const uint8_t* __restric
         while (e > a && (text[e - 1] == '\r' || text[e - 1] == '\n')) e--;           // chomp
         uint32_t flag = 0, seq_len = 0, nsnps = 0, scaf = nm.n_scaf;
         uint64_t pos0 = 0;
-        const int rc = sam_line(text, a, e, nm, flag, pos0, seq_len, nsnps, scaf);
+        const int rc = sam_line(text, a, e, nm, s_win + threadIdx.x, flag, pos0, seq_len, nsnps, scaf);
         if (rc) atomicMin(err, (unsigned long long)(l + 1) << 8 | (unsigned)rc);     // the first refused line wins
         rec = 1;
         kp = (rc == 0 && !(flag & 0x4u) && nsnps <= max_snps && !(flag & 0x100u)) ? 1u : 0u;    // src/abawaca-build.cpp:546
