@@ -88,3 +88,52 @@ def test_empty_text_and_headers_only(ctx):
     assert [len(a) for a in coverage.parse_sam(ctx, b"", ["s0"])] == [0, 0, 0]
     kept, ev = coverage.parse_sam(ctx, b"@HD\tVN:1.0\n@SQ\tSN:s0\tLN:5\n", ["s0"], every_record=True)
     assert ev["records"] == 0 and ev["lines"] == 2 and len(kept[0]) == 0
+
+
+def test_mutated_lines_agree_with_the_oracle(ctx):
+    """Random edits of one record of a good file (characters that matter to the reader: tabs, digits, bases, CIGAR / MD:Z
+    letters, blanks, line ends): the library and the oracle either both read the file to the same arrays or both refuse
+    the same line with the same code."""
+    rng = np.random.default_rng(99)
+    names = ["scaffold_%d" % i for i in range(20)]
+    base = bytes(_random_sam(5, 60, names))
+    lines = base.split(b"\n")[:-1]
+    alphabet = b"\t\t\t0123456789ACGTNMDIZ:^*n =\r-SH"
+    refused = agreed = 0
+    for trial in range(400):
+        ls = list(lines)
+        k = int(rng.integers(6, len(ls)))                                  # a record line
+        row = bytearray(ls[k])
+        for _ in range(int(rng.integers(1, 4))):
+            at = int(rng.integers(0, len(row) + 1))
+            # edits near the front of the line (the short fields) and in the tags are the interesting ones
+            if rng.random() < 0.7:
+                tabs = [i for i, c in enumerate(row) if c == 9]
+                if len(tabs) >= 10:
+                    lo, hi = (0, tabs[5]) if rng.random() < 0.5 else (tabs[9], len(row))
+                    at = int(rng.integers(lo, hi + 1))
+            op = rng.integers(0, 3)
+            ch = alphabet[int(rng.integers(0, len(alphabet)))]
+            if op == 0 and at < len(row):
+                row[at] = ch
+            elif op == 1:
+                row.insert(at, ch)
+            elif at < len(row):
+                del row[at]
+        ls[k] = bytes(row)
+        text = np.frombuffer(b"\n".join(ls) + b"\n", dtype=np.uint8)
+        try:
+            want = orc.sam_parse(text, names)
+            err = None
+        except ValueError as ex:
+            err = ex.args[0]
+        if err is None:
+            (rs, rp, rl), ev = coverage.parse_sam(ctx, text, names, every_record=True)
+            assert np.array_equal(ev["scaf"], want[0]) and np.array_equal(ev["pos0"], want[1]) and np.array_equal(ev["len"], want[2])
+            assert np.array_equal(ev["flag"], want[3]) and np.array_equal(ev["nsnps"], want[4])
+            agreed += 1
+        else:
+            with pytest.raises(Exception, match=r"line %d: .*\(code %d\)" % err):
+                coverage.parse_sam(ctx, text, names)
+            refused += 1
+    assert refused > 50 and agreed > 50
