@@ -101,6 +101,24 @@ def test_synthetic_features_match_oracle(ctx, seed, n_scaf, G, S_cov):
     assert np.array_equal(s2c, os2c) and np.array_equal(d2c, od2c)
 
 
+def test_scaffolds_of_thousands_of_dps_match_oracle(ctx):
+    """Scaffolds of up to 4 000 dps (a tile of the narrow accumulation then holds more than 65 535 dps; the order statistic
+    of a scaffold takes its long form), next to a table of ordinary ones."""
+    for seed, n_scaf, n_hi in ((31, 40, 4000), (32, 400, 60)):
+        f = synth.make_features(seed, n_scaf, 2, 2, n_lo=2, n_hi=n_hi)
+        assert (f["scaf_ndps"].sum() > 65535) == (n_hi == 4000)
+        off, ids = separator.scg_csr(f["scg_scaf"], f["scg_id"], n_scaf)
+        store = separator.ColumnStore(ctx, f["milli"], f["dp2scaf"], f["scaf_len"], off, ids, f["n_scg"])
+        arrays = (f["milli"], f["dp2scaf"], f["scaf_ndps"], f["scaf_len"], off, ids, f["n_scg"])
+        _compare_node(store, None, arrays)
+        sub = np.sort(np.random.default_rng(seed).choice(n_scaf, size=n_scaf * 3 // 4, replace=False)).astype(np.int32)
+        _compare_node(store, sub, arrays)                            # the scattered form of the same kernel
+        want, s2c, _d2c = separator.binning(store)
+        got, s2c_t, _dt = separator.binning_tree(store)
+        key = lambda r: (r["id"], r["ndps"], r["split"], r["dim"], r["key"], r["spec"], r["sens"], r["c1"], r["n1"], r["c2"], r["n2"])
+        assert [key(r) for r in got] == [key(r) for r in want] and np.array_equal(s2c_t, s2c)
+
+
 def test_load_rejects_bad_layout(ctx):
     keys = np.zeros((2, 6), dtype=np.int32)
     with pytest.raises(_lib.AbwError):      # singleton scaffold
