@@ -228,6 +228,16 @@ def cpu_separator_baseline(keys_host, dp2scaf, scaf_len, n_scaf_sample=12000):
                        f"-p {cores}) on the root node of the first {S} scaffolds ({n} dps x {D} dims), {usec / 1e6:.2f} s")
 
 
+def side_leg(name, fn, *a, **kw):
+    """A side leg must not cost the run its headline line: what it raises is reported in its place."""
+    try:
+        return fn(*a, **kw)
+    except Exception as e:                                   # noqa: BLE001 -- reported, not hidden
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        return dict(error=f"{name}: {type(e).__name__}: {e}"[:500])
+
+
 def sam_leg(ctx, dev, with_cpu, n_blocks=100, block_lines=20000, n_names=100_000):
     """Row N1, the reader side: SAM text resident in HBM -> the arrays abw_cov_accumulate takes (abw_sam_parse_dev)."""
     import subprocess
@@ -1182,8 +1192,8 @@ def main():
                                                    sample=f"oracle abw_or_coverage (the reference's loops, its SAM text parsing not included), "
                                                           f"first {ns} reads, {dt:.1f} s")
         del t_ascii
-        out["sam"] = sam_leg(ctx, dev, world == 1 and not args.no_cpu)
-        out["lrn"] = lrn_bench(ctx, world == 1 and not args.no_cpu)
+        out["sam"] = side_leg("sam", sam_leg, ctx, dev, world == 1 and not args.no_cpu)
+        out["lrn"] = side_leg("lrn", lrn_bench, ctx, world == 1 and not args.no_cpu)
 
     # ---------------- one GPU: configs[2]'s job and table on this GPU (the base of the N > 1 strong-scaling runs) ------
     x_host = x_t[:, :min(N, 200_000)].cpu().numpy() if (world == 1 and not args.no_cpu) else None
@@ -1191,21 +1201,21 @@ def main():
         del x_t, keys_t
         x_t = keys_t = None
         torch.cuda.empty_cache()
-        out["configs2_one_gpu"] = configs2_on_one_gpu(ctx, dev, args)
+        out["configs2_one_gpu"] = side_leg("configs2_one_gpu", configs2_on_one_gpu, ctx, dev, args)
 
     # ---------------- optional: configs[0], the reference's own CPU-runnable case, end to end -----------------
     if args.c1 and world == 1:
-        out["recursion_c1"] = recursion_c1(ctx)
+        out["recursion_c1"] = side_leg("recursion_c1", recursion_c1, ctx)
 
     # ---------------- CPU baselines (rank 0, N = 1 only) -------------------------------------------
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_kmeans_baseline(x_host, R, iters, args.chunk)
         out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         if not args.no_extras:
-            b = cpu_signature_baseline(blob, off)
+            b = side_leg("signature cpu_baseline", cpu_signature_baseline, blob, off)
             if b:
                 out["signature"]["cpu_baseline"] = b
-            b = cpu_separator_baseline(keys_host, dp2scaf, scaf_len)
+            b = side_leg("separator cpu_baseline", cpu_separator_baseline, keys_host, dp2scaf, scaf_len)
             if b:
                 out["separator"]["cpu_baseline"] = b
     print(json.dumps(out))
