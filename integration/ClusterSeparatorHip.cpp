@@ -7,6 +7,7 @@
 static inline int abw_env_device() { const char* e = getenv("ABW_DEVICE"); return e ? atoi(e) : 0; }
 #include <algorithm>
 #include <map>
+#include <thread>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -48,15 +49,26 @@ void build_table(const ScafDpData& scaf_db, const SCGdb& scg_db, const ClusterDa
 	// keys: rank of every value among the column's distinct values (order-preserving, exact for any
 	// .lrn; for abawaca-build's 3-decimal output the table has <= 1001 entries per signature column)
 	t.keys.assign(D * N, 0);
-	for(size_t d = 0; d < D; d++) {
-		const Dimension& dim = root.get_dimension(d + 1);
-		st.dim_names[d] = dim.get_dimension_name();
-		std::vector<double>& u = st.values[d];
-		u.assign(dim.get_values().begin(), dim.get_values().end());	// std::set<double>: sorted, distinct
-		for(auto it = dim.begin(); it != dim.end(); it++) {
-			const size_t key = std::lower_bound(u.begin(), u.end(), it->value) - u.begin();
-			t.keys[d * N + (it->dp - 1)] = (int32_t)key;
-		}
+	{
+		// the dimensions are independent and only read here: one thread each, as many at a time as the reference's own
+		// fan-out allows itself (reference src/abawaca.cpp:326-332 caps -p at 40)
+		unsigned nt = std::max(1u, std::min(40u, std::thread::hardware_concurrency()));
+		auto work = [&](unsigned first) {
+			for(size_t d = first; d < D; d += nt) {
+				const Dimension& dim = root.get_dimension(d + 1);
+				st.dim_names[d] = dim.get_dimension_name();
+				std::vector<double>& u = st.values[d];
+				u.assign(dim.get_values().begin(), dim.get_values().end());	// std::set<double>: sorted, distinct
+				for(auto it = dim.begin(); it != dim.end(); it++) {
+					const size_t key = std::lower_bound(u.begin(), u.end(), it->value) - u.begin();
+					t.keys[d * N + (it->dp - 1)] = (int32_t)key;
+				}
+			}
+		};
+		std::vector<std::thread> pool;
+		for(unsigned k = 1; k < nt; k++) pool.emplace_back(work, k);
+		work(0);
+		for(auto& th : pool) th.join();
 	}
 	t.dp2scaf.resize(N);
 	for(size_t dp = 1; dp <= N; dp++) t.dp2scaf[dp - 1] = (int32_t)scaf_db.dp2scaf(dp) - 1;
