@@ -171,7 +171,8 @@ int main(int argc, const char* argv[])
 			if(!(which && !strcmp(which, "reference"))) {
 				FILE* fp = fopen(vit->c_str(), "rb");
 				if(fp == NULL) { cerr << "abawaca-build (hip): failed to open SAM file " << *vit << endl; return -1; }
-				const size_t piece = (size_t)64 << 20;
+				size_t piece = (size_t)64 << 20;				// bytes read per step (ABW_SAM_PIECE_KB: another size, for the tests)
+				if(const char* pk = getenv("ABW_SAM_PIECE_KB")) { if(atol(pk) > 0) piece = (size_t)atol(pk) << 10; }
 				vector<uint8_t>	buf;
 				vector<size_t>	nbps_add(dimension == this_sample ? n_scaf : 0, 0);
 				size_t have = 0;

@@ -84,12 +84,15 @@ def test_driver_beside_the_reference_program(seed, n_scaf):
         ref = _run(REF, fasta, os.path.join(wd, "ref"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"))
         got = _run(HIP, fasta, os.path.join(wd, "hip"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"))
         old = _run(HIP, fasta, os.path.join(wd, "hip2"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"), env={"ABW_SAM_READER": "reference"})
+        # the SAM files in pieces of 1 KiB (shorter than some lines: a piece grows until it holds a line end) and of 7 KiB
+        cut1 = _run(HIP, fasta, os.path.join(wd, "hip4"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"), env={"ABW_SAM_PIECE_KB": "1"})
+        cut7 = _run(HIP, fasta, os.path.join(wd, "hip5"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"), env={"ABW_SAM_PIECE_KB": "7"})
         # a record abw_sam_parse refuses and the reference reads (atoi stops at the blank): that file falls back, the result stands
         with open(os.path.join(wd, "s1.sam"), "a") as f:
             f.write(f"u6\t0 \t{asm.names[3]}\t7\t255\t150M\t*\t0\t0\t{seq}\t{q}\n")
         ref3 = _run(REF, fasta, os.path.join(wd, "ref3"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"))
         got3 = _run(HIP, fasta, os.path.join(wd, "hip3"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"), stderr_has="FLAG or POS is not a plain number")
     assert got["lrn"] == ref["lrn"] and got["names"] == ref["names"] and got["info"] == ref["info"]
-    assert old == got
+    assert old == got and cut1 == got and cut7 == got
     assert got3 == ref3 and got3["lrn"] != got["lrn"]
     assert got["lrn"].count(b"\n") > n_scaf
