@@ -137,3 +137,19 @@ def test_mutated_lines_agree_with_the_oracle(ctx):
                 coverage.parse_sam(ctx, text, names)
             refused += 1
     assert refused > 50 and agreed > 50
+
+
+def test_capacity_is_checked(ctx):
+    import ctypes as C
+    names = ["scaffold_%d" % i for i in range(10)]
+    text = _random_sam(8, 500, names)
+    blob, off = coverage.names_table(names)
+    cap = 100
+    rs, rp, rl = np.zeros(cap, np.uint32), np.zeros(cap, np.uint64), np.zeros(cap, np.uint32)
+    cnt = coverage.SamCounts()
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    rc = _lib.lib().abw_sam_parse(ctx.handle, p(text), len(text), p(blob), p(off), len(names), 15, cap, p(rs), p(rp), p(rl),
+                                  None, None, None, None, None, C.byref(cnt))
+    assert rc == -3 and cnt.records == 500 and cnt.lines == 506            # ABW_ERR_CAPACITY, counts filled: call again with room
+    with pytest.raises(_lib.AbwError):
+        ctx.check(rc)
