@@ -1161,6 +1161,7 @@ def main():
         ctx.prof_enable(False)
         alg_cov = 16.0 * n_reads + 8.0 * 2 * n_seg
         # the same reads as a coordinate-sorted SAM file has them (another order of the additions: its own result)
+        cov_unsorted = t_cov.clone()
         order = torch.argsort(r_scaf * 20_000 + r_pos, stable=True)
         t_rscaf, t_rpos = t_rscaf[order].contiguous(), t_rpos[order].contiguous()
         del order
@@ -1170,7 +1171,11 @@ def main():
             cov_step()
         ncs, mscs = ctx.prof_read("cov_accumulate")
         ctx.prof_enable(False)
+        # the two ways (pairs + stable sort; grouped reads summed where they lie) add the same contributions in another order
+        cov_paths_agree = bool(torch.allclose(cov_unsorted, t_cov, rtol=1e-11, atol=1e-11) and float(t_cov.sum()) > 0)
+        del cov_unsorted
         out["coverage"] = dict(value=n_reads / cov_s / 1e6, unit="M reads/s", reads=n_reads, segments=int(n_seg), ms_per_sample=cov_s * 1e3,
+                               both_paths_agree_to_1e_11=cov_paths_agree,
                                coordinate_sorted=dict(ms_per_sample=round(mscs / ncs, 4), value=round(n_reads / (mscs / ncs * 1e-3) / 1e6, 1), unit="M reads/s",
                                                       frac=round(alg_cov / (mscs / ncs * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
                                note="row N1 (next): per-segment overlap sums in SAM order, fp64; reads and segments resident; "
