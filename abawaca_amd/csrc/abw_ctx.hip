@@ -35,6 +35,10 @@ int abw_reserve(abw_ctx* ctx, abw_devbuf& b, size_t bytes)
 
 int abw_reserve_pinned(abw_ctx* ctx, size_t bytes)
 {
+    // the level calls of abw_sep_tree also keep a level's host records in ctx->pinned between calls: whoever reserves the
+    // pinned block outside those calls is about to write it from offset 0 (or to grow = free it), and counts like a
+    // reservation of scratch[] does
+    if (!ctx->scratch_quiet) ctx->scratch_epoch++;
     if (bytes <= ctx->pinned_cap) return ABW_OK;
     if (ctx->pinned) { ABW_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
     const size_t want = bytes + bytes / 4 + 4096;

@@ -2,7 +2,9 @@
 """bench.py — throughput of the abawaca hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+     -- or bare: with no WORLD_SIZE in the environment the process starts its own N ranks, one fresh child per GPU, before it
+     touches a GPU, and exits with their status; n_gpus in the line is always the number of ranks that ran.)
 
 Headline (BASELINE.json "metric"): k-means point·iterations/s over the whole node, plus the signature
 build in Gbp/s and the real separator in dimension·points/s as extra keys of the same JSON line.  A
@@ -772,14 +774,60 @@ def configs2_on_one_gpu(ctx, dev, args):
     return res
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: this process has made no GPU call yet (counting devices does
+    not initialise HIP on this image), so it starts N fresh children, one per GPU, with the launcher's environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), waits for all of them and exits with the first failure.  Rank 0 prints the
+    JSON line on the stdout it inherits.  Nothing is re-exec'ed."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py: no GPU visible")
+    if args.gpus > n_dev and args.backend == "nccl":
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n_dev} device(s) visible (RCCL needs one GPU per rank; "
+                         f"--backend gloo lets the ranks share a GPU for a rehearsal)")
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ABW_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0 and rc == 0:
+                rc = r if r > 0 else 1
+                for q in alive:              # a rank died: its peers would wait in a collective for ever
+                    q.terminate()
+        time.sleep(0.05)
+    raise SystemExit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     dev_index = local_rank % max(1, torch.cuda.device_count()) if args.backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)

@@ -93,6 +93,19 @@ def test_calls_out_of_order_are_refused():
         best = run.eval()
         run.assign(best, np.ones(len(best), bool))
         run.advance()
+        # the most likely interleaved call -- looking at a node of the same table with abw_sep_node, which reserves none of
+        # the device work buffers but writes the pinned block the level's host records live in -- is noticed, too
+        best = run.eval()
+        sep = separator.ClusterSeparatorHip(st)
+        sep.separate()
+        with pytest.raises(_lib.AbwError, match="another entry point"):
+            run.assign(best, np.ones(len(best), bool))
+        run = separator.DimShardRun(st)
+        best = run.eval()
+        run.assign(best, np.ones(len(best), bool))
+        sep.separate()
+        with pytest.raises(_lib.AbwError, match="another entry point"):
+            run.advance()
         rows, _s2c, _dt = separator.binning_tree(separator.ColumnStore(c, f["milli"], f["dp2scaf"], f["scaf_len"], off, ids, f["n_scg"]))
         assert len(rows) >= 1
     finally:

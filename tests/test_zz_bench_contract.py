@@ -30,3 +30,29 @@ def test_default_run_prints_the_contract_line():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     for leg in ("separator", "signature", "coverage", "lrn"):
         assert leg in d and d[leg]["value"] > 0
+
+
+def test_bare_gpus_2_starts_its_own_ranks():
+    """`bench.py --gpus 2` with no launcher around it: two ranks (sharing this box's one GPU over gloo), n_gpus == --gpus,
+    configs[2]'s job under both partitions (at a reduced table so the test stays short)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "1",
+                        "--scaffolds", "40000", "--restarts", "64", "--iters", "5", "--sep-scaffolds", "40000", "--sep-nodes", "7",
+                        "--sig-mbp", "200", "--cov-mreads", "1", "--no-cpu"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "configs[2]" in d["config"]["workload"]
+    assert set(d["partitions"]) == {"restarts", "points"} and d["partitions"]["points"]["identical_on_all_ranks"]
+    assert d["separator_dimension_sharded"]["same_tree_on_all_ranks"]
+
+
+def test_more_ranks_than_devices_is_refused():
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.split("\n") if ln.startswith("{")]
+    assert "device(s) visible" in p.stderr
