@@ -92,6 +92,7 @@ __global__ void sep_static_srec_kernel(SepDev P, int32_t S, int4* __restrict__ s
 }
 
 // ---- the node's histograms of the narrow dimensions.  grid (ceil(m / TILE_A), groups) ----------------------------------
+template <bool PACKED>
 __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const NGroup* __restrict__ groups, const uint4* __restrict__ nk16,
                                                        const uint4* __restrict__ ts8, const int4* __restrict__ srec, int32_t S,
                                                        const int32_t* __restrict__ node_scaf, int32_t m)
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const NGroup* 
     const int j = blockIdx.y;
     const NGroup G = groups[j];
     const int begin = blockIdx.x * TILE_A;
-    accum_group_tile(G, nk16 + (int64_t)j * P.N, ts8 + (int64_t)j * S, srec, node_scaf, begin, min(m, begin + TILE_A), P, P.scg_lo, P.scg_hi,
+    accum_group_tile<PACKED>(G, nk16 + (int64_t)j * P.N, ts8 + (int64_t)j * S, srec, node_scaf, begin, min(m, begin + TILE_A), P, nullptr, nullptr,
                      [&](int b, unsigned long long a, uint32_t c3, unsigned long long e) {
                          int dim = G.dim[0], lo = 0;                    // the bin's dimension: selects, no indexed copy of G
 #pragma unroll
@@ -109,6 +110,39 @@ __global__ __launch_bounds__(256) void sep_accum_kernel(SepDev P, const NGroup* 
                          if (c3) atomicAdd(&P.h_tot[at], c3);
                          if (e) atomicAdd(&P.h_bp[at], e);
                      });
+}
+
+// ---- the node's SCG lists: per dimension and SCG the smallest / largest flip value over the node's scaffolds that carry it
+// (what ClusterQuality::is_split_better's SCGdb::get_scg2count calls come to, ref src/ClusterQuality.cpp:96-136, SCGdb.cpp:21-38).
+// The flip values are static, only a few scaffolds carry SCGs, and every (dimension, SCG) is the target of one update per
+// carrier: the carriers are kept by SCG as well, and one wave per (dimension, SCG) takes the minimum / maximum over them and
+// writes the pair once -- no atomics (as global atomics of the accumulation kernels they were a third of the root node's time).
+// One wave per (dimension, SCG) walks the SCG's carriers (member = NULL: every scaffold is in the node).  wext = NULL: narrow
+// dimensions only (the wide ones' own kernels fill their lists).  grid (ceil(D x n_scg / 4))
+__global__ __launch_bounds__(256) void sep_scg_kernel(SepDev P, int32_t D, const int32_t* __restrict__ dim_slot, const uint16_t* __restrict__ ts8,
+                                                     const uint4* __restrict__ wext, int32_t S, const int32_t* __restrict__ g2c_off,
+                                                     const int32_t* __restrict__ g2c, const uint8_t* __restrict__ member)
+{
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pair >= D * P.n_scg) return;
+    const int d = pair / P.n_scg, g = pair % P.n_scg;
+    const int slot = dim_slot[d];
+    if (slot < 0 && !wext) return;
+    int lo = INT_MAX, hi = -1;
+    for (int i = g2c_off[g] + lane; i < g2c_off[g + 1]; i += 64) {
+        const int s = g2c[i];
+        if (member && !member[s]) continue;
+        const int ts = slot >= 0 ? (int)(ts8[((int64_t)(slot >> 3) * S + s) * 8 + (slot & 7)] & 0x3FFu) : (int)wext[(int64_t)(-slot - 1) * S + s].w;
+        lo = min(lo, ts); hi = max(hi, ts);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+    if (lane == 0) { P.scg_lo[(int64_t)d * P.n_scg + g] = lo; P.scg_hi[(int64_t)d * P.n_scg + g] = hi; }
+}
+
+__global__ void sep_member_kernel(const int32_t* __restrict__ list, int32_t m, uint8_t* __restrict__ member)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) member[list[i]] = 1;
 }
 
 // ---- wide dimensions (coverage: about as many distinct keys as dps) -----------------------------------
@@ -658,7 +692,7 @@ extern "C" void abw_sep_free(abw_ctx* ctx)
     if (e) {
         void* q[] = {e->h.d_narrow, e->h.d_wide, e->h.d_dim_first_chunk, e->h.d_dim_nchunks, e->h.d_chunks,
                      e->h.d_chunk_sums, e->h.d_dim_total, e->h.d_chunk_best, e->h.d_sscaf, e->h.d_sbin, e->h.d_sdp,
-                     e->h.d_wts, e->h.d_wbelow, e->h.d_range, e->h.d_groups, e->h.d_nsort, e->h.d_toffn, e->h.d_dim_slot, e->h.d_ts8, e->h.d_nk16, e->h.d_srec, e->h.d_wword, e->h.d_wext, e->h.d_wpack, e->h.d_carriers};
+                     e->h.d_wts, e->h.d_wbelow, e->h.d_range, e->h.d_groups, e->h.d_nsort, e->h.d_toffn, e->h.d_dim_slot, e->h.d_ts8, e->h.d_nk16, e->h.d_srec, e->h.d_wword, e->h.d_wext, e->h.d_wpack, e->h.d_carriers, e->h.d_nw, e->h.d_g2c_off, e->h.d_g2c, e->h.d_member};
         for (void* p : q) if (p) (void)hipFree(p);
         abw_tree_run_free(e->h.tree_run);
         delete e;
@@ -1061,7 +1095,22 @@ static int sep_load_upload_impl(abw_ctx* ctx, std::vector<int32_t>& st_first, st
     if (n_scg > 0) {
         if ((rc = upload(ctx, &s.d_scg_off, scg_off, (size_t)S + 1))) return rc;
         if ((rc = upload(ctx, &s.d_scg_ids, scg_ids, (size_t)scg_off[S]))) return rc;
+        std::vector<int32_t> carriers;                    // the scaffolds that carry an SCG: all that the SCG lists of a node depend on
+        for (int32_t sc = 0; sc < S; sc++) if (scg_off[sc + 1] > scg_off[sc]) carriers.push_back(sc);
+        H.n_carriers = (int32_t)carriers.size();
+        if ((rc = upload(ctx, &H.d_carriers, carriers.data(), carriers.size()))) return rc;
+        // ... and the same pairs by SCG: g2c_off[g] .. g2c_off[g + 1] = the scaffolds that carry SCG g
+        std::vector<int32_t> goff((size_t)n_scg + 1, 0), g2c((size_t)scg_off[S]);
+        for (int32_t e = 0; e < scg_off[S]; e++) goff[(size_t)scg_ids[e] + 1]++;
+        for (int32_t g = 0; g < n_scg; g++) goff[(size_t)g + 1] += goff[g];
+        {
+            std::vector<int32_t> at(goff.begin(), goff.end() - 1);
+            for (int32_t sc = 0; sc < S; sc++) for (int32_t e = scg_off[sc]; e < scg_off[sc + 1]; e++) g2c[(size_t)at[scg_ids[e]]++] = sc;
+        }
+        if ((rc = upload(ctx, &H.d_g2c_off, goff.data(), goff.size()))) return rc;
+        if ((rc = upload(ctx, &H.d_g2c, g2c.data(), g2c.size()))) return rc;
     }
+    if ((rc = upload<uint8_t>(ctx, &H.d_member, nullptr, (size_t)S + 64))) return rc;
     if ((rc = upload(ctx, &s.d_T, s.h_T.data(), (size_t)D))) return rc;
     if ((rc = upload(ctx, &s.d_Toff, s.h_Toff.data(), (size_t)D + 1))) return rc;
     if ((rc = upload(ctx, &H.d_narrow, H.narrow_dims.data(), H.narrow_dims.size()))) return rc;
@@ -1112,6 +1161,9 @@ static int sep_load_upload_impl(abw_ctx* ctx, std::vector<int32_t>& st_first, st
         if ((rc = upload(ctx, &H.d_range, none.data(), none.size()))) return rc;
     }
     H.sharded = sharded;
+    H.packed = true;
+    for (int32_t sc = 0; sc < S; sc++) if (s.h_scaf_ndps[sc] > PACK_MAX_NDPS) { H.packed = false; break; }
+    if (getenv("ABW_SEP_UNPACKED")) H.packed = false;      // the tests run both forms of the accumulation
     if ((rc = sep_build_narrow(ctx, st_span, dp2scaf))) return rc;
     if ((rc = abw_reserve(ctx, s.scg_lohi, (size_t)std::max<int64_t>(1, (int64_t)D * n_scg) * 8))) return rc;
     if ((rc = abw_reserve(ctx, s.dimbest, (size_t)D * sizeof(DimBestDev) + sizeof(GlobalRes)))) return rc;
@@ -1184,18 +1236,39 @@ static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_
     const int32_t* d_node_scaf = all ? nullptr : (const int32_t*)s.node_scaf.p;
 
     SepDev P = sep_params(s, H);
-    // small nodes scatter their wide-dimension dps (cost ~ node); big ones and sharded tables take the sorted walk
+    // wide dimensions: small nodes scatter their dps into the histograms (cost ~ node); big ones evaluate prefix sums along
+    // the table's static (bin, dp) order and keep no histogram at all (abw_tree.hip: node_wide_*); shards, whose histograms
+    // are what they exchange, take the sorted walk into the histograms
     const bool scatter = !H.sharded && n * 6 < s.N;
+    const bool scan = !scatter && m > 0 && abw_node_wide_usable(ctx);
+    H.node_scan = scan;
     hipLaunchKernelGGL(sep_clear_kernel, dim3((unsigned)H.chunks.size()), dim3(256), 0, st, P, H.d_chunks);      // what the node before touched
     ABW_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(sep_range_reset_kernel, dim3((s.D + 63) / 64), dim3(64), 0, st, P, s.D, H.d_wide, (int32_t)H.wide_dims.size(), scatter ? 0 : 1);
+    hipLaunchKernelGGL(sep_range_reset_kernel, dim3((s.D + 63) / 64), dim3(64), 0, st, P, s.D, H.d_wide, (int32_t)H.wide_dims.size(), (scatter || scan) ? 0 : 1);
     ABW_LAUNCH_CHECK(ctx);
     if (m > 0) {
         const unsigned gx = (unsigned)((m + TILE_A - 1) / TILE_A);
         ABW_PROF(ctx, "sep_accum");
+        const uint8_t* d_member = nullptr;                 // a byte per scaffold: in the node (NULL: all are)
+        if (!all) {
+            ABW_HIP(ctx, hipMemsetAsync(H.d_member, 0, (size_t)s.S, st));
+            hipLaunchKernelGGL(sep_member_kernel, dim3((unsigned)std::min<int64_t>((m + 255) / 256, ctx->num_cu * 8)), dim3(256), 0, st, d_node_scaf, m, H.d_member);
+            ABW_LAUNCH_CHECK(ctx);
+            d_member = H.d_member;
+        }
+        if (s.n_scg > 0) {
+            // narrow dimensions always; the wide ones when their flip values are static tables (the scan), else their own kernels do it
+            if (scan && (rc = abw_tree_static_ensure(ctx))) return rc;
+            hipLaunchKernelGGL(sep_scg_kernel, dim3((unsigned)(((int64_t)s.D * s.n_scg + 3) / 4)), dim3(256), 0, st, P, s.D, (const int32_t*)H.d_dim_slot,
+                               (const uint16_t*)H.d_ts8, scan ? (const uint4*)H.d_wext : (const uint4*)nullptr, s.S, (const int32_t*)H.d_g2c_off,
+                               (const int32_t*)H.d_g2c, d_member);
+            ABW_LAUNCH_CHECK(ctx);
+        }
         if (!H.narrow_dims.empty()) {
-            hipLaunchKernelGGL(sep_accum_kernel, dim3(gx, (unsigned)H.groups.size()), dim3(256), 0, st, P, H.d_groups, (const uint4*)H.d_nk16,
-                               (const uint4*)H.d_ts8, (const int4*)H.d_srec, s.S, d_node_scaf, m);
+            if (H.packed) hipLaunchKernelGGL(sep_accum_kernel<true>, dim3(gx, (unsigned)H.groups.size()), dim3(256), 0, st, P, H.d_groups, (const uint4*)H.d_nk16,
+                                             (const uint4*)H.d_ts8, (const int4*)H.d_srec, s.S, d_node_scaf, m);
+            else hipLaunchKernelGGL(sep_accum_kernel<false>, dim3(gx, (unsigned)H.groups.size()), dim3(256), 0, st, P, H.d_groups, (const uint4*)H.d_nk16,
+                                    (const uint4*)H.d_ts8, (const int4*)H.d_srec, s.S, d_node_scaf, m);
             ABW_LAUNCH_CHECK(ctx);
         }
         if (!H.wide_dims.empty()) {
@@ -1203,6 +1276,8 @@ static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_
             if (scatter) {
                 hipLaunchKernelGGL(sep_wide_scatter_kernel, dim3((unsigned)((m + 255) / 256), Dw), dim3(256), 0, st, P, H.d_wide, d_node_scaf, m);
                 ABW_LAUNCH_CHECK(ctx);
+            } else if (scan) {
+                if ((rc = abw_node_wide_accum(ctx, d_member))) return rc;
             } else {
             WideDev W = {H.d_sscaf, H.d_sbin, H.d_wts, H.d_wbelow, s.S};
             ABW_HIP(ctx, hipMemsetAsync(H.d_wts, 0xFF, (size_t)Dw * (size_t)s.S * 4, st));      // -1: not in the node
@@ -1259,6 +1334,12 @@ static int sep_eval_phase(abw_ctx* ctx, const char* who, int32_t min_ndps, abw_s
     ABW_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(sep_dimbest_kernel, dim3(s.D), dim3(64), 0, st, H.d_dim_first_chunk, H.d_dim_nchunks, s.D, H.d_chunk_best, H.d_dim_total, d_dimbest);
     ABW_LAUNCH_CHECK(ctx);
+    }
+    if (H.node_scan) {
+        // the wide dimensions' thresholds along the sorted positions (their histogram ranges are empty: the chunk kernels
+        // above skipped them), with the narrow dimensions' best product as the bar
+        ABW_PROF(ctx, "sep_wide");
+        if ((rc = abw_node_wide_eval(ctx, s.node_all ? (const uint8_t*)nullptr : (const uint8_t*)H.d_member, per_dim != nullptr, min_ndps, P.scg_lo, P.scg_hi, d_dimbest))) return rc;
     }
     // the global winner and this context's part of the finalisation follow on the device without a host round trip
     hipLaunchKernelGGL(sep_global_kernel, dim3(1), dim3(64), 0, st, d_dimbest, s.D, d_win, d_tot);

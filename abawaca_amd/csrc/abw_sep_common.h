@@ -111,6 +111,12 @@ struct SepHost {
     uint32_t* d_wpack = nullptr;       // [n_wide][S] the first three of d_wext in one word (scaffolds of <= 127 dps), else all ones
     int32_t* d_carriers = nullptr;     // scaffolds that carry at least one SCG
     int32_t n_carriers = 0;
+    int32_t *d_g2c_off = nullptr, *d_g2c = nullptr;   // the (scaffold, SCG) pairs by SCG: [n_scg + 1] offsets, scaffolds
+    uint8_t* d_member = nullptr;       // [S] a byte per scaffold: in the node in hand (abw_sep_node on a subset)
+    void* d_nw = nullptr;              // abw_sep_node's scan of the wide dimensions: member bytes, tile sums, tile bests (abw_tree.hip)
+    size_t nw_cap = 0;
+    bool packed = false;               // every scaffold has at most PACK_MAX_NDPS dps: accum_group_tile<true>
+    bool node_scan = false;            // the node accumulated last evaluates its wide dimensions by that scan
     void* tree_run = nullptr;          // the recursion in progress (abw_sep_tree_begin .. abw_sep_tree_result; abw_tree.hip)
     bool sharded = false;              // table loaded with a shared bin layout (abw_sep_shard_load)
 };
@@ -119,6 +125,10 @@ struct SepHost {
 struct abw_sep_extra { SepHost h; };
 SepHost& abw_sep_host(abw_ctx* ctx);     // abw_sep.hip
 void abw_tree_run_free(void* run);       // abw_tree.hip
+int abw_tree_static_ensure(abw_ctx* ctx);
+bool abw_node_wide_usable(abw_ctx* ctx);
+int abw_node_wide_accum(abw_ctx* ctx, const uint8_t* d_member);
+int abw_node_wide_eval(abw_ctx* ctx, const uint8_t* d_member, bool exact_per_dim, int32_t min_ndps, const int32_t* scg_lo, const int32_t* scg_hi, struct DimBestDev* d_dimbest);
 
 // sorts the 8 ints x[0..8) ascending in place (Batcher's 19-comparator network; unused slots padded with INT_MAX)
 #define ABW_CX8(x, a, b) { const int lo_ = min(x[a], x[b]), hi_ = max(x[a], x[b]); x[a] = lo_; x[b] = hi_; }
@@ -139,23 +149,44 @@ void abw_tree_run_free(void* run);       // abw_tree.hip
 // -- into workgroup-private LDS histograms, handed bin by bin to flush(b, size | tp1 << 32, tot, bp) at the end (b: bin
 // in the group's LDS layout; only non-empty bins).  scg_lo / scg_hi (NULL: none): [D][n_scg] min / max flip value over
 // the scaffolds that carry each SCG.
-template <typename Flush>
+// PACKED (tables whose scaffolds all have at most PACK_MAX_NDPS dps, so that a tile of TILE_A scaffolds holds fewer than 65 536
+// dps): a bin's size and tp1 counts share one 32-bit LDS word (16 bits each), so do what a scaffold puts on bin t_s (its dps |
+// its dps at or below t_s), and bp sums min(len, 500 000) in 32 bits -- one LDS atomic per dp and dimension instead of up to
+// two, two per scaffold and dimension instead of three of which one of 64 bits (experiments/accum_range.hip: 121 -> 92 us at
+// the root of the bench table).  The clamped lengths change no verdict: bp only ever meets ">= 500 000" (ref
+// ClusterQuality.cpp:118-121), and a sum of clamped lengths reaches 500 000 exactly when the sum of the lengths does.
+constexpr int PACK_MAX_NDPS = 63;
+template <bool PACKED, typename Flush>
 static __device__ __forceinline__ void accum_group_tile(const NGroup& G, const uint4* __restrict__ codes, const uint4* __restrict__ tsv,
                                                         const int4* __restrict__ srec, const int32_t* __restrict__ list, int begin, int end,
                                                         const SepDev& P, int32_t* __restrict__ scg_lo, int32_t* __restrict__ scg_hi, Flush flush)
 {
     __shared__ uint32_t s_size[GRP_BINS];                  // LDS atomics: 32-bit ones are the fast ones
-    __shared__ uint32_t s_tp1[GRP_BINS];
+    __shared__ uint32_t s_tp1[PACKED ? 1 : GRP_BINS];
     __shared__ uint32_t s_tot[GRP_BINS];
-    __shared__ unsigned long long s_bp[GRP_BINS];
+    __shared__ unsigned long long s_bp[PACKED ? 1 : GRP_BINS];
+    __shared__ uint32_t s_bp32[PACKED ? GRP_BINS : 1];
     // k-mer frequencies crowd into a handful of bins, and LDS atomics of one instruction on one word are served one after
     // the other: the histograms are kept in as many copies as fit (a power of two, at most 16), BIN-major -- bin b of copy
     // c at b * copies + c, the copy of a lane = lane mod copies -- so that lanes of different copies never share a bank.
     int lg = 0;
     while (lg < 4 && (G.total << (lg + 1)) <= GRP_BINS) lg++;
     const int copies = 1 << lg, mine = threadIdx.x & (copies - 1);
-    for (int i = threadIdx.x; i < (G.total << lg); i += 256) { s_size[i] = 0; s_tp1[i] = 0; s_tot[i] = 0; s_bp[i] = 0; }
+    for (int i = threadIdx.x; i < (G.total << lg); i += 256) {
+        s_size[i] = 0; s_tot[i] = 0;
+        if (PACKED) s_bp32[i] = 0; else { s_tp1[i] = 0; s_bp[i] = 0; }
+    }
     __syncthreads();
+    // one dp's value in one dimension: size += 1 and, above the flip value, tp1 += 1
+    auto add_dp = [&](int at, uint32_t code) {
+        if (PACKED) atomicAdd(&s_size[at], 1u + ((code & 0x8000u) << 1));
+        else { atomicAdd(&s_size[at], 1u); if (code & 0x8000u) atomicAdd(&s_tp1[at], 1u); }
+    };
+    // what a scaffold puts on bin t_s of one dimension: tp1 += its dps at or below t_s, tot += n, bp += len
+    auto add_scaf = [&](int at, uint32_t n, uint32_t le, unsigned long long len) {
+        if (PACKED) { atomicAdd(&s_tot[at], n | (le << 16)); atomicAdd(&s_bp32[at], (uint32_t)(len < 500000ull ? len : 500000ull)); }
+        else { atomicAdd(&s_tp1[at], le); atomicAdd(&s_tot[at], n); atomicAdd(&s_bp[at], len); }
+    };
     if (!list) {
         // The tile is a RANGE of scaffold ids: its dps are one contiguous run, and with the flags and the counts above the flip
         // value precomputed nothing a dp needs depends on its scaffold.  Two loops without a dependent load: a thread per dp
@@ -168,9 +199,7 @@ static __device__ __forceinline__ void accum_group_tile(const NGroup& G, const u
             for (int q = 0; q < 8; q++) {
                 if (q < G.cnt) {
                     const uint32_t code = (cw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
-                    const int at = ((G.loff[q] + (int)(code & 0x7FFFu)) << lg) + mine;
-                    atomicAdd(&s_size[at], 1u);
-                    if (code & 0x8000u) atomicAdd(&s_tp1[at], 1u);
+                    add_dp(((G.loff[q] + (int)(code & 0x7FFFu)) << lg) + mine, code);
                 }
             }
         }
@@ -194,10 +223,7 @@ static __device__ __forceinline__ void accum_group_tile(const NGroup& G, const u
                             gt += (w >> (16 * (q & 1) + 15)) & 1u;
                         }
                     }
-                    const int at = ((G.loff[q] + ts) << lg) + mine;
-                    atomicAdd(&s_tp1[at], (uint32_t)n - gt);
-                    atomicAdd(&s_tot[at], (uint32_t)n);
-                    atomicAdd(&s_bp[at], len);
+                    add_scaf(((G.loff[q] + ts) << lg) + mine, (uint32_t)n, (uint32_t)n - gt, len);
                     if (scg_lo && P.n_scg > 0) {
                         for (int k = P.scg_off[s]; k < P.scg_off[s + 1]; k++) {
                             const int g = P.scg_ids[k];
@@ -227,9 +253,8 @@ static __device__ __forceinline__ void accum_group_tile(const NGroup& G, const u
                     for (int q = 0; q < 8; q++) {
                         if (q < G.cnt) {
                             const uint32_t code = (cw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
-                            const int at = ((G.loff[q] + (int)(code & 0x7FFFu)) << lg) + mine;
-                            atomicAdd(&s_size[at], 1u);
-                            if (code & 0x8000u) atomicAdd(&s_tp1[at], 1u); else le[q]++;
+                            add_dp(((G.loff[q] + (int)(code & 0x7FFFu)) << lg) + mine, code);
+                            if (!(code & 0x8000u)) le[q]++;
                         }
                     }
                 }
@@ -239,12 +264,7 @@ static __device__ __forceinline__ void accum_group_tile(const NGroup& G, const u
         const unsigned long long len = (unsigned long long)(uint32_t)rec.z | ((unsigned long long)(uint32_t)rec.w << 32);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            if (q < G.cnt) {
-                const int at = ((G.loff[q] + (int)((tw[q >> 1] >> (16 * (q & 1))) & 0x3FFu)) << lg) + mine;
-                atomicAdd(&s_tp1[at], le[q]);
-                atomicAdd(&s_tot[at], (uint32_t)n);
-                atomicAdd(&s_bp[at], len);
-            }
+            if (q < G.cnt) add_scaf(((G.loff[q] + (int)((tw[q >> 1] >> (16 * (q & 1))) & 0x3FFu)) << lg) + mine, (uint32_t)n, le[q], len);
         }
         if (scg_lo && P.n_scg > 0) {
             for (int e = P.scg_off[s]; e < P.scg_off[s + 1]; e++) {
@@ -266,9 +286,16 @@ static __device__ __forceinline__ void accum_group_tile(const NGroup& G, const u
         uint32_t c3 = 0;
         for (int c = 0; c < copies; c++) {
             const int i = (b << lg) + ((c + b) & (copies - 1));          // rotated: the lanes of a wave read different banks
-            a += (unsigned long long)s_size[i] | ((unsigned long long)s_tp1[i] << 32);
-            c3 += s_tot[i];
-            e += s_bp[i];
+            if (PACKED) {
+                const uint32_t w0 = s_size[i], w1 = s_tot[i];
+                a += (unsigned long long)(w0 & 0xFFFFu) | ((unsigned long long)((w0 >> 16) + (w1 >> 16)) << 32);
+                c3 += w1 & 0xFFFFu;
+                e += s_bp32[i];
+            } else {
+                a += (unsigned long long)s_size[i] | ((unsigned long long)s_tp1[i] << 32);
+                c3 += s_tot[i];
+                e += s_bp[i];
+            }
         }
         if (a | c3 | e) flush(b, a, c3, e);
     }

@@ -77,7 +77,8 @@ struct TreeDev {
     int32_t D, S;
 };
 
-constexpr uint32_t W_GE = 0x80000000u, W_OWN = 0x40000000u, W_SC = 0x3FFFFFFFu;
+// W_END (static, abw_sep_node's scan over the table's own order only): the last position of its bin in the table
+constexpr uint32_t W_GE = 0x80000000u, W_OWN = 0x40000000u, W_END = 0x20000000u, W_SC = 0x1FFFFFFFu;
 
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* sh)
 {
@@ -172,20 +173,22 @@ __global__ __launch_bounds__(256) void tree_static_wide_kernel(SepDev P, const i
 }
 
 // the word of every sorted position: scaffold | flags.  grid (blocks, wide dimensions)
-__global__ void tree_static_words_kernel(const int32_t* __restrict__ sdp, const uint8_t* __restrict__ flags, const int32_t* __restrict__ dp2scaf,
-                                         int64_t N, int64_t Np, uint32_t* __restrict__ wword)
+__global__ void tree_static_words_kernel(const int32_t* __restrict__ sdp, const int32_t* __restrict__ sbin, const uint8_t* __restrict__ flags,
+                                         const int32_t* __restrict__ dp2scaf, int64_t N, int64_t Np, uint32_t* __restrict__ wword)
 {
     const int64_t base = (int64_t)blockIdx.y * N, obase = (int64_t)blockIdx.y * Np;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         const int dp = sdp[base + i];
         const uint8_t f = flags[base + dp];
-        wword[obase + i] = (uint32_t)dp2scaf[dp] | ((f & 1) ? W_GE : 0u) | ((f & 2) ? W_OWN : 0u);
+        const bool end = (i + 1 == N) || sbin[base + i + 1] != sbin[base + i];
+        wword[obase + i] = (uint32_t)dp2scaf[dp] | ((f & 1) ? W_GE : 0u) | ((f & 2) ? W_OWN : 0u) | (end ? W_END : 0u);
     }
 }
 
 // ---- narrow dimensions ----------------------------------------------------------------------------------------------
 // Histograms of one tile of scaffolds in one GROUP of narrow dimensions (accum_group_tile, abw_sep_common.h), flushed with
 // one atomic per non-empty bin into the slice of the tile's node.  grid (tiles to accumulate, groups)
+template <bool PACKED>
 __global__ __launch_bounds__(256) void tree_accum_kernel(TreeDev Tr, const Tile* __restrict__ tiles, const int32_t* __restrict__ order,
                                                         unsigned long long* __restrict__ h_st, unsigned long long* __restrict__ h_bp,
                                                         uint32_t* __restrict__ h_tot)
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void tree_accum_kernel(TreeDev Tr, const Tile*
     const int j = blockIdx.y;
     const NGroup G = Tr.groups[j];
     const int64_t at = (int64_t)t.node * Tr.TBn + G.goff;
-    accum_group_tile(G, Tr.nk16 + (int64_t)j * Tr.P.N, Tr.ts8 + (int64_t)j * Tr.S, Tr.srec, order, t.begin, t.end, Tr.P, nullptr, nullptr,
+    accum_group_tile<PACKED>(G, Tr.nk16 + (int64_t)j * Tr.P.N, Tr.ts8 + (int64_t)j * Tr.S, Tr.srec, order, t.begin, t.end, Tr.P, nullptr, nullptr,
                      [&](int b, unsigned long long a, uint32_t c3, unsigned long long e) {
                          if (a) atomicAdd(&h_st[at + b], a);
                          if (c3) atomicAdd(&h_tot[at + b], c3);
@@ -247,6 +250,37 @@ __global__ __launch_bounds__(256) void tree_scg_kernel(TreeDev Tr, const int32_t
         const int g = Tr.P.scg_ids[e];
         atomicMin(&scg_lo[sg + g], ts);
         atomicMax(&scg_hi[sg + g], ts);
+    }
+}
+
+// the same lists with the minima / maxima taken in LDS: one workgroup per dimension holds the lists of all K nodes of the
+// level (K x n_scg <= SCG_LEVEL_LDS entries), walks the carriers once and writes every list whole -- no reset pass, no
+// global atomics.  grid (dimensions)
+constexpr int SCG_LEVEL_LDS = 6144;
+__global__ __launch_bounds__(256) void tree_scg_lds_kernel(TreeDev Tr, const int32_t* __restrict__ carriers, int32_t n_carriers, const int32_t* __restrict__ scaf_slot,
+                                                          int32_t K, int32_t* __restrict__ scg_lo, int32_t* __restrict__ scg_hi)
+{
+    __shared__ int32_t s_lo[SCG_LEVEL_LDS], s_hi[SCG_LEVEL_LDS];
+    const int d = blockIdx.x, n_scg = Tr.P.n_scg, total = K * n_scg;
+    for (int i = threadIdx.x; i < total; i += 256) { s_lo[i] = INT_MAX; s_hi[i] = -1; }
+    __syncthreads();
+    const int slot = Tr.dim_slot[d];
+    for (int i = threadIdx.x; i < n_carriers; i += 256) {
+        const int s = carriers[i];
+        const int k = scaf_slot[s];
+        if (k < 0 || k >= K) continue;
+        const int ts = slot >= 0 ? (int)(reinterpret_cast<const uint16_t*>(Tr.ts8)[((int64_t)(slot >> 3) * Tr.S + s) * 8 + (slot & 7)] & 0x3FFu)
+                                 : (int)Tr.wext[(int64_t)(-slot - 1) * Tr.S + s].w;
+        for (int e = Tr.P.scg_off[s]; e < Tr.P.scg_off[s + 1]; e++) {
+            const int g = Tr.P.scg_ids[e];
+            atomicMin(&s_lo[k * n_scg + g], ts);
+            atomicMax(&s_hi[k * n_scg + g], ts);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int64_t at = ((int64_t)(i / n_scg) * Tr.D + d) * n_scg + (i % n_scg);
+        scg_lo[at] = s_lo[i]; scg_hi[at] = s_hi[i];
     }
 }
 
@@ -514,6 +548,180 @@ __global__ __launch_bounds__(64) void tree_wide_best_kernel(TreeDev Tr, const No
     if (lane == 0) cand[(int64_t)k * Tr.D + Tr.wide[w]] = c;
 }
 
+// ---- abw_sep_node's wide dimensions: the same prefix sums along the TABLE's own static (bin, dp) order -------------------
+// One node, no partition: the positions of a wide dimension in the table's order, a node below the root picked out by one
+// byte per scaffold (member; NULL: the root).  Thresholds are evaluated at the static run ends (W_END) whether or not the
+// node holds a dp of that bin: a bin the node does not hold leaves all four sums, and the SCG counts (the lists hold flip
+// values, which are values of the node), as its predecessor left them -- the same product at a larger threshold, which
+// never replaces the smaller one (ref ...Specificity.h:25-30); before the node's first value size1 = 0 fails the size
+// check, or 0 / 0 = NaN is never better.  The bin is read only for a candidate that gets as far as the gate.
+struct WSums4 { unsigned long long size, tp1, tot, bp; };
+
+template <bool MASKED>
+__global__ __launch_bounds__(256) void node_wide_sums_kernel(TreeDev Tr, int32_t N, int32_t n_tiles, const uint32_t* __restrict__ wword, int64_t wstride,
+                                                            const uint8_t* __restrict__ member, WSums4* __restrict__ tile_sums)
+{
+    __shared__ unsigned long long sh[8];
+    const int w = blockIdx.y;
+    const uint32_t* __restrict__ words = wword + (int64_t)w * wstride;
+    const int begin = blockIdx.x * TILE_P, end = min(N, begin + TILE_P);
+    const int i0 = begin + 8 * threadIdx.x;
+    uint32_t wd[8];
+    load8(words, i0, begin, end, wd, 0u);
+    WSums4 a = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i0 + i < end && (!MASKED || member[wd[i] & W_SC])) {
+            const WSums r = position_terms(Tr, w, wd[i]);
+            a.size++; a.tp1 += r.tp1; a.tot += r.tot; a.bp += r.bp;
+        }
+    }
+    const unsigned long long s0 = block_sum_u64(a.size | (a.tot << 32), sh);          // a tile holds 2048 positions; tot of a tile < 2^32
+    const unsigned long long s1 = block_sum_u64(a.tp1, sh + 4);
+    const unsigned long long s2 = block_sum_u64(a.bp, sh);
+    if (threadIdx.x == 0) tile_sums[(int64_t)w * n_tiles + blockIdx.x] = WSums4{s0 & 0xFFFFFFFFull, s1, s0 >> 32, s2};
+}
+
+// exclusive scan of the tile sums of every wide dimension; totals.  grid (wide dimensions), one wave
+__global__ __launch_bounds__(64) void node_wide_scan_kernel(int32_t n_tiles, WSums4* __restrict__ tile_sums, WSums4* __restrict__ total)
+{
+    const int w = blockIdx.x, lane = threadIdx.x;
+    WSums4* ts = tile_sums + (int64_t)w * n_tiles;
+    WSums4 run = {0, 0, 0, 0};
+    for (int i0 = 0; i0 < n_tiles; i0 += 64) {
+        const int i = i0 + lane;
+        WSums4 v = {0, 0, 0, 0};
+        if (i < n_tiles) v = ts[i];
+        WSums4 x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long a = __shfl_up(x.size, o, 64), b = __shfl_up(x.tp1, o, 64), c = __shfl_up(x.tot, o, 64), e = __shfl_up(x.bp, o, 64);
+            if (lane >= o) { x.size += a; x.tp1 += b; x.tot += c; x.bp += e; }
+        }
+        if (i < n_tiles) ts[i] = WSums4{run.size + x.size - v.size, run.tp1 + x.tp1 - v.tp1, run.tot + x.tot - v.tot, run.bp + x.bp - v.bp};
+        run.size += __shfl(x.size, 63, 64); run.tp1 += __shfl(x.tp1, 63, 64); run.tot += __shfl(x.tot, 63, 64); run.bp += __shfl(x.bp, 63, 64);
+    }
+    if (lane == 0) total[w] = run;
+}
+
+// eval_threshold for a walk in ascending order of bins (a later threshold of the same thread must be strictly better), the
+// bin fetched by get_bin() only when the candidate reaches the gate
+template <typename BinFn>
+__device__ __forceinline__ void eval_threshold_lazy(long long size1, long long tp1, long long tot1, unsigned long long bp1, long long n,
+                                                    unsigned long long bp_total, int32_t min_ndps, BinFn get_bin, const ScgView& scg, Cand& best, double bar)
+{
+    const long long size2 = n - size1, tot2 = n - tot1;
+    const long long tp2 = n - (size1 + tot1 - tp1);
+    if (size1 < min_ndps || size2 < min_ndps) return;              // ref :151
+    const bool small1 = size1 < size2;                             // ref :155 (tie -> cluster2)
+    const long long TP = small1 ? tp1 : tp2, TOT = small1 ? tot1 : tot2, SZ = small1 ? size1 : size2;
+    {
+        const double need = best.found ? (best.prod > bar ? best.prod : bar) : bar;     // see eval_threshold
+        const double tp = (double)TP;
+        if (tp * tp < need * ((double)TOT * (double)SZ) * (1.0 - 1e-9)) return;
+    }
+    const double sens = (double)(int)TP / (double)(int)TOT;        // ref .h:75 (int fields)
+    const double spec = (double)(int)TP / (double)(int)SZ;         // ref .h:74
+    const double prod = sens * spec;
+    if (!(prod == prod)) return;                                   // NaN is never better (ref .h:28)
+    if (best.found && !(prod > best.prod)) return;                 // equal products keep the smaller threshold
+    const int bin = get_bin();
+    int cl = 0, chh = 0, ng = scg.n;
+    if (scg.compact) {
+        for (int g = 0; g < scg.n; g++) { cl += scg.lo[g] <= bin; chh += scg.hi[g] <= bin; }
+    } else {
+        ng = 0;
+        for (int g = 0; g < scg.n; g++) { const int l = scg.lo[g]; if (l != INT_MAX) { ng++; cl += l <= bin; chh += scg.hi[g] <= bin; } }
+    }
+    const int G1 = cl, G2 = ng - chh, both = cl - chh;
+    bool pass;
+    if (G1 == 0 || G2 == 0) pass = (bp1 >= 500000ull) && (bp_total - bp1 >= 500000ull);
+    else pass = !((double)both / (double)(G1 < G2 ? G1 : G2) < 0.2);
+    if (pass) best = Cand{prod, bin, 1, sens, spec, size1};
+}
+
+// pass 2: rescan every tile with its carry, evaluate at the static run ends.  grid (position tiles, wide dimensions)
+template <bool MASKED>
+__global__ __launch_bounds__(256) void node_wide_eval_kernel(TreeDev Tr, int32_t N, int32_t n_tiles, int32_t min_ndps, const int32_t* __restrict__ sbin,
+                                                            const uint32_t* __restrict__ wword, int64_t wstride, const uint8_t* __restrict__ member,
+                                                            const WSums4* __restrict__ tile_carry, const WSums4* __restrict__ total,
+                                                            const int32_t* __restrict__ scg_lo, const int32_t* __restrict__ scg_hi,
+                                                            const double* __restrict__ bar, Cand* __restrict__ tile_best)
+{
+    __shared__ unsigned long long sh[3][5];
+    __shared__ int32_t s_lo[SCG_LDS], s_hi[SCG_LDS];
+    __shared__ int s_ng;
+    __shared__ Cand wbest[4];
+    const int w = blockIdx.y;
+    const int d = Tr.wide[w];
+    const WSums4 tot = total[w];
+    const long long n = (long long)tot.size;
+    const int64_t sg = (int64_t)d * Tr.P.n_scg;
+    const ScgView scg = stage_scgs(scg_lo + sg, scg_hi + sg, Tr.P.n_scg, s_lo, s_hi, &s_ng);
+    const int32_t* __restrict__ bins = sbin + (int64_t)w * N;
+    const uint32_t* __restrict__ words = wword + (int64_t)w * wstride;
+    const double node_bar = bar[0];
+    const int begin = blockIdx.x * TILE_P, end = min(N, begin + TILE_P);
+    const int i0 = begin + 8 * threadIdx.x;
+    uint32_t wd[8];
+    uint32_t r_tp[8], r_tot[8], r_bp[8];
+    uint32_t in = 0;
+    WSums4 a = {0, 0, 0, 0};
+    load8(words, i0, begin, end, wd, 0u);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r_tp[i] = r_tot[i] = r_bp[i] = 0;
+        if (i0 + i < end && (!MASKED || member[wd[i] & W_SC])) {
+            const WSums r = position_terms(Tr, w, wd[i]);
+            r_tp[i] = (uint32_t)r.tp1; r_tot[i] = (uint32_t)r.tot; r_bp[i] = (uint32_t)r.bp;
+            in |= 1u << i;
+            a.size++; a.tp1 += r.tp1; a.tot += r.tot; a.bp += r.bp;
+        }
+    }
+    const WSums4 carry = tile_carry[(int64_t)w * n_tiles + blockIdx.x];
+    const unsigned long long o0 = block_excl_scan_u64(a.size | (a.tot << 32), sh[0], nullptr);
+    const unsigned long long o1 = block_excl_scan_u64(a.tp1, sh[1], nullptr);
+    const unsigned long long o2 = block_excl_scan_u64(a.bp, sh[2], nullptr);
+    long long size1 = (long long)(carry.size + (o0 & 0xFFFFFFFFull)), tp1 = (long long)(carry.tp1 + o1), tot1 = (long long)(carry.tot + (o0 >> 32));
+    unsigned long long bp1 = carry.bp + o2;
+    Cand best = {0.0, 0, 0, 0.0, 0.0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i0 + i < end) {
+            if (in & (1u << i)) { size1++; tp1 += (long long)r_tp[i]; tot1 += (long long)r_tot[i]; bp1 += r_bp[i]; }
+            if (wd[i] & W_END)
+                eval_threshold_lazy(size1, tp1, tot1, bp1, n, tot.bp, min_ndps, [&]() { return bins[i0 + i]; }, scg, best, node_bar);
+        }
+    }
+    const Cand bb = block_best(best, wbest);
+    if (threadIdx.x == 0) tile_best[(int64_t)w * n_tiles + blockIdx.x] = bb;
+}
+
+// best tile of every wide dimension -> the dimension's record of abw_sep_node.  grid (wide dimensions), one wave
+__global__ __launch_bounds__(64) void node_wide_best_kernel(TreeDev Tr, int32_t n_tiles, const Cand* __restrict__ tile_best, const WSums4* __restrict__ total,
+                                                           DimBestDev* __restrict__ out)
+{
+    const int w = blockIdx.x, lane = threadIdx.x;
+    Cand c = {0.0, 0, 0, 0.0, 0.0, 0};
+    for (int t = lane; t < n_tiles; t += 64) { const Cand o = tile_best[(int64_t)w * n_tiles + t]; if (cand_better(o, c)) c = o; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const Cand other = cand_shfl_xor(c, o); if (cand_better(other, c)) c = other; }
+    if (lane == 0) {
+        DimBestDev& r = out[Tr.wide[w]];
+        r.found = c.found; r.bin = c.bin; r.sens = c.sens; r.spec = c.spec; r.prod = c.prod; r.size1 = c.size1; r.n = (long long)total[w].size;
+    }
+}
+
+// the best product of the node's narrow dimensions: the bar of eval_threshold for the wide ones.  one wave
+__global__ __launch_bounds__(64) void node_bar_kernel(TreeDev Tr, const DimBestDev* __restrict__ db, double* __restrict__ bar)
+{
+    double b = 0.0;
+    for (int i = threadIdx.x; i < Tr.n_narrow; i += 64) { const DimBestDev c = db[Tr.narrow[i]]; if (c.found && c.prod > b) b = c.prod; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(b, o, 64); if (y > b) b = y; }
+    if (threadIdx.x == 0) bar[0] = b;
+}
+
 // ---- the winner of every node ----------------------------------------------------------------------------------------
 // ClusteringResult::is_better over the dimensions in dimension order (ref ...Specificity.h:25-30 + ClusterSeparator.cpp:11-16):
 // the largest product, on equal products the smallest dimension; then is_legal (ref .h:31-35).  grid (nodes), one wave.
@@ -715,7 +923,6 @@ int tree_static_build(abw_ctx* ctx, SepHost& H, const SepDev& P, const int32_t* 
     if (H.d_wword) { (void)hipFree(H.d_wword); H.d_wword = nullptr; }
     if (H.d_wext) { (void)hipFree(H.d_wext); H.d_wext = nullptr; }
     if (H.d_wpack) { (void)hipFree(H.d_wpack); H.d_wpack = nullptr; }
-    if (H.d_carriers) { (void)hipFree(H.d_carriers); H.d_carriers = nullptr; }
     if (n_wide) {
         const int64_t Np = (N + 7) & ~(int64_t)7;
         ABW_HIP(ctx, hipMalloc((void**)&H.d_wword, (size_t)n_wide * Np * 4));
@@ -726,18 +933,9 @@ int tree_static_build(abw_ctx* ctx, SepHost& H, const SepDev& P, const int32_t* 
         hipLaunchKernelGGL(tree_static_wide_kernel, dim3((unsigned)((S + 255) / 256), (unsigned)n_wide), dim3(256), 0, st, P, H.d_wide, S,
                            (uint8_t*)ctx->scratch[3].p, (uint4*)H.d_wext, H.d_wpack);
         ABW_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(tree_static_words_kernel, dim3((unsigned)(ctx->num_cu * 8), (unsigned)n_wide), dim3(256), 0, st, H.d_sdp,
+        hipLaunchKernelGGL(tree_static_words_kernel, dim3((unsigned)(ctx->num_cu * 8), (unsigned)n_wide), dim3(256), 0, st, H.d_sdp, H.d_sbin,
                            (const uint8_t*)ctx->scratch[3].p, d_dp2scaf, N, Np, H.d_wword);
         ABW_LAUNCH_CHECK(ctx);
-    }
-    if (s.n_scg > 0) {
-        std::vector<int32_t> off((size_t)S + 1), carriers;
-        ABW_HIP(ctx, hipMemcpyAsync(off.data(), s.d_scg_off, ((size_t)S + 1) * 4, hipMemcpyDeviceToHost, st));
-        ABW_HIP(ctx, hipStreamSynchronize(st));
-        for (int32_t sc = 0; sc < S; sc++) if (off[sc + 1] > off[sc]) carriers.push_back(sc);
-        H.n_carriers = (int32_t)carriers.size();
-        ABW_HIP(ctx, hipMalloc((void**)&H.d_carriers, std::max<size_t>(4, carriers.size() * 4)));
-        if (!carriers.empty()) ABW_HIP(ctx, hipMemcpy(H.d_carriers, carriers.data(), carriers.size() * 4, hipMemcpyHostToDevice));
     }
     ABW_HIP(ctx, hipStreamSynchronize(st));
     return ABW_OK;
@@ -799,7 +997,7 @@ int TreeRun::begin(int32_t min_ndps_, int64_t max_nodes_)
     int rc;
     D = s.D; S = s.S; n_narrow = (int32_t)H.narrow_dims.size(); n_wide = (int32_t)H.wide_dims.size();
     N = s.N; Np = (N + 7) & ~(int64_t)7; Sp = ((int64_t)S + 7) & ~(int64_t)7;      // strides of the position / scaffold arrays
-    if (S > (int32_t)W_SC) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree: more than 2^30 scaffolds");
+    if (S > (int32_t)W_SC) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree: more than 2^29 scaffolds");
     n_groups = (int32_t)H.groups.size();
     TBn = std::max<int64_t>(1, n_narrow ? H.toffn[n_narrow] : 0);      // a node's slice: the narrow dimensions in H.nsort order
 
@@ -821,14 +1019,7 @@ int TreeRun::begin(int32_t min_ndps_, int64_t max_nodes_)
     Tr.P.scg_off = s.d_scg_off; Tr.P.scg_ids = s.d_scg_ids; Tr.P.n_scg = s.n_scg;
     Tr.P.T = s.d_T; Tr.P.Toff = s.d_Toff;
     Tr.P.h_st = nullptr; Tr.P.h_tot = nullptr; Tr.P.h_bp = nullptr; Tr.P.scg_lo = nullptr; Tr.P.scg_hi = nullptr; Tr.P.range = nullptr;
-    if ((n_wide && !(H.d_wword && H.d_wpack)) || (s.n_scg > 0 && !H.d_carriers)) {
-        // dp -> scaffold (only the static build needs it)
-        std::vector<int32_t> d2s((size_t)N);
-        for (int32_t sc = 0; sc < S; sc++) std::fill(d2s.begin() + s.h_scaf_first[sc], d2s.begin() + s.h_scaf_first[sc] + s.h_scaf_ndps[sc], sc);
-        ABW_HIP(ctx, hipMemcpyAsync(d_dp2scaf, d2s.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
-        ABW_HIP(ctx, hipStreamSynchronize(st));
-        if ((rc = tree_static_build(ctx, H, Tr.P, d_dp2scaf))) return rc;
-    }
+    if ((rc = abw_tree_static_ensure(ctx))) return rc;
     Tr.narrow = H.d_nsort; Tr.n_narrow = n_narrow; Tr.toffn = H.d_toffn; Tr.TBn = TBn;
     Tr.groups = H.d_groups; Tr.n_groups = n_groups; Tr.nk16 = (const uint4*)H.d_nk16; Tr.ts8 = (const uint4*)H.d_ts8; Tr.srec = (const int4*)H.d_srec;
     Tr.wide = H.d_wide; Tr.n_wide = n_wide; Tr.dp2scaf = d_dp2scaf; Tr.dim_slot = H.d_dim_slot;
@@ -937,7 +1128,10 @@ int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
     d_pmask = (uint8_t*)b_tile.p + t_cand + t_sums + t_best + t_tot + t_cnt;
     d_smask = d_pmask + (size_t)std::max(1, n_wide) * n_pt * 256;
     double* d_bar = (double*)(d_pmask + t_mask);
-    if (scg_n > 0) {
+    if (scg_n > 0 && (int64_t)K * s.n_scg <= SCG_LEVEL_LDS) {
+        hipLaunchKernelGGL(tree_scg_lds_kernel, dim3((unsigned)D), dim3(256), 0, st, Tr, H.d_carriers, H.n_carriers, d_scaf_slot, K, d_scg_lo, d_scg_hi);
+        ABW_LAUNCH_CHECK(ctx);
+    } else if (scg_n > 0) {
         hipLaunchKernelGGL(tree_scg_reset_kernel, dim3((unsigned)std::min<int64_t>((scg_n + 255) / 256, ctx->num_cu * 8)), dim3(256), 0, st, d_scg_lo, d_scg_hi, scg_n);
         ABW_LAUNCH_CHECK(ctx);
         if (H.n_carriers > 0) {
@@ -968,8 +1162,10 @@ int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
         if (n_at) {
             // level 0 holds all scaffolds in id order: no list (accum_group_tile then takes its tiles as ranges of ids)
             const bool identity = (K == 1 && level[0].parent < 0);
-            hipLaunchKernelGGL(tree_accum_kernel, dim3((unsigned)n_at, (unsigned)n_groups), dim3(256), 0, st, Tr, d_atiles,
-                               identity ? (const int32_t*)nullptr : (const int32_t*)order[cur], c_st, c_bp, c_tot);
+            if (H.packed) hipLaunchKernelGGL(tree_accum_kernel<true>, dim3((unsigned)n_at, (unsigned)n_groups), dim3(256), 0, st, Tr, d_atiles,
+                                             identity ? (const int32_t*)nullptr : (const int32_t*)order[cur], c_st, c_bp, c_tot);
+            else hipLaunchKernelGGL(tree_accum_kernel<false>, dim3((unsigned)n_at, (unsigned)n_groups), dim3(256), 0, st, Tr, d_atiles,
+                                    identity ? (const int32_t*)nullptr : (const int32_t*)order[cur], c_st, c_bp, c_tot);
             ABW_LAUNCH_CHECK(ctx);
         }
         if (!subs.empty()) {
@@ -1142,6 +1338,118 @@ TreeRun* run_of(abw_ctx* ctx, const char* who, bool create)
 }  // namespace
 
 void abw_tree_run_free(void* run) { delete (TreeRun*)run; }
+
+static SepDev static_params(const abw_sep_state& s)
+{
+    SepDev P;
+    P.bins = s.d_bins ? s.d_bins : s.d_keys; P.N = s.N;
+    P.scaf_first = s.d_scaf_first; P.scaf_ndps = s.d_scaf_ndps; P.scaf_len = s.d_scaf_len;
+    P.scg_off = s.d_scg_off; P.scg_ids = s.d_scg_ids; P.n_scg = s.n_scg;
+    P.T = s.d_T; P.Toff = s.d_Toff;
+    P.h_st = nullptr; P.h_tot = nullptr; P.h_bp = nullptr; P.scg_lo = nullptr; P.scg_hi = nullptr; P.range = nullptr;
+    return P;
+}
+
+// The static tables of the wide dimensions (position words, per-scaffold records, SCG carriers), built at the first call that
+// needs them on a loaded table -- abw_sep_tree_begin, or abw_sep_node on a node large enough for the scan.
+int abw_tree_static_ensure(abw_ctx* ctx)
+{
+    abw_sep_state& s = ctx->sep;
+    SepHost& H = abw_sep_host(ctx);
+    const size_t n_wide = H.wide_dims.size();
+    if (!(n_wide && !(H.d_wword && H.d_wpack))) return ABW_OK;
+    int rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[8], (size_t)s.N * 4 + 64))) return rc;
+    int32_t* d_dp2scaf = (int32_t*)ctx->scratch[8].p;                        // dp -> scaffold: only this build needs it
+    std::vector<int32_t> d2s((size_t)s.N);
+    for (int32_t sc = 0; sc < s.S; sc++) std::fill(d2s.begin() + s.h_scaf_first[sc], d2s.begin() + s.h_scaf_first[sc] + s.h_scaf_ndps[sc], sc);
+    ABW_HIP(ctx, hipMemcpyAsync(d_dp2scaf, d2s.data(), (size_t)s.N * 4, hipMemcpyHostToDevice, ctx->stream));
+    ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return tree_static_build(ctx, H, static_params(s), d_dp2scaf);
+}
+
+// ---- abw_sep_node's wide dimensions (see node_wide_*_kernel): host side --------------------------------------------------
+namespace {
+struct NodeWide { TreeDev Tr; int32_t n_tiles, n_wide; WSums4 *tile_sums, *total; Cand* tile_best; double* bar; };
+
+int node_wide_plan(abw_ctx* ctx, NodeWide& W)
+{
+    abw_sep_state& s = ctx->sep;
+    SepHost& H = abw_sep_host(ctx);
+    W.n_wide = (int32_t)H.wide_dims.size();
+    W.n_tiles = (int32_t)((s.N + TILE_P - 1) / TILE_P);
+    const size_t o_sums = 0, o_tot = o_sums + (size_t)W.n_wide * W.n_tiles * sizeof(WSums4),
+                 o_best = o_tot + (size_t)W.n_wide * sizeof(WSums4), o_bar = o_best + (size_t)W.n_wide * W.n_tiles * sizeof(Cand), bytes = o_bar + 64;
+    if (H.nw_cap < bytes) {
+        if (H.d_nw) { ABW_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(H.d_nw); H.d_nw = nullptr; H.nw_cap = 0; }
+        ABW_HIP(ctx, hipMalloc(&H.d_nw, bytes));
+        H.nw_cap = bytes;
+    }
+    uint8_t* p = (uint8_t*)H.d_nw;
+    W.tile_sums = (WSums4*)(p + o_sums); W.total = (WSums4*)(p + o_tot); W.tile_best = (Cand*)(p + o_best); W.bar = (double*)(p + o_bar);
+    memset(&W.Tr, 0, sizeof(W.Tr));
+    W.Tr.P = static_params(s);
+    W.Tr.narrow = H.d_nsort; W.Tr.n_narrow = (int32_t)H.narrow_dims.size();
+    W.Tr.wide = H.d_wide; W.Tr.n_wide = W.n_wide;
+    W.Tr.wext = (const uint4*)H.d_wext; W.Tr.wpack = H.d_wpack; W.Tr.D = s.D; W.Tr.S = s.S;
+    return ABW_OK;
+}
+}  // namespace
+
+bool abw_node_wide_usable(abw_ctx* ctx)
+{
+    const abw_sep_state& s = ctx->sep;
+    SepHost& H = abw_sep_host(ctx);
+    return !H.sharded && !H.wide_dims.empty() && s.S <= (int32_t)W_SC && s.N < ((int64_t)1 << 31) - TILE_P;
+}
+
+// tile sums and their scan for the node (d_member: a byte per scaffold, NULL = every scaffold)
+int abw_node_wide_accum(abw_ctx* ctx, const uint8_t* d_member)
+{
+    abw_sep_state& s = ctx->sep;
+    SepHost& H = abw_sep_host(ctx);
+    hipStream_t st = ctx->stream;
+    int rc;
+    if ((rc = abw_tree_static_ensure(ctx))) return rc;
+    NodeWide W;
+    if ((rc = node_wide_plan(ctx, W))) return rc;
+    const bool masked = d_member != nullptr;
+    const int64_t Np = (s.N + 7) & ~(int64_t)7;
+    const dim3 grid((unsigned)W.n_tiles, (unsigned)W.n_wide);
+    if (masked) hipLaunchKernelGGL(node_wide_sums_kernel<true>, grid, dim3(256), 0, st, W.Tr, (int32_t)s.N, W.n_tiles, (const uint32_t*)H.d_wword, Np, d_member, W.tile_sums);
+    else hipLaunchKernelGGL(node_wide_sums_kernel<false>, grid, dim3(256), 0, st, W.Tr, (int32_t)s.N, W.n_tiles, (const uint32_t*)H.d_wword, Np, (const uint8_t*)nullptr, W.tile_sums);
+    ABW_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(node_wide_scan_kernel, dim3((unsigned)W.n_wide), dim3(64), 0, st, W.n_tiles, W.tile_sums, W.total);
+    ABW_LAUNCH_CHECK(ctx);
+    return ABW_OK;
+}
+
+// every threshold of the wide dimensions, once the narrow dimensions' records are in d_dimbest (their best product is the bar)
+// exact_per_dim: the caller wants every dimension's own winner (abw_sep_node's per_dim), not only the node's: no bar then
+int abw_node_wide_eval(abw_ctx* ctx, const uint8_t* d_member, bool exact_per_dim, int32_t min_ndps, const int32_t* scg_lo, const int32_t* scg_hi, DimBestDev* d_dimbest)
+{
+    abw_sep_state& s = ctx->sep;
+    SepHost& H = abw_sep_host(ctx);
+    hipStream_t st = ctx->stream;
+    int rc;
+    NodeWide W;
+    if ((rc = node_wide_plan(ctx, W))) return rc;
+    const int64_t Np = (s.N + 7) & ~(int64_t)7;
+    if (exact_per_dim) ABW_HIP(ctx, hipMemsetAsync(W.bar, 0, 8, st));
+    else {
+        hipLaunchKernelGGL(node_bar_kernel, dim3(1), dim3(64), 0, st, W.Tr, (const DimBestDev*)d_dimbest, W.bar);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    const dim3 grid((unsigned)W.n_tiles, (unsigned)W.n_wide);
+    if (d_member) hipLaunchKernelGGL(node_wide_eval_kernel<true>, grid, dim3(256), 0, st, W.Tr, (int32_t)s.N, W.n_tiles, min_ndps, (const int32_t*)H.d_sbin, (const uint32_t*)H.d_wword, Np,
+                                   d_member, (const WSums4*)W.tile_sums, (const WSums4*)W.total, scg_lo, scg_hi, (const double*)W.bar, W.tile_best);
+    else hipLaunchKernelGGL(node_wide_eval_kernel<false>, grid, dim3(256), 0, st, W.Tr, (int32_t)s.N, W.n_tiles, min_ndps, (const int32_t*)H.d_sbin, (const uint32_t*)H.d_wword, Np,
+                            (const uint8_t*)nullptr, (const WSums4*)W.tile_sums, (const WSums4*)W.total, scg_lo, scg_hi, (const double*)W.bar, W.tile_best);
+    ABW_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(node_wide_best_kernel, dim3((unsigned)W.n_wide), dim3(64), 0, st, W.Tr, W.n_tiles, (const Cand*)W.tile_best, (const WSums4*)W.total, d_dimbest);
+    ABW_LAUNCH_CHECK(ctx);
+    return ABW_OK;
+}
 
 namespace {
 // The level of a recursion lives in the context's scratch buffers between the calls of the phase API.  Another entry point

@@ -65,8 +65,11 @@ class ClusterSeparatorHip:
     """One node of the recursion: the drop-in for ClusterSeparatorBySensitivitySpecificity."""
     cluster_ndps_threshold = 100      # reference src/ClusterSeparator.h:72
 
-    def __init__(self, store: ColumnStore, scaf_ids=None):
+    def __init__(self, store: ColumnStore, scaf_ids=None, per_dim: bool = True):
+        """per_dim = False: only the node's winner is asked for, as the reference's separate() reports it (the C++ adapter's call);
+        the library may then skip thresholds that cannot beat what another dimension has reached."""
         self.store = store
+        self.want_per_dim = per_dim
         self.scaf_ids = None if scaf_ids is None else np.ascontiguousarray(scaf_ids, dtype=np.int32)
         self._res = None
 
@@ -76,7 +79,7 @@ class ClusterSeparatorHip:
         ids = np.arange(st.S, dtype=np.int32) if self.scaf_ids is None else self.scaf_ids
         n = int(st.scaf_ndps[ids].sum())
         out = Split()
-        per = (DimBest * st.D)()
+        per = (DimBest * st.D)() if self.want_per_dim else None
         # output buffers are kept on the store and re-used (fresh numpy pages would be faulted in by the copy)
         buf = st.__dict__.setdefault("_outbuf", {})
         if "side" not in buf or len(buf["side"]) < m:
@@ -91,7 +94,7 @@ class ClusterSeparatorHip:
                                         C.c_void_p(side.ctypes.data), C.c_void_p(raw.ctypes.data)))
         self.last_call_s = time.perf_counter() - t0          # the C-ABI call alone (host buffers in and out)
         self._res, self._side, self._raw, self._ids = out, side.copy(), raw.copy(), ids
-        self._per = np.frombuffer(per, dtype=_PER_DTYPE).copy()
+        self._per = np.frombuffer(per, dtype=_PER_DTYPE).copy() if per is not None else None
         return bool(out.split)
 
     # -- accessors named after the reference's (ClusterSeparator.h:45-52, ...Specificity.h:51-52) --
@@ -145,7 +148,7 @@ def binning(store: ColumnStore, max_nodes: int = 1 << 30):
     while work and len(nodes) < max_nodes:
         nid = min(work)
         ids = work.pop(nid)
-        sep = ClusterSeparatorHip(store, ids)
+        sep = ClusterSeparatorHip(store, ids, per_dim=False)
         split = sep.separate()
         all_ids = np.arange(store.S, dtype=np.int32) if ids is None else ids
         n = int(store.scaf_ndps[all_ids].sum())

@@ -675,7 +675,7 @@ def separator_leg(ctx, keys_host, dp2scaf, scaf_len, genome, G, seed, label, tra
     t0 = time.perf_counter()
     store = separator.ColumnStore(ctx, keys_host, dp2scaf, scaf_len, so, si, 30)
     load_s = time.perf_counter() - t0
-    sep = separator.ClusterSeparatorHip(store)
+    sep = separator.ClusterSeparatorHip(store, per_dim=False)       # the node's winner, as the reference's separate() reports it
     sep.separate()
     ctx.prof_reset(); ctx.prof_enable(True)
     t0 = time.perf_counter()
@@ -688,14 +688,20 @@ def separator_leg(ctx, keys_host, dp2scaf, scaf_len, genome, G, seed, label, tra
     sep_s = call_s / reps                                 # abw_sep_node alone: host node list in, host sides out
     na, msa = ctx.prof_read("sep_accum")
     ne, mse = ctx.prof_read("sep_eval")
+    nw, msw = ctx.prof_read("sep_wide")
     ctx.prof_enable(False)
+    # every pass over the table counts: the accumulation bracket (narrow histograms, SCG lists, the wide dimensions' tile sums)
+    # and the wide dimensions' second pass (evaluation along the sorted positions)
+    msa, accum_only_ms = msa + msw, msa / na
     alg_bytes = 4.0 * D * N + 4.0 * N + 16.0 * D * 1001
     res = dict(value=D * N / sep_s, unit="dimension*points/s", ms_per_node=sep_s * 1e3, ms_per_node_with_python_glue=round(wrap_s * 1e3, 3), node="root",
                table=f"{label}: {S} scaffolds -> {N} dps x {D} dims, 30 SCGs x {G} genomes",
                split=int(sep._res.split), dimension=int(sep._res.dimension), load_s=round(load_s, 3), load_from_device_keys_s=round(load_dev_s, 3),
                roofline=dict(kernel="sep_accum_kernel", bound="hbm", achieved=round(alg_bytes / (msa / na * 1e-3) / 1e9, 1),
                              peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg_bytes / (msa / na * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                             traffic=traffic, ms_per_launch=round(msa / na, 4), eval_ms=round(mse / max(ne, 1), 4)))
+                             traffic=traffic, ms_per_launch=round(msa / na, 4), accumulate_ms=round(accum_only_ms, 4),
+                             wide_second_pass_ms=round(msw / max(nw, 1), 4), eval_ms=round(mse / max(ne, 1), 4),
+                             kernels="sep_accum_kernel + sep_scg_kernel + node_wide_sums / scan / eval (all passes over the table)"))
     # the whole recursion on this table (reference src/abawaca.cpp:95-197 with the GPU separator)
     t0 = time.perf_counter()
     nodes_all, s2c_all, _d2c = separator.binning(store)

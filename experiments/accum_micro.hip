@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void k_accum(const NGroup* groups, const uint4
     const int begin = blockIdx.x * tile, end = min(m, begin + tile);
     SepDev P; P.n_scg = 0;
     if (MODE == 0 || MODE == 2) {
-        accum_group_tile(G, nk16 + (int64_t)j * N, ts8 + (int64_t)j * S, srec, list, begin, end, P, nullptr, nullptr,
+        accum_group_tile<false>(G, nk16 + (int64_t)j * N, ts8 + (int64_t)j * S, srec, list, begin, end, P, nullptr, nullptr,
                          [&](int b, unsigned long long a, uint32_t c3, unsigned long long e) {
                              if (MODE == 2) { if (a == 0xdeadbeefull) sink[0] = c3; return; }
                              if (a) atomicAdd(&h_st[G.goff + b], a);

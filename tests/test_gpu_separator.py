@@ -63,6 +63,15 @@ def _compare_node(store, scaf_ids, g_arrays, min_ndps=100):
         assert np.array_equal(sep._raw, raw)
     if res.split:
         assert np.array_equal(sep._side, side[all_ids])
+    # the same node asked for its winner only (the reference's separate(); the library may then skip thresholds below the bar
+    # another dimension set): same verdict, same bits
+    only = separator.ClusterSeparatorHip(store, scaf_ids, per_dim=False)
+    only.cluster_ndps_threshold = min_ndps
+    only.separate()
+    a, b = only._res, sep._res
+    assert (a.split, a.dimension, a.key, a.legal, a.sensitivity, a.specificity, a.ndps1, a.ndps2) == \
+           (b.split, b.dimension, b.key, b.legal, b.sensitivity, b.specificity, b.ndps1, b.ndps2)
+    assert np.array_equal(only._side, sep._side) and np.array_equal(only._raw, sep._raw)
     return res
 
 
@@ -167,3 +176,23 @@ def test_configs0_whole_recursion_matches_the_reference(ctx, golden_dir):
         assert a["spec"] == r[5] and a["sens"] == r[6]                          # the reference's doubles, bit for bit
         assert (a["c1"], a["n1"], a["c2"], a["n2"]) == (int(r[7]), int(r[8]), int(r[9]), int(r[10]))
     assert np.array_equal(s2c, g["scaf2cluster"])
+
+
+@pytest.mark.parametrize("path", GOLD[:2], ids=lambda p: os.path.basename(p)[:-4])
+def test_unpacked_accumulation_gives_the_same_recursion(path, monkeypatch):
+    """The narrow accumulation has two forms: counters packed two to an LDS word (tables whose scaffolds have at most 63 dps) and
+    one counter per word.  The goldens run packed everywhere else; here the other form, against the reference's nodes."""
+    monkeypatch.setenv("ABW_SEP_UNPACKED", "1")
+    c = _lib.Context(0)
+    try:
+        g = np.load(path)
+        store, _o, _i = _store(c, g)
+        nodes, s2c, _d2c = separator.binning(store)
+        assert [(n["id"], n["ndps"], n["split"], n["dim"], n["spec"], n["sens"]) for n in nodes] == \
+               [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), r[5], r[6]) for r in g["nodes"]]
+        assert np.array_equal(s2c, g["scaf2cluster"])
+        rows, s2c_t, _dt = separator.binning_tree(store)
+        assert [(r["id"], r["split"], r["dim"], r["key"]) for r in rows] == [(n["id"], n["split"], n["dim"], n["key"]) for n in nodes]
+        assert np.array_equal(s2c_t, s2c)
+    finally:
+        c.close()
