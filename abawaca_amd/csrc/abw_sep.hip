@@ -650,6 +650,29 @@ __global__ __launch_bounds__(256) void sep_assign_kernel(SepDev P, const int32_t
     if (threadIdx.x == 0) { if (b1) atomicAdd(&totals[0], b1); if (b2) atomicAdd(&totals[1], b2); }
 }
 
+// abw_sep_node_assign: the node's dps on the "<=" side of a given threshold (what the histogram scan knows as size1 of the
+// winner), added into win->size1.  One thread per scaffold of the node.
+__global__ __launch_bounds__(256) void sep_count_le_kernel(SepDev P, const int32_t* __restrict__ node_scaf, int32_t m, GlobalRes* __restrict__ win)
+{
+    __shared__ unsigned long long b;
+    if (threadIdx.x == 0) b = 0;
+    __syncthreads();
+    const int ls = blockIdx.x * 256 + threadIdx.x;
+    int c = 0;
+    if (ls < m) {
+        const int s = node_scaf ? node_scaf[ls] : ls;
+        const int f = P.scaf_first[s], tot = P.scaf_ndps[s];
+        const int32_t* col = P.bins + (int64_t)win->dim * P.N;
+        const int tbin = win->bin;
+        for (int i = 0; i < tot; i++) c += col[f + i] <= tbin;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&b, (unsigned long long)c);
+    __syncthreads();
+    if (threadIdx.x == 0 && b) atomicAdd(reinterpret_cast<unsigned long long*>(&win->size1), b);
+}
+
 }  // namespace
 
 static abw_sep_extra* g_extra_of(abw_ctx* ctx);
@@ -1197,15 +1220,12 @@ static SepDev sep_params(abw_sep_state& s, SepHost& H)
     return P;
 }
 
-// Phase 1: the node's scaffolds held by this context -> histograms and SCG lo/hi lists.
-// all = every scaffold of the table (scaf_ids ignored); otherwise m >= 0 ids (an empty shard of a node is fine).
-static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_t* scaf_ids, int32_t m)
+// The node's scaffold ids and the offsets of their dps in the node's own numbering go up in one copy (s.node_scaf: ids[m] then
+// dp offsets[m + 1]); *n_out = the node's dps.  all: every scaffold, nothing to upload.
+static int sep_upload_node(abw_ctx* ctx, const char* who, bool all, const int32_t* scaf_ids, int32_t m, int64_t* n_out)
 {
     abw_sep_state& s = ctx->sep;
-    SepHost& H = g_extra_of(ctx)->h;
     hipStream_t st = ctx->stream;
-    s.node_open = false;
-    if (all) m = s.S;
     if (m < 0 || (!all && m > 0 && !scaf_ids)) return abw_fail(ctx, ABW_ERR_ARG, "%s: bad scaffold list", who);
     int64_t n = 0;
     int rc;
@@ -1233,6 +1253,22 @@ static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_
         if ((rc = abw_reserve(ctx, s.node_scaf, ((size_t)2 * m + 1) * 4))) return rc;      // ids[m] then dp offsets[m + 1]
         ABW_HIP(ctx, hipMemcpyAsync(s.node_scaf.p, h_ids, ((size_t)2 * m + 1) * 4, hipMemcpyHostToDevice, st));
     } else if (all) n = s.N;
+    *n_out = n;
+    return ABW_OK;
+}
+
+// Phase 1: the node's scaffolds held by this context -> histograms and SCG lo/hi lists.
+// all = every scaffold of the table (scaf_ids ignored); otherwise m >= 0 ids (an empty shard of a node is fine).
+static int sep_accum_phase(abw_ctx* ctx, const char* who, bool all, const int32_t* scaf_ids, int32_t m)
+{
+    abw_sep_state& s = ctx->sep;
+    SepHost& H = g_extra_of(ctx)->h;
+    hipStream_t st = ctx->stream;
+    s.node_open = false;
+    if (all) m = s.S;
+    int64_t n = 0;
+    int rc;
+    if ((rc = sep_upload_node(ctx, who, all, scaf_ids, m, &n))) return rc;
     const int32_t* d_node_scaf = all ? nullptr : (const int32_t*)s.node_scaf.p;
 
     SepDev P = sep_params(s, H);
@@ -1439,6 +1475,68 @@ int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t 
     const int32_t legal = out->legal;
     abw_sep_shard_decide(out, out->ndps1, out->ndps2, min_ndps);
     if (legal && !out->split && scaf_side) memset(scaf_side, 0, (size_t)m);
+    return ABW_OK;
+}
+
+// The finalisation of a node whose winner is known already (ref ClusterSeparator.cpp:35-53,87-132 given best_separation): a
+// caller that ran the whole recursion in one call (abw_sep_tree) and now needs a node's raw sets and scaffold sides.
+int abw_sep_node_assign(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t dimension, int32_t key, int32_t min_ndps,
+                        abw_split* out, uint8_t* scaf_side, uint8_t* dp_raw_side)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    abw_sep_state& s = ctx->sep;
+    if (!s.loaded) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_node_assign: call abw_sep_load first");
+    SepHost& H = g_extra_of(ctx)->h;
+    if (H.sharded) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_node_assign: the table is one shard of a scaffold-sharded problem");
+    if (!out || dimension < 1 || dimension > s.D) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_node_assign: bad argument");
+    if (scaf_ids && n_scaf <= 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_node_assign: empty node");
+    const int32_t d = dimension - 1;
+    int32_t bin = key;
+    if (s.h_binval_off[d] >= 0) {                              // a wide dimension: the key's rank among the column's distinct keys
+        const int32_t* v = s.h_binval.data() + s.h_binval_off[d];
+        const int32_t* e = std::lower_bound(v, v + s.h_T[d], key);
+        if (e == v + s.h_T[d] || *e != key) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_node_assign: dimension %d holds no key %d", dimension, key);
+        bin = (int32_t)(e - v);
+    } else if (key < 0 || key >= s.h_T[d]) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_node_assign: dimension %d holds no key %d", dimension, key);
+    abw_device_guard g(ctx->device);
+    hipStream_t st = ctx->stream;
+    s.node_open = false;
+    const bool all = scaf_ids == nullptr;
+    const int32_t m = all ? s.S : n_scaf;
+    int64_t n = 0;
+    int rc;
+    if ((rc = sep_upload_node(ctx, "abw_sep_node_assign", all, scaf_ids, m, &n))) return rc;
+    const int32_t* d_node_scaf = all ? nullptr : (const int32_t*)s.node_scaf.p;
+    const int32_t* d_node_dpoff = all ? nullptr : (const int32_t*)s.node_scaf.p + m;
+    memset(out, 0, sizeof(*out));
+    SepDev P = sep_params(s, H);
+    // the same block layout as the evaluation phase: global winner | 2 totals | scaffold sides | raw flags
+    const size_t b_db = (size_t)s.D * sizeof(DimBestDev) + sizeof(GlobalRes);
+    const size_t o_tot = (b_db + 15) & ~(size_t)15, o_side = o_tot + 16, o_raw = o_side + (((size_t)m + 15) & ~(size_t)15);
+    if ((rc = abw_reserve(ctx, s.dimbest, o_raw + (size_t)n + 16))) return rc;
+    if ((rc = abw_reserve_pinned(ctx, o_raw + (size_t)n + 16 + sizeof(GlobalRes) + 64))) return rc;
+    uint8_t* d_back = (uint8_t*)s.dimbest.p;
+    GlobalRes* d_win = (GlobalRes*)(d_back + (size_t)s.D * sizeof(DimBestDev));
+    unsigned long long* d_tot = (unsigned long long*)(d_back + o_tot);
+    uint8_t* hp = (uint8_t*)ctx->pinned;
+    GlobalRes* h_win = (GlobalRes*)(hp + ((o_raw + (size_t)n + 16 + 15) & ~(size_t)15));
+    ABW_HIP(ctx, hipStreamSynchronize(st));                    // the upload of the ids has left the pinned block
+    h_win->found = 1; h_win->dim = d; h_win->bin = bin; h_win->legal = 1; h_win->sens = 0; h_win->spec = 0; h_win->size1 = 0; h_win->n = n;
+    ABW_HIP(ctx, hipMemcpyAsync(d_win, h_win, sizeof(GlobalRes), hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemsetAsync(d_tot, 0, 16, st));
+    hipLaunchKernelGGL(sep_count_le_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, d_node_scaf, m, d_win);
+    ABW_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(sep_assign_kernel, dim3((m + 255) / 256), dim3(256), 0, st, P, d_node_scaf, d_node_dpoff, m, d_win, d_back + o_raw, d_back + o_side, d_tot);
+    ABW_LAUNCH_CHECK(ctx);
+    const size_t back_bytes = dp_raw_side ? o_raw + (size_t)n : o_side + (size_t)m;
+    ABW_HIP(ctx, hipMemcpyAsync(hp + o_tot, d_back + o_tot, back_bytes - o_tot, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    if (scaf_side) memcpy(scaf_side, hp + o_side, (size_t)m);
+    if (dp_raw_side) memcpy(dp_raw_side, hp + o_raw, (size_t)n);
+    const unsigned long long* tot2 = (const unsigned long long*)(hp + o_tot);
+    out->dimension = dimension; out->key = key; out->legal = 1;
+    abw_sep_shard_decide(out, (int64_t)tot2[0], (int64_t)tot2[1], min_ndps);
+    if (!out->split && scaf_side) memset(scaf_side, 0, (size_t)m);
     return ABW_OK;
 }
 

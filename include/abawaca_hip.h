@@ -183,6 +183,15 @@ int abw_sep_load_dev(abw_ctx* ctx, const int32_t* d_keys, int32_t D, int64_t N, 
 int abw_sep_node(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t min_ndps,
                  abw_split* out, abw_dimbest* per_dim, uint8_t* scaf_side, uint8_t* dp_raw_side);
 
+/* The second half of separate() for a node whose winner is known (ref: src/ClusterSeparator.cpp:35-53 reconstruct_best_clusters,
+ * :87-132 raw sets, scaffold assignment, datapoints following their scaffolds, size check -- given best_separation): for a
+ * caller that has run the whole recursion in one call (abw_sep_tree below) and needs a node's raw sets and scaffold sides to
+ * rebuild the reference's Cluster objects.  dimension (1-based) / key: the node's legal winner as abw_sep_tree reported it.
+ * out: split, ndps1 / ndps2 and the winner handed in (sensitivity / specificity are not recomputed: 0); scaf_side / dp_raw_side
+ * as abw_sep_node.  After abw_sep_node on the same node with the same winner the outputs are identical. */
+int abw_sep_node_assign(abw_ctx* ctx, const int32_t* scaf_ids, int32_t n_scaf, int32_t dimension, int32_t key, int32_t min_ndps,
+                        abw_split* out, uint8_t* scaf_side, uint8_t* dp_raw_side);
+
 /* ---- the whole recursion in one call: the work-list loop of ref src/abawaca.cpp:95-197 around separate(), on the table of
  *      abw_sep_load.  The reference takes the node with the smallest id from its std::map and gives the children of a split
  *      the next two ids (ref :98-100,155-194), i.e. it visits the nodes breadth first: abw_sep_tree evaluates every LEVEL of

@@ -24,6 +24,14 @@ struct HipStore {
 	std::vector<std::vector<double> >	values;		// [D] sorted distinct values: key -> .lrn value
 	std::vector<std::string>		dim_names;
 	std::vector<uint8_t>			raw_of;		// [N + 1] scratch of separate(): raw side of a datapoint
+	std::vector<size_t>			first_dp;	// [S + 1] smallest datapoint id of every scaffold (its datapoints are consecutive ids)
+	std::vector<uint32_t>			cnt;		// [S + 1] scratch of separate(): datapoints of the node per scaffold (all zero between calls)
+	// the whole recursion, run at the root (ClusterSeparatorHip::run_tree)
+	std::vector<ClusterSeparatorHip::TreeRec>	tree;	// in id order = the order the reference's driver visits them
+	std::vector<int32_t>			s2c;		// [S] final bin (terminal node id) of every scaffold
+	std::vector<int32_t>			idx_of, tin, tout;	// node id -> index in tree; depth-first intervals by index
+	size_t					cursor = 0;	// the next separate() call is tree[cursor]
+	size_t					from_tree = 0, node_by_node = 0;
 };
 HipStore g_store;
 
@@ -71,7 +79,13 @@ void build_table(const ScafDpData& scaf_db, const SCGdb& scg_db, const ClusterDa
 		for(auto& th : pool) th.join();
 	}
 	t.dp2scaf.resize(N);
-	for(size_t dp = 1; dp <= N; dp++) t.dp2scaf[dp - 1] = (int32_t)scaf_db.dp2scaf(dp) - 1;
+	st.first_dp.assign(S + 1, 0);
+	st.cnt.assign(S + 1, 0);
+	for(size_t dp = N; dp >= 1; dp--) {
+		const size_t sc = scaf_db.dp2scaf(dp);
+		t.dp2scaf[dp - 1] = (int32_t)sc - 1;
+		st.first_dp[sc] = dp;
+	}
 	t.scaf_len.resize(S);
 	for(size_t s = 1; s <= S; s++) t.scaf_len[s - 1] = (int64_t)scaf_db.get_scaf(s)->get_seq_size();
 	// scaffold -> SCG ids through SCGdb's public interface
@@ -130,6 +144,47 @@ void ClusterSeparatorHip::run_node(const std::vector<int32_t>& scaf_ids, size_t 
 }
 
 //////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
+bool ClusterSeparatorHip::run_tree(std::vector<TreeRec>& nodes, std::vector<int32_t>& scaf2cluster)
+{
+	HipStore& st = g_store;
+	std::vector<abw_tree_node> buf(1024);
+	scaf2cluster.assign(st.S, 0);
+	int64_t n = 0;
+	int rc = abw_sep_tree(st.ctx, (int32_t)this->cluster_ndps_threshold, 0, buf.data(), (int64_t)buf.size(), &n, scaf2cluster.data());
+	if(rc == ABW_ERR_CAPACITY && n > (int64_t)buf.size()) {
+		buf.resize((size_t)n);
+		rc = abw_sep_tree(st.ctx, (int32_t)this->cluster_ndps_threshold, 0, buf.data(), (int64_t)buf.size(), &n, scaf2cluster.data());
+	}
+	if(rc != ABW_OK) fail("ClusterSeparatorHip: abw_sep_tree failed");
+	nodes.resize((size_t)n);
+	for(int64_t i = 0; i < n; i++) {
+		const abw_tree_node& b = buf[(size_t)i];
+		TreeRec& r = nodes[(size_t)i];
+		r.id = b.id; r.split = b.split; r.dimension = b.dimension; r.key = b.key; r.legal = b.legal; r.child1 = b.child1; r.child2 = b.child2;
+		r.n_scaf = b.n_scaf; r.ndps = (long)b.ndps; r.sensitivity = b.sensitivity; r.specificity = b.specificity;
+	}
+	return true;
+}
+
+//////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
+void ClusterSeparatorHip::run_assign(const std::vector<int32_t>& scaf_ids, size_t n_dps, int dimension, int key, NodeResult& r)
+{
+	abw_split out;
+	r.side.assign(scaf_ids.size(), 0);
+	r.raw.assign(n_dps, 0);
+	if(abw_sep_node_assign(g_store.ctx, scaf_ids.data(), (int32_t)scaf_ids.size(), dimension, key, (int32_t)this->cluster_ndps_threshold, &out,
+			r.side.data(), r.raw.data()) != ABW_OK)
+		fail("ClusterSeparatorHip: abw_sep_node_assign failed");
+	r.split = out.split;
+}
+
+//////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
+void ClusterSeparatorHip::stats(size_t& from_tree, size_t& node_by_node)
+{
+	from_tree = g_store.from_tree; node_by_node = g_store.node_by_node;
+}
+
+//////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////////
 void ClusterSeparatorHip::shutdown()
 {
 	if(g_store.ctx) abw_ctx_destroy(g_store.ctx);
@@ -164,22 +219,76 @@ bool ClusterSeparatorHip::separate()
 		Table t;
 		build_table(scaf_db, scg_db, clustering_db, st, t);
 		load_table(t);
+		// the root: the whole recursion in one call; the records serve every later separate() on this table
+		st.tree.clear(); st.cursor = 0; st.from_tree = st.node_by_node = 0;
+		if(!getenv("ABW_NODE_BY_NODE") && run_tree(st.tree, st.s2c)) {
+			int max_id = 0;
+			for(size_t i = 0; i < st.tree.size(); i++) max_id = std::max(max_id, std::max(st.tree[i].id, std::max(st.tree[i].child1, st.tree[i].child2)));
+			st.idx_of.assign((size_t)max_id + 1, -1);
+			for(size_t i = 0; i < st.tree.size(); i++) st.idx_of[st.tree[i].id] = (int32_t)i;
+			// depth-first intervals: node X lies above bin b iff tin[X] <= tin[b] and tout[b] <= tout[X]
+			st.tin.assign(st.tree.size(), 0); st.tout.assign(st.tree.size(), 0);
+			std::vector<std::pair<int32_t, int> > stack;
+			int32_t clock = 0;
+			if(!st.tree.empty()) stack.push_back(std::pair<int32_t, int>(0, 0));
+			while(!stack.empty()) {
+				const int32_t i = stack.back().first;
+				const int stage = stack.back().second++;
+				const TreeRec& r = st.tree[i];
+				if(stage == 0) st.tin[i] = clock++;
+				const int child = stage == 0 ? r.child1 : stage == 1 ? r.child2 : 0;
+				if(stage >= 2 || !r.split) { st.tout[i] = clock++; stack.pop_back(); continue; }
+				if(child > 0 && child < (int)st.idx_of.size() && st.idx_of[child] >= 0) stack.push_back(std::pair<int32_t, int>(st.idx_of[child], 0));
+			}
+		}
 	}
 
 	// the node as a list of whole scaffolds (separate() always hands whole scaffolds to its children,
 	// reference src/ClusterSeparator.cpp:94-122)
 	const unordered_set<size_t>& dps = clustering_db.datapoints();
-	std::map<size_t, size_t> per_scaf;
-	for(auto it = dps.begin(); it != dps.end(); it++) per_scaf[scaf_db.dp2scaf(*it)]++;
 	std::vector<int32_t> scaf_ids;
-	for(auto it = per_scaf.begin(); it != per_scaf.end(); it++) {
-		if(it->second != scaf_db.ndps(it->first))
-			throw std::invalid_argument("ClusterSeparatorHip: node holds only part of scaffold " + scaf_db.scaf_id2name(it->first));
-		scaf_ids.push_back((int32_t)it->first - 1);
+	for(auto it = dps.begin(); it != dps.end(); it++) {
+		const size_t sc = scaf_db.dp2scaf(*it);
+		if(st.cnt[sc]++ == 0) scaf_ids.push_back((int32_t)sc - 1);
 	}
+	std::sort(scaf_ids.begin(), scaf_ids.end());
 	const int32_t m = (int32_t)scaf_ids.size();
+	bool whole = true;
+	for(int32_t i = 0; i < m; i++) {
+		const size_t sc = (size_t)scaf_ids[i] + 1;
+		if(st.cnt[sc] != scaf_db.ndps(sc)) whole = false;
+		st.cnt[sc] = 0;
+	}
+	if(!whole)
+		throw std::invalid_argument("ClusterSeparatorHip: the node holds only part of a scaffold");
+
+	// is this the node the recursion's records expect next?
+	const TreeRec* rec = NULL;
+	if(st.cursor < st.tree.size()) {
+		const TreeRec& c = st.tree[st.cursor];
+		bool same = (size_t)c.ndps == dps.size() && c.n_scaf == m;
+		for(int32_t i = 0; same && i < m; i++) {
+			const int32_t bin = st.s2c[scaf_ids[i]];
+			const int32_t b = (bin > 0 && bin < (int32_t)st.idx_of.size()) ? st.idx_of[bin] : -1;
+			same = b >= 0 && st.tin[st.cursor] <= st.tin[b] && st.tout[b] <= st.tout[st.cursor];
+		}
+		if(same) rec = &c;
+		else st.tree.clear();					// another order of visits, or other nodes: node by node from here on
+	}
+	st.cursor++;
+
 	NodeResult out;
-	run_node(scaf_ids, dps.size(), out);
+	(rec ? st.from_tree : st.node_by_node)++;
+	if(rec) {
+		out.dimension = rec->dimension; out.key = rec->key; out.legal = rec->legal; out.split = rec->split;
+		out.sensitivity = rec->sensitivity; out.specificity = rec->specificity;
+		if(rec->split) {
+			run_assign(scaf_ids, dps.size(), rec->dimension, rec->key, out);
+			if(!out.split) throw std::logic_error("ClusterSeparatorHip: abw_sep_node_assign and abw_sep_tree disagree about a node");
+		}
+	}
+	else
+		run_node(scaf_ids, dps.size(), out);
 	const std::vector<uint8_t>& side = out.side;
 	const std::vector<uint8_t>& raw = out.raw;
 
@@ -189,17 +298,17 @@ bool ClusterSeparatorHip::separate()
 	if(!out.legal || out.dimension <= 0)
 		return false;								// reference src/ClusterSeparator.cpp:83-84
 
-	// dps are listed to the library scaffold by scaffold, ascending dp id inside a scaffold
-	std::vector<std::vector<size_t> > scaf_dps(m);
-	std::map<size_t, size_t> pos;
-	for(int32_t i = 0; i < m; i++) pos[(size_t)scaf_ids[i] + 1] = i;
-	for(auto it = dps.begin(); it != dps.end(); it++) scaf_dps[pos[scaf_db.dp2scaf(*it)]].push_back(*it);
-	for(int32_t i = 0; i < m; i++) std::sort(scaf_dps[i].begin(), scaf_dps[i].end());
+	// dps are listed to the library scaffold by scaffold, ascending dp id inside a scaffold -- consecutive ids from the
+	// scaffold's first (reference src/ScafDpData.cpp:91-99)
 	std::vector<uint8_t>& raw_of = st.raw_of;					// by datapoint id; only the node's entries are read
-	size_t k = 0;
-	for(int32_t i = 0; i < m; i++)
-		for(size_t j = 0; j < scaf_dps[i].size(); j++, k++)
-			raw_of[scaf_dps[i][j]] = raw[k];
+	{
+		size_t off = 0;
+		for(int32_t i = 0; i < m; i++) {
+			const size_t sc = (size_t)scaf_ids[i] + 1, n_s = scaf_db.ndps(sc);
+			for(size_t j = 0; j < n_s; j++) raw_of[st.first_dp[sc] + j] = raw[off + j];
+			off += n_s;
+		}
+	}
 
 	// The two clusters are built by the reference's own sequence of set operations, so that their unordered_sets
 	// iterate in the reference's order (the cluster files are written in that order, reference

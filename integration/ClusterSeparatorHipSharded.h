@@ -25,6 +25,7 @@ protected:
 	void		load_table(const Table& t) override;
 	void		run_node(const std::vector<int32_t>& scaf_ids, size_t n_dps, NodeResult& r) override;
 	bool		loaded_for(const ScafDpData* db) const override;
+	bool		run_tree(std::vector<TreeRec>&, std::vector<int32_t>&) override	{return false;}	// shards go node by node (abw_sep_shard_*)
 };
 
 #endif // CLUSTERSEPARATORHIPSHARDED_H

@@ -150,6 +150,14 @@ int main(int argc, const char** argv)
 		if(fw) { fprintf(fw, "%ld\t%ld\n", write_usec, written); fclose(fw); }
 	}
 
+#if defined(ABW_USE_HIP_SEPARATOR) && !defined(ABW_USE_HIP_SHARDED_SEPARATOR)
+	{	// how the adapter answered: from the one-call recursion's records / node by node
+		size_t from_tree = 0, node_by_node = 0;
+		ClusterSeparatorHip::stats(from_tree, node_by_node);
+		FILE* fx = fopen((prefix + ".sep_stats.tsv").c_str(), "w");
+		if(fx) { fprintf(fx, "%lu\t%lu\n", from_tree, node_by_node); fclose(fx); }
+	}
+#endif
 	FILE* fs = fopen((prefix + ".scaf2cluster.tsv").c_str(), "w");
 	FILE* fd = fopen((prefix + ".dp2cluster.tsv").c_str(), "w");
 	if(!fs || !fd) { perror("open output"); return 1; }

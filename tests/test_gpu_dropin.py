@@ -19,9 +19,9 @@ HIP = os.path.join(ROOT, "oracle", "_ref", "hip_sep_driver")
 HIP_SHARDED = os.path.join(ROOT, "oracle", "_ref", "hip_sharded_sep_driver")
 
 
-def _run(exe, files, prefix, env=None):
+def _run(exe, files, prefix, env=None, max_nodes=None):
     subprocess.run([exe, files["names"], files["fasta"], files["info"], files["lrn"], files["scg"], files["scg_list"],
-                    "8", prefix], check=True, timeout=300, env=env)
+                    "8", prefix] + ([str(max_nodes)] if max_nodes else []), check=True, timeout=300, env=env)
     nodes = [ln.split("\t")[:11] for ln in open(prefix + ".nodes.tsv").read().strip().split("\n")]
     return nodes, open(prefix + ".scaf2cluster.tsv").read(), open(prefix + ".dp2cluster.tsv").read()
 
@@ -99,3 +99,30 @@ def test_reference_main_loop_with_the_sharded_hip_separator(golden_dir, case):
             assert names == sorted(os.listdir(out_dir))
             for nm in names:
                 assert open(os.path.join(ref_dir, nm), "rb").read() == open(os.path.join(out_dir, nm), "rb").read(), (shards, nm)
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HIP)), reason="oracle/_ref drivers not built")
+@pytest.mark.parametrize("case", ["sep_g2noisy", "sep_g5", "sep_g6"])
+def test_the_adapter_answers_from_the_one_call_recursion(golden_dir, case):
+    """integration/ClusterSeparatorHip runs abw_sep_tree at the root and serves the driver's later separate() calls from its
+    records (+ abw_sep_node_assign for the raw sets and sides): every node must have been answered that way, with the text
+    and the cluster files of the node-by-node path (ABW_NODE_BY_NODE=1) and of the reference; also when the driver cuts
+    its work list."""
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    with tempfile.TemporaryDirectory(prefix="abwdropt_") as wd:
+        files = synth.write_build_dir(wd, g["milli"], g["dp2scaf"], g["scaf_len"], g["scg_scaf"], g["scg_id"], int(g["n_scg"]))
+        out = {}
+        for tag, exe, extra in (("ref", REF, {}), ("tree", HIP, {}), ("node", HIP, {"ABW_NODE_BY_NODE": "1"})):
+            d = os.path.join(wd, "clusters_" + tag)
+            os.makedirs(d)
+            out[tag] = _run(exe, files, os.path.join(wd, tag), dict(os.environ, ABW_CLUSTER_DIR=d, **extra))
+            out[tag + "_files"] = {nm: open(os.path.join(d, nm), "rb").read() for nm in sorted(os.listdir(d))}
+        assert out["tree"] == out["node"] == out["ref"]
+        assert out["tree_files"] == out["node_files"] == out["ref_files"]
+        n_nodes = len(out["ref"][0])
+        assert open(os.path.join(wd, "tree.sep_stats.tsv")).read().split() == [str(n_nodes), "0"]
+        assert open(os.path.join(wd, "node.sep_stats.tsv")).read().split() == ["0", str(n_nodes)]
+        if n_nodes > 3:
+            cut_ref = _run(REF, files, os.path.join(wd, "cref"), max_nodes=3)
+            cut_hip = _run(HIP, files, os.path.join(wd, "chip"), max_nodes=3)
+            assert cut_ref == cut_hip and len(cut_hip[0]) == 3
