@@ -25,6 +25,7 @@ EXPORTS = [
     "abw_cov_accumulate", "abw_cov_accumulate_dev", "abw_km_load", "abw_km_node", "abw_lrn_header", "abw_lrn_parse", "abw_lrn_emit", "abw_lrn_emit_rows", "abw_lrn_emit_rows_dev", "abw_lrn_table_load",
     "abw_sep_shard_load", "abw_sep_shard_accum", "abw_sep_shard_eval", "abw_sep_shard_decide", "abw_sep_shard_combine", "abw_device_count",
     "abw_sep_tree_begin", "abw_sep_tree_eval", "abw_sep_tree_assign", "abw_sep_tree_advance", "abw_sep_tree_result", "abw_sep_tree_merge",
+    "abw_sep_tree_level", "abw_sep_narrow_bins", "abw_sep_stree_begin", "abw_sep_stree_accum", "abw_sep_stree_eval", "abw_sep_stree_assign",
     "abw_km_shard_begin", "abw_km_shard_ready", "abw_km_shard_step", "abw_km_shard_update", "abw_km_shard_finish",
 ]
 
@@ -107,6 +108,12 @@ def lib():
     L.abw_sep_tree_advance.argtypes = [vp]
     L.abw_sep_tree_result.argtypes = [vp, vp, i64, C.POINTER(i64), vp]
     L.abw_sep_tree_merge.argtypes = [vp, i32, i64, vp, vp]
+    L.abw_sep_tree_level.argtypes = [vp, vp, vp, i64]
+    L.abw_sep_narrow_bins.argtypes = [vp, vp, i32]
+    L.abw_sep_stree_begin.argtypes = [vp, i32]
+    L.abw_sep_stree_accum.argtypes = [vp, vp, i64, vp, vp]
+    L.abw_sep_stree_eval.argtypes = [vp, i32, vp, i64]
+    L.abw_sep_stree_assign.argtypes = [vp, vp, i64, vp, vp]
     L.abw_sep_dev_keys.restype = vp
     L.abw_km_run_dev.argtypes = [vp, vp, i64, i32, i32, u32, i32, i32, vp, vp, vp]
     L.abw_km_run.argtypes = [vp, vp, i64, i32, i32, u32, i32, i32, vp, vp, vp]

@@ -89,6 +89,7 @@ struct abw_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     abw_sep_state sep;
+    std::vector<int32_t> sep_min_bins; // abw_sep_narrow_bins: bins per narrow column for the next load (shared histogram layout)
     abw_devbuf  scratch[12];           // general-purpose grow-only scratch (valid only inside one entry-point call)
     uint64_t    scratch_epoch = 0;     // counts the reservations of scratch[] made outside a recursion's own phases: the phase
     bool        scratch_quiet = false; // API of abw_sep_tree keeps its level in scratch[] between calls and checks the count

@@ -718,6 +718,7 @@ extern "C" void abw_sep_free(abw_ctx* ctx)
                      e->h.d_wts, e->h.d_wbelow, e->h.d_range, e->h.d_groups, e->h.d_nsort, e->h.d_toffn, e->h.d_dim_slot, e->h.d_ts8, e->h.d_nk16, e->h.d_srec, e->h.d_wword, e->h.d_wext, e->h.d_wpack, e->h.d_carriers, e->h.d_nw, e->h.d_g2c_off, e->h.d_g2c, e->h.d_member};
         for (void* p : q) if (p) (void)hipFree(p);
         abw_tree_run_free(e->h.tree_run);
+        abw_stree_run_free(e->h.stree_run);
         delete e;
     }
 }
@@ -786,6 +787,12 @@ __global__ __launch_bounds__(256) void load_rank_kernel(const uint32_t* __restri
 
 }  // namespace
 
+// abw_sep_narrow_bins: bins the NEXT load gives a narrow column at least (tables that share a histogram layout)
+static int32_t narrow_bins_floor(abw_ctx* ctx, int32_t d, int32_t D)
+{
+    return ((int32_t)ctx->sep_min_bins.size() == D) ? std::min(ctx->sep_min_bins[(size_t)d], (int32_t)NARROW_T) : 0;
+}
+
 // keys: [D][N] on the host or on the device.  Fills T / span / is_wide / uniq (the distinct keys of every wide column) and
 // leaves keys, bins and the sorted tables of the wide columns on the device (ctx->sep.d_keys, d_bins; H.d_sscaf, d_sbin, d_sdp).
 static int sep_device_build(abw_ctx* ctx, const int32_t* keys, bool keys_on_device, int32_t D, int64_t N, const int32_t* dp2scaf,
@@ -811,7 +818,7 @@ static int sep_device_build(abw_ctx* ctx, const int32_t* keys, bool keys_on_devi
     size_t n_wide = 0;
     for (int32_t d = 0; d < D; d++) {
         const int32_t mn = mm[2 * d], mx = mm[2 * d + 1];
-        if (mn >= 0 && mx < NARROW_T) { h_T[d] = mx + 1; h_span[d] = mx + 1; }
+        if (mn >= 0 && mx < NARROW_T) { h_T[d] = std::max(mx + 1, narrow_bins_floor(ctx, d, D)); h_span[d] = mx + 1; }
         else { is_wide[d] = 1; n_wide++; }
     }
     if (n_wide == 0) return ABW_OK;
@@ -964,7 +971,7 @@ static int sep_load_impl(abw_ctx* ctx, const char* who, const int32_t* keys, int
                     }
                     continue;
                 }
-                if (mn >= 0 && mx < NARROW_T) { s.h_T[d] = mx + 1; s.h_span[d] = mx + 1; continue; }
+                if (mn >= 0 && mx < NARROW_T) { s.h_T[d] = std::max(mx + 1, narrow_bins_floor(ctx, d, D)); s.h_span[d] = mx + 1; continue; }
                 is_wide[d] = 1;
                 std::vector<int32_t>& u = uniq[d];
                 u.assign(col, col + N);
@@ -1033,6 +1040,7 @@ static int sep_build_narrow(abw_ctx* ctx, const std::vector<int32_t>& span, cons
         }
         NGroup& g = H.groups.back();
         g.loff[g.cnt] = g.total;
+        g.toff[g.cnt] = (int32_t)(H.toffn[i] - g.goff);
         g.dim[g.cnt] = d;
         H.nslot[i] = (int32_t)(H.groups.size() - 1) * 8 + g.cnt;
         g.cnt++; g.total += w;
@@ -1425,14 +1433,30 @@ int abw_sep_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const 
                  const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
                  int32_t n_scg)
 {
-    return sep_load_impl(ctx, "abw_sep_load", keys, D, N, dp2scaf, scaf_len, S, scg_off, scg_ids, n_scg, nullptr, nullptr);
+    const int rc = sep_load_impl(ctx, "abw_sep_load", keys, D, N, dp2scaf, scaf_len, S, scg_off, scg_ids, n_scg, nullptr, nullptr);
+    if (ctx) ctx->sep_min_bins.clear();
+    return rc;
+}
+
+// Tables whose histograms are added up bin by bin (the shards of abw_sep_stree_*) need the same number of bins in every narrow
+// column: bins[d] = the largest key of column d over ALL of them + 1.  Applies to the next abw_sep_load / abw_sep_load_dev of
+// this context only (a column with more keys than that in its own table keeps its own count).  bins = NULL: forget it.
+int abw_sep_narrow_bins(abw_ctx* ctx, const int32_t* bins, int32_t D)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (bins && D <= 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_narrow_bins: bad argument");
+    ctx->sep_min_bins.clear();
+    if (bins) ctx->sep_min_bins.assign(bins, bins + D);
+    return ABW_OK;
 }
 
 int abw_sep_load_dev(abw_ctx* ctx, const int32_t* d_keys, int32_t D, int64_t N, const int32_t* dp2scaf,
                      const int64_t* scaf_len, int32_t S, const int32_t* scg_off, const int32_t* scg_ids,
                      int32_t n_scg)
 {
-    return sep_load_impl(ctx, "abw_sep_load_dev", d_keys, D, N, dp2scaf, scaf_len, S, scg_off, scg_ids, n_scg, nullptr, nullptr, true);
+    const int rc = sep_load_impl(ctx, "abw_sep_load_dev", d_keys, D, N, dp2scaf, scaf_len, S, scg_off, scg_ids, n_scg, nullptr, nullptr, true);
+    if (ctx) ctx->sep_min_bins.clear();
+    return rc;
 }
 
 int abw_sep_shard_load(abw_ctx* ctx, const int32_t* keys, int32_t D, int64_t N, const int32_t* dp2scaf,

@@ -21,7 +21,9 @@ constexpr int MAX_SCG = 4096;
 // [dimension][dp] layout every (scaffold, dimension) is a cache line of its own).
 // The dimensions of a group are consecutive in SepHost::nsort (ascending number of bins); their bins lie side by side in
 // LDS (loff: offsets by the values the table really holds, `total` <= GRP_BINS in all).
-struct NGroup { int32_t cnt, total; int32_t loff[8]; int32_t dim[8]; int64_t goff; };     // goff: offset in a slice laid out in nsort order
+// goff: offset of the group in a slice laid out in nsort order; toff[q]: offset of dimension q behind goff there (bins T per
+// dimension, which may exceed the table's own span when tables share a layout: abw_sep_narrow_bins)
+struct NGroup { int32_t cnt, total; int32_t loff[8]; int32_t dim[8]; int32_t toff[8]; int64_t goff; };
 
 struct DimBestDev { int32_t found; int32_t bin; double sens; double spec; double prod; long long size1; long long n; };
 
@@ -117,6 +119,7 @@ struct SepHost {
     size_t nw_cap = 0;
     bool packed = false;               // every scaffold has at most PACK_MAX_NDPS dps: accum_group_tile<true>
     bool node_scan = false;            // the node accumulated last evaluates its wide dimensions by that scan
+    void* stree_run = nullptr;         // this table's part in a scaffold-sharded recursion (abw_sep_stree_*; abw_tree.hip)
     void* tree_run = nullptr;          // the recursion in progress (abw_sep_tree_begin .. abw_sep_tree_result; abw_tree.hip)
     bool sharded = false;              // table loaded with a shared bin layout (abw_sep_shard_load)
 };
@@ -125,6 +128,7 @@ struct SepHost {
 struct abw_sep_extra { SepHost h; };
 SepHost& abw_sep_host(abw_ctx* ctx);     // abw_sep.hip
 void abw_tree_run_free(void* run);       // abw_tree.hip
+void abw_stree_run_free(void* run);
 int abw_tree_static_ensure(abw_ctx* ctx);
 bool abw_node_wide_usable(abw_ctx* ctx);
 int abw_node_wide_accum(abw_ctx* ctx, const uint8_t* d_member);

@@ -86,11 +86,13 @@ void build_tables(SigTables& t, std::vector<std::string>* names)
     }
 }
 
+// Built once per process, whichever thread asks first (contexts are independent: two host threads may make their first
+// call on two contexts at the same moment).
 const SigTables& host_tables()
 {
     static SigTables t;
-    static bool init = false;
-    if (!init) { build_tables(t, nullptr); init = true; }
+    static std::once_flag once;
+    std::call_once(once, [] { build_tables(t, nullptr); });
     return t;
 }
 
@@ -654,10 +656,13 @@ constexpr uint64_t STATIC_OFF_SCAN = STATIC_OFF_SEGOFF + align256((ABW_SIG_STATI
 constexpr uint64_t STATIC_BYTES = STATIC_OFF_SCAN + align256((2 * ((STATIC_SCAN_N + 1023) / 1024) + 2) * 8);
 static __device__ __align__(256) unsigned char scratch[STATIC_BYTES];
 
+// One copy of the constant tables per device, uploaded under a lock by the first context that counts on that device.
 bool g_tables_uploaded[64] = {};
+std::mutex g_tables_mtx;
 
 int upload_tables(abw_ctx* ctx)
 {
+    std::lock_guard<std::mutex> lock(g_tables_mtx);
     if (ctx->device < 64 && g_tables_uploaded[ctx->device]) return ABW_OK;
     const SigTables& t = host_tables();
     ABW_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_tabs), &t, sizeof(t)));

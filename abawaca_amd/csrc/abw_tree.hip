@@ -199,9 +199,13 @@ __global__ __launch_bounds__(256) void tree_accum_kernel(TreeDev Tr, const Tile*
     const int64_t at = (int64_t)t.node * Tr.TBn + G.goff;
     accum_group_tile<PACKED>(G, Tr.nk16 + (int64_t)j * Tr.P.N, Tr.ts8 + (int64_t)j * Tr.S, Tr.srec, order, t.begin, t.end, Tr.P, nullptr, nullptr,
                      [&](int b, unsigned long long a, uint32_t c3, unsigned long long e) {
-                         if (a) atomicAdd(&h_st[at + b], a);
-                         if (c3) atomicAdd(&h_tot[at + b], c3);
-                         if (e) atomicAdd(&h_bp[at + b], e);
+                         int lo = 0, to = 0;                            // the bin's dimension: from the LDS layout (spans) to the slice's (bins)
+#pragma unroll
+                         for (int i = 1; i < 8; i++) if (i < G.cnt && b >= G.loff[i]) { lo = G.loff[i]; to = G.toff[i]; }
+                         const int64_t x = at + to + (b - lo);
+                         if (a) atomicAdd(&h_st[x], a);
+                         if (c3) atomicAdd(&h_tot[x], c3);
+                         if (e) atomicAdd(&h_bp[x], e);
                      });
 }
 
@@ -1587,6 +1591,398 @@ int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, abw_tree_nod
         if ((rc = abw_sep_tree_advance(ctx))) return rc;
     }
     return abw_sep_tree_result(ctx, nodes_out, node_cap, n_nodes, scaf2cluster);
+}
+
+// The level in flight of a recursion (after abw_sep_tree_eval): its nodes and the device arrays that say where every scaffold
+// of the table is -- what a context holding OTHER columns of some of the scaffolds (abw_sep_stree_*) needs to follow the walk.
+int abw_sep_tree_level(abw_ctx* ctx, abw_tree_level* info, abw_tree_level_node* nodes_out, int64_t cap)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!info) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree_level: bad argument");
+    TreeRun* r = run_of(ctx, "abw_sep_tree_level", false);
+    if (!r) return ABW_ERR_STATE;
+    if (r->phase != 1 && r->phase != 2) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_tree_level: no evaluated level (abw_sep_tree_eval)");
+    TreeGuard tg(ctx, r);
+    if (int rc = tg.stale("abw_sep_tree_level")) return rc;
+    info->n_nodes = r->K; info->n_scaf = r->S; info->d_scaf_slot = r->d_scaf_slot; info->d_side = r->d_scaf_side;
+    if (cap < r->K || (r->K > 0 && !nodes_out)) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_sep_tree_level: %d nodes in the level, capacity %lld", r->K, (long long)cap);
+    for (int32_t k = 0; k < r->K; k++) {
+        nodes_out[k].id = r->level[k].id; nodes_out[k].n_scaf = r->level[k].m; nodes_out[k].ndps = r->level[k].n;
+        nodes_out[k].parent = r->level[k].parent; nodes_out[k].reserved = 0;
+    }
+    return ABW_OK;
+}
+
+}  // extern "C"
+
+// ---- the recursion with the SCAFFOLDS of the narrow columns sharded ("separator sweep (B)"; BASELINE
+// configs[4]) ---------------------------------------------------------------------------------------------------------------
+// A shard = one context loaded (abw_sep_load) with a contiguous range of the table's scaffolds and the narrow (signature)
+// columns only; the coverage columns are spread over other contexts by DIMENSION, which walk the recursion with the level
+// calls above over ALL scaffolds.  Per level a shard follows that walk:
+//   accum  : its scaffolds are sorted by the node they are in (their slots come from the walking context's device array),
+//            the nodes that are the smaller child of their parent (or have no sibling) are accumulated into histogram
+//            slices (tree_accum_kernel), the SCG lists of every node filled from its own carriers -- and both are handed
+//            out for the exchange: the slices packed side by side (20 B x narrow bins x accumulated nodes: about 0.1 MB a
+//            node at the bench's tables), integer SUM over the shards; the lists MIN / MAX.
+//   eval   : slices unpacked, the bigger children = parent - smaller child (every shard holds the same parents), every
+//            threshold of every narrow column evaluated: the node's best narrow candidate, identical on all shards.
+//   assign : the scaffolds of the shard that lie in nodes won by a narrow column get their sides (the walking contexts
+//            combine the sides by MAX, as they do among themselves).
+// All quantities exchanged are integers: the tree is the one of abw_sep_tree bit for bit.
+namespace {
+
+struct STreeRun {
+    abw_ctx* ctx = nullptr;
+    int32_t scaf_first = 0, K = 0, cur = 0, phase = 0;       // phase 0: waits for accum, 1: eval, 2: assign
+    TreeDev Tr;
+    int64_t TBn = 1;
+    int32_t n_acc = 0;
+    std::vector<abw_tree_level_node> level;
+    std::vector<int32_t> acc_nodes;                           // slots accumulated this level, ascending
+    std::vector<SubJob> subs;
+    abw_devbuf pool[2], lvl, list, cand, ex, scg, canon;
+    size_t pool_nodes[2] = {0, 0};
+    std::vector<NodeRes> h_res;
+    ~STreeRun() { abw_release(pool[0]); abw_release(pool[1]); abw_release(lvl); abw_release(list); abw_release(cand); abw_release(ex); abw_release(scg); abw_release(canon); }
+};
+
+// grow-only buffers of the run itself (not the context's scratch: other entry points may use that between the calls)
+int own_reserve(abw_ctx* ctx, abw_devbuf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return ABW_OK;
+    if (b.p) { ABW_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    const size_t want = bytes + bytes / 4 + 256;
+    ABW_HIP(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return ABW_OK;
+}
+
+// scaffolds of the shard per node (slot[s]: the node of local scaffold s in this level; acc[k] != 0: node k is accumulated)
+__global__ __launch_bounds__(256) void stree_count_kernel(const int32_t* __restrict__ slot, int32_t S, const int32_t* __restrict__ acc, int32_t K, int32_t* __restrict__ counts)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    const int k = slot[s];
+    if (k >= 0 && k < K && acc[k]) atomicAdd(&counts[k], 1);
+}
+__global__ __launch_bounds__(256) void stree_scatter_kernel(const int32_t* __restrict__ slot, int32_t S, const int32_t* __restrict__ acc, int32_t K,
+                                                           const int32_t* __restrict__ off, int32_t* __restrict__ cursor, int32_t* __restrict__ list)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    const int k = slot[s];
+    if (k >= 0 && k < K && acc[k]) list[off[k] + atomicAdd(&cursor[k], 1)] = s;
+}
+
+// slices of the accumulated nodes <-> one block of 64-bit words per node: st[TBn] | bp[TBn] | tot[TBn] (32-bit, two to a word),
+// the columns in ASCENDING COLUMN ORDER there (a slice keeps them in the table's own order of groups, which follows the
+// table's own spans and differs from shard to shard; the bins per column are shared, abw_sep_narrow_bins).
+// grid (accumulated nodes, narrow columns); canon[dn]: offset of column Tr.narrow[dn] in the exchange order
+__global__ __launch_bounds__(256) void stree_pack_kernel(TreeDev Tr, const int32_t* __restrict__ acc_nodes, const int64_t* __restrict__ canon, int64_t words,
+                                                        unsigned long long* __restrict__ h_st, unsigned long long* __restrict__ h_bp, uint32_t* __restrict__ h_tot,
+                                                        unsigned long long* __restrict__ ex, int unpack)
+{
+    const int dn = blockIdx.y;
+    const int64_t TBn = Tr.TBn;
+    const int64_t at = (int64_t)acc_nodes[blockIdx.x] * TBn + Tr.toffn[dn], to = canon[dn];
+    const int T = (int)(Tr.toffn[dn + 1] - Tr.toffn[dn]);
+    unsigned long long* e = ex + (int64_t)blockIdx.x * words;
+    uint32_t* e32 = reinterpret_cast<uint32_t*>(e + 2 * TBn);
+    for (int b = threadIdx.x; b < T; b += 256) {
+        if (unpack) { h_st[at + b] = e[to + b]; h_bp[at + b] = e[TBn + to + b]; h_tot[at + b] = e32[to + b]; }
+        else { e[to + b] = h_st[at + b]; e[TBn + to + b] = h_bp[at + b]; e32[to + b] = h_tot[at + b]; }
+    }
+    if (!unpack && (TBn & 1) && dn == 0 && threadIdx.x == 0) e32[TBn] = 0;
+}
+
+// sides of the shard's scaffolds in the nodes a narrow column won (res[k].win.legal set for exactly those).  slot / side: the
+// walking context's arrays, offset to this shard's first scaffold
+__global__ __launch_bounds__(256) void stree_assign_kernel(TreeDev Tr, const int32_t* __restrict__ slot, int32_t K, const NodeRes* __restrict__ res, uint8_t* __restrict__ side)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= Tr.S) return;
+    const int k = slot[s];
+    if (k < 0 || k >= K) return;
+    const GlobalRes win = res[k].win;
+    if (!win.legal) return;
+    const bool swap = win.n - win.size1 < win.size1;
+    const int32_t* __restrict__ col = Tr.P.bins + (int64_t)win.dim * Tr.P.N;
+    const int f = Tr.P.scaf_first[s], tot = Tr.P.scaf_ndps[s];
+    int c = 0;
+    for (int i = 0; i < tot; i++) c += col[f + i] <= win.bin;
+    const int c1 = swap ? tot - c : c;
+    side[s] = (c1 > 0 && 2 * (long long)c1 >= tot) ? 1 : 2;
+}
+
+STreeRun* stree_of(abw_ctx* ctx, const char* who, bool create)
+{
+    if (!ctx) return nullptr;
+    if (!ctx->sep.loaded) { abw_fail(ctx, ABW_ERR_STATE, "%s: call abw_sep_load first", who); return nullptr; }
+    SepHost& H = abw_sep_host(ctx);
+    if (H.sharded) { abw_fail(ctx, ABW_ERR_STATE, "%s: the table was loaded with abw_sep_shard_load (node-by-node shards)", who); return nullptr; }
+    if (!H.wide_dims.empty()) { abw_fail(ctx, ABW_ERR_STATE, "%s: a scaffold shard holds narrow columns only (keys below %d); give the others to a context that walks them by dimension", who, NARROW_T); return nullptr; }
+    if (create) { delete (STreeRun*)H.stree_run; STreeRun* r = new STreeRun(); r->ctx = ctx; H.stree_run = r; }
+    if (!H.stree_run) { abw_fail(ctx, ABW_ERR_STATE, "%s: no recursion in progress (abw_sep_stree_begin)", who); return nullptr; }
+    return (STreeRun*)H.stree_run;
+}
+
+}  // namespace
+
+void abw_stree_run_free(void* run) { delete (STreeRun*)run; }
+
+extern "C" {
+
+int abw_sep_stree_begin(abw_ctx* ctx, int32_t scaf_first)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (scaf_first < 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_stree_begin: bad argument");
+    STreeRun* r = stree_of(ctx, "abw_sep_stree_begin", true);
+    if (!r) return ABW_ERR_STATE;
+    abw_sep_state& s = ctx->sep;
+    SepHost& H = abw_sep_host(ctx);
+    r->scaf_first = scaf_first;
+    memset(&r->Tr, 0, sizeof(r->Tr));
+    TreeDev& Tr = r->Tr;
+    Tr.P = static_params(s);
+    const int32_t n_narrow = (int32_t)H.narrow_dims.size();
+    r->TBn = std::max<int64_t>(1, n_narrow ? H.toffn[n_narrow] : 0);
+    Tr.narrow = H.d_nsort; Tr.n_narrow = n_narrow; Tr.toffn = H.d_toffn; Tr.TBn = r->TBn;
+    Tr.groups = H.d_groups; Tr.n_groups = (int32_t)H.groups.size(); Tr.nk16 = (const uint4*)H.d_nk16; Tr.ts8 = (const uint4*)H.d_ts8; Tr.srec = (const int4*)H.d_srec;
+    Tr.wide = H.d_wide; Tr.n_wide = 0; Tr.dim_slot = H.d_dim_slot; Tr.D = s.D; Tr.S = s.S;
+    r->cur = 0; r->phase = 0; r->K = 0; r->pool_nodes[0] = r->pool_nodes[1] = 0;
+    if (n_narrow) {
+        // where every column of the slice goes in the exchange order: ascending column number, the shared bins per column
+        std::vector<int64_t> by_dim((size_t)s.D + 1, 0), canon((size_t)n_narrow);
+        for (int32_t d = 0; d < s.D; d++) by_dim[(size_t)d + 1] = by_dim[d] + s.h_T[d];
+        for (int32_t dn = 0; dn < n_narrow; dn++) canon[(size_t)dn] = by_dim[H.nsort[(size_t)dn]];
+        abw_device_guard g(ctx->device);
+        int rc;
+        if ((rc = own_reserve(ctx, r->canon, (size_t)n_narrow * 8))) return rc;
+        ABW_HIP(ctx, hipMemcpy(r->canon.p, canon.data(), (size_t)n_narrow * 8, hipMemcpyHostToDevice));
+    }
+    return ABW_OK;
+}
+
+int abw_sep_stree_accum(abw_ctx* ctx, const abw_tree_level_node* nodes, int64_t n_nodes, const int32_t* d_scaf_slot, abw_sep_exchange* ex)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (!nodes || n_nodes <= 0 || !d_scaf_slot || !ex) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_stree_accum: bad argument");
+    STreeRun* r = stree_of(ctx, "abw_sep_stree_accum", false);
+    if (!r) return ABW_ERR_STATE;
+    if (r->phase != 0) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_stree_accum: the level in flight waits for %s", r->phase == 1 ? "abw_sep_stree_eval" : "abw_sep_stree_assign");
+    abw_device_guard g(ctx->device);
+    abw_sep_state& s = ctx->sep;
+    SepHost& H = abw_sep_host(ctx);
+    hipStream_t st = ctx->stream;
+    const int32_t K = (int32_t)n_nodes, S = s.S, D = s.D;
+    const int64_t TBn = r->TBn;
+    int rc;
+    r->K = K;
+    r->level.assign(nodes, nodes + K);
+    // the plan of TreeRun::eval: children come in pairs (2j, 2j + 1) of one parent, the smaller is accumulated
+    std::vector<int32_t> acc((size_t)K, 0);
+    r->acc_nodes.clear(); r->subs.clear();
+    for (int32_t k = 0; k < K; k++) {
+        const int32_t sib = (nodes[k].parent >= 0) ? (k ^ 1) : -1;
+        const bool has_sib = sib >= 0 && sib < K && nodes[sib].parent == nodes[k].parent;
+        const bool bigger = has_sib && (nodes[k].ndps > nodes[sib].ndps || (nodes[k].ndps == nodes[sib].ndps && k > sib));
+        if (bigger) {
+            if ((size_t)nodes[k].parent >= r->pool_nodes[r->cur ^ 1]) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_stree_accum: node %d names a parent the level before did not have", k);
+            r->subs.push_back(SubJob{k, nodes[k].parent, sib});
+        } else { acc[k] = 1; r->acc_nodes.push_back(k); }
+    }
+    r->n_acc = (int32_t)r->acc_nodes.size();
+    const size_t slice = (size_t)TBn * 20;
+    if ((size_t)K * slice > ((size_t)48 << 30)) return abw_fail(ctx, ABW_ERR_NOMEM, "abw_sep_stree_accum: %d nodes in one level need %zu bytes of histograms", K, (size_t)K * slice);
+    if ((rc = own_reserve(ctx, r->pool[r->cur], (size_t)K * slice + 64))) return rc;
+    r->pool_nodes[r->cur] = (size_t)K;
+    unsigned long long* c_st = (unsigned long long*)r->pool[r->cur].p;
+    unsigned long long* c_bp = c_st + (int64_t)K * TBn;
+    uint32_t* c_tot = (uint32_t*)(c_bp + (int64_t)K * TBn);
+    // level block: acc flags | counts | offsets | cursors | acc node list | NodeDev | sub jobs (one upload), tiles follow the counts
+    std::vector<NodeDev> nd((size_t)K);
+    for (int32_t k = 0; k < K; k++) { memset(&nd[k], 0, sizeof(NodeDev)); nd[k].dp_begin = 0; nd[k].dp_end = (int32_t)nodes[k].ndps; }
+    const size_t o_acc = 0, o_cnt = o_acc + (size_t)K * 4, o_off = o_cnt + (size_t)K * 4, o_cur = o_off + (size_t)K * 4, o_an = o_cur + (size_t)K * 4,
+                 o_nd = (o_an + (size_t)K * 4 + 63) & ~(size_t)63, o_sub = (o_nd + (size_t)K * sizeof(NodeDev) + 63) & ~(size_t)63,
+                 o_res = (o_sub + (size_t)K * sizeof(SubJob) + 63) & ~(size_t)63, o_tiles = (o_res + (size_t)K * sizeof(NodeRes) + 63) & ~(size_t)63;
+    const size_t max_tiles = (size_t)S / TILE_A + (size_t)K + 2;
+    if ((rc = own_reserve(ctx, r->lvl, o_tiles + max_tiles * sizeof(Tile) + 64))) return rc;
+    if ((rc = own_reserve(ctx, r->list, (size_t)std::max(1, S) * 4))) return rc;
+    uint8_t* dl = (uint8_t*)r->lvl.p;
+    int32_t *d_acc = (int32_t*)(dl + o_acc), *d_cnt = (int32_t*)(dl + o_cnt), *d_off = (int32_t*)(dl + o_off), *d_cur = (int32_t*)(dl + o_cur), *d_an = (int32_t*)(dl + o_an);
+    std::vector<uint8_t> blob(o_tiles, 0);
+    memcpy(blob.data() + o_acc, acc.data(), (size_t)K * 4);
+    if (r->n_acc) memcpy(blob.data() + o_an, r->acc_nodes.data(), (size_t)r->n_acc * 4);
+    memcpy(blob.data() + o_nd, nd.data(), (size_t)K * sizeof(NodeDev));
+    if (!r->subs.empty()) memcpy(blob.data() + o_sub, r->subs.data(), r->subs.size() * sizeof(SubJob));
+    ABW_HIP(ctx, hipMemcpyAsync(dl, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+    const int32_t* slot = d_scaf_slot + r->scaf_first;
+    std::vector<int32_t> cnt((size_t)K, 0), off((size_t)K + 1, 0);
+    if (S > 0 && r->n_acc) {
+        hipLaunchKernelGGL(stree_count_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, slot, S, (const int32_t*)d_acc, K, d_cnt);
+        ABW_LAUNCH_CHECK(ctx);
+        ABW_HIP(ctx, hipMemcpyAsync(cnt.data(), d_cnt, (size_t)K * 4, hipMemcpyDeviceToHost, st));
+    }
+    ABW_HIP(ctx, hipStreamSynchronize(st));                    // the counts are here, and blob may go
+    std::vector<Tile> tiles;
+    for (int32_t k = 0; k < K; k++) {
+        off[k + 1] = off[k] + cnt[k];
+        for (int32_t a = off[k]; a < off[k + 1]; a += TILE_A) tiles.push_back(Tile{k, a, std::min(off[k + 1], a + TILE_A)});
+    }
+    const Tile* d_tiles = (const Tile*)(dl + o_tiles);
+    if (!tiles.empty()) {
+        ABW_HIP(ctx, hipMemcpyAsync(d_off, off.data(), (size_t)K * 4, hipMemcpyHostToDevice, st));
+        ABW_HIP(ctx, hipMemcpyAsync(dl + o_tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(stree_scatter_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, slot, S, (const int32_t*)d_acc, K, (const int32_t*)d_off, d_cur, (int32_t*)r->list.p);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    const unsigned gy = (unsigned)((TBn + 1023) / 1024);
+    {
+        ABW_PROF(ctx, "sep_accum");
+        if (r->n_acc) {
+            hipLaunchKernelGGL(tree_zero_kernel, dim3((unsigned)r->n_acc, gy), dim3(256), 0, st, (const int32_t*)d_an, TBn, c_st, c_bp, c_tot);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        if (!tiles.empty() && r->Tr.n_groups > 0) {
+            if (H.packed) hipLaunchKernelGGL(tree_accum_kernel<true>, dim3((unsigned)tiles.size(), (unsigned)r->Tr.n_groups), dim3(256), 0, st, r->Tr, d_tiles, (const int32_t*)r->list.p, c_st, c_bp, c_tot);
+            else hipLaunchKernelGGL(tree_accum_kernel<false>, dim3((unsigned)tiles.size(), (unsigned)r->Tr.n_groups), dim3(256), 0, st, r->Tr, d_tiles, (const int32_t*)r->list.p, c_st, c_bp, c_tot);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+    }
+    // the SCG lists of every node from this shard's carriers
+    const int64_t scg_n = (int64_t)K * D * s.n_scg;
+    if ((rc = own_reserve(ctx, r->scg, (size_t)std::max<int64_t>(1, scg_n) * 8))) return rc;
+    int32_t* d_scg_lo = (int32_t*)r->scg.p; int32_t* d_scg_hi = d_scg_lo + scg_n;
+    if (scg_n > 0 && (int64_t)K * s.n_scg <= SCG_LEVEL_LDS) {
+        hipLaunchKernelGGL(tree_scg_lds_kernel, dim3((unsigned)D), dim3(256), 0, st, r->Tr, H.d_carriers, H.n_carriers, slot, K, d_scg_lo, d_scg_hi);
+        ABW_LAUNCH_CHECK(ctx);
+    } else if (scg_n > 0) {
+        hipLaunchKernelGGL(tree_scg_reset_kernel, dim3((unsigned)std::min<int64_t>((scg_n + 255) / 256, ctx->num_cu * 8)), dim3(256), 0, st, d_scg_lo, d_scg_hi, scg_n);
+        ABW_LAUNCH_CHECK(ctx);
+        if (H.n_carriers > 0) {
+            hipLaunchKernelGGL(tree_scg_kernel, dim3((unsigned)(((int64_t)H.n_carriers * D + 255) / 256)), dim3(256), 0, st, r->Tr, H.d_carriers, H.n_carriers, slot, K, d_scg_lo, d_scg_hi);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+    }
+    // the slices of the accumulated nodes, packed for the exchange
+    const int64_t words = 2 * TBn + (TBn + 1) / 2;
+    if ((rc = own_reserve(ctx, r->ex, (size_t)std::max<int64_t>(1, (int64_t)r->n_acc * words) * 8))) return rc;
+    if (r->n_acc && r->Tr.n_narrow > 0) {
+        hipLaunchKernelGGL(stree_pack_kernel, dim3((unsigned)r->n_acc, (unsigned)r->Tr.n_narrow), dim3(256), 0, st, r->Tr, (const int32_t*)d_an, (const int64_t*)r->canon.p, words,
+                           c_st, c_bp, c_tot, (unsigned long long*)r->ex.p, 0);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    ex->d_hist = (int64_t*)r->ex.p; ex->hist_count = (uint64_t)((int64_t)r->n_acc * words);
+    ex->d_scg_lo = d_scg_lo; ex->d_scg_hi = d_scg_hi; ex->scg_count = (uint64_t)scg_n;
+    r->phase = 1;
+    return ABW_OK;
+}
+
+// After the exchange buffers hold the SUM / MIN / MAX over the shards: this level's best narrow candidate of every node.
+int abw_sep_stree_eval(abw_ctx* ctx, int32_t min_ndps, abw_tree_winner* best, int64_t cap)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    STreeRun* r = stree_of(ctx, "abw_sep_stree_eval", false);
+    if (!r) return ABW_ERR_STATE;
+    if (r->phase != 1) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_stree_eval: no accumulated level (abw_sep_stree_accum)");
+    if (!best || cap < r->K || min_ndps < 0) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_stree_eval: bad argument");
+    abw_device_guard g(ctx->device);
+    abw_sep_state& s = ctx->sep;
+    hipStream_t st = ctx->stream;
+    const int32_t K = r->K, D = s.D;
+    const int64_t TBn = r->TBn;
+    int rc;
+    unsigned long long* c_st = (unsigned long long*)r->pool[r->cur].p;
+    unsigned long long* c_bp = c_st + (int64_t)K * TBn;
+    uint32_t* c_tot = (uint32_t*)(c_bp + (int64_t)K * TBn);
+    const int64_t Kp = (int64_t)r->pool_nodes[r->cur ^ 1];
+    const unsigned long long* p_st = (const unsigned long long*)r->pool[r->cur ^ 1].p;
+    const unsigned long long* p_bp = p_st ? p_st + Kp * TBn : nullptr;
+    const uint32_t* p_tot = p_st ? (const uint32_t*)(p_bp + Kp * TBn) : nullptr;
+    uint8_t* dl = (uint8_t*)r->lvl.p;
+    const size_t o_an = (size_t)K * 16, o_nd = (o_an + (size_t)K * 4 + 63) & ~(size_t)63, o_sub = (o_nd + (size_t)K * sizeof(NodeDev) + 63) & ~(size_t)63,
+                 o_res = (o_sub + (size_t)K * sizeof(SubJob) + 63) & ~(size_t)63;
+    const int32_t* d_an = (const int32_t*)(dl + o_an);
+    const NodeDev* d_nodes = (const NodeDev*)(dl + o_nd);
+    const SubJob* d_subs = (const SubJob*)(dl + o_sub);
+    NodeRes* d_res = (NodeRes*)(dl + o_res);
+    const int64_t words = 2 * TBn + (TBn + 1) / 2;
+    const unsigned gy = (unsigned)((TBn + 1023) / 1024);
+    const int64_t scg_n = (int64_t)K * D * s.n_scg;
+    const int32_t* d_scg_lo = (const int32_t*)r->scg.p; const int32_t* d_scg_hi = d_scg_lo + scg_n;
+    if ((rc = own_reserve(ctx, r->cand, (size_t)K * D * sizeof(Cand) + 64))) return rc;
+    Cand* d_cand = (Cand*)r->cand.p;
+    {
+        ABW_PROF(ctx, "sep_accum");
+        if (r->n_acc && r->Tr.n_narrow > 0) {
+            hipLaunchKernelGGL(stree_pack_kernel, dim3((unsigned)r->n_acc, (unsigned)r->Tr.n_narrow), dim3(256), 0, st, r->Tr, d_an, (const int64_t*)r->canon.p, words,
+                               c_st, c_bp, c_tot, (unsigned long long*)r->ex.p, 1);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        if (!r->subs.empty()) {
+            hipLaunchKernelGGL(tree_sub_kernel, dim3((unsigned)r->subs.size(), gy), dim3(256), 0, st, d_subs, TBn, c_st, c_bp, c_tot, p_st, p_bp, p_tot);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        if (r->Tr.n_narrow > 0) {
+            hipLaunchKernelGGL(tree_eval_narrow_kernel, dim3((unsigned)K, (unsigned)r->Tr.n_narrow), dim3(256), 0, st, r->Tr, d_nodes, min_ndps, (const unsigned long long*)c_st,
+                               (const unsigned long long*)c_bp, (const uint32_t*)c_tot, d_scg_lo, d_scg_hi, d_cand);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        hipLaunchKernelGGL(tree_winner_kernel, dim3((unsigned)K), dim3(64), 0, st, r->Tr, d_nodes, (const Cand*)d_cand, d_res);
+        ABW_LAUNCH_CHECK(ctx);
+    }
+    r->h_res.resize((size_t)K);
+    ABW_HIP(ctx, hipMemcpyAsync(r->h_res.data(), d_res, (size_t)K * sizeof(NodeRes), hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    for (int32_t k = 0; k < K; k++) {
+        const GlobalRes& w = r->h_res[k].win;
+        abw_tree_winner& b = best[k];
+        memset(&b, 0, sizeof(b));
+        b.found = w.found; b.dimension = w.found ? w.dim : -1; b.key = w.found ? w.bin : -1;      // narrow columns: the bin is the key
+        b.legal = w.legal; b.sensitivity = w.sens; b.specificity = w.spec;
+        b.global_dimension = w.found ? w.dim + 1 : -1;
+    }
+    r->phase = 2;
+    return ABW_OK;
+}
+
+// winners[k].dimension >= 0: node k was won by THIS table's column `dimension` (as eval returned it; the same on every shard);
+// the shard's scaffolds in those nodes get their sides in d_side (the walking context's array, all scaffolds of the table).
+int abw_sep_stree_assign(abw_ctx* ctx, const abw_tree_winner* winners, int64_t n, const int32_t* d_scaf_slot, uint8_t* d_side)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    STreeRun* r = stree_of(ctx, "abw_sep_stree_assign", false);
+    if (!r) return ABW_ERR_STATE;
+    if (r->phase != 2) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_stree_assign: no evaluated level (abw_sep_stree_eval)");
+    if (!winners || n != r->K || !d_scaf_slot || !d_side) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_stree_assign: bad argument");
+    abw_device_guard g(ctx->device);
+    hipStream_t st = ctx->stream;
+    const int32_t K = r->K;
+    bool any = false;
+    for (int32_t k = 0; k < K; k++) {
+        const abw_tree_winner& w = winners[k];
+        GlobalRes& mine = r->h_res[k].win;
+        const bool is_mine = w.found && w.dimension >= 0 && mine.found && w.dimension == mine.dim && w.key == mine.bin;
+        if (w.found && w.dimension >= 0 && !is_mine)
+            return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_stree_assign: node %d: the winner named as this table's is not the one abw_sep_stree_eval returned", k);
+        if (!(is_mine && w.legal)) mine.legal = 0;
+        any |= mine.legal != 0;
+    }
+    if (any && r->Tr.S > 0) {
+        uint8_t* dl = (uint8_t*)r->lvl.p;
+        const size_t o_an = (size_t)K * 16, o_nd = (o_an + (size_t)K * 4 + 63) & ~(size_t)63, o_sub = (o_nd + (size_t)K * sizeof(NodeDev) + 63) & ~(size_t)63,
+                     o_res = (o_sub + (size_t)K * sizeof(SubJob) + 63) & ~(size_t)63;
+        NodeRes* d_res = (NodeRes*)(dl + o_res);
+        ABW_HIP(ctx, hipMemcpyAsync(d_res, r->h_res.data(), (size_t)K * sizeof(NodeRes), hipMemcpyHostToDevice, st));
+        ABW_PROF(ctx, "sep_eval");
+        hipLaunchKernelGGL(stree_assign_kernel, dim3((unsigned)((r->Tr.S + 255) / 256)), dim3(256), 0, st, r->Tr, d_scaf_slot + r->scaf_first, K, (const NodeRes*)d_res, d_side + r->scaf_first);
+        ABW_LAUNCH_CHECK(ctx);
+        ABW_HIP(ctx, hipStreamSynchronize(st));                // h_res may change at the next level
+    }
+    r->cur ^= 1;
+    r->phase = 0;
+    return ABW_OK;
 }
 
 }  // extern "C"

@@ -546,3 +546,236 @@ def binning_tree_dims(store: DimShardStore, dist, max_nodes: int = 0):
         run.advance()
     rows, s2c = run.result()
     return rows, s2c, time.perf_counter() - t0, exchanged
+
+
+# ---- scaffold-sharded recursion (abw_sep_stree_*): the signature columns cut by SCAFFOLD, the coverage columns by DIMENSION ----
+# Rank r holds (a) the narrow columns of a contiguous range of scaffolds in one context and (b) ALL scaffolds with its share of
+# the wide columns in a second one, which walks the recursion with the level calls.  Per level the ranks exchange the packed
+# histogram slices of the nodes that are accumulated (integer SUM), the SCG lists (MIN / MAX), one record per node and one byte
+# per scaffold.
+
+_LEVEL_NODE_DTYPE = np.dtype([("id", "i4"), ("n_scaf", "i4"), ("ndps", "i8"), ("parent", "i4"), ("reserved", "i4")])    # = struct abw_tree_level_node
+
+
+class TreeLevel(C.Structure):
+    _fields_ = [("n_nodes", C.c_int64), ("n_scaf", C.c_int64), ("d_scaf_slot", C.c_void_p), ("d_side", C.c_void_p)]
+
+
+def scaffold_ranges(scaf_ndps, world: int):
+    """Contiguous scaffold ranges with about the same number of datapoints each -> world + 1 bounds."""
+    cum = np.concatenate([[0], np.cumsum(np.asarray(scaf_ndps, dtype=np.int64))])
+    b = [0]
+    for k in range(1, world):
+        b.append(max(b[-1], int(np.searchsorted(cum, cum[-1] * k / world, side="left"))))
+    b.append(len(scaf_ndps))
+    return b
+
+
+def stree_mine(best_n, best_w):
+    """A rank's candidate of every node: the better of the node's narrow best (the same on every rank) and this rank's own wide
+    best -- the larger product sensitivity x specificity, on equal products the smaller column of the whole table."""
+    out = best_w.copy()
+    pn, pw = best_n["sens"] * best_n["spec"], best_w["sens"] * best_w["spec"]
+    take_n = (best_n["found"] != 0) & ((best_w["found"] == 0) | (pn > pw) | ((pn == pw) & (best_n["gdim"] < best_w["gdim"])))
+    out[take_n] = best_n[take_n]
+    return out
+
+
+class ScafShard:
+    """One rank of the scaffold-sharded recursion.  keys: the whole [D, N] table is only SLICED here (rows / columns this rank
+    holds); rank r loads narrow columns x its scaffolds [s0, s1) and its wide columns x all scaffolds."""
+
+    def __init__(self, ctx_n: Context, ctx_w: Context, keys, dp2scaf, scaf_len, scg_off, scg_ids, n_scg, s0: int, s1: int, wide_mine, narrow_cols,
+                 narrow_bins=None):
+        """narrow_bins: the largest key + 1 of every narrow column over ALL ranks' scaffolds (int32 [len(narrow_cols)]; one MAX over the
+        ranks when each holds only its own rows): the shards' histograms share that layout."""
+        keys = np.asarray(keys)
+        dp2scaf = np.ascontiguousarray(dp2scaf, dtype=np.int32)
+        scaf_len = np.ascontiguousarray(scaf_len, dtype=np.int64)
+        S = len(scaf_len)
+        self.s0, self.s1 = int(s0), int(s1)
+        self.narrow_cols = np.ascontiguousarray(narrow_cols, dtype=np.int64)
+        self.wide_mine = np.ascontiguousarray(wide_mine, dtype=np.int64)
+        p0, p1 = int(np.searchsorted(dp2scaf, s0, side="left")), int(np.searchsorted(dp2scaf, s1, side="left"))
+        # (a) the narrow columns of my scaffolds, renumbered from 0
+        so = np.ascontiguousarray(scg_off, dtype=np.int32) if n_scg else None
+        if n_scg:
+            lo_off = (so[s0:s1 + 1] - so[s0]).astype(np.int32)
+            lo_ids = np.ascontiguousarray(np.asarray(scg_ids, dtype=np.int32)[so[s0]:so[s1]])
+        else:
+            lo_off = lo_ids = None
+        if narrow_bins is None:
+            narrow_bins = keys[self.narrow_cols].max(axis=1) + 1
+        nb = np.ascontiguousarray(narrow_bins, dtype=np.int32)
+        ctx_n.check(lib().abw_sep_narrow_bins(ctx_n.handle, C.c_void_p(nb.ctypes.data), len(nb)))
+        self.store_n = ColumnStore(ctx_n, np.ascontiguousarray(keys[self.narrow_cols][:, p0:p1]), dp2scaf[p0:p1] - s0, scaf_len[s0:s1], lo_off, lo_ids, n_scg)
+        # (b) all scaffolds, my wide columns (a rank without one walks a constant column: it never finds a threshold)
+        if len(self.wide_mine):
+            kw, dims = np.ascontiguousarray(keys[self.wide_mine]), self.wide_mine
+        else:
+            kw, dims = np.zeros((1, keys.shape[1]), dtype=np.int32), np.array([keys.shape[0]], dtype=np.int64)
+        self.store_w = DimShardStore(ctx_w, kw, np.arange(kw.shape[0]), dp2scaf, scaf_len, scg_off, scg_ids, n_scg)
+        self.store_w.dims = dims
+        self.S = S
+
+    # -- the level calls of the narrow shard
+    def begin(self, max_nodes: int = 0):
+        self.run_w = DimShardRun(self.store_w, max_nodes)
+        self.store_n.ctx.check(lib().abw_sep_stree_begin(self.store_n.ctx.handle, self.s0))
+
+    def level(self):
+        info = TreeLevel()
+        cap = 256
+        while True:
+            nodes = np.zeros(cap, dtype=_LEVEL_NODE_DTYPE)
+            rc = lib().abw_sep_tree_level(self.store_w.ctx.handle, C.byref(info), C.c_void_p(nodes.ctypes.data), cap)
+            if rc == -3 and info.n_nodes > cap:
+                cap = int(info.n_nodes)
+                continue
+            self.store_w.ctx.check(rc)
+            break
+        self.info, self.nodes = info, np.ascontiguousarray(nodes[:int(info.n_nodes)])
+        return self.nodes
+
+    def accum(self):
+        """-> (hist int64 tensor, scg_lo, scg_hi int32 tensors or None): this shard's part, to be combined over the shards in place"""
+        import torch
+        from .kmeans import _DevView
+        ex = SepExchange()
+        ctx = self.store_n.ctx
+        ctx.check(lib().abw_sep_stree_accum(ctx.handle, C.c_void_p(self.nodes.ctypes.data), len(self.nodes), C.c_void_p(self.info.d_scaf_slot), C.byref(ex)))
+        dev = torch.device("cuda", ctx.device)
+        hist = torch.as_tensor(_DevView(ex.d_hist, ex.hist_count, "<i8"), device=dev) if ex.hist_count else None
+        lo = torch.as_tensor(_DevView(ex.d_scg_lo, ex.scg_count, "<i4"), device=dev) if ex.scg_count else None
+        hi = torch.as_tensor(_DevView(ex.d_scg_hi, ex.scg_count, "<i4"), device=dev) if ex.scg_count else None
+        return hist, lo, hi
+
+    def eval_narrow(self):
+        ctx = self.store_n.ctx
+        best = np.zeros(len(self.nodes), dtype=_WIN_DTYPE)
+        ctx.check(lib().abw_sep_stree_eval(ctx.handle, ClusterSeparatorHip.cluster_ndps_threshold, C.c_void_p(best.ctypes.data), len(best)))
+        f = best["found"] != 0
+        best["gdim"][f] = self.narrow_cols[best["dim"][f]] + 1
+        return best
+
+    def assign_sides(self, winners, owner_is_me):
+        """winners: merged records.  -> the walking context's side array (torch uint8 [S], device) with this rank's part filled in"""
+        narrow_pos = {int(c) + 1: i for i, c in enumerate(self.narrow_cols)}
+        is_narrow = np.array([bool(w["found"]) and int(w["gdim"]) in narrow_pos for w in winners], dtype=bool)
+        side = self.run_w.assign(winners, np.asarray(owner_is_me, dtype=bool) & ~is_narrow)
+        wn = np.ascontiguousarray(winners.copy())
+        wn["dim"] = -1
+        for k in np.flatnonzero(is_narrow):
+            wn["dim"][k] = narrow_pos[int(winners["gdim"][k])]
+        self.store_w.ctx.synchronize()                          # the walking context has cleared the side array
+        ctx = self.store_n.ctx
+        ctx.check(lib().abw_sep_stree_assign(ctx.handle, C.c_void_p(wn.ctypes.data), len(wn), C.c_void_p(self.info.d_scaf_slot), C.c_void_p(self.info.d_side)))
+        ctx.synchronize()
+        return side
+
+
+def make_scaf_shards(ctx_pairs, keys, dp2scaf, scaf_len, scg_off, scg_ids, n_scg):
+    """The table cut for len(ctx_pairs) ranks: (narrow context, walking context) per rank."""
+    keys = np.asarray(keys)
+    world = len(ctx_pairs)
+    wide = np.array([bool(keys[d].max() >= 1024 or keys[d].min() < 0) for d in range(keys.shape[0])])
+    w_cols, n_cols = np.flatnonzero(wide), np.flatnonzero(~wide)
+    S = len(scaf_len)
+    b = scaffold_ranges(np.bincount(np.asarray(dp2scaf), minlength=S), world)
+    return [ScafShard(cn, cw, keys, dp2scaf, scaf_len, scg_off, scg_ids, n_scg, b[r], b[r + 1], w_cols[r::world], n_cols)
+            for r, (cn, cw) in enumerate(ctx_pairs)]
+
+
+def binning_stree_local(shards, max_nodes: int = 0):
+    """The scaffold-sharded recursion with all ranks driven from one process (tests; the contexts may share a GPU).
+    -> ([(rows, scaf2cluster) per rank], bytes one rank exchanges per direction, levels)"""
+    import torch
+    for sh in shards:
+        sh.begin(max_nodes)
+    exchanged = levels = 0
+    while True:
+        bests_w = [sh.run_w.eval() for sh in shards]
+        if bests_w[0] is None:
+            assert all(b is None for b in bests_w)
+            break
+        parts = []
+        for sh in shards:
+            sh.level()
+            parts.append(sh.accum())
+        for sh in shards:
+            sh.store_n.ctx.synchronize()
+        if parts[0][0] is not None:
+            tot = torch.stack([p[0] for p in parts]).sum(0)
+            for p in parts:
+                p[0].copy_(tot)
+            exchanged += int(tot.numel()) * 8
+        if parts[0][1] is not None:
+            lo = torch.stack([p[1] for p in parts]).amin(0)
+            hi = torch.stack([p[2] for p in parts]).amax(0)
+            for p in parts:
+                p[1].copy_(lo)
+                p[2].copy_(hi)
+            exchanged += int(lo.numel()) * 8
+        torch.cuda.synchronize()
+        mines = [stree_mine(sh.eval_narrow(), bw) for sh, bw in zip(shards, bests_w)]
+        winners, owner = merge_winners(mines)
+        sides = [sh.assign_sides(winners, owner == k) for k, sh in enumerate(shards)]
+        tot = torch.stack(sides).amax(0)
+        for t in sides:
+            t.copy_(tot)
+        torch.cuda.synchronize()
+        exchanged += winners.nbytes + int(tot.numel())
+        for sh in shards:
+            sh.run_w.advance()
+        levels += 1
+    return [sh.run_w.result() for sh in shards], exchanged, levels
+
+
+def binning_stree(shard: ScafShard, dist, max_nodes: int = 0):
+    """One rank of the scaffold-sharded recursion over torch.distributed (RCCL on GPUs; gloo stages through the host).
+    -> (rows, scaf2cluster, seconds, bytes this rank exchanged per direction, levels)"""
+    import torch
+    from . import multi
+    rank, world = dist.get_rank(), dist.get_world_size()
+    on_dev = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", shard.store_w.ctx.device) if on_dev else torch.device("cpu")
+    t0 = time.perf_counter()
+    shard.begin(max_nodes)
+    exchanged = levels = 0
+    while True:
+        best_w = shard.run_w.eval()
+        k = torch.tensor([0 if best_w is None else len(best_w)], dtype=torch.int64, device=dev)
+        ks = [torch.zeros_like(k) for _ in range(world)]
+        dist.all_gather(ks, k)
+        if best_w is None:
+            assert all(int(x) == 0 for x in ks)
+            break
+        assert all(int(x) == len(best_w) for x in ks), "the ranks walk different trees"
+        shard.level()
+        hist, lo, hi = shard.accum()
+        shard.store_n.ctx.synchronize()
+        if hist is not None:                                    # every rank accumulates the same set of nodes: the same shapes everywhere
+            multi._all_reduce(hist, dist.ReduceOp.SUM, dist)
+        if lo is not None:
+            multi._all_reduce(lo, dist.ReduceOp.MIN, dist)
+            multi._all_reduce(hi, dist.ReduceOp.MAX, dist)
+        torch.cuda.synchronize()
+        exchanged += (int(hist.numel()) * 8 if hist is not None else 0) + (int(lo.numel()) * 8 if lo is not None else 0)
+        mine = stree_mine(shard.eval_narrow(), best_w)
+        mt = torch.from_numpy(mine.view(np.uint8).reshape(-1).copy()).to(dev)
+        parts = [torch.zeros_like(mt) for _ in range(world)]
+        dist.all_gather(parts, mt)
+        winners, owner = merge_winners([p.cpu().numpy().view(_WIN_DTYPE) for p in parts])
+        side = shard.assign_sides(winners, owner == rank)
+        if on_dev:
+            dist.all_reduce(side, op=dist.ReduceOp.MAX)
+        else:
+            h = side.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            side.copy_(h)
+        torch.cuda.synchronize()
+        exchanged += mt.numel() * world + side.numel()
+        shard.run_w.advance()
+        levels += 1
+    rows, s2c = shard.run_w.result()
+    return rows, s2c, time.perf_counter() - t0, exchanged, levels

@@ -53,7 +53,7 @@ int main(int argc, char** argv)
     // 25 groups: 17 of 8 tetramers (span 14), 4 of 8 trimers (span 40), 2 of 5 dimers (span 130), 2 single monomers (span 700)
     std::vector<NGroup> groups;
     int64_t goff = 0;
-    auto add = [&](int cnt, int span) { NGroup g = NGroup(); g.cnt = cnt; for (int q = 0; q < cnt; q++) { g.loff[q] = g.total; g.total += span; } g.goff = goff; goff += g.total; groups.push_back(g); };
+    auto add = [&](int cnt, int span) { NGroup g = NGroup(); g.cnt = cnt; for (int q = 0; q < cnt; q++) { g.loff[q] = g.total; g.toff[q] = g.total; g.total += span; } g.goff = goff; goff += g.total; groups.push_back(g); };
     for (int i = 0; i < 17; i++) add(8, 14);
     for (int i = 0; i < 4; i++) add(8, 40);
     for (int i = 0; i < 2; i++) add(5, 130);

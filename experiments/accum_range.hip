@@ -102,7 +102,7 @@ int main(int argc, char** argv)
     for (int s = 0; s < S; s++) { const int n = 2 + rng() % 5; srec[s] = make_int4((int)N, n, 9000, 0); N += n; }
     std::vector<NGroup> groups;
     int64_t goff = 0;
-    auto add = [&](int cnt, int span) { NGroup g = NGroup(); g.cnt = cnt; for (int q = 0; q < cnt; q++) { g.loff[q] = g.total; g.total += span; } g.goff = goff; goff += g.total; groups.push_back(g); };
+    auto add = [&](int cnt, int span) { NGroup g = NGroup(); g.cnt = cnt; for (int q = 0; q < cnt; q++) { g.loff[q] = g.total; g.toff[q] = g.total; g.total += span; } g.goff = goff; goff += g.total; groups.push_back(g); };
     for (int i = 0; i < 17; i++) add(8, 14);
     for (int i = 0; i < 4; i++) add(8, 40);
     for (int i = 0; i < 2; i++) add(5, 130);

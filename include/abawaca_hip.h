@@ -256,6 +256,7 @@ int abw_sep_tree_result(abw_ctx* ctx, abw_tree_node* nodes_out, int64_t node_cap
 /* host only: all = [n_ctx][n] records of eval (global_dimension filled in); out[k] = the winner, owner[k] = its context (-1: none) */
 int abw_sep_tree_merge(const abw_tree_winner* all, int32_t n_ctx, int64_t n, abw_tree_winner* out, int32_t* owner);
 
+
 /* ---- the separator with the SCAFFOLDS sharded over several contexts / processes / GPUs (SURVEY §8(e):
  *      "scaffold-sharded" full recursive binning; the reference itself is one process with a thread per
  *      dimension, ref: src/ClusterSeparator.cpp:72-78).  A shard holds whole scaffolds (a node of the
@@ -299,6 +300,33 @@ int abw_sep_shard_decide(abw_split* out, int64_t ndps1_total, int64_t ndps2_tota
  * counterpart (it is single-threaded per dimension, ref: src/ClusterSeparator.cpp:70-78).  Every context must have an
  * accumulated node (abw_sep_shard_accum) under the same bin layout.  Returns when all contexts hold the result. */
 int abw_sep_shard_combine(abw_ctx* const* ctxs, int32_t n_ctx);
+
+/* ---- ... and with the SCAFFOLDS sharded for the signature columns (SURVEY section 8(e) "separator sweep (B)", BASELINE configs[4]:
+ *      "scaffold-sharded at 2/4/8 GPUs"; the reference is one process, ref: src/ClusterSeparator.cpp:70-78).  The coverage columns
+ *      (few, about as many distinct keys as datapoints) are spread over the ranks by dimension and walked with the level calls
+ *      above over all scaffolds; the signature columns (many, keys below 1024) are cut by SCAFFOLD: rank r loads a contiguous
+ *      range of the scaffolds with those columns only (abw_sep_load on a second context) and follows the walk level by level:
+ *        abw_sep_tree_level (walking context) : the level's nodes, and the device arrays with every scaffold's node / side
+ *        accum  : the shard's scaffolds of the nodes that are the SMALLER child of their parent (the root; a node without
+ *                 sibling) -> histogram slices; SCG lists of all nodes from the shard's carriers.  ex: the slices packed side by
+ *                 side (int64 words; integer SUM over the shards) and the lists (MIN of scg_lo, MAX of scg_hi)
+ *        eval   : after the exchange: bigger child = parent - smaller child on every shard, every threshold of every signature
+ *                 column -> best[k] (identical on all shards; key = the column's value, global_dimension = dimension + 1 in
+ *                 THIS table: the caller translates it)
+ *        assign : winners[k].dimension >= 0 where this table's column won node k: the shard's scaffolds there get their sides
+ *                 in d_side (the walking context's array; the ranks then combine it by MAX as among themselves)
+ *      Per level the ranks exchange 20 B x signature bins x accumulated nodes (about 0.1 MB a node for abawaca-build's tables),
+ *      the SCG lists, one record per node and one byte per scaffold.  Integers only: the tree is abw_sep_tree's bit for bit. */
+/* The shards add their histogram slices bin by bin, so every shard's table needs the same number of bins in every column:
+ * before abw_sep_load of a shard, bins[d] = the largest key of column d over ALL shards + 1 (one MAX over the ranks). */
+int abw_sep_narrow_bins(abw_ctx* ctx, const int32_t* bins, int32_t D);
+typedef struct abw_tree_level_node { int32_t id; int32_t n_scaf; int64_t ndps; int32_t parent; int32_t reserved; } abw_tree_level_node;
+typedef struct abw_tree_level { int64_t n_nodes; int64_t n_scaf; const int32_t* d_scaf_slot; uint8_t* d_side; } abw_tree_level;
+int abw_sep_tree_level(abw_ctx* ctx, abw_tree_level* info, abw_tree_level_node* nodes_out, int64_t cap);
+int abw_sep_stree_begin(abw_ctx* ctx, int32_t scaf_first);
+int abw_sep_stree_accum(abw_ctx* ctx, const abw_tree_level_node* nodes, int64_t n_nodes, const int32_t* d_scaf_slot, abw_sep_exchange* ex);
+int abw_sep_stree_eval(abw_ctx* ctx, int32_t min_ndps, abw_tree_winner* best, int64_t cap);
+int abw_sep_stree_assign(abw_ctx* ctx, const abw_tree_winner* winners, int64_t n, const int32_t* d_scaf_slot, uint8_t* d_side);
 
 /* Device pointer to the resident column store [D][N] int32 (for abw_km_features_from_keys). */
 const int32_t* abw_sep_dev_keys(const abw_ctx* ctx);

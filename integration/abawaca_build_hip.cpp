@@ -15,8 +15,17 @@
 //     the row loop of abawaca.lrn               (ref :600-605)      ->  abw_lrn_emit
 //
 // It is linked with the reference's unmodified ReadMapping.cpp, ReadMappingReader.cpp, common.cpp and String.cpp
-// (oracle/Makefile: oracle/_ref/hip_build_driver); it contains none of the reference's code.  tests/test_gpu_build_driver.py
-// runs it beside the reference's own abawaca-build and requires byte-identical abawaca.lrn / .names / .info.
+// (oracle/Makefile: oracle/_ref/hip_build_driver).  tests/test_gpu_build_driver.py runs it beside the reference's own
+// abawaca-build and requires byte-identical abawaca.lrn / .names / .info.
+//
+// What this file is: a PATCH of the reference's main, written out as a whole file because Scaf / Scaf_segment are file-local
+// to src/abawaca-build.cpp and cannot be linked.  About 45 of its lines are therefore the reference's own main with small
+// edits, kept because they ARE the command line and the wire formats: the option loop (ref :449-479), the four output names
+// and the mkdir (ref :492-505), the SAM loop of the fall-back reader with its filter (ref :522-552, the links bookkeeping
+// removed), the header fprintfs of abawaca.lrn and the per-segment / per-scaffold lines of abawaca.names / abawaca.info
+// (ref :578-599), data.txt (ref :615-630).  Everything else -- the batching of the FASTA loop, the chunked SAM text, the
+// bookkeeping between the three library calls -- is this repository's.  INTEGRATION.md section 2 shows the same change as a
+// diff against src/abawaca-build.cpp.
 //
 // Not done here, as in the rest of this repository: the paired-end links file (ref :249-367,519-557) and the
 // gene / SCG prediction that shells out to prodigal (ref :401-431); data.txt is written with the same keys.
@@ -30,6 +39,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <iostream>
 #include <map>
 #include <string>
@@ -52,6 +63,8 @@ void die(abw_ctx* ctx, const char* what)
 	cerr << "abawaca-build (hip): " << what << ": " << (ctx ? abw_last_error(ctx) : "no context") << endl;
 	exit(-1);
 }
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct ScafRec {
 	string		name;
@@ -91,30 +104,91 @@ int main(int argc, const char* argv[])
 		return -1;
 	}
 
-	// ---- the assembly (ref :481-490): the reference's reader; sequences go into one blob instead of Scaf objects
+	// ---- the assembly (ref :481-490): the reference's reader; the sequences go to the GPU in BATCHES of whole scaffolds
+	// (ABW_BUILD_BATCH_MB of sequence, default 256) instead of into Scaf objects: while the reader -- one host thread, as
+	// in the reference -- parses batch i + 1, a worker thread has batch i segmented and counted (abw_sig_build, ref :198-228,
+	// :103-174) and counts the N of every segment for abawaca.names; then the batch's sequence is dropped.  Memory stays at
+	// two batches however large the assembly is, and the GPU's work hides behind the parsing.
 	cerr << time_since_epoch() << "Reading assembly file (" << assembly_file << ")" << endl;
+	const double t_start = now_s();
 	vector<ScafRec>		recs;
 	map<string, size_t>	by_name;			// the reference's std::map order = byte-wise name order
-	vector<uint8_t>		blob;
-	vector<uint64_t>	off(1, 0);
+	uint64_t		n_seg = 0;
+	vector<uint32_t>	seg_scaf;
+	vector<uint64_t>	seg_start, seg_end;
+	vector<uint32_t>	seg_nn;				// N of every segment (abawaca.names prints "<non-N>/<size> non-Ns bps", ref :218)
+	vector<int32_t>		sig_milli;			// [n_seg][179]: int(1000.0 * x) of every printed signature column
+	double			gpu_busy_s = 0;
 	{
+		size_t batch_bytes = (size_t)256 << 20;
+		if(const char* bm = getenv("ABW_BUILD_BATCH_MB")) { if(atol(bm) > 0) batch_bytes = (size_t)atol(bm) << 20; }
+		if(const char* bk = getenv("ABW_BUILD_BATCH_KB")) { if(atol(bk) > 0) batch_bytes = (size_t)atol(bk) << 10; }	// the tests
+		struct Batch { vector<uint8_t> blob; vector<uint64_t> off; size_t first_scaf; };
+		std::thread	worker;
+		string		worker_error;
+		auto run_batch = [&](Batch* b) {			// on the worker thread: the only user of ctx until it is joined
+			const double t0 = now_s();
+			const size_t nb = b->off.size() - 1;
+			uint64_t got = 0, cap = b->blob.size() / window_size + nb + 16;
+			vector<uint32_t> sc; vector<uint64_t> st, en; vector<int32_t> mi;
+			for(;;) {
+				sc.resize(cap); st.resize(cap); en.resize(cap); mi.resize(cap * ABW_SIG_NCOLS);
+				const int rc = abw_sig_build(ctx, b->blob.data(), b->off.data(), nb, (uint32_t)window_size, cap, sc.data(), st.data(), en.data(),
+				                             NULL, mi.data(), &got);
+				if(rc == ABW_ERR_CAPACITY) { cap = got; continue; }	// scaffolds of N only make a segment per base
+				// (ABW_ERR_LOWER_N cannot happen: DNAString's constructor already threw on a lower-case n, ref src/String.cpp:45-49)
+				if(rc != ABW_OK) worker_error = string("abw_sig_build: ") + abw_last_error(ctx);
+				break;
+			}
+			if(worker_error.empty()) {
+				const size_t at = seg_scaf.size();
+				seg_scaf.resize(at + got); seg_start.resize(at + got); seg_end.resize(at + got); seg_nn.resize(at + got);
+				sig_milli.resize((at + got) * ABW_SIG_NCOLS);
+				for(uint64_t g = 0; g < got; g++) {
+					seg_scaf[at + g] = sc[g] + (uint32_t)b->first_scaf; seg_start[at + g] = st[g]; seg_end[at + g] = en[g];
+					const uint8_t* p = b->blob.data() + b->off[sc[g]] + st[g] - 1;
+					const size_t size = (size_t)(en[g] - st[g] + 1);
+					uint32_t nn = 0;
+					for(size_t q = 0; q < size; q++) nn += p[q] == 'N';
+					seg_nn[at + g] = nn;
+				}
+				memcpy(&sig_milli[at * ABW_SIG_NCOLS], mi.data(), (size_t)got * ABW_SIG_NCOLS * sizeof(int32_t));
+				n_seg += got;
+			}
+			gpu_busy_s += now_s() - t0;
+			delete b;
+		};
+		auto hand_over = [&](Batch* b) {
+			if(worker.joinable()) worker.join();
+			if(!worker_error.empty()) { cerr << "abawaca-build (hip): " << worker_error << endl; exit(-1); }
+			if(b) worker = std::thread(run_batch, b);
+		};
+		Batch* cur = new Batch();
+		cur->off.assign(1, 0); cur->first_scaf = 0;
 		Bio::SeqIORead_fasta<Bio::DNASequence>	in(assembly_file);
 		Bio::DNASequence*			seq = NULL;
 		while((seq = in.next_seq()) != NULL) {
 			const Bio::DNAString& dna = seq->seq();
-			const string s = string(dna);
 			if(!by_name.insert(pair<string, size_t>(seq->display_id(), recs.size())).second) {
 				cerr << "abawaca-build (hip): two sequences named " << seq->display_id() << endl;
 				return -1;
 			}
 			ScafRec r;
-			r.name = seq->display_id(); r.len = s.size(); r.ns = Bio::Ns(dna); r.gc = Bio::gc(dna); r.nbps = 0;
+			r.name = seq->display_id(); r.len = dna.size(); r.ns = Bio::Ns(dna); r.gc = Bio::gc(dna); r.nbps = 0;
 			recs.push_back(r);
-			blob.insert(blob.end(), s.begin(), s.end());
-			off.push_back(blob.size());
+			cur->blob.insert(cur->blob.end(), dna.begin(), dna.end());
+			cur->off.push_back(cur->blob.size());
 			delete seq;
+			if(cur->blob.size() >= batch_bytes) {
+				hand_over(cur);
+				cur = new Batch();
+				cur->off.assign(1, 0); cur->first_scaf = recs.size();
+			}
 		}
+		if(cur->off.size() > 1) hand_over(cur); else delete cur;
+		hand_over(NULL);
 	}
+	const double t_assembly = now_s();
 	const size_t n_scaf = recs.size();
 	vector<uint8_t>		name_blob;				// the scaffold names as abw_sam_parse takes them, in input order
 	vector<uint64_t>	name_off(1, 0);
@@ -123,21 +197,6 @@ int main(int argc, const char* argv[])
 		name_off.push_back(name_blob.size());
 	}
 	name_blob.push_back(0);
-
-	// ---- segments + signatures of every scaffold in one call (ref :198-228, :103-174)
-	uint64_t		n_seg = 0, cap = blob.size() / window_size + n_scaf + 16;
-	vector<uint32_t>	seg_scaf;
-	vector<uint64_t>	seg_start, seg_end;
-	vector<int32_t>		sig_milli;			// [n_seg][179]: int(1000.0 * x) of every printed signature column
-	for(;;) {
-		seg_scaf.resize(cap); seg_start.resize(cap); seg_end.resize(cap); sig_milli.resize(cap * ABW_SIG_NCOLS);
-		int rc = abw_sig_build(ctx, blob.data(), off.data(), n_scaf, (uint32_t)window_size, cap, seg_scaf.data(), seg_start.data(),
-		                       seg_end.data(), NULL, sig_milli.data(), &n_seg);
-		if(rc == ABW_ERR_CAPACITY) { cap = n_seg; continue; }		// scaffolds of N only make a segment per base
-		// (ABW_ERR_LOWER_N cannot happen: DNAString's constructor already threw on a lower-case n, ref src/String.cpp:45-49)
-		if(rc != ABW_OK) die(ctx, "abw_sig_build");
-		break;
-	}
 
 	// ---- coverage (ref :507-559): the reference's SAM reader and filter, sums on the GPU in SAM order
 	vector<string>		sample_names;
@@ -242,6 +301,7 @@ int main(int argc, const char* argv[])
 		}
 	}
 	const size_t n_samples = sample_names.size();
+	const double t_sam = now_s();
 
 	// ---- rows in the reference's order: scaffolds by name, their segments by position (ref :596-598)
 	vector<uint64_t>	first_seg(n_scaf + 1, 0);			// segments arrive grouped by scaffold, in input order
@@ -317,10 +377,8 @@ int main(int argc, const char* argv[])
 		fprintf(finfo, "%s\t%lu\t%.3lf\t%.3lf\t%lu\n", r.name.c_str(), (unsigned long)r.len, int(1000.0*cvg)/1000.0, int(1000.0*r.gc)/1000.0, (unsigned long)r.ns);
 		size_t k = 0;
 		for(uint64_t g = first_seg[it->second]; g < first_seg[it->second + 1]; g++) {
-			const uint8_t* p = blob.data() + off[it->second] + seg_start[g] - 1;
 			const size_t size = (size_t)(seg_end[g] - seg_start[g] + 1);
-			size_t nn = 0;
-			for(size_t j = 0; j < size; j++) nn += p[j] == 'N';
+			const size_t nn = seg_nn[g];
 			fprintf(fout, "%lu\t%s_%lu\t%s:(%lu, %lu), %lu/%lu non-Ns bps\n", (unsigned long)++i, r.name.c_str(), (unsigned long)++k, r.name.c_str(),
 			        (unsigned long)seg_start[g], (unsigned long)seg_end[g], (unsigned long)(size - nn), (unsigned long)size);
 		}
@@ -345,6 +403,15 @@ int main(int argc, const char* argv[])
 		fclose(fp);
 	}
 	abw_ctx_destroy(ctx);
+	if(const char* tf = getenv("ABW_BUILD_TIMES")) {			// where the wall clock went (bench.py's end-to-end leg)
+		FILE* ft = fopen(tf, "w");
+		if(ft) {
+			fprintf(ft, "{\"assembly_s\": %.4f, \"of_which_sig_build_on_the_worker_s\": %.4f, \"sam_and_coverage_s\": %.4f, \"output_s\": %.4f, "
+			            "\"total_s\": %.4f, \"scaffolds\": %lu, \"segments\": %lu}\n", t_assembly - t_start, gpu_busy_s, t_sam - t_assembly,
+			        now_s() - t_sam, now_s() - t_start, (unsigned long)n_scaf, (unsigned long)n_seg);
+			fclose(ft);
+		}
+	}
 	cerr << time_since_epoch() << "Finished successfully" << endl;
 	return 0;
 }

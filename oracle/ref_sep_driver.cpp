@@ -19,6 +19,9 @@
 //   <out_prefix>.scaf2cluster.tsv scaffold-name <tab> terminal cluster id (0 = none), ids 1..S
 //   <out_prefix>.dp2cluster.tsv   internal dp id <tab> terminal cluster id
 //   <out_prefix>.dpmap.tsv        internal dp id <tab> internal scaffold id   (the ScafDpData numbering)
+//   <out_prefix>.summary.txt      the reference's summary.txt: its header and one row per terminal cluster, computed by the
+//        reference's unmodified ClusterQuality / SCGdb and printed with the expressions of reference src/abawaca.cpp:93,144-152
+//        (scaffolds, datapoints, bps, GC, coverage, unique SCGs = completeness, average copies = contamination)
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -48,6 +51,8 @@
 #endif
 #include "Semaphore.h"
 #include "SCGdb.h"
+#include "ClusterQuality.h"
+#include <fstream>
 
 int main(int argc, const char** argv)
 {
@@ -74,6 +79,8 @@ int main(int argc, const char** argv)
 		fprintf(fm, "%lu\t%lu\n", dp, scaf_db.dp2scaf(dp));
 	fclose(fm);
 
+	std::ofstream summary((prefix + ".summary.txt").c_str());
+	summary << "Cluster\t# scafs\t# dps\t# bps\t%G+C\tStdev\tCvg\tstdev\t#SCG" << '/' << scg_db.get_total_num_scgs() << "\tAvg" << endl;	// reference :93
 	const char* cluster_dir = getenv("ABW_CLUSTER_DIR");
 	long write_usec = 0, written = 0;
 	std::map<size_t, Cluster*> work;
@@ -95,8 +102,10 @@ int main(int argc, const char** argv)
 #if defined(ABW_USE_HIP_SEPARATOR) || defined(ABW_USE_KMEANS_SEPARATOR)
 		// the GPU separators keep the table resident: after the first node a node needs only its datapoint set
 		// (integration/ClusterDataView.h; this driver has no ClusterEsomWriter that would read the node's values)
-		ClusterData* node_db = (visited == 1 || getenv("ABW_FULL_NODE_TABLES")) ? new ClusterData(clustering_db, cur->get_dps())
-		                                                                          : new ClusterDataView(clustering_db, cur->get_dps());
+		// (the root IS the loaded table: no copy of it either, unless the reference's per-node subset tables are asked for)
+		const bool full_tables = getenv("ABW_FULL_NODE_TABLES") != NULL;
+		ClusterData* node_db = full_tables ? new ClusterData(clustering_db, cur->get_dps())
+		                     : visited == 1 ? &clustering_db : new ClusterDataView(clustering_db, cur->get_dps());
 #else
 		ClusterData* node_db = new ClusterData(clustering_db, cur->get_dps());
 #endif
@@ -113,6 +122,16 @@ int main(int argc, const char** argv)
 				sep.get_best_specificity(), sep.get_best_sensitivity(), usec);
 			for(auto s = cur->dps_begin(); s != cur->dps_end(); s++) dp2cluster[*s] = id;
 			for(auto s = cur->assigned_scafs_begin(); s != cur->assigned_scafs_end(); s++) scaf2cluster[*s] = id;
+			// the bin's row of summary.txt (reference src/abawaca.cpp:137-152)
+			ClusterQuality cq(scaf_db, scg_db);
+			double nunique_scgs, avg_ncopies_scgs, avg_gc, stdev_gc, avg_cvg = -1, stdev_cvg = -1;
+			const size_t total_bps = cq.total_size(*cur), nscaffolds = cq.num_scaffolds(*cur);
+			cq.scg(*cur, nunique_scgs, avg_ncopies_scgs);
+			cq.gc(*cur, avg_gc, stdev_gc);
+			cq.cvg(*cur, avg_cvg, stdev_cvg);
+			summary << id << '\t' << nscaffolds << '\t' << cur->ndps() << '\t' << total_bps << '\t'
+				<< int(1000*avg_gc)/10.0 << '\t' << int(1000*stdev_gc)/100.0 << '\t' << int(10*avg_cvg)/10.0
+				<< '\t' << int(10*stdev_cvg)/10.0 << '\t' << nunique_scgs << '\t' << int(100*avg_ncopies_scgs)/100.0 << endl;
 		}
 		else {
 			size_t c1 = next_id++, c2 = next_id++;
@@ -141,7 +160,7 @@ int main(int argc, const char** argv)
 			work[c2] = sep.get_cluster2();
 		}
 		fflush(fn);
-		delete node_db;
+		if(node_db != &clustering_db) delete node_db;
 		delete cur;
 	}
 	fclose(fn);

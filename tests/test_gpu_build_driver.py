@@ -87,12 +87,15 @@ def test_driver_beside_the_reference_program(seed, n_scaf):
         # the SAM files in pieces of 1 KiB (shorter than some lines: a piece grows until it holds a line end) and of 7 KiB
         cut1 = _run(HIP, fasta, os.path.join(wd, "hip4"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"), env={"ABW_SAM_PIECE_KB": "1"})
         cut7 = _run(HIP, fasta, os.path.join(wd, "hip5"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"), env={"ABW_SAM_PIECE_KB": "7"})
+        # the assembly in batches of 16 KiB of sequence (a handful of scaffolds each; the default is 256 MiB): every batch is
+        # segmented and counted by the worker thread while the reference's reader parses the next
+        small = _run(HIP, fasta, os.path.join(wd, "hip6"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"), env={"ABW_BUILD_BATCH_KB": "16"})
         # a record abw_sam_parse refuses and the reference reads (atoi stops at the blank): that file falls back, the result stands
         with open(os.path.join(wd, "s1.sam"), "a") as f:
             f.write(f"u6\t0 \t{asm.names[3]}\t7\t255\t150M\t*\t0\t0\t{seq}\t{q}\n")
         ref3 = _run(REF, fasta, os.path.join(wd, "ref3"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"))
         got3 = _run(HIP, fasta, os.path.join(wd, "hip3"), os.path.join(wd, "s*.sam"), os.path.join(wd, "s1.sam"), stderr_has="FLAG or POS is not a plain number")
     assert got["lrn"] == ref["lrn"] and got["names"] == ref["names"] and got["info"] == ref["info"]
-    assert old == got and cut1 == got and cut7 == got
+    assert old == got and cut1 == got and cut7 == got and small == got
     assert got3 == ref3 and got3["lrn"] != got["lrn"]
     assert got["lrn"].count(b"\n") > n_scaf

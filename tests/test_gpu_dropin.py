@@ -23,7 +23,9 @@ def _run(exe, files, prefix, env=None, max_nodes=None):
     subprocess.run([exe, files["names"], files["fasta"], files["info"], files["lrn"], files["scg"], files["scg_list"],
                     "8", prefix] + ([str(max_nodes)] if max_nodes else []), check=True, timeout=300, env=env)
     nodes = [ln.split("\t")[:11] for ln in open(prefix + ".nodes.tsv").read().strip().split("\n")]
-    return nodes, open(prefix + ".scaf2cluster.tsv").read(), open(prefix + ".dp2cluster.tsv").read()
+    # ... and the reference's summary.txt (bins with their sizes, GC, coverage, unique SCGs and average copies: the SCG
+    # completeness / contamination columns), printed by the reference's own ClusterQuality in both drivers
+    return nodes, open(prefix + ".scaf2cluster.tsv").read(), open(prefix + ".dp2cluster.tsv").read(), open(prefix + ".summary.txt").read()
 
 
 @pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HIP)), reason="oracle/_ref drivers not built")
@@ -38,6 +40,7 @@ def test_reference_main_loop_with_hip_separator(golden_dir, case):
     assert hip_full == hip
     assert ref[0] == hip[0]          # per node: id ndps split dim value spec sens children sizes (%.17g text)
     assert ref[1] == hip[1] and ref[2] == hip[2]
+    assert ref[3] == hip[3] and ref[3].count("\n") == 1 + sum(1 for r in ref[0] if r[2] == "0")      # summary.txt: a row per bin
     # and the reference run on these regenerated files reproduces the committed golden nodes
     gold = g["nodes"]
     assert len(ref[0]) == len(gold)
@@ -94,7 +97,7 @@ def test_reference_main_loop_with_the_sharded_hip_separator(golden_dir, case):
             os.makedirs(out_dir)
             got = _run(HIP_SHARDED, files, os.path.join(wd, f"sh{shards}"), dict(os.environ, ABW_SHARDS=str(shards), ABW_CLUSTER_DIR=out_dir))
             assert got[0] == ref[0], shards
-            assert got[1] == ref[1] and got[2] == ref[2], shards
+            assert got[1] == ref[1] and got[2] == ref[2] and got[3] == ref[3], shards
             names = sorted(os.listdir(ref_dir))
             assert names == sorted(os.listdir(out_dir))
             for nm in names:

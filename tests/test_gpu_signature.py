@@ -236,3 +236,35 @@ def test_pipelined_build_over_several_chunks_equals_the_resident_path():
         assert rc == _lib.ABW_ERR_CAPACITY and k.value == n
     finally:
         ctx.close()
+
+
+def test_first_calls_of_two_contexts_from_two_threads():
+    """The header promises that different contexts are independent: two host threads whose FIRST library calls run at the same
+    moment on two contexts (the process-wide k-mer tables are built and uploaded by whoever comes first).  In a fresh process,
+    because these tests have long since made their first call."""
+    import subprocess, sys, os
+    code = r'''
+import sys, threading
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from abawaca_amd import _lib, signature, synth
+asm = synth.make_assembly(77, 40, 3, 1, frac_n_run=0.3)
+blob = np.concatenate(asm.seqs)
+off = np.zeros(len(asm.seqs) + 1, dtype=np.uint64); off[1:] = np.cumsum([len(s) for s in asm.seqs])
+out, start = [None, None], threading.Barrier(2)
+def work(k):
+    start.wait()
+    ctx = _lib.Context(0)
+    out[k] = signature.build_signatures(ctx, blob, off)
+    ctx.close()
+th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+[t.start() for t in th]; [t.join() for t in th]
+import _oracle as orc
+_s, st, en, dims = orc.build_signatures(blob, off)
+for r in out:
+    assert r is not None and np.array_equal(r["seg_start"], st) and np.array_equal(r["dims"].view(np.uint64), dims.view(np.uint64))
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stderr[-2000:]

@@ -237,6 +237,78 @@ def test_sharded_separator_histograms_add_up_to_the_reference_sweep(tmp_path, wo
         assert np.array_equal(z["sens"][f], per["sens"][f]) and np.array_equal(z["spec"][f], per["spec"][f])
 
 
+# ---- scaffold-sharded LEVEL exchange (abw_sep_stree_*): narrow columns by scaffold range, wide columns by dimension ----
+
+def _stree_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from abawaca_amd import separator
+        keys, dp2scaf, scaf_len, scg_scaf, scg_id, n_scg = _sep_tables()
+        D, S = keys.shape[0], len(scaf_len)
+        wide = np.array([keys[d].max() >= 1024 for d in range(D)])
+        n_cols, w_cols = np.flatnonzero(~wide), np.flatnonzero(wide)
+        b = separator.scaffold_ranges(np.bincount(dp2scaf, minlength=S), world)
+        # narrow columns of my scaffold range: local histograms (bin = key), summed over the ranks; SCG lists MIN / MAX
+        p = separator.carve_shard(keys[n_cols], dp2scaf, scaf_len, np.arange(b[rank], b[rank + 1]), scg_scaf, scg_id)
+        none = np.zeros(len(n_cols) + 1, dtype=np.int64)
+        hist, lo, hi, Tn = _np_local_hist(p["keys"], p["dp2scaf"], p["scaf_len"], p["scg_scaf"], p["scg_id"], n_scg, np.zeros(0, np.int32), none)
+        th, tl, thi = torch.from_numpy(hist), torch.from_numpy(lo), torch.from_numpy(hi)
+        multi.combine_sep(th, tl, thi, dist)
+        per_n = _np_eval(th.numpy(), tl.numpy(), thi.numpy(), Tn, n_scg)
+        # my wide columns over ALL scaffolds: nothing to exchange
+        mine_w = w_cols[rank::world]
+        per_w, dvw, dow = [], None, None
+        if len(mine_w):
+            dvw, dow = multi.merge_dictionaries([keys[mine_w]])
+            hw, lw, hiw, Tw = _np_local_hist(keys[mine_w], dp2scaf, scaf_len, scg_scaf, scg_id, n_scg, dvw, dow)
+            per_w = _np_eval(hw, lw, hiw, Tw, n_scg)
+
+        def best_of(per, cols, keyof):
+            r = np.zeros(1, dtype=separator._WIN_DTYPE)
+            r[0] = (0, -1, -1, 0, 0.0, 0.0, -1, 0)
+            for i, (f, bn, sens, spec) in enumerate(per):
+                if f and (not r["found"][0] or sens * spec > r["sens"][0] * r["spec"][0]):      # ascending columns: ties keep the smaller
+                    legal = sens >= 0.8 and spec >= 0.8 and sens + spec >= 1.6 and sens * spec >= 0.8
+                    r[0] = (1, i, keyof(i, bn), int(legal), sens, spec, int(cols[i]) + 1, 0)
+            return r
+        best_n = best_of(per_n, n_cols, lambda i, bn: bn)
+        best_w = best_of(per_w, mine_w, lambda i, bn: int(dvw[dow[i] + bn]))
+        mine = separator.stree_mine(best_n, best_w)
+        mt = torch.from_numpy(mine.view(np.uint8).reshape(-1).copy())
+        parts = [torch.zeros_like(mt) for _ in range(world)]
+        dist.all_gather(parts, mt)
+        winners, owner = separator.merge_winners([q.numpy().view(separator._WIN_DTYPE) for q in parts])
+        np.savez(os.path.join(out_dir, f"t{rank}.npz"), win=winners.view(np.uint8), owner=owner, narrow_best=best_n.view(np.uint8))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_scaffold_sharded_level_exchange_and_merge_find_the_reference_winner(tmp_path, world):
+    """World-size 2 / 3 over gloo: the narrow columns' histograms of contiguous scaffold ranges summed over the ranks, every rank's
+    own coverage columns over all scaffolds, each rank's candidate = the better of the two (separator.stree_mine), merged over
+    the ranks (abw_sep_tree_merge) -> the node's winner as the oracle's sweep over the whole table finds it, on every rank."""
+    from abawaca_amd import separator
+    mp.spawn(_stree_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    keys, dp2scaf, scaf_len, scg_scaf, scg_id, n_scg = _sep_tables()
+    S = len(scaf_len)
+    off, ids = orc.scg_csr(scg_scaf, scg_id, S)
+    ndps = np.bincount(dp2scaf, minlength=S).astype(np.int32)
+    res, per, raw, side = orc.separate(keys, dp2scaf, ndps, scaf_len, off, ids, n_scg, np.arange(keys.shape[1], dtype=np.int32), 100)
+    assert res.dimension > 0
+    first = None
+    for rank in range(world):
+        z = np.load(tmp_path / f"t{rank}.npz")
+        w = z["win"].view(separator._WIN_DTYPE)[0]
+        assert (int(w["gdim"]), int(w["key"]), float(w["sens"]), float(w["spec"]), int(w["legal"])) == \
+               (res.dimension, res.key, res.sensitivity, res.specificity, res.legal)
+        first = z if first is None else first
+        assert np.array_equal(z["win"], first["win"]) and np.array_equal(z["owner"], first["owner"])
+        assert np.array_equal(z["narrow_best"], first["narrow_best"])                       # identical on every rank
+
+
 def test_scaffold_bounds_balance_dps():
     rng = np.random.default_rng(0)
     ndps = rng.integers(2, 9, size=1000)
