@@ -582,17 +582,19 @@ def stree_mine(best_n, best_w):
 
 
 class ScafShard:
-    """One rank of the scaffold-sharded recursion.  keys: the whole [D, N] table is only SLICED here (rows / columns this rank
-    holds); rank r loads narrow columns x its scaffolds [s0, s1) and its wide columns x all scaffolds."""
+    """One rank of the scaffold-sharded recursion: the narrow columns of its scaffolds [s0, s1) (renumbered from 0) in ctx_n, all
+    scaffolds with its wide columns in ctx_w.
+      narrow_local : int32 [len(narrow_cols), dps of its scaffolds]   wide_rows : int32 [len(wide_mine), N] (or None: no wide column)
+      narrow_cols / wide_mine : the columns' numbers in the whole table
+      narrow_bins  : the largest key + 1 of every narrow column over ALL ranks' scaffolds (one MAX over the ranks): the shards'
+                     histograms share that layout
+    dp2scaf, scaf_len, scg_off, scg_ids describe ALL scaffolds (a few bytes each)."""
 
-    def __init__(self, ctx_n: Context, ctx_w: Context, keys, dp2scaf, scaf_len, scg_off, scg_ids, n_scg, s0: int, s1: int, wide_mine, narrow_cols,
-                 narrow_bins=None):
-        """narrow_bins: the largest key + 1 of every narrow column over ALL ranks' scaffolds (int32 [len(narrow_cols)]; one MAX over the
-        ranks when each holds only its own rows): the shards' histograms share that layout."""
-        keys = np.asarray(keys)
+    def __init__(self, ctx_n: Context, ctx_w: Context, narrow_local, wide_rows, dp2scaf, scaf_len, scg_off, scg_ids, n_scg, s0: int, s1: int,
+                 wide_mine, narrow_cols, narrow_bins):
         dp2scaf = np.ascontiguousarray(dp2scaf, dtype=np.int32)
         scaf_len = np.ascontiguousarray(scaf_len, dtype=np.int64)
-        S = len(scaf_len)
+        S, N = len(scaf_len), len(dp2scaf)
         self.s0, self.s1 = int(s0), int(s1)
         self.narrow_cols = np.ascontiguousarray(narrow_cols, dtype=np.int64)
         self.wide_mine = np.ascontiguousarray(wide_mine, dtype=np.int64)
@@ -604,16 +606,14 @@ class ScafShard:
             lo_ids = np.ascontiguousarray(np.asarray(scg_ids, dtype=np.int32)[so[s0]:so[s1]])
         else:
             lo_off = lo_ids = None
-        if narrow_bins is None:
-            narrow_bins = keys[self.narrow_cols].max(axis=1) + 1
         nb = np.ascontiguousarray(narrow_bins, dtype=np.int32)
         ctx_n.check(lib().abw_sep_narrow_bins(ctx_n.handle, C.c_void_p(nb.ctypes.data), len(nb)))
-        self.store_n = ColumnStore(ctx_n, np.ascontiguousarray(keys[self.narrow_cols][:, p0:p1]), dp2scaf[p0:p1] - s0, scaf_len[s0:s1], lo_off, lo_ids, n_scg)
+        self.store_n = ColumnStore(ctx_n, np.ascontiguousarray(narrow_local), dp2scaf[p0:p1] - s0, scaf_len[s0:s1], lo_off, lo_ids, n_scg)
         # (b) all scaffolds, my wide columns (a rank without one walks a constant column: it never finds a threshold)
-        if len(self.wide_mine):
-            kw, dims = np.ascontiguousarray(keys[self.wide_mine]), self.wide_mine
+        if wide_rows is not None and len(self.wide_mine):
+            kw, dims = np.ascontiguousarray(wide_rows), self.wide_mine
         else:
-            kw, dims = np.zeros((1, keys.shape[1]), dtype=np.int32), np.array([keys.shape[0]], dtype=np.int64)
+            kw, dims = np.zeros((1, N), dtype=np.int32), np.array([len(self.narrow_cols) + 4096], dtype=np.int64)
         self.store_w = DimShardStore(ctx_w, kw, np.arange(kw.shape[0]), dp2scaf, scaf_len, scg_off, scg_ids, n_scg)
         self.store_w.dims = dims
         self.S = S
@@ -675,15 +675,22 @@ class ScafShard:
 
 
 def make_scaf_shards(ctx_pairs, keys, dp2scaf, scaf_len, scg_off, scg_ids, n_scg):
-    """The table cut for len(ctx_pairs) ranks: (narrow context, walking context) per rank."""
+    """The table [D, N] cut for len(ctx_pairs) ranks: (narrow context, walking context) per rank."""
     keys = np.asarray(keys)
+    dp2scaf = np.asarray(dp2scaf)
     world = len(ctx_pairs)
     wide = np.array([bool(keys[d].max() >= 1024 or keys[d].min() < 0) for d in range(keys.shape[0])])
     w_cols, n_cols = np.flatnonzero(wide), np.flatnonzero(~wide)
     S = len(scaf_len)
-    b = scaffold_ranges(np.bincount(np.asarray(dp2scaf), minlength=S), world)
-    return [ScafShard(cn, cw, keys, dp2scaf, scaf_len, scg_off, scg_ids, n_scg, b[r], b[r + 1], w_cols[r::world], n_cols)
-            for r, (cn, cw) in enumerate(ctx_pairs)]
+    b = scaffold_ranges(np.bincount(dp2scaf, minlength=S), world)
+    bins = keys[n_cols].max(axis=1) + 1
+    out = []
+    for r, (cn, cw) in enumerate(ctx_pairs):
+        p0, p1 = int(np.searchsorted(dp2scaf, b[r], side="left")), int(np.searchsorted(dp2scaf, b[r + 1], side="left"))
+        mine = w_cols[r::world]
+        out.append(ScafShard(cn, cw, keys[n_cols][:, p0:p1], keys[mine] if len(mine) else None, dp2scaf, scaf_len, scg_off, scg_ids, n_scg,
+                             b[r], b[r + 1], mine, n_cols, bins))
+    return out
 
 
 def binning_stree_local(shards, max_nodes: int = 0):

@@ -60,7 +60,9 @@ def parse():
     ap.add_argument("--restarts", type=int, default=0, help="restarts of the whole job; 0 = the configuration's own (64 / 256)")
     ap.add_argument("--genomes", type=int, default=0, help="planted genomes; 0 = the configuration's own (100 / 200)")
     ap.add_argument("--sep-scaffolds", type=int, default=2_000_000, help="N > 1: scaffolds of the sharded separator leg in total (configs[4])")
-    ap.add_argument("--sep-nodes", type=int, default=127, help="N > 1: nodes of the sharded recursion to run (0 = all)")
+    ap.add_argument("--sep-nodes", type=int, default=127, help="N > 1, with --sep-node-by-node: nodes of that recursion to run (0 = all)")
+    ap.add_argument("--sep-node-by-node", action="store_true", help="N > 1: also the older scaffold-sharded separator that exchanges every histogram "
+                    "bin of the table per NODE (abw_sep_shard_*), as separator_sharded_node_by_node")
     ap.add_argument("--sep-nodes-dims", type=int, default=0, help="N > 1: nodes of the dimension-sharded recursion to run (0 = all)")
     ap.add_argument("--no-c2", action="store_true", help="N = 1: skip the configs[2] job on the one GPU")
     ap.add_argument("--iters", type=int, default=20)
@@ -1022,7 +1024,7 @@ def main():
     # per node one integer all-reduce of the histograms + min/max of the SCG flip values.)  The recursion is run for
     # --sep-nodes nodes (0 = to the end).
     sep_sharded = None
-    if dist is not None and not args.no_sep_sharded:
+    if dist is not None and not args.no_sep_sharded and args.sep_node_by_node:
         c4 = CONFIGS[4]
         s_loc = args.sep_scaffolds // world
         keys_k, dp2scaf_k, scaf_len_k, genome_k, G4 = make_points(20244 + 1000 * rank, s_loc, c4["samples"], dev, c4["genomes"])
@@ -1065,6 +1067,55 @@ def main():
                            collective=f"all-reduce SUM int64 x{hist_words} per node over {args.backend}")
         del sstore, nd
         sctx.close()
+        dist.barrier()
+
+    # ---------------- multi-rank only: the separator with the SCAFFOLDS sharded, level by level ---------------------------
+    # (configs[4]: "scaffold-sharded at 2/4/8 GPUs".  ONE table of --sep-scaffolds scaffolds, the same on every rank (same seed); rank r
+    # keeps the signature columns of a contiguous range of scaffolds and its share of the coverage columns over all scaffolds
+    # (abw_sep_stree_* + the level calls).  Per level: one integer all-reduce of the accumulated nodes' histogram slices, MIN / MAX
+    # of the SCG lists, a record per node, a byte per scaffold.  Strong scaling of one recursion.)
+    sep_stree = None
+    if dist is not None and not args.no_sep_sharded:
+        c4 = CONFIGS[4]
+        keys_s, dp2scaf_s, scaf_len_s, genome_s, G4s = make_points(20244, args.sep_scaffolds, c4["samples"], dev, c4["genomes"])
+        scg_scaf_s, scg_id_s = make_scgs(20244, genome_s, G4s)
+        so_s, si_s = separator.scg_csr(scg_scaf_s, scg_id_s, args.sep_scaffolds)
+        D4s, N4s = keys_s.shape
+        colmax_s = keys_s.amax(dim=1).cpu().numpy()
+        w_cols, n_cols = np.flatnonzero(colmax_s >= 1024), np.flatnonzero(colmax_s < 1024)
+        bnd = separator.scaffold_ranges(np.bincount(dp2scaf_s, minlength=args.sep_scaffolds), world)
+        p0, p1 = int(np.searchsorted(dp2scaf_s, bnd[rank])), int(np.searchsorted(dp2scaf_s, bnd[rank + 1]))
+        mine_w = w_cols[rank::world]
+        narrow_local = keys_s[torch.from_numpy(n_cols).to(dev)][:, p0:p1].cpu().numpy()
+        wide_rows = keys_s[torch.from_numpy(mine_w).to(dev)].cpu().numpy() if len(mine_w) else None
+        del keys_s
+        torch.cuda.empty_cache()
+        cn, cw = _lib.Context(dev_index), _lib.Context(dev_index)
+        t0 = time.perf_counter()
+        shard = separator.ScafShard(cn, cw, narrow_local, wide_rows, dp2scaf_s, scaf_len_s, so_s, si_s, 30, bnd[rank], bnd[rank + 1], mine_w, n_cols,
+                                    colmax_s[n_cols] + 1)
+        load_st = time.perf_counter() - t0
+        del narrow_local, wide_rows
+        separator.binning_stree(shard, dist, max_nodes=3)               # warm-up: static tables, RCCL channels
+        barrier()
+        best_st = None
+        for _ in range(2):
+            rows_st, s2c_st, dt_st, ex_st, lv_st = separator.binning_stree(shard, dist)
+            dt_st = multi.max_elapsed(dt_st, dist, dev)
+            best_st = dt_st if best_st is None else min(best_st, dt_st)
+        chk = torch.tensor([len(rows_st), int(np.asarray(s2c_st, dtype=np.int64).sum() % (1 << 31))], dtype=torch.int64, device=dev)
+        chks = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(chks, chk)
+        sep_stree = dict(value=sum(r["ndps"] for r in rows_st) * D4s / best_st, unit="dimension*points/s (every node's datapoints x all dimensions)",
+                         s=round(best_st, 4), nodes=len(rows_st), bins=int(sum(1 for r in rows_st if not r["split"])), levels=int(lv_st),
+                         workload=f"configs[4]: ONE recursion on {args.sep_scaffolds} scaffolds -> {N4s} dps x {D4s} dims, 30 SCGs x {G4s} genomes",
+                         scaffolds_per_rank=int(bnd[rank + 1] - bnd[rank]), signature_columns=int(len(n_cols)), coverage_columns_per_rank=int(len(mine_w)),
+                         exchange_bytes_total=int(ex_st), exchange_bytes_per_level=int(ex_st // max(1, lv_st)), load_s=round(load_st, 2), scaling="strong",
+                         same_tree_on_all_ranks=bool(all(torch.equal(c, chks[0]) for c in chks)),
+                         collective=f"per level over {args.backend}: all-reduce SUM int64 of the accumulated nodes' histogram slices, MIN / MAX of the SCG lists, "
+                                    f"all-gather of {separator._WIN_DTYPE.itemsize} B per node, all-reduce MAX of 1 B per scaffold")
+        del shard
+        cn.close(); cw.close()
         dist.barrier()
 
     # ---------------- multi-rank only: the separator with the DIMENSIONS spread over the ranks -------------------------
@@ -1184,8 +1235,10 @@ def main():
         out["partitions"] = legs
     if weak is not None:
         out["weak_restarts"] = weak
+    if sep_stree is not None:
+        out["separator_sharded"] = sep_stree
     if sep_sharded is not None:
-        out["separator_sharded"] = sep_sharded
+        out["separator_sharded_node_by_node"] = sep_sharded
     if sep_dims is not None:
         out["separator_dimension_sharded"] = sep_dims
     if sig_sharded is not None:

@@ -156,6 +156,20 @@ def test_configs4_whole_recursion_unsharded_and_scaffold_sharded():
         finally:
             for c in ctxs:
                 c.close()
+    # ... and with the SCAFFOLDS of the signature columns sharded over 2 and 8 ranks, the coverage columns by dimension
+    # (abw_sep_stree_*): the same nodes and bins on every rank, at most 8 MB exchanged per rank and level
+    for world in (2, 8):
+        pairs = [(_lib.Context(0), _lib.Context(0)) for _ in range(world)]
+        try:
+            shards = separator.make_scaf_shards(pairs, keys, dp2scaf, scaf_len, so, si, 30)
+            res, exchanged, levels = separator.binning_stree_local(shards)
+            for rows_k, s2c_k in res:
+                assert [_tree_key(r) for r in rows_k] == [_tree_key(r) for r in nodes] and np.array_equal(s2c_k, s2c)
+            assert levels >= 10 and exchanged <= levels * (8 << 20)
+            del shards
+        finally:
+            for a, b in pairs:
+                a.close(); b.close()
     by_id = {r["id"]: r for r in nodes}
     assert nodes[0]["ndps"] == N and nodes[0]["split"] == 1
     # root winner from its definition (reference ...Specificity.cpp:6-76, .h:74-75)

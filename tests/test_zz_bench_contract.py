@@ -47,6 +47,9 @@ def test_bare_gpus_2_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "configs[2]" in d["config"]["workload"]
     assert set(d["partitions"]) == {"restarts", "points"} and d["partitions"]["points"]["identical_on_all_ranks"]
     assert d["separator_dimension_sharded"]["same_tree_on_all_ranks"]
+    sh = d["separator_sharded"]                                  # scaffold-sharded, level by level: the same recursion, a small exchange
+    assert sh["same_tree_on_all_ranks"] and sh["nodes"] == d["separator_dimension_sharded"]["nodes"]
+    assert sh["exchange_bytes_per_level"] <= 8 << 20
 
 
 def test_more_ranks_than_devices_is_refused():
