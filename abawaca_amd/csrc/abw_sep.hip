@@ -715,7 +715,7 @@ extern "C" void abw_sep_free(abw_ctx* ctx)
     if (e) {
         void* q[] = {e->h.d_narrow, e->h.d_wide, e->h.d_dim_first_chunk, e->h.d_dim_nchunks, e->h.d_chunks,
                      e->h.d_chunk_sums, e->h.d_dim_total, e->h.d_chunk_best, e->h.d_sscaf, e->h.d_sbin, e->h.d_sdp,
-                     e->h.d_wts, e->h.d_wbelow, e->h.d_range, e->h.d_groups, e->h.d_nsort, e->h.d_toffn, e->h.d_dim_slot, e->h.d_ts8, e->h.d_nk16, e->h.d_srec, e->h.d_wword, e->h.d_wext, e->h.d_wpack, e->h.d_carriers, e->h.d_nw, e->h.d_g2c_off, e->h.d_g2c, e->h.d_member};
+                     e->h.d_wts, e->h.d_wbelow, e->h.d_range, e->h.d_groups, e->h.d_nsort, e->h.d_toffn, e->h.d_dim_slot, e->h.d_ts8, e->h.d_nk16, e->h.d_srec, e->h.d_wword, e->h.d_wext, e->h.d_wpack, e->h.d_posof, e->h.d_sinfo, e->h.d_carriers, e->h.d_nw, e->h.d_g2c_off, e->h.d_g2c, e->h.d_member};
         for (void* p : q) if (p) (void)hipFree(p);
         abw_tree_run_free(e->h.tree_run);
         abw_stree_run_free(e->h.stree_run);

@@ -110,6 +110,8 @@ struct SepHost {
     // abw_sep_tree's static tables of the wide dimensions, built at its first call on this table (abw_tree.hip)
     uint32_t* d_wword = nullptr;       // [n_wide][N] per sorted position: scaffold | (v >= t_s) << 31 | (owner) << 30
     uint32_t* d_wext = nullptr;        // [n_wide][S][4] per scaffold: dps below t_s, dps, min(length, 500000), bin of t_s
+    uint32_t* d_sinfo = nullptr;       // [S] dps | min(length, 500000) << 7: the inline form of the position words (abw_tree.hip), else NULL
+    int32_t* d_posof = nullptr;        // [n_wide][N] the position of every dp in the static order (the inverse of d_sdp)
     uint32_t* d_wpack = nullptr;       // [n_wide][S] the first three of d_wext in one word (scaffolds of <= 127 dps), else all ones
     int32_t* d_carriers = nullptr;     // scaffolds that carry at least one SCG
     int32_t n_carriers = 0;

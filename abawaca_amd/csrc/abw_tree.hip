@@ -42,7 +42,8 @@ constexpr uint32_t PACK_ESCAPE = 0xFFFFFFFFu;
 
 struct NodeDev {
     int32_t scaf_begin, scaf_end;       // its scaffolds in `order`
-    int32_t dp_begin, dp_end;           // its positions in every wide dimension's sorted arrays
+    int32_t dp_begin, dp_end;           // its SEGMENT in every wide dimension's sorted arrays: its own positions and dead ones
+    int32_t n;                          // its datapoints (the live positions of the segment)
     int32_t stile_begin, stile_end;     // its scaffold tiles
     int32_t ptile_begin, ptile_end;     // its position tiles
 };
@@ -56,11 +57,14 @@ struct NodeRes {                        // per node of a level, device -> host
 struct NodePart {                       // per node, host -> device for the partition
     int32_t split, id;
     int32_t scaf_base1, scaf_base2;     // where the children's scaffolds start in the next level's order
-    int32_t dp_base1, dp_base2;         // ... and their positions in the sorted arrays
+    int32_t dp_base1, dp_base2;         // ... and where their positions are copied to in the sorted arrays (-1: that child KEEPS the
+                                        // node's segment; the positions of its sibling are marked dead there)
     int32_t slot1, slot2;               // the children's slots in the next level
+    int32_t bits, reserved;             // bits: the positions that leave are marked in the bit map (tree_mark_kernel), not looked up
 };
 
 struct WSums { unsigned long long tp1, tot, bp; };
+struct WSums4 { unsigned long long size, tp1, tot, bp; };
 
 struct TreeDev {
     SepDev P;
@@ -74,11 +78,19 @@ struct TreeDev {
     const int4* srec;                   // [S]: first dp, dps, length (lo, hi)
     const uint4* wext;                  // [n_wide][S]: x = dps below t_s, y = dps, z = min(length, 500000), w = bin of t_s
     const uint32_t* wpack;              // [n_wide][S]: x | y << 6 | z << 13 where y <= 127 (4 MB per million scaffolds: L2), else PACK_ESCAPE
+    const uint32_t* sinfo;              // the INLINE form of the position words (at most 2^22 scaffolds of at most 63 dps each): [S] y | z << 7,
+                                        // and x of the dimension sits in the word itself -- no gather from a table per dimension.  NULL: not in use
+    uint32_t sc_mask;                   // the scaffold of a position word: W_SC, or W_SC22 in the inline form
     int32_t D, S;
 };
 
 // W_END (static, abw_sep_node's scan over the table's own order only): the last position of its bin in the table
-constexpr uint32_t W_GE = 0x80000000u, W_OWN = 0x40000000u, W_END = 0x20000000u, W_SC = 0x1FFFFFFFu;
+// W_DEAD (the recursion's own copies only): the position's dp has left the node whose segment this is (it went to the
+// smaller child, which was copied out; the bigger child keeps the segment)
+constexpr uint32_t W_GE = 0x80000000u, W_OWN = 0x40000000u, W_END = 0x20000000u, W_DEAD = 0x10000000u, W_SC = 0x0FFFFFFFu;
+// the inline form: bits 22..27 of a W_OWN word hold the scaffold's dps below its flip value in this dimension (<= 31)
+constexpr uint32_t W_SC22 = 0x003FFFFFu;
+constexpr int W_X_SHIFT = 22;
 
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* sh)
 {
@@ -120,6 +132,22 @@ __device__ __forceinline__ void load8(const T* __restrict__ p, int i0, int begin
     }
 }
 
+// the same for arrays that are streamed once per kernel beside tables that are gathered from (the per-scaffold records of a
+// wide dimension): loaded with the non-temporal hint, so that the stream does not push the tables out of the L2
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ void load8_stream(const T* __restrict__ p, int i0, int begin, int end, T (&v)[8], T fill)
+{
+    static_assert(sizeof(T) == 4, "32-bit items");
+    if (i0 >= begin && i0 + 8 <= end) {
+        const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + i0)), b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + i0 + 4));
+        v[0] = (T)a.x; v[1] = (T)a.y; v[2] = (T)a.z; v[3] = (T)a.w; v[4] = (T)b.x; v[5] = (T)b.y; v[6] = (T)b.z; v[7] = (T)b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = (i0 + i >= begin && i0 + i < end) ? p[i0 + i] : fill;
+    }
+}
+
 // ---- level set-up: the SCG lo / hi lists of every (node, dimension) start empty ------------------------------------
 __global__ void tree_scg_reset_kernel(int32_t* __restrict__ lo, int32_t* __restrict__ hi, int64_t n)
 {
@@ -130,7 +158,7 @@ __global__ void tree_scg_reset_kernel(int32_t* __restrict__ lo, int32_t* __restr
 // wide dimensions: flip value (as a bin), dps below it, one byte per dp (bit 0: v >= t_s; bit 1: the first dp of the
 // scaffold on bin t_s).  grid (ceil(S / 256), wide dimensions)
 __global__ __launch_bounds__(256) void tree_static_wide_kernel(SepDev P, const int32_t* __restrict__ wide, int32_t S, uint8_t* __restrict__ flags,
-                                                              uint4* __restrict__ wext, uint32_t* __restrict__ wpack)
+                                                              uint4* __restrict__ wext, uint32_t* __restrict__ wpack, uint32_t* __restrict__ sinfo)
 {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= S) return;
@@ -170,18 +198,23 @@ __global__ __launch_bounds__(256) void tree_static_wide_kernel(SepDev P, const i
     const uint32_t lenc = (uint32_t)(len < 500000 ? (len < 0 ? 0 : len) : 500000);
     wext[(int64_t)w * S + s] = make_uint4((uint32_t)nb, (uint32_t)n, lenc, (uint32_t)ts);
     wpack[(int64_t)w * S + s] = (n <= 127) ? ((uint32_t)nb | (uint32_t)n << 6 | lenc << 13) : PACK_ESCAPE;      // nb <= n / 2 <= 63
+    if (sinfo && w == 0) sinfo[s] = (uint32_t)n | lenc << 7;
 }
 
 // the word of every sorted position: scaffold | flags.  grid (blocks, wide dimensions)
 __global__ void tree_static_words_kernel(const int32_t* __restrict__ sdp, const int32_t* __restrict__ sbin, const uint8_t* __restrict__ flags,
-                                         const int32_t* __restrict__ dp2scaf, int64_t N, int64_t Np, uint32_t* __restrict__ wword)
+                                         const int32_t* __restrict__ dp2scaf, int64_t N, int64_t Np, const uint4* __restrict__ wext, int32_t S, int inl,
+                                         uint32_t* __restrict__ wword)
 {
     const int64_t base = (int64_t)blockIdx.y * N, obase = (int64_t)blockIdx.y * Np;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         const int dp = sdp[base + i];
         const uint8_t f = flags[base + dp];
         const bool end = (i + 1 == N) || sbin[base + i + 1] != sbin[base + i];
-        wword[obase + i] = (uint32_t)dp2scaf[dp] | ((f & 1) ? W_GE : 0u) | ((f & 2) ? W_OWN : 0u) | (end ? W_END : 0u);
+        const int sc = dp2scaf[dp];
+        uint32_t word = (uint32_t)sc | ((f & 1) ? W_GE : 0u) | ((f & 2) ? W_OWN : 0u) | (end ? W_END : 0u);
+        if (inl && (f & 2)) word |= wext[(int64_t)blockIdx.y * S + sc].x << W_X_SHIFT;
+        wword[obase + i] = word;
     }
 }
 
@@ -331,6 +364,25 @@ __device__ __forceinline__ void eval_threshold(long long size1, long long tp1, l
     if (pass) best = cnd;
 }
 
+// The screen in front of eval_threshold for the wide dimensions' walks (one candidate per run end: tens of millions a level,
+// of which a handful can win): the same size check and small side in 32-bit integers (all counts are below 2^31), and
+// TP^2 against need x TOT x SZ in fp32 with a margin of 1e-5 -- far above what the five fp32 roundings and the rounding of
+// `need` itself can add up to (< 1e-6) -- so that it only drops candidates the exact test below would drop as well.
+__device__ __forceinline__ float screen_need(const Cand& best, double bar)
+{
+    const double need = best.found ? (best.prod > bar ? best.prod : bar) : bar;
+    return (float)need * (1.0f - 1e-5f);
+}
+__device__ __forceinline__ bool screen32(uint32_t size1, uint32_t tp1, uint32_t tot1, uint32_t n, uint32_t min_ndps, float need)
+{
+    const uint32_t size2 = n - size1;
+    if (size1 < min_ndps || size2 < min_ndps) return false;
+    const bool small1 = size1 < size2;
+    const uint32_t TP = small1 ? tp1 : n - (size1 + tot1 - tp1), TOT = small1 ? tot1 : n - tot1, SZ = small1 ? size1 : size2;
+    const float tp = (float)TP;
+    return !(tp * tp < need * ((float)TOT * (float)SZ));
+}
+
 // SCGs present in the (node, dimension): lo != INT_MAX.  Up to SCG_LDS SCGs are compacted into LDS (the gate of a candidate
 // then walks the present ones only); a table with more is read in place.  Call by all threads.
 __device__ __forceinline__ ScgView stage_scgs(const int32_t* __restrict__ lo, const int32_t* __restrict__ hi, int n_scg, int32_t* s_lo, int32_t* s_hi, int* s_ng)
@@ -373,7 +425,7 @@ __global__ __launch_bounds__(256) void tree_eval_narrow_kernel(TreeDev Tr, const
     const int d = Tr.narrow[dn];
     const int T = Tr.P.T[d];
     const NodeDev nd = nodes[k];
-    const long long n = nd.dp_end - nd.dp_begin;
+    const long long n = nd.n;
     const int64_t at = (int64_t)k * Tr.TBn + Tr.toffn[dn];
     const int64_t sg = ((int64_t)k * Tr.D + d) * Tr.P.n_scg;
     const ScgView scg = stage_scgs(scg_lo + sg, scg_hi + sg, Tr.P.n_scg, s_lo, s_hi, &s_ng);
@@ -422,121 +474,257 @@ __global__ __launch_bounds__(64) void tree_bar_kernel(TreeDev Tr, const Cand* __
 }
 
 // ---- wide dimensions ------------------------------------------------------------------------------------------------
-// what the dp at a sorted position adds to the prefix sums of its node (all static: see tree_static_wide_kernel)
-__device__ __forceinline__ WSums position_terms(const TreeDev& Tr, int w, uint32_t word)
+// What the dps at a thread's 8 sorted positions add to the prefix sums of their node (all static: see tree_static_wide_kernel).
+// First the packed records of the scaffolds that OWN one of the positions (x | y << 6 | z << 13; 0 where the position adds
+// no record: not W_OWN, dead, or its bit of `use` clear; PACK_ESCAPE: a scaffold too large for the packed form) -- as eight
+// independent loads with no branch around them: a load under a branch is waited for before the next is issued, and eight
+// round trips in a row were most of these kernels' time.  A position without a record reads entry 0.
+__device__ __forceinline__ void load_packs(const TreeDev& Tr, int w, const uint32_t (&wd)[8], uint32_t use, uint32_t (&pk)[8])
 {
-    WSums r = {(unsigned long long)(word >> 31), 0, 0};
-    if (word & W_OWN) {
-        const uint32_t pk = Tr.wpack[(int64_t)w * Tr.S + (word & W_SC)];
-        if (pk != PACK_ESCAPE) { r.tp1 += pk & 63u; r.tot = (pk >> 6) & 127u; r.bp = pk >> 13; }
-        else { const uint4 e = Tr.wext[(int64_t)w * Tr.S + (word & W_SC)]; r.tp1 += e.x; r.tot = e.y; r.bp = e.z; }
+    uint32_t own = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) own |= (uint32_t)((wd[i] & (W_OWN | W_DEAD)) == W_OWN) << i;
+    own &= use;
+    if (Tr.sinfo) {
+        uint32_t si[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) si[i] = Tr.sinfo[((own >> i) & 1u) ? (wd[i] & W_SC22) : 0u];
+#pragma unroll
+        for (int i = 0; i < 8; i++) pk[i] = ((own >> i) & 1u) ? (((wd[i] >> W_X_SHIFT) & 63u) | (si[i] & 127u) << 6 | (si[i] >> 7) << 13) : 0u;
+    } else {
+        const uint32_t* __restrict__ tab = Tr.wpack + (int64_t)w * Tr.S;
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = tab[((own >> i) & 1u) ? (wd[i] & W_SC) : 0u];
+#pragma unroll
+        for (int i = 0; i < 8; i++) pk[i] = ((own >> i) & 1u) ? v[i] : 0u;
     }
+}
+// ... then the terms of one position from its word and its record (live: the position counts at all)
+__device__ __forceinline__ WSums pack_wsums(const TreeDev& Tr, int w, uint32_t word, uint32_t pk, bool live)
+{
+    WSums r = {live ? (unsigned long long)(word >> 31) : 0ull, 0, 0};
+    if (pk == PACK_ESCAPE) { const uint4 e = Tr.wext[(int64_t)w * Tr.S + (word & W_SC)]; r.tp1 += e.x; r.tot = e.y; r.bp = e.z; }      // rare
+    else { r.tp1 += pk & 63u; r.tot = (pk >> 6) & 127u; r.bp = pk >> 13; }
     return r;
 }
+__device__ __forceinline__ void pack_terms(uint32_t word, uint32_t pk, uint32_t& tp, uint32_t& tot)      // pk != PACK_ESCAPE
+{
+    tp = ((word & W_DEAD) ? 0u : (word >> 31)) + (pk & 63u);
+    tot = (pk >> 6) & 127u;
+}
+// one byte per scaffold (a node's members, the sides of a split) for the scaffolds of 8 position words, the same way
+__device__ __forceinline__ void load_scaf_bytes(const uint8_t* __restrict__ tab, const uint32_t (&wd)[8], uint32_t use, uint32_t sc_mask, uint8_t (&out)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = tab[((use >> i) & 1u) ? (wd[i] & sc_mask) : 0u];
+}
 
-// pass 1: sums of every position tile.  grid (position tiles, wide dimensions)
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* sh)          // sh: 4 words
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    __syncthreads();
+    if (lane == 63) sh[wid] = x;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int k = 0; k < wid; k++) off += sh[k];
+    return off + x - v;
+}
+
+// pass 1: sums of every position tile (live positions only; a tile's count and tot share a word: both < 2^32).
+// grid (position tiles, wide dimensions)
 __global__ __launch_bounds__(256) void tree_wide_sums_kernel(TreeDev Tr, const Tile* __restrict__ tiles, int32_t n_tiles, const uint32_t* __restrict__ wword,
-                                                            int64_t wstride, WSums* __restrict__ tile_sums)
+                                                            int64_t wstride, WSums4* __restrict__ tile_sums)
 {
     __shared__ unsigned long long sh[8];
     const Tile t = tiles[blockIdx.x];
     const int w = blockIdx.y;
     const uint32_t* __restrict__ words = wword + (int64_t)w * wstride;
-    WSums a = {0, 0, 0};
+    WSums4 a = {0, 0, 0, 0};
     const int i0 = (t.begin & ~(TILE_P - 1)) + 8 * threadIdx.x;
     uint32_t wd[8];
-    load8(words, i0, t.begin, t.end, wd, 0u);                 // a zero word adds nothing
+    load8_stream(words, i0, t.begin, t.end, wd, W_DEAD);             // a dead word adds nothing
+    uint32_t pk[8];
+    load_packs(Tr, w, wd, 0xFFu, pk);
 #pragma unroll
-    for (int i = 0; i < 8; i++) { const WSums r = position_terms(Tr, w, wd[i]); a.tp1 += r.tp1; a.tot += r.tot; a.bp += r.bp; }
-    const unsigned long long s1 = block_sum_u64(a.tp1, sh);
-    const unsigned long long s3 = block_sum_u64(a.tot, sh + 4);
-    const unsigned long long s2 = block_sum_u64(a.bp, sh);
-    if (threadIdx.x == 0) tile_sums[(int64_t)w * n_tiles + blockIdx.x] = WSums{s1, s3, s2};
+    for (int i = 0; i < 8; i++) {
+        const bool live = !(wd[i] & W_DEAD);
+        const WSums r = pack_wsums(Tr, w, wd[i], pk[i], live);
+        a.size += live ? 1u : 0u; a.tp1 += r.tp1; a.tot += r.tot; a.bp += r.bp;
+    }
+    const unsigned long long s0 = block_sum_u64(a.size | (a.tot << 32), sh);           // inside a tile every sum fits 32 bits (see the eval kernel)
+    const unsigned long long s1 = block_sum_u64(a.tp1 | (a.bp << 32), sh + 4);
+    if (threadIdx.x == 0) tile_sums[(int64_t)w * n_tiles + blockIdx.x] = WSums4{s0 & 0xFFFFFFFFull, s1 & 0xFFFFFFFFull, s0 >> 32, s1 >> 32};
 }
 
 // pass 1b: exclusive scan of the tile sums inside every node; node totals.  grid (nodes, wide dimensions), one wave
-__global__ __launch_bounds__(64) void tree_wide_scan_kernel(const NodeDev* __restrict__ nodes, int32_t n_tiles, WSums* __restrict__ tile_sums,
-                                                           WSums* __restrict__ node_total, int32_t K)
+__global__ __launch_bounds__(64) void tree_wide_scan_kernel(const NodeDev* __restrict__ nodes, int32_t n_tiles, WSums4* __restrict__ tile_sums,
+                                                           WSums4* __restrict__ node_total, int32_t K)
 {
     const int k = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
     const NodeDev nd = nodes[k];
-    WSums* ts = tile_sums + (int64_t)w * n_tiles;
-    WSums run = {0, 0, 0};
+    WSums4* ts = tile_sums + (int64_t)w * n_tiles;
+    WSums4 run = {0, 0, 0, 0};
     for (int i0 = nd.ptile_begin; i0 < nd.ptile_end; i0 += 64) {
         const int i = i0 + lane;
-        WSums v = {0, 0, 0};
+        WSums4 v = {0, 0, 0, 0};
         if (i < nd.ptile_end) v = ts[i];
-        WSums x = v;
+        WSums4 x = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long a = __shfl_up(x.tp1, o, 64), b = __shfl_up(x.tot, o, 64), c = __shfl_up(x.bp, o, 64);
-            if (lane >= o) { x.tp1 += a; x.tot += b; x.bp += c; }
+            const unsigned long long z = __shfl_up(x.size, o, 64), a = __shfl_up(x.tp1, o, 64), b = __shfl_up(x.tot, o, 64), c = __shfl_up(x.bp, o, 64);
+            if (lane >= o) { x.size += z; x.tp1 += a; x.tot += b; x.bp += c; }
         }
-        if (i < nd.ptile_end) ts[i] = WSums{run.tp1 + x.tp1 - v.tp1, run.tot + x.tot - v.tot, run.bp + x.bp - v.bp};
-        run.tp1 += __shfl(x.tp1, 63, 64); run.tot += __shfl(x.tot, 63, 64); run.bp += __shfl(x.bp, 63, 64);
+        if (i < nd.ptile_end) ts[i] = WSums4{run.size + x.size - v.size, run.tp1 + x.tp1 - v.tp1, run.tot + x.tot - v.tot, run.bp + x.bp - v.bp};
+        run.size += __shfl(x.size, 63, 64); run.tp1 += __shfl(x.tp1, 63, 64); run.tot += __shfl(x.tot, 63, 64); run.bp += __shfl(x.bp, 63, 64);
     }
     if (lane == 0) node_total[(int64_t)w * K + k] = run;
 }
 
-// pass 2: rescan every tile with its carry, evaluate the threshold at every run end (the last position of a bin inside
-// the node), keep the tile's best.  grid (position tiles, wide dimensions)
+// pass 2a, the screen: rescan every tile with its carry and ask at every run end (the last position of a bin inside the
+// node's segment) whether its threshold could reach the node's bar at all (screen32).  The tiles where one does -- a few, once
+// the narrow dimensions have set a bar -- are listed for pass 2b; the others are done.  Kept lean (no candidate, no SCG lists,
+// no fp64: 8 waves per SIMD), because a block lives about as long as a handful of memory round trips.
+// grid (position tiles, wide dimensions)
+__global__ __launch_bounds__(256) void tree_wide_screen_kernel(TreeDev Tr, const Tile* __restrict__ tiles, int32_t n_tiles, const NodeDev* __restrict__ nodes,
+                                                              int32_t min_ndps, const int32_t* __restrict__ wbin, const uint32_t* __restrict__ wword,
+                                                              int64_t wstride, const WSums4* __restrict__ tile_carry, const double* __restrict__ bar,
+                                                              Cand* __restrict__ tile_best, int32_t* __restrict__ list, int32_t* __restrict__ list_n)
+{
+    __shared__ unsigned long long sh[5];
+    __shared__ uint32_t sh32[4];
+    const Tile t = tiles[blockIdx.x];
+    const int w = blockIdx.y;
+    const int32_t* __restrict__ bins = wbin + (int64_t)w * wstride;
+    const uint32_t* __restrict__ words = wword + (int64_t)w * wstride;
+    const int i0 = (t.begin & ~(TILE_P - 1)) + 8 * threadIdx.x;
+    uint32_t wd[8], pk[8];
+    int b[9];
+    load8_stream(words, i0, t.begin, t.end, wd, W_DEAD);
+    {
+        int b8[8];
+        load8_stream(bins, i0, t.begin, t.end, b8, -1);
+#pragma unroll
+        for (int i = 0; i < 8; i++) b[i] = b8[i];
+    }
+    const NodeDev nd = nodes[t.node];
+    b[8] = (i0 + 8 < nd.dp_end) ? bins[i0 + 8] : -1;              // -1 past the segment's end (where a partial tile ends, too): the last run ends there
+    const WSums4 carry = tile_carry[(int64_t)w * n_tiles + blockIdx.x];
+    const double node_bar = bar[t.node];
+    load_packs(Tr, w, wd, 0xFFu, pk);
+    // all the walk needs of a position, in one register: live | run end << 1 | tp << 2 | tot << 9
+    uint32_t info[8];
+    uint32_t a_size = 0, a_tp = 0, a_tot = 0;
+    bool hit = false;                                         // a tile with a scaffold too large for the packed form goes to pass 2b as it is
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t tp, tot;
+        hit |= pk[i] == PACK_ESCAPE;
+        pack_terms(wd[i], pk[i], tp, tot);
+        const uint32_t live = (wd[i] & W_DEAD) ? 0u : 1u;
+        const uint32_t run_end = (i0 + i >= t.begin && i0 + i < t.end && b[i + 1] != b[i]) ? 2u : 0u;      // threshold = this bin
+        info[i] = live | run_end | tp << 2 | tot << 9;
+        a_size += live; a_tp += tp; a_tot += tot;
+    }
+    // inside a tile every sum fits 32 bits (tp1, tot: a scaffold owns one position per dimension, so they stay below N + 2048)
+    const unsigned long long o0 = block_excl_scan_u64((unsigned long long)a_size | ((unsigned long long)a_tot << 32), sh, nullptr);
+    const uint32_t o1 = block_excl_scan_u32(a_tp, sh32);
+    uint32_t size1 = (uint32_t)(carry.size + (o0 & 0xFFFFFFFFull)), tp1 = (uint32_t)carry.tp1 + o1, tot1 = (uint32_t)(carry.tot + (o0 >> 32));
+    const uint32_t n32 = (uint32_t)nd.n, mn32 = (uint32_t)max(min_ndps, 0);
+    const Cand none = {0.0, 0, 0, 0.0, 0.0, 0};
+    const float need = screen_need(none, node_bar);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        size1 += info[i] & 1u; tp1 += (info[i] >> 2) & 127u; tot1 += (info[i] >> 9) & 127u;      // (nothing outside the tile: dead words there)
+        hit |= (info[i] & 2u) && screen32(size1, tp1, tot1, n32, mn32, need);
+    }
+    const int any = __syncthreads_or(hit);
+    if (threadIdx.x == 0) {
+        tile_best[(int64_t)w * n_tiles + blockIdx.x] = none;
+        if (any) list[atomicAdd(list_n, 1)] = w * n_tiles + (int)blockIdx.x;
+    }
+}
+
+// pass 2b: the listed tiles again, with everything: evaluate the threshold at every run end (the last position of a bin inside
+// the node's segment), keep the tile's best.  A run end whose bin holds only dead positions repeats its predecessor's sums
+// at a larger threshold: never better (see node_wide_eval_kernel).  grid (position tiles, wide dimensions)
 __global__ __launch_bounds__(256) void tree_wide_eval_kernel(TreeDev Tr, const Tile* __restrict__ tiles, int32_t n_tiles, const NodeDev* __restrict__ nodes,
                                                             int32_t K, int32_t min_ndps, const int32_t* __restrict__ wbin, const uint32_t* __restrict__ wword,
-                                                            int64_t wstride, const WSums* __restrict__ tile_carry, const WSums* __restrict__ node_total,
+                                                            int64_t wstride, const WSums4* __restrict__ tile_carry, const WSums4* __restrict__ node_total,
                                                             const int32_t* __restrict__ scg_lo, const int32_t* __restrict__ scg_hi,
-                                                            const double* __restrict__ bar, Cand* __restrict__ tile_best)
+                                                            const double* __restrict__ bar, Cand* __restrict__ tile_best,
+                                                            const int32_t* __restrict__ list, const int32_t* __restrict__ list_n)
 {
-    __shared__ unsigned long long sh[3][5];
+    __shared__ unsigned long long sh[2][5];
     __shared__ int32_t s_lo[SCG_LDS], s_hi[SCG_LDS];
     __shared__ int s_ng;
     __shared__ Cand wbest[4];
-    const Tile t = tiles[blockIdx.x];
-    const int w = blockIdx.y;
+    const int n_listed = *list_n;
+  for (int li = blockIdx.x; li < n_listed; li += gridDim.x) {         // (a block's turns are separated by the barriers of block_best)
+    const int entry = list[li];
+    const int w = entry / n_tiles, tile = entry - w * n_tiles;
+    const Tile t = tiles[tile];
     const int d = Tr.wide[w];
     const NodeDev nd = nodes[t.node];
-    const long long n = nd.dp_end - nd.dp_begin;
-    const int64_t sg = ((int64_t)t.node * Tr.D + d) * Tr.P.n_scg;
-    const ScgView scg = stage_scgs(scg_lo + sg, scg_hi + sg, Tr.P.n_scg, s_lo, s_hi, &s_ng);
+    const long long n = nd.n;
     const int32_t* __restrict__ bins = wbin + (int64_t)w * wstride;
     const uint32_t* __restrict__ words = wword + (int64_t)w * wstride;
-    const unsigned long long bp_total = node_total[(int64_t)w * K + t.node].bp;
-    const double node_bar = bar[t.node];
     const int i0 = (t.begin & ~(TILE_P - 1)) + 8 * threadIdx.x;
     int b[9];
     uint32_t wd[8];
     uint32_t r_tp[8], r_tot[8], r_bp[8];                 // one position's terms fit 32 bits each (dps of a scaffold; a clamped length)
-    WSums a = {0, 0, 0};
+    WSums4 a = {0, 0, 0, 0};
+    // the tile's own loads first: a block lives about as long as a handful of memory round trips, and the SCG staging below
+    // (a round trip, LDS atomics, two barriers) would otherwise stand in front of them
+    load8_stream(words, i0, t.begin, t.end, wd, W_DEAD);
     {
         int b8[8];
-        load8(bins, i0, t.begin, t.end, b8, -1);
+        load8_stream(bins, i0, t.begin, t.end, b8, -1);
 #pragma unroll
         for (int i = 0; i < 8; i++) b[i] = b8[i];
-        b[8] = (i0 + 8 < nd.dp_end) ? bins[i0 + 8] : -1;            // -1 past the node's end (where a partial tile ends, too): the last run ends there
+        b[8] = (i0 + 8 < nd.dp_end) ? bins[i0 + 8] : -1;            // -1 past the segment's end (where a partial tile ends, too): the last run ends there
     }
-    load8(words, i0, t.begin, t.end, wd, 0u);
+    const WSums4 carry = tile_carry[(int64_t)w * n_tiles + tile];
+    const unsigned long long bp_total = node_total[(int64_t)w * K + t.node].bp;
+    const double node_bar = bar[t.node];
+    {
+        uint32_t pk[8];
+        load_packs(Tr, w, wd, 0xFFu, pk);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const WSums r = position_terms(Tr, w, wd[i]);
-        r_tp[i] = (uint32_t)r.tp1; r_tot[i] = (uint32_t)r.tot; r_bp[i] = (uint32_t)r.bp;
-        a.tp1 += r.tp1; a.tot += r.tot; a.bp += r.bp;
+        for (int i = 0; i < 8; i++) {
+            const bool live = !(wd[i] & W_DEAD);
+            const WSums r = pack_wsums(Tr, w, wd[i], pk[i], live);
+            r_tp[i] = (uint32_t)r.tp1; r_tot[i] = (uint32_t)r.tot; r_bp[i] = (uint32_t)r.bp;
+            a.size += live ? 1u : 0u; a.tp1 += r.tp1; a.tot += r.tot; a.bp += r.bp;
+        }
     }
-    const WSums carry = tile_carry[(int64_t)w * n_tiles + blockIdx.x];
-    const unsigned long long o1 = block_excl_scan_u64(a.tp1, sh[0], nullptr);
-    const unsigned long long o3 = block_excl_scan_u64(a.tot, sh[2], nullptr);
-    const unsigned long long o2 = block_excl_scan_u64(a.bp, sh[1], nullptr);
-    long long tp1 = (long long)(carry.tp1 + o1), tot1 = (long long)(carry.tot + o3);
-    unsigned long long bp1 = carry.bp + o2;
+    // inside a tile every sum fits 32 bits (tp1, tot: a scaffold owns one position per dimension, so they stay below
+    // N + 2048; bp: 2048 lengths clamped to 500 000)
+    const unsigned long long o0 = block_excl_scan_u64(a.size | (a.tot << 32), sh[0], nullptr);
+    const unsigned long long o1 = block_excl_scan_u64(a.tp1 | (a.bp << 32), sh[1], nullptr);
+    uint32_t size1 = (uint32_t)(carry.size + (o0 & 0xFFFFFFFFull)), tp1 = (uint32_t)(carry.tp1 + (o1 & 0xFFFFFFFFull)), tot1 = (uint32_t)(carry.tot + (o0 >> 32));
+    unsigned long long bp1 = carry.bp + (o1 >> 32);
     Cand best = {0.0, 0, 0, 0.0, 0.0, 0};
+    const uint32_t n32 = (uint32_t)n, mn32 = (uint32_t)max(min_ndps, 0);
+    float need = screen_need(best, node_bar);
+    const int64_t sg = ((int64_t)t.node * Tr.D + d) * Tr.P.n_scg;
+    const ScgView scg = stage_scgs(scg_lo + sg, scg_hi + sg, Tr.P.n_scg, s_lo, s_hi, &s_ng);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         if (i0 + i >= t.begin && i0 + i < t.end) {
-            tp1 += (long long)r_tp[i]; tot1 += (long long)r_tot[i]; bp1 += r_bp[i];
-            if (b[i + 1] != b[i])                                                       // a run end: threshold = this bin
-                eval_threshold((long long)(i0 + i - nd.dp_begin + 1), tp1, tot1, bp1, n, bp_total, min_ndps, b[i], scg, best, node_bar);
+            size1 += (wd[i] & W_DEAD) ? 0u : 1u; tp1 += r_tp[i]; tot1 += r_tot[i]; bp1 += r_bp[i];
+            if (b[i + 1] != b[i] && screen32(size1, tp1, tot1, n32, mn32, need)) {       // a run end: threshold = this bin
+                eval_threshold((long long)size1, (long long)tp1, (long long)tot1, bp1, n, bp_total, min_ndps, b[i], scg, best, node_bar);
+                need = screen_need(best, node_bar);
+            }
         }
     }
     const Cand bb = block_best(best, wbest);
-    if (threadIdx.x == 0) tile_best[(int64_t)w * n_tiles + blockIdx.x] = bb;
+    if (threadIdx.x == 0) tile_best[(int64_t)w * n_tiles + tile] = bb;
+  }
 }
 
 // best tile of every (node, wide dimension).  grid (nodes, wide dimensions), one wave
@@ -559,8 +747,6 @@ __global__ __launch_bounds__(64) void tree_wide_best_kernel(TreeDev Tr, const No
 // values, which are values of the node), as its predecessor left them -- the same product at a larger threshold, which
 // never replaces the smaller one (ref ...Specificity.h:25-30); before the node's first value size1 = 0 fails the size
 // check, or 0 / 0 = NaN is never better.  The bin is read only for a candidate that gets as far as the gate.
-struct WSums4 { unsigned long long size, tp1, tot, bp; };
-
 template <bool MASKED>
 __global__ __launch_bounds__(256) void node_wide_sums_kernel(TreeDev Tr, int32_t N, int32_t n_tiles, const uint32_t* __restrict__ wword, int64_t wstride,
                                                             const uint8_t* __restrict__ member, WSums4* __restrict__ tile_sums)
@@ -571,19 +757,28 @@ __global__ __launch_bounds__(256) void node_wide_sums_kernel(TreeDev Tr, int32_t
     const int begin = blockIdx.x * TILE_P, end = min(N, begin + TILE_P);
     const int i0 = begin + 8 * threadIdx.x;
     uint32_t wd[8];
-    load8(words, i0, begin, end, wd, 0u);
+    load8_stream(words, i0, begin, end, wd, 0u);
     WSums4 a = {0, 0, 0, 0};
+    uint32_t in = 0;                                          // the positions of the tile that belong to the node
+#pragma unroll
+    for (int i = 0; i < 8; i++) in |= (uint32_t)(i0 + i < end) << i;
+    if (MASKED) {
+        uint8_t mb[8];
+        load_scaf_bytes(member, wd, in, Tr.sc_mask, mb);
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (!mb[i]) in &= ~(1u << i);
+    }
+    uint32_t pk[8];
+    load_packs(Tr, w, wd, in, pk);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        if (i0 + i < end && (!MASKED || member[wd[i] & W_SC])) {
-            const WSums r = position_terms(Tr, w, wd[i]);
-            a.size++; a.tp1 += r.tp1; a.tot += r.tot; a.bp += r.bp;
-        }
+        const bool live = (in >> i) & 1u;
+        const WSums r = pack_wsums(Tr, w, wd[i], pk[i], live);
+        a.size += live ? 1u : 0u; a.tp1 += r.tp1; a.tot += r.tot; a.bp += r.bp;
     }
-    const unsigned long long s0 = block_sum_u64(a.size | (a.tot << 32), sh);          // a tile holds 2048 positions; tot of a tile < 2^32
-    const unsigned long long s1 = block_sum_u64(a.tp1, sh + 4);
-    const unsigned long long s2 = block_sum_u64(a.bp, sh);
-    if (threadIdx.x == 0) tile_sums[(int64_t)w * n_tiles + blockIdx.x] = WSums4{s0 & 0xFFFFFFFFull, s1, s0 >> 32, s2};
+    const unsigned long long s0 = block_sum_u64(a.size | (a.tot << 32), sh);          // a tile holds 2048 positions: every sum of a tile < 2^32
+    const unsigned long long s1 = block_sum_u64(a.tp1 | (a.bp << 32), sh + 4);
+    if (threadIdx.x == 0) tile_sums[(int64_t)w * n_tiles + blockIdx.x] = WSums4{s0 & 0xFFFFFFFFull, s1 & 0xFFFFFFFFull, s0 >> 32, s1 >> 32};
 }
 
 // exclusive scan of the tile sums of every wide dimension; totals.  grid (wide dimensions), one wave
@@ -644,61 +839,138 @@ __device__ __forceinline__ void eval_threshold_lazy(long long size1, long long t
     if (pass) best = Cand{prod, bin, 1, sens, spec, size1};
 }
 
-// pass 2: rescan every tile with its carry, evaluate at the static run ends.  grid (position tiles, wide dimensions)
+// pass 2a, the screen (as tree_wide_screen_kernel): which tiles hold a static run end whose threshold could reach the node's
+// bar.  grid (position tiles, wide dimensions)
+template <bool MASKED>
+__global__ __launch_bounds__(256) void node_wide_screen_kernel(TreeDev Tr, int32_t N, int32_t n_tiles, int32_t min_ndps, const uint32_t* __restrict__ wword,
+                                                              int64_t wstride, const uint8_t* __restrict__ member, const WSums4* __restrict__ tile_carry,
+                                                              const WSums4* __restrict__ total, const double* __restrict__ bar, Cand* __restrict__ tile_best,
+                                                              int32_t* __restrict__ list, int32_t* __restrict__ list_n)
+{
+    __shared__ unsigned long long sh[5];
+    __shared__ uint32_t sh32[4];
+    const int w = blockIdx.y;
+    const uint32_t* __restrict__ words = wword + (int64_t)w * wstride;
+    const int begin = blockIdx.x * TILE_P, end = min(N, begin + TILE_P);
+    const int i0 = begin + 8 * threadIdx.x;
+    uint32_t wd[8], pk[8];
+    load8_stream(words, i0, begin, end, wd, 0u);
+    const WSums4 carry = tile_carry[(int64_t)w * n_tiles + blockIdx.x];
+    const uint32_t n32 = (uint32_t)total[w].size;
+    const double node_bar = bar[0];
+    uint32_t in = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) in |= (uint32_t)(i0 + i < end) << i;
+    const uint32_t inside = in;
+    if (MASKED) {
+        uint8_t mb[8];
+        load_scaf_bytes(member, wd, in, Tr.sc_mask, mb);
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (!mb[i]) in &= ~(1u << i);
+    }
+    load_packs(Tr, w, wd, in, pk);
+    uint32_t info[8];                                         // live | run end << 1 | tp << 2 | tot << 9
+    uint32_t a_size = 0, a_tp = 0, a_tot = 0;
+    bool hit = false;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t live = (in >> i) & 1u;
+        hit |= pk[i] == PACK_ESCAPE;
+        const uint32_t tp = (live ? (wd[i] >> 31) : 0u) + (pk[i] & 63u), tot = (pk[i] >> 6) & 127u;
+        const uint32_t run_end = (((inside >> i) & 1u) && (wd[i] & W_END)) ? 2u : 0u;
+        info[i] = live | run_end | tp << 2 | tot << 9;
+        a_size += live; a_tp += tp; a_tot += tot;
+    }
+    const unsigned long long o0 = block_excl_scan_u64((unsigned long long)a_size | ((unsigned long long)a_tot << 32), sh, nullptr);
+    const uint32_t o1 = block_excl_scan_u32(a_tp, sh32);
+    uint32_t size1 = (uint32_t)(carry.size + (o0 & 0xFFFFFFFFull)), tp1 = (uint32_t)carry.tp1 + o1, tot1 = (uint32_t)(carry.tot + (o0 >> 32));
+    const uint32_t mn32 = (uint32_t)max(min_ndps, 0);
+    const Cand none = {0.0, 0, 0, 0.0, 0.0, 0};
+    const float need = screen_need(none, node_bar);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        size1 += info[i] & 1u; tp1 += (info[i] >> 2) & 127u; tot1 += (info[i] >> 9) & 127u;
+        hit |= (info[i] & 2u) && screen32(size1, tp1, tot1, n32, mn32, need);
+    }
+    const int any = __syncthreads_or(hit);
+    if (threadIdx.x == 0) {
+        tile_best[(int64_t)w * n_tiles + blockIdx.x] = none;
+        if (any) list[atomicAdd(list_n, 1)] = w * n_tiles + (int)blockIdx.x;
+    }
+}
+
+// pass 2b: the listed tiles (list == NULL: every tile) again with everything; evaluate at the static run ends.  grid: any
 template <bool MASKED>
 __global__ __launch_bounds__(256) void node_wide_eval_kernel(TreeDev Tr, int32_t N, int32_t n_tiles, int32_t min_ndps, const int32_t* __restrict__ sbin,
                                                             const uint32_t* __restrict__ wword, int64_t wstride, const uint8_t* __restrict__ member,
                                                             const WSums4* __restrict__ tile_carry, const WSums4* __restrict__ total,
                                                             const int32_t* __restrict__ scg_lo, const int32_t* __restrict__ scg_hi,
-                                                            const double* __restrict__ bar, Cand* __restrict__ tile_best)
+                                                            const double* __restrict__ bar, Cand* __restrict__ tile_best,
+                                                            const int32_t* __restrict__ list, const int32_t* __restrict__ list_n)
 {
-    __shared__ unsigned long long sh[3][5];
+    __shared__ unsigned long long sh[2][5];
     __shared__ int32_t s_lo[SCG_LDS], s_hi[SCG_LDS];
     __shared__ int s_ng;
     __shared__ Cand wbest[4];
-    const int w = blockIdx.y;
+    const int n_listed = list ? *list_n : n_tiles * Tr.n_wide;
+  for (int li = blockIdx.x; li < n_listed; li += gridDim.x) {         // (a block's turns are separated by the barriers of block_best)
+    const int entry = list ? list[li] : li;
+    const int w = entry / n_tiles, tile = entry - w * n_tiles;
     const int d = Tr.wide[w];
     const WSums4 tot = total[w];
     const long long n = (long long)tot.size;
-    const int64_t sg = (int64_t)d * Tr.P.n_scg;
-    const ScgView scg = stage_scgs(scg_lo + sg, scg_hi + sg, Tr.P.n_scg, s_lo, s_hi, &s_ng);
     const int32_t* __restrict__ bins = sbin + (int64_t)w * N;
     const uint32_t* __restrict__ words = wword + (int64_t)w * wstride;
     const double node_bar = bar[0];
-    const int begin = blockIdx.x * TILE_P, end = min(N, begin + TILE_P);
+    const int begin = tile * TILE_P, end = min(N, begin + TILE_P);
     const int i0 = begin + 8 * threadIdx.x;
     uint32_t wd[8];
     uint32_t r_tp[8], r_tot[8], r_bp[8];
     uint32_t in = 0;
     WSums4 a = {0, 0, 0, 0};
-    load8(words, i0, begin, end, wd, 0u);
+    load8_stream(words, i0, begin, end, wd, 0u);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        r_tp[i] = r_tot[i] = r_bp[i] = 0;
-        if (i0 + i < end && (!MASKED || member[wd[i] & W_SC])) {
-            const WSums r = position_terms(Tr, w, wd[i]);
+    for (int i = 0; i < 8; i++) in |= (uint32_t)(i0 + i < end) << i;
+    if (MASKED) {
+        uint8_t mb[8];
+        load_scaf_bytes(member, wd, in, Tr.sc_mask, mb);
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (!mb[i]) in &= ~(1u << i);
+    }
+    {
+        uint32_t pk[8];
+        load_packs(Tr, w, wd, in, pk);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const bool live = (in >> i) & 1u;
+            const WSums r = pack_wsums(Tr, w, wd[i], pk[i], live);
             r_tp[i] = (uint32_t)r.tp1; r_tot[i] = (uint32_t)r.tot; r_bp[i] = (uint32_t)r.bp;
-            in |= 1u << i;
-            a.size++; a.tp1 += r.tp1; a.tot += r.tot; a.bp += r.bp;
+            a.size += live ? 1u : 0u; a.tp1 += r.tp1; a.tot += r.tot; a.bp += r.bp;
         }
     }
-    const WSums4 carry = tile_carry[(int64_t)w * n_tiles + blockIdx.x];
+    const WSums4 carry = tile_carry[(int64_t)w * n_tiles + tile];
     const unsigned long long o0 = block_excl_scan_u64(a.size | (a.tot << 32), sh[0], nullptr);
-    const unsigned long long o1 = block_excl_scan_u64(a.tp1, sh[1], nullptr);
-    const unsigned long long o2 = block_excl_scan_u64(a.bp, sh[2], nullptr);
-    long long size1 = (long long)(carry.size + (o0 & 0xFFFFFFFFull)), tp1 = (long long)(carry.tp1 + o1), tot1 = (long long)(carry.tot + (o0 >> 32));
-    unsigned long long bp1 = carry.bp + o2;
+    const unsigned long long o1 = block_excl_scan_u64(a.tp1 | (a.bp << 32), sh[1], nullptr);
+    uint32_t size1 = (uint32_t)(carry.size + (o0 & 0xFFFFFFFFull)), tp1 = (uint32_t)(carry.tp1 + (o1 & 0xFFFFFFFFull)), tot1 = (uint32_t)(carry.tot + (o0 >> 32));
+    unsigned long long bp1 = carry.bp + (o1 >> 32);
     Cand best = {0.0, 0, 0, 0.0, 0.0, 0};
+    const uint32_t n32 = (uint32_t)n, mn32 = (uint32_t)max(min_ndps, 0);
+    float need = screen_need(best, node_bar);
+    const int64_t sg = (int64_t)d * Tr.P.n_scg;
+    const ScgView scg = stage_scgs(scg_lo + sg, scg_hi + sg, Tr.P.n_scg, s_lo, s_hi, &s_ng);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         if (i0 + i < end) {
-            if (in & (1u << i)) { size1++; tp1 += (long long)r_tp[i]; tot1 += (long long)r_tot[i]; bp1 += r_bp[i]; }
-            if (wd[i] & W_END)
-                eval_threshold_lazy(size1, tp1, tot1, bp1, n, tot.bp, min_ndps, [&]() { return bins[i0 + i]; }, scg, best, node_bar);
+            if (in & (1u << i)) { size1++; tp1 += r_tp[i]; tot1 += r_tot[i]; bp1 += r_bp[i]; }
+            if ((wd[i] & W_END) && screen32(size1, tp1, tot1, n32, mn32, need)) {
+                eval_threshold_lazy((long long)size1, (long long)tp1, (long long)tot1, bp1, n, tot.bp, min_ndps, [&]() { return bins[i0 + i]; }, scg, best, node_bar);
+                need = screen_need(best, node_bar);
+            }
         }
     }
     const Cand bb = block_best(best, wbest);
-    if (threadIdx.x == 0) tile_best[(int64_t)w * n_tiles + blockIdx.x] = bb;
+    if (threadIdx.x == 0) tile_best[(int64_t)w * n_tiles + tile] = bb;
+  }
 }
 
 // best tile of every wide dimension -> the dimension's record of abw_sep_node.  grid (wide dimensions), one wave
@@ -751,7 +1023,7 @@ __global__ __launch_bounds__(64) void tree_winner_kernel(TreeDev Tr, const NodeD
     r.win.found = bd >= 0; r.win.dim = bd; r.win.bin = bd >= 0 ? bc.bin : -1;
     r.win.sens = bd >= 0 ? bc.sens : 0.0; r.win.spec = bd >= 0 ? bc.spec : 0.0;
     r.win.legal = (bd >= 0) && (bc.sens >= 0.8) && (bc.spec >= 0.8) && (bc.sens + bc.spec >= 1.6) && (bc.sens * bc.spec >= 0.8);
-    r.win.size1 = bd >= 0 ? bc.size1 : 0; r.win.n = nd.dp_end - nd.dp_begin;
+    r.win.size1 = bd >= 0 ? bc.size1 : 0; r.win.n = nd.n;
     r.n1 = r.n2 = 0; r.m1 = r.m2 = 0;
     res[k] = r;
 }
@@ -805,56 +1077,80 @@ __global__ __launch_bounds__(256) void tree_count_kernel(TreeDev Tr, const Tile*
 }
 
 // ---- partition: the next level's order of scaffolds and of every wide dimension's positions ---------------------------
-// count of cluster-1 members per tile, and their mask (one byte per thread of the tile = 8 items: the scatter does not look
-// the sides up again).  items: scaffold ids (order) or position words (scaffold in the low 30 bits); side: per scaffold.
-// grid (tiles, arrays); istride: a multiple of 8
+// The scaffold order is rewritten whole every level (a few bytes per scaffold).  The position arrays of the wide dimensions are
+// not: a child whose base is -1 KEEPS its parent's segment -- the bigger child of a split, as long as at least half of the
+// segment is still its own -- and only its sibling's positions are copied out (to fresh space behind everything in use) and
+// marked dead where they were.  The trees of a metagenome are caterpillars (a giant node sheds a genome per level): moving
+// the giant at every level was three quarters of the recursion's time.
+// Per tile: the number of live items going to cluster 1 and of live items (low / high half of tile_cnt), and their masks
+// (two bytes per thread of the tile = 8 items: the scatter does not look the sides up again).  items: scaffold ids (order) or
+// position words (scaffold in the low 28 bits, W_DEAD); side: per scaffold.  grid (tiles, arrays); istride: a multiple of 8
+// Where a child keeps the segment the items are not looked at: the positions that leave were marked in a bit map by their
+// scaffolds (tree_mark_kernel; bits: one per position of a dimension's array), and the masks are those bits -- as "going to
+// cluster 1" when cluster 1 leaves, as "live, not cluster 1" when cluster 2 does, so that the scatter's ranks come out the same.
 __global__ __launch_bounds__(256) void tree_part_count_kernel(const Tile* __restrict__ tiles, int32_t n_tiles, const NodePart* __restrict__ part,
                                                              const uint32_t* __restrict__ items, int64_t istride,
-                                                             const uint8_t* __restrict__ side, uint32_t* __restrict__ tile_cnt, uint8_t* __restrict__ mask)
+                                                             const uint8_t* __restrict__ side, uint32_t sc_mask, const uint8_t* __restrict__ bits,
+                                                             unsigned long long* __restrict__ tile_cnt, uint16_t* __restrict__ mask)
 {
     __shared__ unsigned long long sh[4];
     const Tile t = tiles[blockIdx.x];
-    if (!part[t.node].split) return;                          // uniform: a terminal node's items go nowhere
-    const uint32_t* __restrict__ it = items + (int64_t)blockIdx.y * istride;
+    const NodePart np = part[t.node];
+    if (!np.split) return;                                    // uniform: a terminal node's items go nowhere
     const int i0 = (t.begin & ~2047) + 8 * threadIdx.x;
-    uint32_t v[8];
-    load8(it, i0, t.begin, t.end, v, 0u);
-    uint32_t m = 0;
+    uint32_t m1 = 0, ma = 0;
+    if (bits && np.bits) {
+        uint32_t m = bits[((int64_t)blockIdx.y * istride + i0) >> 3];
 #pragma unroll
-    for (int i = 0; i < 8; i++) if (i0 + i >= t.begin && i0 + i < t.end) m |= (uint32_t)(side[v[i] & W_SC] == 1) << i;
-    mask[((int64_t)blockIdx.y * n_tiles + blockIdx.x) * 256 + threadIdx.x] = (uint8_t)m;      // by tile: two nodes may share 8 aligned items
-    const unsigned long long s = block_sum_u64((unsigned long long)__popc(m), sh);
-    if (threadIdx.x == 0) tile_cnt[(int64_t)blockIdx.y * n_tiles + blockIdx.x] = (uint32_t)s;
+        for (int i = 0; i < 8; i++) if (i0 + i < t.begin || i0 + i >= t.end) m &= ~(1u << i);
+        ma = m; m1 = np.dp_base1 >= 0 ? m : 0u;
+    } else {
+        const uint32_t* __restrict__ it = items + (int64_t)blockIdx.y * istride;
+        uint32_t v[8];
+        load8(it, i0, t.begin, t.end, v, W_DEAD);
+#pragma unroll
+        for (int i = 0; i < 8; i++) ma |= (uint32_t)(i0 + i >= t.begin && i0 + i < t.end && !(v[i] & W_DEAD)) << i;
+        uint8_t sd[8];
+        load_scaf_bytes(side, v, ma, sc_mask, sd);             // eight loads in flight, not one after the other
+#pragma unroll
+        for (int i = 0; i < 8; i++) m1 |= (uint32_t)(sd[i] == 1) << i;
+        m1 &= ma;
+    }
+    mask[((int64_t)blockIdx.y * n_tiles + blockIdx.x) * 256 + threadIdx.x] = (uint16_t)(m1 | (ma << 8));      // by tile: two nodes may share 8 aligned items
+    const unsigned long long s = block_sum_u64((unsigned long long)__popc(m1) | ((unsigned long long)__popc(ma) << 32), sh);
+    if (threadIdx.x == 0) tile_cnt[(int64_t)blockIdx.y * n_tiles + blockIdx.x] = s;
 }
 
 // exclusive scan of the tile counts inside every split node.  grid (nodes, arrays), one wave.  scaf = 1: scaffold tiles
 __global__ __launch_bounds__(64) void tree_part_scan_kernel(const NodeDev* __restrict__ nodes, const NodePart* __restrict__ part, int32_t n_tiles,
-                                                           uint32_t* __restrict__ tile_cnt, int scaf)
+                                                           unsigned long long* __restrict__ tile_cnt, int scaf)
 {
     const int k = blockIdx.x, lane = threadIdx.x;
     if (!part[k].split) return;
     const NodeDev nd = nodes[k];
     const int tb = scaf ? nd.stile_begin : nd.ptile_begin, te = scaf ? nd.stile_end : nd.ptile_end;
-    uint32_t* tc = tile_cnt + (int64_t)blockIdx.y * n_tiles;
-    uint32_t run = 0;
+    unsigned long long* tc = tile_cnt + (int64_t)blockIdx.y * n_tiles;
+    unsigned long long run = 0;
     for (int i0 = tb; i0 < te; i0 += 64) {
         const int i = i0 + lane;
-        const uint32_t v = (i < te) ? tc[i] : 0;
-        uint32_t x = v;
+        const unsigned long long v = (i < te) ? tc[i] : 0;
+        unsigned long long x = v;                              // both halves stay below 2^31: no carry between them
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
         if (i < te) tc[i] = run + x - v;
         run += __shfl(x, 63, 64);
     }
 }
 
-// stable scatter of a split node's items into its two children's ranges.  For scaffolds (scaf = 1) every scaffold also
-// learns the slot of its node in the next level (-1: none) and, in a terminal node, its final cluster id.  grid (tiles, arrays)
+// stable scatter of a split node's live items into its children's ranges (a child with base -1 stays where it is, and the
+// items that leave are marked dead in place: `marks`, the array itself).  For scaffolds (scaf = 1) every scaffold also learns
+// the slot of its node in the next level (-1: none) and, in a terminal node, its final cluster id.  grid (tiles, arrays)
 __global__ __launch_bounds__(256) void tree_part_scatter_kernel(const Tile* __restrict__ tiles, int32_t n_tiles, const NodeDev* __restrict__ nodes,
                                                                const NodePart* __restrict__ part, const uint32_t* __restrict__ items,
-                                                               const int32_t* __restrict__ items2, int64_t istride, const uint8_t* __restrict__ mask,
-                                                               const uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ out, int32_t* __restrict__ out2,
-                                                               int scaf, int32_t* __restrict__ scaf2cluster, int32_t* __restrict__ scaf_slot)
+                                                               const int32_t* __restrict__ items2, int64_t istride,
+                                                               const uint16_t* __restrict__ mask, const unsigned long long* __restrict__ tile_cnt,
+                                                               uint32_t* __restrict__ out, int32_t* __restrict__ out2,
+                                                               uint32_t* __restrict__ marks, int scaf, int32_t* __restrict__ scaf2cluster, int32_t* __restrict__ scaf_slot)
 {
     __shared__ unsigned long long sh[5];
     const Tile t = tiles[blockIdx.x];
@@ -870,28 +1166,61 @@ __global__ __launch_bounds__(256) void tree_part_scatter_kernel(const Tile* __re
         }
         return;
     }
-    const NodeDev nd = nodes[t.node];
-    const int nbeg = scaf ? nd.scaf_begin : nd.dp_begin;
     const int base1 = scaf ? np.scaf_base1 : np.dp_base1, base2 = scaf ? np.scaf_base2 : np.dp_base2;
-    load8(it, i0, t.begin, t.end, v, 0u);
+    const uint32_t mk = mask[((int64_t)blockIdx.y * n_tiles + blockIdx.x) * 256 + threadIdx.x];
+    const uint32_t m1 = mk & 0xFFu, ma = mk >> 8;
+    // the items are read only by the threads that have one to copy: where a child keeps the segment, almost none do
+    const uint32_t moving = (base1 >= 0 ? m1 : 0u) | (base2 >= 0 ? (ma & ~m1) : 0u);
     int32_t v2[8];
-    if (items2) load8(items2 + (int64_t)blockIdx.y * istride, i0, t.begin, t.end, v2, 0);
-    const uint32_t m = mask[((int64_t)blockIdx.y * n_tiles + blockIdx.x) * 256 + threadIdx.x];
-    unsigned long long ones_before = block_excl_scan_u64((unsigned long long)__popc(m), sh, nullptr) + tile_cnt[(int64_t)blockIdx.y * n_tiles + blockIdx.x];   // inside the node
+    if (moving || scaf) {
+        load8(it, i0, t.begin, t.end, v, W_DEAD);
+        if (items2) load8(items2 + (int64_t)blockIdx.y * istride, i0, t.begin, t.end, v2, 0);
+    }
+    const unsigned long long before = block_excl_scan_u64((unsigned long long)__popc(m1) | ((unsigned long long)__popc(ma) << 32), sh, nullptr) +
+                                      tile_cnt[(int64_t)blockIdx.y * n_tiles + blockIdx.x];                 // inside the node
+    long long ones_before = (long long)(before & 0xFFFFFFFFull), alive_before = (long long)(before >> 32);
     uint32_t* o1 = out + (int64_t)blockIdx.y * istride;
     int32_t* o2 = out2 ? out2 + (int64_t)blockIdx.y * istride : nullptr;
+    uint32_t* mkp = marks ? marks + (int64_t)blockIdx.y * istride : nullptr;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        if (i0 + i >= t.begin && i0 + i < t.end) {
-            const uint32_t one = (m >> i) & 1u;
-            const long long rank_in_node = i0 + i - nbeg;
-            const long long dest = one ? base1 + (long long)ones_before : base2 + (rank_in_node - (long long)ones_before);
-            o1[dest] = v[i];
-            if (o2) o2[dest] = v2[i];
+        if ((ma >> i) & 1u) {
+            const uint32_t one = (m1 >> i) & 1u;
+            const int base = one ? base1 : base2;
+            if (base >= 0) {
+                const long long dest = base + (one ? ones_before : alive_before - ones_before);
+                o1[dest] = v[i];
+                if (o2) o2[dest] = v2[i];
+                if (mkp && (one ? base2 : base1) < 0) mkp[i0 + i] = v[i] | W_DEAD;      // its sibling keeps the segment
+            }
             if (scaf) scaf_slot[v[i]] = one ? np.slot1 : np.slot2;
-            ones_before += one;
+            ones_before += one; alive_before++;
         }
     }
+}
+
+// The node that still lives in the ROOT's segment (the table's static order, where every dp's position is a static table:
+// pos_of) -- the giant of a caterpillar -- finds the positions that leave it from the scaffolds that leave, not by looking at
+// all of its positions: the leaving scaffolds (a range of the next level's scaffold order, which the scaffolds' own partition
+// has just written) mark their dps' positions in every wide dimension's bit map (tree_mark_kernel).
+// grid (ceil(listed scaffolds / 256), wide dimensions)
+__global__ __launch_bounds__(256) void tree_mark_kernel(TreeDev Tr, const int32_t* __restrict__ list, int32_t n_list, const int32_t* __restrict__ pos_of, int64_t pstride,
+                                                       uint32_t* __restrict__ bits, int64_t bstride)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_list) return;
+    const int s = list[i];
+    const int32_t* __restrict__ pof = pos_of + (int64_t)blockIdx.y * pstride;
+    uint32_t* __restrict__ bw = bits + (int64_t)blockIdx.y * bstride;
+    const int f = Tr.P.scaf_first[s], n = Tr.P.scaf_ndps[s];
+    for (int k = 0; k < n; k++) { const int p = pof[f + k]; atomicOr(&bw[p >> 5], 1u << (p & 31)); }
+}
+
+// pos_of at the root: the inverse of the table's static order.  grid (blocks, wide dimensions)
+__global__ void tree_posof_kernel(const int32_t* __restrict__ sdp, int64_t N, int32_t* __restrict__ pos_of)
+{
+    const int64_t base = (int64_t)blockIdx.y * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) pos_of[base + sdp[base + i]] = (int32_t)i;
 }
 
 __global__ void tree_iota_kernel(uint32_t* p, int32_t n)
@@ -927,18 +1256,25 @@ int tree_static_build(abw_ctx* ctx, SepHost& H, const SepDev& P, const int32_t* 
     if (H.d_wword) { (void)hipFree(H.d_wword); H.d_wword = nullptr; }
     if (H.d_wext) { (void)hipFree(H.d_wext); H.d_wext = nullptr; }
     if (H.d_wpack) { (void)hipFree(H.d_wpack); H.d_wpack = nullptr; }
+    if (H.d_posof) { (void)hipFree(H.d_posof); H.d_posof = nullptr; }
+    if (H.d_sinfo) { (void)hipFree(H.d_sinfo); H.d_sinfo = nullptr; }
     if (n_wide) {
+        const bool inl = H.packed && S <= (int32_t)W_SC22 + 1 && !getenv("ABW_SEP_NO_INLINE");
+        if (inl) ABW_HIP(ctx, hipMalloc((void**)&H.d_sinfo, (size_t)S * 4));
         const int64_t Np = (N + 7) & ~(int64_t)7;
         ABW_HIP(ctx, hipMalloc((void**)&H.d_wword, (size_t)n_wide * Np * 4));
         ABW_HIP(ctx, hipMalloc((void**)&H.d_wext, (size_t)n_wide * S * 16));
         ABW_HIP(ctx, hipMalloc((void**)&H.d_wpack, (size_t)n_wide * S * 4));
+        ABW_HIP(ctx, hipMalloc((void**)&H.d_posof, (size_t)n_wide * N * 4));
         int rc;
         if ((rc = abw_reserve(ctx, ctx->scratch[3], (size_t)n_wide * N))) return rc;         // per-dp flags, temporary
         hipLaunchKernelGGL(tree_static_wide_kernel, dim3((unsigned)((S + 255) / 256), (unsigned)n_wide), dim3(256), 0, st, P, H.d_wide, S,
-                           (uint8_t*)ctx->scratch[3].p, (uint4*)H.d_wext, H.d_wpack);
+                           (uint8_t*)ctx->scratch[3].p, (uint4*)H.d_wext, H.d_wpack, H.d_sinfo);
         ABW_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(tree_static_words_kernel, dim3((unsigned)(ctx->num_cu * 8), (unsigned)n_wide), dim3(256), 0, st, H.d_sdp, H.d_sbin,
-                           (const uint8_t*)ctx->scratch[3].p, d_dp2scaf, N, Np, H.d_wword);
+                           (const uint8_t*)ctx->scratch[3].p, d_dp2scaf, N, Np, (const uint4*)H.d_wext, S, inl ? 1 : 0, H.d_wword);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(tree_posof_kernel, dim3((unsigned)(ctx->num_cu * 8), (unsigned)n_wide), dim3(256), 0, st, (const int32_t*)H.d_sdp, N, H.d_posof);
         ABW_LAUNCH_CHECK(ctx);
     }
     ABW_HIP(ctx, hipStreamSynchronize(st));
@@ -947,14 +1283,17 @@ int tree_static_build(abw_ctx* ctx, SepHost& H, const SepDev& P, const int32_t* 
 
 // ---- the recursion as a sequence of levels that a caller can interleave with an exchange ------------------------------
 // node of a level: id, size, and where its histogram comes from
-struct HostNode { int32_t id; int32_t m; int64_t n; int32_t parent; };      // parent: its slot in the previous level (-1: the root)
+struct HostNode { int32_t id; int32_t m; int64_t n; int32_t parent; int64_t seg_begin, seg_len; bool root_seg; };   // parent: its slot in the previous level
+                                                                          // (-1: the root); seg: its segment of the wide position arrays
 
 struct TreeRun {
     abw_ctx* ctx = nullptr;
     int32_t min_ndps = 0;
     int64_t max_nodes = 0, visited = 0;
     int32_t next_id = 2;
-    int cur = 0;
+    int cur = 0;                         // scaffold order and histogram pool of the level in flight
+    int wcur = 0;                        // the buffer the wide dimensions' position arrays live in (changes only when they are compacted)
+    int64_t Wp = 0, arena_end = 0;       // stride of those arrays (2 Np: room to copy children out behind what is in use), and what is in use
     int phase = 0;                       // 0: a level waits for eval, 1: for assign, 2: for advance, 3: the recursion is over
     uint64_t scratch_epoch = 0;          // ctx->scratch_epoch when the last phase returned (TreeGuard)
     std::vector<HostNode> level;
@@ -968,6 +1307,7 @@ struct TreeRun {
     uint32_t* order[2] = {nullptr, nullptr};
     int32_t* wbin[2] = {nullptr, nullptr};
     uint32_t* wword[2] = {nullptr, nullptr};
+    uint32_t* bits = nullptr;               // [n_wide][Wp / 32] the positions that leave the root's segment this level
     uint8_t* d_scaf_side = nullptr;
     int32_t* d_scaf_slot = nullptr;
     // the level in flight
@@ -977,8 +1317,8 @@ struct TreeRun {
     const Tile *d_stiles = nullptr, *d_ptiles = nullptr;
     NodeRes* d_res = nullptr;
     NodePart* d_part = nullptr;
-    uint32_t *d_pcnt = nullptr, *d_scnt = nullptr;
-    uint8_t *d_pmask = nullptr, *d_smask = nullptr;
+    unsigned long long *d_pcnt = nullptr, *d_scnt = nullptr;
+    uint16_t *d_pmask = nullptr, *d_smask = nullptr;
 
     int32_t key_of(int32_t d, int32_t bin) const
     {
@@ -1001,22 +1341,22 @@ int TreeRun::begin(int32_t min_ndps_, int64_t max_nodes_)
     int rc;
     D = s.D; S = s.S; n_narrow = (int32_t)H.narrow_dims.size(); n_wide = (int32_t)H.wide_dims.size();
     N = s.N; Np = (N + 7) & ~(int64_t)7; Sp = ((int64_t)S + 7) & ~(int64_t)7;      // strides of the position / scaffold arrays
-    if (S > (int32_t)W_SC) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree: more than 2^29 scaffolds");
+    Wp = (2 * Np + 31) & ~(int64_t)31;                          // (a multiple of 32: a dimension's bit map is whole words)
+    if (Wp >= ((int64_t)1 << 31) - TILE_P) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree: more than 2^30 datapoints");
+    if (S > (int32_t)W_SC) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree: more than 2^28 scaffolds");
     n_groups = (int32_t)H.groups.size();
     TBn = std::max<int64_t>(1, n_narrow ? H.toffn[n_narrow] : 0);      // a node's slice: the narrow dimensions in H.nsort order
 
     // buffers of the run (grow-only scratch of the context: no other entry point may run on the context until the run is over)
     abw_devbuf &b_order = ctx->scratch[0], &b_wbin = ctx->scratch[1], &b_wword = ctx->scratch[2], &b_side = ctx->scratch[4],
-               &b_misc = ctx->scratch[8], &b_s2c = ctx->scratch[9];
+               &b_s2c = ctx->scratch[9];
     if ((rc = abw_reserve(ctx, b_order, (size_t)2 * Sp * 4))) return rc;
     if ((rc = abw_reserve(ctx, b_side, (size_t)S + 64 + (size_t)S * 4))) return rc;
     if ((rc = abw_reserve(ctx, b_s2c, (size_t)S * 4))) return rc;
     if (n_wide) {
-        if ((rc = abw_reserve(ctx, b_wbin, (size_t)2 * n_wide * Np * 4))) return rc;
-        if ((rc = abw_reserve(ctx, b_wword, (size_t)2 * n_wide * Np * 4))) return rc;
+        if ((rc = abw_reserve(ctx, b_wbin, (size_t)2 * n_wide * Wp * 4))) return rc;
+        if ((rc = abw_reserve(ctx, b_wword, (size_t)2 * n_wide * Wp * 4))) return rc;
     }
-    if ((rc = abw_reserve(ctx, b_misc, (size_t)N * 4 + 64))) return rc;
-    int32_t* d_dp2scaf = (int32_t*)b_misc.p;
 
     Tr.P.bins = s.d_bins ? s.d_bins : s.d_keys; Tr.P.N = N;
     Tr.P.scaf_first = s.d_scaf_first; Tr.P.scaf_ndps = s.d_scaf_ndps; Tr.P.scaf_len = s.d_scaf_len;
@@ -1024,14 +1364,20 @@ int TreeRun::begin(int32_t min_ndps_, int64_t max_nodes_)
     Tr.P.T = s.d_T; Tr.P.Toff = s.d_Toff;
     Tr.P.h_st = nullptr; Tr.P.h_tot = nullptr; Tr.P.h_bp = nullptr; Tr.P.scg_lo = nullptr; Tr.P.scg_hi = nullptr; Tr.P.range = nullptr;
     if ((rc = abw_tree_static_ensure(ctx))) return rc;
+    if (n_wide) {                                              // (after the static build, which uses this slot itself)
+        abw_devbuf& b_bits = ctx->scratch[3];
+        if ((rc = abw_reserve(ctx, b_bits, (size_t)n_wide * (Wp / 8) + 64))) return rc;
+        bits = (uint32_t*)b_bits.p;
+    }
     Tr.narrow = H.d_nsort; Tr.n_narrow = n_narrow; Tr.toffn = H.d_toffn; Tr.TBn = TBn;
     Tr.groups = H.d_groups; Tr.n_groups = n_groups; Tr.nk16 = (const uint4*)H.d_nk16; Tr.ts8 = (const uint4*)H.d_ts8; Tr.srec = (const int4*)H.d_srec;
-    Tr.wide = H.d_wide; Tr.n_wide = n_wide; Tr.dp2scaf = d_dp2scaf; Tr.dim_slot = H.d_dim_slot;
+    Tr.wide = H.d_wide; Tr.n_wide = n_wide; Tr.dp2scaf = nullptr; Tr.dim_slot = H.d_dim_slot;
     Tr.wext = (const uint4*)H.d_wext; Tr.wpack = H.d_wpack; Tr.D = D; Tr.S = S;
+    Tr.sinfo = H.d_sinfo; Tr.sc_mask = H.d_sinfo ? W_SC22 : W_SC;
 
     order[0] = (uint32_t*)b_order.p; order[1] = (uint32_t*)b_order.p + Sp;
-    wbin[0] = (int32_t*)b_wbin.p; wbin[1] = n_wide ? (int32_t*)b_wbin.p + (int64_t)n_wide * Np : nullptr;
-    wword[0] = (uint32_t*)b_wword.p; wword[1] = n_wide ? (uint32_t*)b_wword.p + (int64_t)n_wide * Np : nullptr;
+    wbin[0] = (int32_t*)b_wbin.p; wbin[1] = n_wide ? (int32_t*)b_wbin.p + (int64_t)n_wide * Wp : nullptr;
+    wword[0] = (uint32_t*)b_wword.p; wword[1] = n_wide ? (uint32_t*)b_wword.p + (int64_t)n_wide * Wp : nullptr;
     d_scaf_side = (uint8_t*)b_side.p;
     d_scaf_slot = (int32_t*)((uint8_t*)b_side.p + (((size_t)S + 63) & ~(size_t)63));
     hipLaunchKernelGGL(tree_iota_kernel, dim3(ctx->num_cu * 4), dim3(256), 0, st, order[0], S);
@@ -1039,12 +1385,13 @@ int TreeRun::begin(int32_t min_ndps_, int64_t max_nodes_)
     ABW_HIP(ctx, hipMemsetAsync(d_scaf_slot, 0, (size_t)S * 4, st));          // every scaffold starts in node slot 0 (the root)
     ABW_HIP(ctx, hipMemsetAsync(b_s2c.p, 0, (size_t)S * 4, st));
     if (n_wide) {
-        ABW_HIP(ctx, hipMemcpy2DAsync(wbin[0], (size_t)Np * 4, H.d_sbin, (size_t)N * 4, (size_t)N * 4, (size_t)n_wide, hipMemcpyDeviceToDevice, st));
-        ABW_HIP(ctx, hipMemcpyAsync(wword[0], H.d_wword, (size_t)n_wide * Np * 4, hipMemcpyDeviceToDevice, st));
+        ABW_HIP(ctx, hipMemcpy2DAsync(wbin[0], (size_t)Wp * 4, H.d_sbin, (size_t)N * 4, (size_t)N * 4, (size_t)n_wide, hipMemcpyDeviceToDevice, st));
+        ABW_HIP(ctx, hipMemcpy2DAsync(wword[0], (size_t)Wp * 4, H.d_wword, (size_t)Np * 4, (size_t)N * 4, (size_t)n_wide, hipMemcpyDeviceToDevice, st));
+
     }
-    level.assign(1, HostNode{1, S, N, -1});
+    level.assign(1, HostNode{1, S, N, -1, 0, N, true});        // root_seg: still in the static order, where pos_of holds
     nodes.clear();
-    next_id = 2; visited = 0; cur = 0; phase = 0;
+    next_id = 2; visited = 0; cur = 0; wcur = 0; arena_end = N; phase = 0;
     return ABW_OK;
 }
 
@@ -1068,13 +1415,13 @@ int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
     std::vector<Tile> stiles, ptiles, atiles;
     std::vector<int32_t> zero_slots;
     std::vector<SubJob> subs;
-    int32_t sb = 0, pb = 0;
+    int32_t sb = 0;
     for (int32_t k = 0; k < K; k++) {
         nd[k].scaf_begin = sb; nd[k].scaf_end = sb + level[k].m;
-        nd[k].dp_begin = pb; nd[k].dp_end = pb + (int32_t)level[k].n;
+        nd[k].dp_begin = (int32_t)level[k].seg_begin; nd[k].dp_end = (int32_t)(level[k].seg_begin + level[k].seg_len); nd[k].n = (int32_t)level[k].n;
         make_tiles(stiles, k, nd[k].scaf_begin, nd[k].scaf_end, TILE_S, nd[k].stile_begin, nd[k].stile_end);
         make_tiles(ptiles, k, nd[k].dp_begin, nd[k].dp_end, TILE_P, nd[k].ptile_begin, nd[k].ptile_end);
-        sb += level[k].m; pb += (int32_t)level[k].n;
+        sb += level[k].m;
     }
     // children come in pairs (2j, 2j + 1) of one parent: the smaller is accumulated, the bigger subtracted; a node without
     // its sibling in this (cut) level, and the root, are accumulated
@@ -1117,21 +1464,24 @@ int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
     if ((rc = abw_reserve(ctx, b_scg, (size_t)std::max<int64_t>(1, scg_n) * 8))) return rc;
     int32_t* d_scg_lo = (int32_t*)b_scg.p; int32_t* d_scg_hi = d_scg_lo + scg_n;
     const size_t t_cand = ((size_t)K * D * sizeof(Cand) + 63) & ~(size_t)63,
-                 t_sums = ((size_t)std::max(1, n_wide) * n_pt * sizeof(WSums) + 63) & ~(size_t)63,
+                 t_sums = ((size_t)std::max(1, n_wide) * n_pt * sizeof(WSums4) + 63) & ~(size_t)63,
                  t_best = ((size_t)std::max(1, n_wide) * n_pt * sizeof(Cand) + 63) & ~(size_t)63,
-                 t_tot = ((size_t)std::max(1, n_wide) * K * sizeof(WSums) + 63) & ~(size_t)63,
-                 t_cnt = ((size_t)(std::max(1, n_wide) * (size_t)n_pt + n_st) * 4 + 63) & ~(size_t)63,
-                 t_mask = (((size_t)std::max(1, n_wide) * n_pt + n_st) * 256 + 63) & ~(size_t)63;
-    if ((rc = abw_reserve(ctx, b_tile, t_cand + t_sums + t_best + t_tot + t_cnt + t_mask + (size_t)K * 8))) return rc;
+                 t_tot = ((size_t)std::max(1, n_wide) * K * sizeof(WSums4) + 63) & ~(size_t)63,
+                 t_cnt = ((size_t)(std::max(1, n_wide) * (size_t)n_pt + n_st) * 8 + 63) & ~(size_t)63,
+                 t_mask = (((size_t)std::max(1, n_wide) * n_pt + n_st) * 512 + 63) & ~(size_t)63;
+    if ((int64_t)std::max(1, n_wide) * n_pt >= ((int64_t)1 << 31)) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree: too many position tiles");
+    if ((rc = abw_reserve(ctx, b_tile, t_cand + t_sums + t_best + t_tot + t_cnt + t_mask + (size_t)K * 8 + 64 + (size_t)std::max(1, n_wide) * n_pt * 4))) return rc;
     Cand* d_cand = (Cand*)b_tile.p;
-    WSums* d_tsums = (WSums*)((uint8_t*)b_tile.p + t_cand);
+    WSums4* d_tsums = (WSums4*)((uint8_t*)b_tile.p + t_cand);
     Cand* d_tbest = (Cand*)((uint8_t*)b_tile.p + t_cand + t_sums);
-    WSums* d_ntot = (WSums*)((uint8_t*)b_tile.p + t_cand + t_sums + t_best);
-    d_pcnt = (uint32_t*)((uint8_t*)b_tile.p + t_cand + t_sums + t_best + t_tot);
+    WSums4* d_ntot = (WSums4*)((uint8_t*)b_tile.p + t_cand + t_sums + t_best);
+    d_pcnt = (unsigned long long*)((uint8_t*)b_tile.p + t_cand + t_sums + t_best + t_tot);
     d_scnt = d_pcnt + (size_t)std::max(1, n_wide) * n_pt;
-    d_pmask = (uint8_t*)b_tile.p + t_cand + t_sums + t_best + t_tot + t_cnt;
+    d_pmask = (uint16_t*)((uint8_t*)b_tile.p + t_cand + t_sums + t_best + t_tot + t_cnt);
     d_smask = d_pmask + (size_t)std::max(1, n_wide) * n_pt * 256;
-    double* d_bar = (double*)(d_pmask + t_mask);
+    double* d_bar = (double*)((uint8_t*)d_pmask + t_mask);
+    int32_t* d_wlist_n = (int32_t*)(d_bar + K);                                             // tiles listed by the screen for the full evaluation
+    int32_t* d_wlist = d_wlist_n + 16;
     if (scg_n > 0 && (int64_t)K * s.n_scg <= SCG_LEVEL_LDS) {
         hipLaunchKernelGGL(tree_scg_lds_kernel, dim3((unsigned)D), dim3(256), 0, st, Tr, H.d_carriers, H.n_carriers, d_scaf_slot, K, d_scg_lo, d_scg_hi);
         ABW_LAUNCH_CHECK(ctx);
@@ -1185,12 +1535,16 @@ int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
         ABW_PROF(ctx, "sep_wide");
         hipLaunchKernelGGL(tree_bar_kernel, dim3((unsigned)K), dim3(64), 0, st, Tr, d_cand, d_bar);
         ABW_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(tree_wide_sums_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, wword[cur], Np, d_tsums);
+        hipLaunchKernelGGL(tree_wide_sums_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, wword[wcur], Wp, d_tsums);
         ABW_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(tree_wide_scan_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, d_nodes, n_pt, d_tsums, d_ntot, K);
         ABW_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(tree_wide_eval_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, d_nodes, K, min_ndps,
-                           wbin[cur], wword[cur], Np, d_tsums, d_ntot, d_scg_lo, d_scg_hi, d_bar, d_tbest);
+        ABW_HIP(ctx, hipMemsetAsync(d_wlist_n, 0, 4, st));
+        hipLaunchKernelGGL(tree_wide_screen_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, d_nodes, min_ndps,
+                           wbin[wcur], wword[wcur], Wp, d_tsums, d_bar, d_tbest, d_wlist, d_wlist_n);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(tree_wide_eval_kernel, dim3((unsigned)std::min<int64_t>((int64_t)n_pt * n_wide, (int64_t)ctx->num_cu * 4)), dim3(256), 0, st, Tr, d_ptiles, n_pt, d_nodes, K, min_ndps,
+                           wbin[wcur], wword[wcur], Wp, d_tsums, d_ntot, d_scg_lo, d_scg_hi, d_bar, d_tbest, (const int32_t*)d_wlist, (const int32_t*)d_wlist_n);
         ABW_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(tree_wide_best_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, Tr, d_nodes, n_pt, d_tbest, d_cand);
         ABW_LAUNCH_CHECK(ctx);
@@ -1262,7 +1616,8 @@ int TreeRun::advance()
     ABW_HIP(ctx, hipStreamSynchronize(st));
     std::vector<HostNode> next;
     NodePart* h_part = (NodePart*)(hp + o_part);
-    int32_t nsb = 0, npb = 0;
+    int32_t nsb = 0;
+    std::vector<int32_t> split_nodes;
     for (int32_t k = 0; k < K; k++) {
         const NodeRes& r = h_res[k];
         const abw_tree_winner& w = final_winners[k];
@@ -1285,34 +1640,76 @@ int TreeRun::advance()
             o.split = 1; o.child1 = next_id; o.child2 = next_id + 1; o.ndps1 = (int64_t)r.n1; o.ndps2 = (int64_t)r.n2;
             next_id += 2;
             np.scaf_base1 = nsb; np.scaf_base2 = nsb + (int32_t)r.m1;
-            np.dp_base1 = npb; np.dp_base2 = npb + (int32_t)r.n1;
             np.slot1 = (int32_t)next.size(); np.slot2 = np.slot1 + 1;
-            nsb += (int32_t)(r.m1 + r.m2); npb += (int32_t)(r.n1 + r.n2);
-            next.push_back(HostNode{o.child1, (int32_t)r.m1, (int64_t)r.n1, k});
-            next.push_back(HostNode{o.child2, (int32_t)r.m2, (int64_t)r.n2, k});
+            nsb += (int32_t)(r.m1 + r.m2);
+            next.push_back(HostNode{o.child1, (int32_t)r.m1, (int64_t)r.n1, k, 0, 0, false});
+            next.push_back(HostNode{o.child2, (int32_t)r.m2, (int64_t)r.n2, k, 0, 0, false});
+            split_nodes.push_back(k);
         }
         nodes.push_back(o);
         visited++;
+    }
+    // Where the children's positions in the wide dimensions' arrays go.  The bigger child of a split keeps its parent's segment
+    // as long as at least half of the segment is its own (the positions of its sibling are copied out behind everything in use
+    // and marked dead where they were); otherwise both children are copied out and the segment is abandoned.  When the
+    // copies do not fit behind what is in use, this level compacts: every child is copied into the other buffer, from 0.
+    bool compact = false;
+    int32_t n_leavers = 0, leavers_at = 0;                     // of the node that still lives in the root's segment, if it keeps it: the child that leaves, in the next order
+    if (n_wide) {
+        auto keeps = [&](int32_t k) -> int {                   // 1 / 2: that child keeps the segment; 0: both are copied out
+            const NodeRes& r = h_res[k];
+            const int64_t big = (int64_t)std::max(r.n1, r.n2);
+            if (2 * big < level[k].seg_len) return 0;
+            return r.n1 > r.n2 ? 1 : 2;
+        };
+        int64_t need = 0;
+        for (int32_t k : split_nodes) { const int kp = keeps(k); need += (kp == 1 ? 0 : (int64_t)h_res[k].n1) + (kp == 2 ? 0 : (int64_t)h_res[k].n2); }
+        compact = arena_end + need > Wp;
+        int64_t at = compact ? 0 : arena_end;
+        for (int32_t k : split_nodes) {
+            const NodeRes& r = h_res[k];
+            NodePart& np = h_part[k];
+            const int kp = compact ? 0 : keeps(k);
+            HostNode &c1 = next[(size_t)np.slot1], &c2 = next[(size_t)np.slot2];
+            if (kp && level[k].root_seg) { np.bits = 1; n_leavers = (int32_t)(kp == 1 ? r.m2 : r.m1); leavers_at = kp == 1 ? np.scaf_base2 : np.scaf_base1; (kp == 1 ? c1 : c2).root_seg = true; }
+            if (kp == 1) { np.dp_base1 = -1; c1.seg_begin = level[k].seg_begin; c1.seg_len = level[k].seg_len; }
+            else { np.dp_base1 = (int32_t)at; c1.seg_begin = at; c1.seg_len = (int64_t)r.n1; at += (int64_t)r.n1; }
+            if (kp == 2) { np.dp_base2 = -1; c2.seg_begin = level[k].seg_begin; c2.seg_len = level[k].seg_len; }
+            else { np.dp_base2 = (int32_t)at; c2.seg_begin = at; c2.seg_len = (int64_t)r.n2; at += (int64_t)r.n2; }
+        }
+        arena_end = at;
     }
     // ---- partition into the next level's order (terminal nodes' scaffolds get their cluster id)
     ABW_HIP(ctx, hipMemcpyAsync(d_part, h_part, (size_t)K * sizeof(NodePart), hipMemcpyHostToDevice, st));
     {
         ABW_PROF(ctx, "sep_partition");
-        hipLaunchKernelGGL(tree_part_count_kernel, dim3((unsigned)n_st, 1), dim3(256), 0, st, d_stiles, n_st, d_part, (const uint32_t*)order[cur], (int64_t)0, d_scaf_side, d_scnt, d_smask);
+        hipLaunchKernelGGL(tree_part_count_kernel, dim3((unsigned)n_st, 1), dim3(256), 0, st, d_stiles, n_st, d_part, (const uint32_t*)order[cur], (int64_t)0, d_scaf_side,
+                           W_SC, (const uint8_t*)nullptr, d_scnt, d_smask);
         ABW_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(tree_part_scan_kernel, dim3((unsigned)K, 1), dim3(64), 0, st, d_nodes, d_part, n_st, d_scnt, 1);
         ABW_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(tree_part_scatter_kernel, dim3((unsigned)n_st, 1), dim3(256), 0, st, d_stiles, n_st, d_nodes, d_part, (const uint32_t*)order[cur],
-                           (const int32_t*)nullptr, (int64_t)0, d_smask, d_scnt, order[cur ^ 1], (int32_t*)nullptr, 1, (int32_t*)ctx->scratch[9].p, d_scaf_slot);
+                           (const int32_t*)nullptr, (int64_t)0, d_smask, d_scnt, order[cur ^ 1], (int32_t*)nullptr,
+                           (uint32_t*)nullptr, 1, (int32_t*)ctx->scratch[9].p, d_scaf_slot);
         ABW_LAUNCH_CHECK(ctx);
         if (n_wide && !next.empty()) {
-            hipLaunchKernelGGL(tree_part_count_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, d_ptiles, n_pt, d_part, (const uint32_t*)wword[cur], Np, d_scaf_side, d_pcnt, d_pmask);
+            if (n_leavers > 0) {
+                ABW_HIP(ctx, hipMemset2DAsync(bits, (size_t)(Wp / 8), 0, (size_t)(((N + 63) / 64) * 8), (size_t)n_wide, st));
+                hipLaunchKernelGGL(tree_mark_kernel, dim3((unsigned)((n_leavers + 255) / 256), (unsigned)n_wide), dim3(256), 0, st, Tr, (const int32_t*)(order[cur ^ 1] + leavers_at), n_leavers,
+                                   (const int32_t*)abw_sep_host(ctx).d_posof, N, bits, Wp / 32);
+                ABW_LAUNCH_CHECK(ctx);
+            }
+            hipLaunchKernelGGL(tree_part_count_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, d_ptiles, n_pt, d_part, (const uint32_t*)wword[wcur], Wp, d_scaf_side,
+                               Tr.sc_mask, n_leavers > 0 ? (const uint8_t*)bits : (const uint8_t*)nullptr, d_pcnt, d_pmask);
             ABW_LAUNCH_CHECK(ctx);
             hipLaunchKernelGGL(tree_part_scan_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, d_nodes, d_part, n_pt, d_pcnt, 0);
             ABW_LAUNCH_CHECK(ctx);
-            hipLaunchKernelGGL(tree_part_scatter_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, d_ptiles, n_pt, d_nodes, d_part, (const uint32_t*)wword[cur],
-                               (const int32_t*)wbin[cur], Np, d_pmask, d_pcnt, wword[cur ^ 1], wbin[cur ^ 1], 0, (int32_t*)nullptr, (int32_t*)nullptr);
+            const int wto = compact ? (wcur ^ 1) : wcur;
+            hipLaunchKernelGGL(tree_part_scatter_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, d_ptiles, n_pt, d_nodes, d_part, (const uint32_t*)wword[wcur],
+                               (const int32_t*)wbin[wcur], Wp, d_pmask, d_pcnt, wword[wto], wbin[wto],
+                               compact ? (uint32_t*)nullptr : wword[wcur], 0, (int32_t*)nullptr, (int32_t*)nullptr);
             ABW_LAUNCH_CHECK(ctx);
+            wcur = wto;
         }
     }
     // the level's pinned block is re-used by the next level's upload: the copy of h_part must have left it
@@ -1374,7 +1771,7 @@ int abw_tree_static_ensure(abw_ctx* ctx)
 
 // ---- abw_sep_node's wide dimensions (see node_wide_*_kernel): host side --------------------------------------------------
 namespace {
-struct NodeWide { TreeDev Tr; int32_t n_tiles, n_wide; WSums4 *tile_sums, *total; Cand* tile_best; double* bar; };
+struct NodeWide { TreeDev Tr; int32_t n_tiles, n_wide; WSums4 *tile_sums, *total; Cand* tile_best; double* bar; int32_t *list_n, *list; };
 
 int node_wide_plan(abw_ctx* ctx, NodeWide& W)
 {
@@ -1383,7 +1780,8 @@ int node_wide_plan(abw_ctx* ctx, NodeWide& W)
     W.n_wide = (int32_t)H.wide_dims.size();
     W.n_tiles = (int32_t)((s.N + TILE_P - 1) / TILE_P);
     const size_t o_sums = 0, o_tot = o_sums + (size_t)W.n_wide * W.n_tiles * sizeof(WSums4),
-                 o_best = o_tot + (size_t)W.n_wide * sizeof(WSums4), o_bar = o_best + (size_t)W.n_wide * W.n_tiles * sizeof(Cand), bytes = o_bar + 64;
+                 o_best = o_tot + (size_t)W.n_wide * sizeof(WSums4), o_bar = o_best + (size_t)W.n_wide * W.n_tiles * sizeof(Cand), o_list = o_bar + 64,
+                 bytes = o_list + 64 + (size_t)W.n_wide * W.n_tiles * 4;
     if (H.nw_cap < bytes) {
         if (H.d_nw) { ABW_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(H.d_nw); H.d_nw = nullptr; H.nw_cap = 0; }
         ABW_HIP(ctx, hipMalloc(&H.d_nw, bytes));
@@ -1391,11 +1789,13 @@ int node_wide_plan(abw_ctx* ctx, NodeWide& W)
     }
     uint8_t* p = (uint8_t*)H.d_nw;
     W.tile_sums = (WSums4*)(p + o_sums); W.total = (WSums4*)(p + o_tot); W.tile_best = (Cand*)(p + o_best); W.bar = (double*)(p + o_bar);
+    W.list_n = (int32_t*)(p + o_list); W.list = W.list_n + 16;
     memset(&W.Tr, 0, sizeof(W.Tr));
     W.Tr.P = static_params(s);
     W.Tr.narrow = H.d_nsort; W.Tr.n_narrow = (int32_t)H.narrow_dims.size();
     W.Tr.wide = H.d_wide; W.Tr.n_wide = W.n_wide;
     W.Tr.wext = (const uint4*)H.d_wext; W.Tr.wpack = H.d_wpack; W.Tr.D = s.D; W.Tr.S = s.S;
+    W.Tr.sinfo = H.d_sinfo; W.Tr.sc_mask = H.d_sinfo ? W_SC22 : W_SC;
     return ABW_OK;
 }
 }  // namespace
@@ -1445,10 +1845,22 @@ int abw_node_wide_eval(abw_ctx* ctx, const uint8_t* d_member, bool exact_per_dim
         ABW_LAUNCH_CHECK(ctx);
     }
     const dim3 grid((unsigned)W.n_tiles, (unsigned)W.n_wide);
-    if (d_member) hipLaunchKernelGGL(node_wide_eval_kernel<true>, grid, dim3(256), 0, st, W.Tr, (int32_t)s.N, W.n_tiles, min_ndps, (const int32_t*)H.d_sbin, (const uint32_t*)H.d_wword, Np,
-                                   d_member, (const WSums4*)W.tile_sums, (const WSums4*)W.total, scg_lo, scg_hi, (const double*)W.bar, W.tile_best);
-    else hipLaunchKernelGGL(node_wide_eval_kernel<false>, grid, dim3(256), 0, st, W.Tr, (int32_t)s.N, W.n_tiles, min_ndps, (const int32_t*)H.d_sbin, (const uint32_t*)H.d_wword, Np,
-                            (const uint8_t*)nullptr, (const WSums4*)W.tile_sums, (const WSums4*)W.total, scg_lo, scg_hi, (const double*)W.bar, W.tile_best);
+    const int64_t all = (int64_t)W.n_tiles * W.n_wide;
+    const int32_t* list = nullptr;
+    if (!exact_per_dim) {                                       // with a bar most tiles are done after the screen
+        ABW_HIP(ctx, hipMemsetAsync(W.list_n, 0, 4, st));
+        if (d_member) hipLaunchKernelGGL(node_wide_screen_kernel<true>, grid, dim3(256), 0, st, W.Tr, (int32_t)s.N, W.n_tiles, min_ndps, (const uint32_t*)H.d_wword, Np, d_member,
+                                         (const WSums4*)W.tile_sums, (const WSums4*)W.total, (const double*)W.bar, W.tile_best, W.list, W.list_n);
+        else hipLaunchKernelGGL(node_wide_screen_kernel<false>, grid, dim3(256), 0, st, W.Tr, (int32_t)s.N, W.n_tiles, min_ndps, (const uint32_t*)H.d_wword, Np, (const uint8_t*)nullptr,
+                                (const WSums4*)W.tile_sums, (const WSums4*)W.total, (const double*)W.bar, W.tile_best, W.list, W.list_n);
+        ABW_LAUNCH_CHECK(ctx);
+        list = W.list;
+    }
+    const dim3 egrid((unsigned)std::min<int64_t>(all, exact_per_dim ? all : (int64_t)ctx->num_cu * 4));
+    if (d_member) hipLaunchKernelGGL(node_wide_eval_kernel<true>, egrid, dim3(256), 0, st, W.Tr, (int32_t)s.N, W.n_tiles, min_ndps, (const int32_t*)H.d_sbin, (const uint32_t*)H.d_wword, Np,
+                                   d_member, (const WSums4*)W.tile_sums, (const WSums4*)W.total, scg_lo, scg_hi, (const double*)W.bar, W.tile_best, list, (const int32_t*)W.list_n);
+    else hipLaunchKernelGGL(node_wide_eval_kernel<false>, egrid, dim3(256), 0, st, W.Tr, (int32_t)s.N, W.n_tiles, min_ndps, (const int32_t*)H.d_sbin, (const uint32_t*)H.d_wword, Np,
+                            (const uint8_t*)nullptr, (const WSums4*)W.tile_sums, (const WSums4*)W.total, scg_lo, scg_hi, (const double*)W.bar, W.tile_best, list, (const int32_t*)W.list_n);
     ABW_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(node_wide_best_kernel, dim3((unsigned)W.n_wide), dim3(64), 0, st, W.Tr, W.n_tiles, (const Cand*)W.tile_best, (const WSums4*)W.total, d_dimbest);
     ABW_LAUNCH_CHECK(ctx);
@@ -1802,7 +2214,7 @@ int abw_sep_stree_accum(abw_ctx* ctx, const abw_tree_level_node* nodes, int64_t 
     uint32_t* c_tot = (uint32_t*)(c_bp + (int64_t)K * TBn);
     // level block: acc flags | counts | offsets | cursors | acc node list | NodeDev | sub jobs (one upload), tiles follow the counts
     std::vector<NodeDev> nd((size_t)K);
-    for (int32_t k = 0; k < K; k++) { memset(&nd[k], 0, sizeof(NodeDev)); nd[k].dp_begin = 0; nd[k].dp_end = (int32_t)nodes[k].ndps; }
+    for (int32_t k = 0; k < K; k++) { memset(&nd[k], 0, sizeof(NodeDev)); nd[k].dp_begin = 0; nd[k].dp_end = (int32_t)nodes[k].ndps; nd[k].n = (int32_t)nodes[k].ndps; }
     const size_t o_acc = 0, o_cnt = o_acc + (size_t)K * 4, o_off = o_cnt + (size_t)K * 4, o_cur = o_off + (size_t)K * 4, o_an = o_cur + (size_t)K * 4,
                  o_nd = (o_an + (size_t)K * 4 + 63) & ~(size_t)63, o_sub = (o_nd + (size_t)K * sizeof(NodeDev) + 63) & ~(size_t)63,
                  o_res = (o_sub + (size_t)K * sizeof(SubJob) + 63) & ~(size_t)63, o_tiles = (o_res + (size_t)K * sizeof(NodeRes) + 63) & ~(size_t)63;
