@@ -80,6 +80,7 @@ struct TreeDev {
     const uint32_t* wpack;              // [n_wide][S]: x | y << 6 | z << 13 where y <= 127 (4 MB per million scaffolds: L2), else PACK_ESCAPE
     const uint32_t* sinfo;              // the INLINE form of the position words (at most 2^22 scaffolds of at most 63 dps each): [S] y | z << 7,
                                         // and x of the dimension sits in the word itself -- no gather from a table per dimension.  NULL: not in use
+    const uint8_t* stot;                // [S] y alone (1 MB per million scaffolds: stays in the L2), for the screen, which does not need z
     uint32_t sc_mask;                   // the scaffold of a position word: W_SC, or W_SC22 in the inline form
     int32_t D, S;
 };
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void tree_static_wide_kernel(SepDev P, const i
     const uint32_t lenc = (uint32_t)(len < 500000 ? (len < 0 ? 0 : len) : 500000);
     wext[(int64_t)w * S + s] = make_uint4((uint32_t)nb, (uint32_t)n, lenc, (uint32_t)ts);
     wpack[(int64_t)w * S + s] = (n <= 127) ? ((uint32_t)nb | (uint32_t)n << 6 | lenc << 13) : PACK_ESCAPE;      // nb <= n / 2 <= 63
-    if (sinfo && w == 0) sinfo[s] = (uint32_t)n | lenc << 7;
+    if (sinfo && w == 0) { sinfo[s] = (uint32_t)n | lenc << 7; reinterpret_cast<uint8_t*>(sinfo + S)[s] = (uint8_t)n; }      // [S] words, then [S] bytes
 }
 
 // the word of every sorted position: scaffold | flags.  grid (blocks, wide dimensions)
@@ -479,13 +480,20 @@ __global__ __launch_bounds__(64) void tree_bar_kernel(TreeDev Tr, const Cand* __
 // no record: not W_OWN, dead, or its bit of `use` clear; PACK_ESCAPE: a scaffold too large for the packed form) -- as eight
 // independent loads with no branch around them: a load under a branch is waited for before the next is issued, and eight
 // round trips in a row were most of these kernels' time.  A position without a record reads entry 0.
+template <bool TOT_ONLY = false>
 __device__ __forceinline__ void load_packs(const TreeDev& Tr, int w, const uint32_t (&wd)[8], uint32_t use, uint32_t (&pk)[8])
 {
     uint32_t own = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) own |= (uint32_t)((wd[i] & (W_OWN | W_DEAD)) == W_OWN) << i;
     own &= use;
-    if (Tr.sinfo) {
+    if (TOT_ONLY && Tr.sinfo) {                                 // z left out (0)
+        uint8_t y[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) y[i] = Tr.stot[((own >> i) & 1u) ? (wd[i] & W_SC22) : 0u];
+#pragma unroll
+        for (int i = 0; i < 8; i++) pk[i] = ((own >> i) & 1u) ? (((wd[i] >> W_X_SHIFT) & 63u) | (uint32_t)y[i] << 6) : 0u;
+    } else if (Tr.sinfo) {
         uint32_t si[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) si[i] = Tr.sinfo[((own >> i) & 1u) ? (wd[i] & W_SC22) : 0u];
@@ -610,11 +618,12 @@ __global__ __launch_bounds__(256) void tree_wide_screen_kernel(TreeDev Tr, const
 #pragma unroll
         for (int i = 0; i < 8; i++) b[i] = b8[i];
     }
+    const int next_bin = bins[min((int64_t)i0 + 8, wstride - 1)];   // (not behind the node's record: one round trip less)
     const NodeDev nd = nodes[t.node];
-    b[8] = (i0 + 8 < nd.dp_end) ? bins[i0 + 8] : -1;              // -1 past the segment's end (where a partial tile ends, too): the last run ends there
     const WSums4 carry = tile_carry[(int64_t)w * n_tiles + blockIdx.x];
     const double node_bar = bar[t.node];
-    load_packs(Tr, w, wd, 0xFFu, pk);
+    load_packs<true>(Tr, w, wd, 0xFFu, pk);
+    b[8] = (i0 + 8 < nd.dp_end) ? next_bin : -1;                  // -1 past the segment's end (where a partial tile ends, too): the last run ends there
     // all the walk needs of a position, in one register: live | run end << 1 | tp << 2 | tot << 9
     uint32_t info[8];
     uint32_t a_size = 0, a_tp = 0, a_tot = 0;
@@ -640,6 +649,7 @@ __global__ __launch_bounds__(256) void tree_wide_screen_kernel(TreeDev Tr, const
     for (int i = 0; i < 8; i++) {
         size1 += info[i] & 1u; tp1 += (info[i] >> 2) & 127u; tot1 += (info[i] >> 9) & 127u;      // (nothing outside the tile: dead words there)
         hit |= (info[i] & 2u) && screen32(size1, tp1, tot1, n32, mn32, need);
+        __builtin_amdgcn_sched_barrier(0);                      // one position after the other: eight at once cost 20 registers
     }
     const int any = __syncthreads_or(hit);
     if (threadIdx.x == 0) {
@@ -868,7 +878,7 @@ __global__ __launch_bounds__(256) void node_wide_screen_kernel(TreeDev Tr, int32
 #pragma unroll
         for (int i = 0; i < 8; i++) if (!mb[i]) in &= ~(1u << i);
     }
-    load_packs(Tr, w, wd, in, pk);
+    load_packs<true>(Tr, w, wd, in, pk);
     uint32_t info[8];                                         // live | run end << 1 | tp << 2 | tot << 9
     uint32_t a_size = 0, a_tp = 0, a_tot = 0;
     bool hit = false;
@@ -891,6 +901,7 @@ __global__ __launch_bounds__(256) void node_wide_screen_kernel(TreeDev Tr, int32
     for (int i = 0; i < 8; i++) {
         size1 += info[i] & 1u; tp1 += (info[i] >> 2) & 127u; tot1 += (info[i] >> 9) & 127u;
         hit |= (info[i] & 2u) && screen32(size1, tp1, tot1, n32, mn32, need);
+        __builtin_amdgcn_sched_barrier(0);
     }
     const int any = __syncthreads_or(hit);
     if (threadIdx.x == 0) {
@@ -1260,7 +1271,7 @@ int tree_static_build(abw_ctx* ctx, SepHost& H, const SepDev& P, const int32_t* 
     if (H.d_sinfo) { (void)hipFree(H.d_sinfo); H.d_sinfo = nullptr; }
     if (n_wide) {
         const bool inl = H.packed && S <= (int32_t)W_SC22 + 1 && !getenv("ABW_SEP_NO_INLINE");
-        if (inl) ABW_HIP(ctx, hipMalloc((void**)&H.d_sinfo, (size_t)S * 4));
+        if (inl) ABW_HIP(ctx, hipMalloc((void**)&H.d_sinfo, (size_t)S * 5 + 64));
         const int64_t Np = (N + 7) & ~(int64_t)7;
         ABW_HIP(ctx, hipMalloc((void**)&H.d_wword, (size_t)n_wide * Np * 4));
         ABW_HIP(ctx, hipMalloc((void**)&H.d_wext, (size_t)n_wide * S * 16));
@@ -1325,6 +1336,13 @@ struct TreeRun {
         const abw_sep_state& s = ctx->sep;
         return s.h_binval_off[d] < 0 ? bin : s.h_binval[(size_t)s.h_binval_off[d] + bin];
     }
+    // solo (abw_sep_tree: one context, nobody between the phases): the winners stay on the device from the evaluation through
+    // the sides to the children's sizes -- one read-back and one wait per level instead of three -- and the partition runs on
+    // while the host lays out the next level
+    bool solo = false;
+    hipEvent_t ev_part = nullptr;           // the level's NodePart records have left the pinned block
+    bool part_pending = false;
+    ~TreeRun() { if (ev_part) (void)hipEventDestroy(ev_part); }
     int begin(int32_t min_ndps_, int64_t max_nodes_);
     int eval(abw_tree_winner* best, int64_t cap, int64_t* n_level);
     int assign(const abw_tree_winner* winners, int64_t n);
@@ -1373,7 +1391,7 @@ int TreeRun::begin(int32_t min_ndps_, int64_t max_nodes_)
     Tr.groups = H.d_groups; Tr.n_groups = n_groups; Tr.nk16 = (const uint4*)H.d_nk16; Tr.ts8 = (const uint4*)H.d_ts8; Tr.srec = (const int4*)H.d_srec;
     Tr.wide = H.d_wide; Tr.n_wide = n_wide; Tr.dp2scaf = nullptr; Tr.dim_slot = H.d_dim_slot;
     Tr.wext = (const uint4*)H.d_wext; Tr.wpack = H.d_wpack; Tr.D = D; Tr.S = S;
-    Tr.sinfo = H.d_sinfo; Tr.sc_mask = H.d_sinfo ? W_SC22 : W_SC;
+    Tr.sinfo = H.d_sinfo; Tr.stot = H.d_sinfo ? (const uint8_t*)(H.d_sinfo + S) : nullptr; Tr.sc_mask = H.d_sinfo ? W_SC22 : W_SC;
 
     order[0] = (uint32_t*)b_order.p; order[1] = (uint32_t*)b_order.p + Sp;
     wbin[0] = (int32_t*)b_wbin.p; wbin[1] = n_wide ? (int32_t*)b_wbin.p + (int64_t)n_wide * Wp : nullptr;
@@ -1408,6 +1426,7 @@ int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
     K = (int32_t)level.size();
     *n_level = K;
     if (cap < K || !best) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_sep_tree_eval: %d nodes in the level, capacity %lld", K, (long long)cap);
+    if (part_pending) { ABW_HIP(ctx, hipEventSynchronize(ev_part)); part_pending = false; }      // the pinned block is written below
     abw_devbuf &b_scg = ctx->scratch[5], &b_lvl = ctx->scratch[6], &b_tile = ctx->scratch[7];
     abw_devbuf* b_hist[2] = {&ctx->scratch[10], &ctx->scratch[11]};
     // ---- node table, tiles, and the plan for the histograms of this level
@@ -1555,6 +1574,7 @@ int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
         hipLaunchKernelGGL(tree_winner_kernel, dim3((unsigned)K), dim3(64), 0, st, Tr, d_nodes, d_cand, d_res);
         ABW_LAUNCH_CHECK(ctx);
     }
+    if (solo) { phase = 1; return ABW_OK; }                    // the winners are read back with the children's sizes (advance)
     NodeRes* h_res = (NodeRes*)(hp + o_res);
     ABW_HIP(ctx, hipMemcpyAsync(h_res, d_res, (size_t)K * sizeof(NodeRes), hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));
@@ -1576,6 +1596,14 @@ int TreeRun::assign(const abw_tree_winner* winners, int64_t n)
 {
     hipStream_t st = ctx->stream;
     if (phase != 1) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_tree_assign: no evaluated level (abw_sep_tree_eval)");
+    if (solo) {                                                 // every winner is this context's own, and already where the kernel reads it
+        ABW_HIP(ctx, hipMemsetAsync(d_scaf_side, 0, (size_t)S, st));
+        ABW_PROF(ctx, "sep_eval");
+        hipLaunchKernelGGL(tree_assign_kernel, dim3((unsigned)n_st), dim3(256), 0, st, Tr, d_stiles, (const int32_t*)order[cur], (const NodeRes*)d_res, d_scaf_side);
+        ABW_LAUNCH_CHECK(ctx);
+        phase = 2;
+        return ABW_OK;
+    }
     if (n != K || !winners) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree_assign: %lld winners for a level of %d nodes", (long long)n, K);
     NodeRes* h_res = (NodeRes*)((uint8_t*)ctx->pinned + o_res);
     final_winners.assign(winners, winners + K);
@@ -1614,6 +1642,17 @@ int TreeRun::advance()
     }
     ABW_HIP(ctx, hipMemcpyAsync(h_res, d_res, (size_t)K * sizeof(NodeRes), hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));
+    if (solo) {
+        final_winners.resize((size_t)K);
+        for (int32_t k = 0; k < K; k++) {
+            const GlobalRes& w = h_res[k].win;
+            abw_tree_winner& b = final_winners[k];
+            memset(&b, 0, sizeof(b));
+            b.found = w.found; b.dimension = w.found ? w.dim : -1; b.key = w.found ? key_of(w.dim, w.bin) : -1;
+            b.legal = w.legal; b.sensitivity = w.sens; b.specificity = w.spec;
+            b.global_dimension = w.found ? w.dim + 1 : -1;
+        }
+    }
     std::vector<HostNode> next;
     NodePart* h_part = (NodePart*)(hp + o_part);
     int32_t nsb = 0;
@@ -1681,6 +1720,11 @@ int TreeRun::advance()
     }
     // ---- partition into the next level's order (terminal nodes' scaffolds get their cluster id)
     ABW_HIP(ctx, hipMemcpyAsync(d_part, h_part, (size_t)K * sizeof(NodePart), hipMemcpyHostToDevice, st));
+    if (solo) {
+        if (!ev_part) ABW_HIP(ctx, hipEventCreateWithFlags(&ev_part, hipEventDisableTiming));
+        ABW_HIP(ctx, hipEventRecord(ev_part, st));
+        part_pending = true;
+    }
     {
         ABW_PROF(ctx, "sep_partition");
         hipLaunchKernelGGL(tree_part_count_kernel, dim3((unsigned)n_st, 1), dim3(256), 0, st, d_stiles, n_st, d_part, (const uint32_t*)order[cur], (int64_t)0, d_scaf_side,
@@ -1712,8 +1756,9 @@ int TreeRun::advance()
             wcur = wto;
         }
     }
-    // the level's pinned block is re-used by the next level's upload: the copy of h_part must have left it
-    ABW_HIP(ctx, hipStreamSynchronize(st));
+    // the level's pinned block is re-used by the next level's upload: the copy of h_part must have left it (solo: the next
+    // eval waits for ev_part instead, and the partition runs on behind the host)
+    if (!solo) ABW_HIP(ctx, hipStreamSynchronize(st));
     cur ^= 1;
     level.swap(next);
     phase = (level.empty() || visited >= max_nodes) ? 3 : 0;
@@ -1795,7 +1840,7 @@ int node_wide_plan(abw_ctx* ctx, NodeWide& W)
     W.Tr.narrow = H.d_nsort; W.Tr.n_narrow = (int32_t)H.narrow_dims.size();
     W.Tr.wide = H.d_wide; W.Tr.n_wide = W.n_wide;
     W.Tr.wext = (const uint4*)H.d_wext; W.Tr.wpack = H.d_wpack; W.Tr.D = s.D; W.Tr.S = s.S;
-    W.Tr.sinfo = H.d_sinfo; W.Tr.sc_mask = H.d_sinfo ? W_SC22 : W_SC;
+    W.Tr.sinfo = H.d_sinfo; W.Tr.stot = H.d_sinfo ? (const uint8_t*)(H.d_sinfo + s.S) : nullptr; W.Tr.sc_mask = H.d_sinfo ? W_SC22 : W_SC;
     return ABW_OK;
 }
 }  // namespace
@@ -1989,6 +2034,7 @@ int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, abw_tree_nod
     *n_nodes = 0;
     int rc;
     if ((rc = abw_sep_tree_begin(ctx, min_ndps, max_nodes))) return rc;
+    ((TreeRun*)abw_sep_host(ctx).tree_run)->solo = true;
     std::vector<abw_tree_winner> best(256);
     for (;;) {
         int64_t k = 0;
@@ -2001,6 +2047,10 @@ int abw_sep_tree(abw_ctx* ctx, int32_t min_ndps, int64_t max_nodes, abw_tree_nod
         if (k == 0) break;
         if ((rc = abw_sep_tree_assign(ctx, best.data(), k, nullptr, nullptr))) return rc;
         if ((rc = abw_sep_tree_advance(ctx))) return rc;
+    }
+    {
+        abw_device_guard g(ctx->device);
+        ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the last level's partition may still be running
     }
     return abw_sep_tree_result(ctx, nodes_out, node_cap, n_nodes, scaf2cluster);
 }
