@@ -1206,11 +1206,11 @@ def main():
     flops_per_unit = 4 * (D + 1)
     ms_avg = ms_launch / max(n_launch, 1)
     achieved = kernel_N * kernel_R * flops_per_unit / (ms_avg * 1e-3) / 1e12      # per launch: the points and restarts ONE GPU's launch covers
-    # HBM bytes per launch from the committed PMC passes (profiles/pmc_r02.json; collected on this
+    # HBM bytes per launch from the committed PMC passes (profiles/pmc_r03.json; collected on this
     # workload with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as the microarchitecture guide says)
     pmc_all = {}
     try:
-        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_r02.json")))
+        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_r03.json")))
     except Exception:
         pmc_all = {}
     default_workload = world == 1 and (args.scaffolds, args.samples, R, args.sig_mbp) == (200000, 10, 64, 1000)
@@ -1249,7 +1249,7 @@ def main():
     if not args.no_extras:
         keys_host = keys_t.cpu().numpy()
         out["separator"] = separator_leg(ctx, keys_host, dp2scaf, scaf_len, genome, G, 20240 + cfg_no, f"configs[{cfg_no}]",
-                                         pmc_all.get("sep_accum_kernel", {}).get("hbm_bytes_per_launch_raw") if default_workload else None)
+                                         pmc_all.get("separator_root_node", {}).get("hbm_bytes_per_launch") if default_workload else None)
 
         blob, off = make_assembly_blob(20244, args.sig_mbp)
         total = len(blob)

@@ -26,7 +26,7 @@ pv = lambda a: C.c_void_p(a.ctypes.data)
 def run(ids, label, n_dps):
     m = store.S if ids is None else len(ids)
     p = None if ids is None else pv(ids)
-    for per in (None, (_lib.DimBest * D)()):
+    for per in ((None,) if os.environ.get("NO_PER_DIM_ONLY") else (None, (_lib.DimBest * D)())):
         ctx.check(L.abw_sep_node(ctx.handle, p, m, 100, C.byref(out), per, pv(side), None))
         ctx.prof_reset(); ctx.prof_enable(True)
         t0 = time.perf_counter()
