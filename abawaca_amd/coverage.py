@@ -87,6 +87,14 @@ def names_table(names):
     return np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8).copy(), off
 
 
+def sam_names_load(ctx: Context, names) -> int:
+    """The name table once per assembly (abw_sam_names_load): afterwards parse_sam(ctx, text, len(names)) -- the NUMBER of
+    names in place of the names -- looks RNAME up in the table resident on the device.  Returns len(names)."""
+    blob, off = names_table(names)
+    ctx.check(lib().abw_sam_names_load(ctx.handle, C.c_void_p(blob.ctypes.data), C.c_void_p(off.ctypes.data), len(names)))
+    return len(names)
+
+
 def parse_sam(ctx: Context, text, names, max_snps: int = MAX_SNPS, every_record: bool = False):
     """SAM text (bytes / uint8 array; a whole file or a part cut at line ends) -> (scaf u32, pos0 u64, len u32) of the records
     the reference accumulates (reference src/ReadMappingReader.cpp:80-116, src/ReadMapping.cpp:23-185,
@@ -94,7 +102,11 @@ def parse_sam(ctx: Context, text, names, max_snps: int = MAX_SNPS, every_record:
     record (scaf, pos0, len, flag, nsnps) and the counts.  Raises (ABW_ERR_FORMAT / ABW_ERR_LOWER_N, the line named in the
     message) where the reference's reader would not return a mapping: fall back to that reader."""
     text = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
-    blob, off = names_table(names)
+    if isinstance(names, int):                                  # the table of sam_names_load(ctx, names): only their number
+        n_names, pb, po = names, None, None
+    else:
+        blob, off = names_table(names)
+        n_names, pb, po = len(names), C.c_void_p(blob.ctypes.data), C.c_void_p(off.ctypes.data)
     cap = int(np.count_nonzero(text == 10)) + 1
     rs, rp, rl = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint32)
     p = lambda a: C.c_void_p(a.ctypes.data)
@@ -105,7 +117,7 @@ def parse_sam(ctx: Context, text, names, max_snps: int = MAX_SNPS, every_record:
         extra = [p(cs), p(cp), p(cl), p(cf), p(cn)]
     else:
         extra = [None] * 5
-    ctx.check(lib().abw_sam_parse(ctx.handle, p(text), len(text), p(blob), p(off), len(names), int(max_snps), cap, p(rs), p(rp), p(rl),
+    ctx.check(lib().abw_sam_parse(ctx.handle, p(text), len(text), pb, po, n_names, int(max_snps), cap, p(rs), p(rp), p(rl),
                                   *extra, C.byref(cnt)))
     k = int(cnt.kept)
     kept = (rs[:k], rp[:k], rl[:k])

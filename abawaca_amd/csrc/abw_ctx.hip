@@ -174,6 +174,7 @@ void abw_ctx_destroy(abw_ctx* ctx)
     for (auto& b : ctx->scratch) abw_release(b);
     for (auto& b : ctx->km_buf) abw_release(b);
     abw_release(ctx->lrn_table);
+    abw_release(ctx->sam_names);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

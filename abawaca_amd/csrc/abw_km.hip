@@ -594,20 +594,25 @@ int abw_km_features_from_keys(abw_ctx* ctx, const int32_t* d_keys, int32_t D, in
     return ABW_OK;
 }
 
-int32_t abw_km_auto_chunk(const abw_ctx* ctx, int64_t N, int32_t R)
+int32_t abw_km_chunk_for(int32_t num_cu, int64_t N, int32_t R)
 {
-    if (!ctx || N < 1 || R < 1) return 0;
+    if (num_cu < 1 || N < 1 || R < 1) return 0;
     // workgroups that run side by side: one per compute unit (the step kernel takes ~150 KiB of LDS);
     // each walks PT chunks at once and covers CW restart tiles (see launch_step)
     const int tiles_r = (R + 31) / 32;
     const int cw = tiles_r >= 3 ? 4 : tiles_r;
     const int pt = 4 / cw, gy = (tiles_r + cw - 1) / cw;
-    const int64_t slots = std::max<int64_t>(1, (int64_t)ctx->num_cu / gy) * pt;
+    const int64_t slots = std::max<int64_t>(1, (int64_t)num_cu / gy) * pt;
     const int64_t tiles = (N + 31) / 32;
     for (int64_t rounds = 1;; rounds++) {
         const int64_t per = (tiles + slots * rounds - 1) / (slots * rounds);
         if (per <= 64) return (int32_t)(32 * std::max<int64_t>(1, per));
     }
+}
+
+int32_t abw_km_auto_chunk(const abw_ctx* ctx, int64_t N, int32_t R)
+{
+    return ctx ? abw_km_chunk_for(ctx->num_cu, N, R) : 0;
 }
 
 int abw_km_shard_begin(abw_ctx* ctx, const float* d_x, int64_t N_local, int64_t first_point, int64_t N_total, int32_t d,

@@ -349,20 +349,14 @@ uint64_t fnv1a(const uint8_t* p, uint64_t n)
 
 }  // namespace
 
-extern "C" int abw_sam_parse_dev(abw_ctx* ctx, const uint8_t* d_text, uint64_t len, const uint8_t* names, const uint64_t* name_off,
-                                 uint64_t n_scaf, uint32_t max_snps, uint64_t cap, uint32_t* d_read_scaf, uint64_t* d_read_pos,
-                                 uint32_t* d_read_len, uint32_t* d_rec_scaf, uint64_t* d_rec_pos, uint32_t* d_rec_len, uint32_t* d_rec_flag,
-                                 uint32_t* d_rec_nsnps, abw_sam_counts* counts)
+namespace {
+size_t up16(size_t b) { return (b + 15) & ~(size_t)15; }
+
+// The scaffold names as an open-addressing table (at most half full; equal names keep the first, as an unordered_map insert
+// does), built on the host and uploaded into `buf`: slot_hash u64[n_slots] | name_off u64[n_scaf + 1] | slot_id u32[n_slots] | blob.
+int build_names(abw_ctx* ctx, abw_devbuf& buf, const uint8_t* names, const uint64_t* name_off, uint64_t n_scaf, uint64_t* n_slots_out)
 {
-    if (!ctx) return ABW_ERR_ARG;
-    if (!counts || (len && !d_text) || (n_scaf && (!names || !name_off)) || n_scaf >= 0xFFFFFFFEull)
-        return abw_fail(ctx, ABW_ERR_ARG, "abw_sam_parse: bad argument");
-    counts->lines = counts->records = counts->kept = 0;
-    if (len == 0) return ABW_OK;
-    abw_device_guard g(ctx->device);
     hipStream_t st = ctx->stream;
-    int rc;
-    // the names: open addressing, at most half full; equal names keep the first (an unordered_map insert does)
     uint64_t n_slots_tab = 16;
     while (n_slots_tab < 2 * n_scaf + 2) n_slots_tab <<= 1;
     std::vector<uint64_t> slot_hash((size_t)n_slots_tab, 0);
@@ -380,19 +374,60 @@ extern "C" int abw_sam_parse_dev(abw_ctx* ctx, const uint8_t* d_text, uint64_t l
         if (!dup) { slot_hash[at] = h; slot_id[at] = (uint32_t)s; }
     }
     const uint64_t blob_len = n_scaf ? name_off[n_scaf] : 0;
-    const uint64_t nblk = (len + SAM_BLK - 1) / SAM_BLK;
-    auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    // scratch[0]: slot_hash | name_off | slot_id | blob;  scratch[1]: blk_prefix u64[nblk + 1] | blk_nl u32[nblk] | err u64
     const size_t b_sh = n_slots_tab * 8, b_no = (n_scaf + 1) * 8, b_si = up16(n_slots_tab * 4), b_bl = up16(blob_len + 1);
-    if ((rc = abw_reserve(ctx, ctx->scratch[0], b_sh + b_no + b_si + b_bl))) return rc;
-    uint8_t* p0 = (uint8_t*)ctx->scratch[0].p;
+    int rc;
+    if ((rc = abw_reserve(ctx, buf, b_sh + b_no + b_si + b_bl))) return rc;
+    uint8_t* p0 = (uint8_t*)buf.p;
+    const uint64_t zero_off = 0;
+    // (pageable sources: each copy has left the host buffer when the call returns)
+    ABW_HIP(ctx, hipMemcpyAsync(p0, slot_hash.data(), b_sh, hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemcpyAsync(p0 + b_sh, n_scaf ? name_off : &zero_off, b_no, hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipMemcpyAsync(p0 + b_sh + b_no, slot_id.data(), n_slots_tab * 4, hipMemcpyHostToDevice, st));
+    if (blob_len) ABW_HIP(ctx, hipMemcpyAsync(p0 + b_sh + b_no + b_si, names, blob_len, hipMemcpyHostToDevice, st));
+    ABW_HIP(ctx, hipStreamSynchronize(st));
+    *n_slots_out = n_slots_tab;
+    return ABW_OK;
+}
+}  // namespace
+
+// The names of an assembly once, for every abw_sam_parse[_dev] call that passes names == NULL afterwards (a SAM file read in
+// pieces, several SAM files): the table stays on the device until the next load or abw_ctx_destroy.  n_scaf = 0 drops it.
+extern "C" int abw_sam_names_load(abw_ctx* ctx, const uint8_t* names, const uint64_t* name_off, uint64_t n_scaf)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if ((n_scaf && (!names || !name_off)) || n_scaf >= 0xFFFFFFFEull) return abw_fail(ctx, ABW_ERR_ARG, "abw_sam_names_load: bad argument");
+    abw_device_guard g(ctx->device);
+    ctx->sam_slots = 0; ctx->sam_n_scaf = 0;
+    if (n_scaf == 0) return ABW_OK;
+    uint64_t n_slots = 0;
+    if (int rc = build_names(ctx, ctx->sam_names, names, name_off, n_scaf, &n_slots)) return rc;
+    ctx->sam_slots = n_slots; ctx->sam_n_scaf = n_scaf;
+    return ABW_OK;
+}
+
+extern "C" int abw_sam_parse_dev(abw_ctx* ctx, const uint8_t* d_text, uint64_t len, const uint8_t* names, const uint64_t* name_off,
+                                 uint64_t n_scaf, uint32_t max_snps, uint64_t cap, uint32_t* d_read_scaf, uint64_t* d_read_pos,
+                                 uint32_t* d_read_len, uint32_t* d_rec_scaf, uint64_t* d_rec_pos, uint32_t* d_rec_len, uint32_t* d_rec_flag,
+                                 uint32_t* d_rec_nsnps, abw_sam_counts* counts)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    const bool resident = !names && !name_off && n_scaf != 0;          // the table of abw_sam_names_load
+    if (!counts || (len && !d_text) || (n_scaf && !resident && (!names || !name_off)) || n_scaf >= 0xFFFFFFFEull)
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_sam_parse: bad argument");
+    if (resident && (ctx->sam_slots == 0 || ctx->sam_n_scaf != n_scaf))
+        return abw_fail(ctx, ABW_ERR_STATE, "abw_sam_parse: names == NULL needs the table of abw_sam_names_load for these %llu scaffolds", (unsigned long long)n_scaf);
+    counts->lines = counts->records = counts->kept = 0;
+    if (len == 0) return ABW_OK;
+    abw_device_guard g(ctx->device);
+    hipStream_t st = ctx->stream;
+    int rc;
+    uint64_t n_slots_tab = ctx->sam_slots;
+    if (!resident && (rc = build_names(ctx, ctx->scratch[0], names, name_off, n_scaf, &n_slots_tab))) return rc;
+    const uint64_t nblk = (len + SAM_BLK - 1) / SAM_BLK;
+    const size_t b_sh = n_slots_tab * 8, b_no = (n_scaf + 1) * 8, b_si = up16(n_slots_tab * 4);
+    uint8_t* p0 = (uint8_t*)(resident ? ctx->sam_names.p : ctx->scratch[0].p);
     uint64_t* d_slot_hash = (uint64_t*)p0; uint64_t* d_name_off = (uint64_t*)(p0 + b_sh);
     uint32_t* d_slot_id = (uint32_t*)(p0 + b_sh + b_no); uint8_t* d_blob = p0 + b_sh + b_no + b_si;
-    ABW_HIP(ctx, hipMemcpyAsync(d_slot_hash, slot_hash.data(), b_sh, hipMemcpyHostToDevice, st));
-    const uint64_t zero_off = 0;
-    ABW_HIP(ctx, hipMemcpyAsync(d_name_off, n_scaf ? name_off : &zero_off, b_no, hipMemcpyHostToDevice, st));
-    ABW_HIP(ctx, hipMemcpyAsync(d_slot_id, slot_id.data(), n_slots_tab * 4, hipMemcpyHostToDevice, st));
-    if (blob_len) ABW_HIP(ctx, hipMemcpyAsync(d_blob, names, blob_len, hipMemcpyHostToDevice, st));
     const size_t b_bp = (nblk + 2) * 8, b_bn = up16(nblk * 4);
     if ((rc = abw_reserve(ctx, ctx->scratch[1], b_bp + b_bn + 16))) return rc;
     uint64_t* blk_prefix = (uint64_t*)ctx->scratch[1].p;

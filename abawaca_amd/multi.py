@@ -112,29 +112,39 @@ def combine_int_sum(t, dist=None):
     return t
 
 
-_fast_combine_failed = False
+_fast_combine = {}       # (backend, world, with a context, on the device) -> bool: the path every rank of this group takes, agreed once (see below)
+
+
+def _fast_combine_agreed(t, dist, ctx) -> bool:
+    """Whether ALL ranks can take the one-buffer all-gather + abw_km_sum_ordered.  Decided once per process group and
+    collectively (an all-reduce MIN of each rank's own answer): ranks that disagreed would issue different collectives and
+    hang.  Nothing is caught around the collectives themselves: a failure after one has been entered propagates."""
+    import torch
+    key = (dist.get_backend(), dist.get_world_size(), ctx is not None, bool(t.is_cuda))      # (the same on all ranks: one program)
+    if key not in _fast_combine:
+        mine = int(ctx is not None and t.is_cuda and dist.get_backend() == "nccl" and bool(getattr(ctx, "shares_torch_stream", False))
+                   and hasattr(dist, "all_gather_into_tensor"))
+        flag = torch.tensor([mine], dtype=torch.int32, device=t.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        _fast_combine[key] = bool(int(flag.item()))
+    return _fast_combine[key]
 
 
 def combine_ordered_sum(t, dist=None, ctx=None):
     """In-place fp64 sum over the shards, added in shard (rank) order on every rank, so that all ranks
     hold identical bits and the result does not depend on the collective's internal order: all-gather
     (a few hundred KB per rank, one direct exchange per peer over xGMI) + local adds.  With `ctx` (a Context whose
-    stream is torch's current stream) on RCCL: one all-gather into one buffer and one kernel (abw_km_sum_ordered)."""
-    global _fast_combine_failed
+    stream is torch's current stream) on RCCL: one all-gather into one buffer and one kernel (abw_km_sum_ordered) --
+    when every rank can (agreed once, _fast_combine_agreed)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return t
     import torch
     world = dist.get_world_size()
-    if ctx is not None and t.is_cuda and dist.get_backend() == "nccl" and ctx.shares_torch_stream and not _fast_combine_failed:
-        try:
-            buf = torch.empty((world, t.numel()), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(buf, t.reshape(-1))
-            sum_ordered(ctx, buf, t)
-            return t
-        except (RuntimeError, AttributeError) as e:       # an older torch / a backend without the flat all-gather: the generic way
-            _fast_combine_failed = True
-            import sys
-            print(f"[abawaca_amd.multi] fast combine unavailable ({e}); using all_gather + adds", file=sys.stderr)
+    if _fast_combine_agreed(t, dist, ctx):
+        buf = torch.empty((world, t.numel()), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(buf, t.reshape(-1))
+        sum_ordered(ctx, buf, t)
+        return t
     src = t.cpu() if (t.is_cuda and dist.get_backend() != "nccl") else t
     parts = [torch.empty_like(src) for _ in range(world)]
     dist.all_gather(parts, src)

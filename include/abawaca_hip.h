@@ -369,6 +369,11 @@ typedef struct abw_sam_counts { uint64_t lines, records, kept; } abw_sam_counts;
 int abw_sam_parse(abw_ctx* ctx, const uint8_t* text, uint64_t len, const uint8_t* names, const uint64_t* name_off, uint64_t n_scaf,
                   uint32_t max_snps, uint64_t cap, uint32_t* read_scaf, uint64_t* read_pos, uint32_t* read_len, uint32_t* rec_scaf,
                   uint64_t* rec_pos, uint32_t* rec_len, uint32_t* rec_flag, uint32_t* rec_nsnps, abw_sam_counts* counts);
+/* The name table once per assembly (a SAM file read in pieces, several SAM files; ref src/abawaca-build.cpp:549-551 looks every
+ * RNAME up in ONE map built at :483-490): after it, abw_sam_parse[_dev] with names == NULL, name_off == NULL and the same
+ * n_scaf uses the table resident on the device instead of hashing and uploading the names again (ABW_ERR_STATE when none
+ * is loaded or n_scaf differs).  Held until the next load (n_scaf = 0: dropped) or abw_ctx_destroy. */
+int abw_sam_names_load(abw_ctx* ctx, const uint8_t* names, const uint64_t* name_off, uint64_t n_scaf);
 /* The same with the text and every output array on the device (names on the host); one or two internal read-backs. */
 int abw_sam_parse_dev(abw_ctx* ctx, const uint8_t* d_text, uint64_t len, const uint8_t* names, const uint64_t* name_off,
                       uint64_t n_scaf, uint32_t max_snps, uint64_t cap, uint32_t* d_read_scaf, uint64_t* d_read_pos,
@@ -424,6 +429,10 @@ int abw_lrn_table_load(abw_ctx* ctx, const double* values, int64_t ld, int32_t n
  * restarts.  Results depend on the chunk (it bounds the fp32 partial sums), so a caller that wants
  * bit-reproducible output across devices passes an explicit chunk instead.  (No reference counterpart.) */
 int32_t abw_km_auto_chunk(const abw_ctx* ctx, int64_t N, int32_t R);
+/* The same rule for a device of num_cu compute units, without a context (no GPU call): what an adapter that wants a run
+ * reproducible bit for bit across devices passes as `chunk` -- integration/ClusterSeparatorKMeans uses num_cu = 256 (MI355X)
+ * whatever the device is.  abw_km_auto_chunk(ctx, N, R) == abw_km_chunk_for(the context's compute units, N, R). */
+int32_t abw_km_chunk_for(int32_t num_cu, int64_t N, int32_t R);
 
 /* d_x: device [d][N] fp32 dimension-major points, d <= 223.  k = 2.  R restarts are run
  * together; restart r seeds TinyMT32 with base_seed + r.  chunk: points per fp32 partial sum

@@ -31,13 +31,7 @@ KmStore g_km;
 // is, so that a run is reproducible bit for bit across devices.  abw_km_split::chunk reports what was used.
 int32_t km_default_chunk(int64_t n, int R)
 {
-	const int tiles_r = (R + 31) / 32, cw = tiles_r >= 3 ? 4 : tiles_r;
-	const int pt = 4 / cw, gy = (tiles_r + cw - 1) / cw;
-	const int64_t slots = std::max<int64_t>(1, 256 / gy) * pt, tiles = (n + 31) / 32;
-	for(int64_t rounds = 1;; rounds++) {
-		const int64_t per = (tiles + slots * rounds - 1) / (slots * rounds);
-		if(per <= 64) return (int32_t)(32 * std::max<int64_t>(1, per));
-	}
+	return abw_km_chunk_for(256, n, (int32_t)R);				// the library's own rule (no copy of it here), for 256 compute units
 }
 
 void km_fail(const std::string& what)

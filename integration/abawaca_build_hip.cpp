@@ -191,6 +191,7 @@ int main(int argc, const char* argv[])
 	const double t_assembly = now_s();
 	const size_t n_scaf = recs.size();
 	vector<uint8_t>		name_blob;				// the scaffold names as abw_sam_parse takes them, in input order
+	bool				names_resident = false;	// ... and whether abw_sam_names_load has put their table on the device
 	vector<uint64_t>	name_off(1, 0);
 	for(size_t sc = 0; sc < n_scaf; sc++) {
 		name_blob.insert(name_blob.end(), recs[sc].name.begin(), recs[sc].name.end());
@@ -247,7 +248,11 @@ int main(int argc, const char* argv[])
 					for(size_t i = 0; i < cut; i++) cap_r += buf[i] == '\n';
 					r_scaf.resize(cap_r); r_pos.resize(cap_r); r_len.resize(cap_r);
 					abw_sam_counts cnt;
-					const int rc = abw_sam_parse(ctx, buf.data(), cut, name_blob.data(), name_off.data(), n_scaf, (uint32_t)max_snps, cap_r,
+					if(!names_resident) {				// once for all pieces of all SAM files
+						if(abw_sam_names_load(ctx, name_blob.data(), name_off.data(), n_scaf) != ABW_OK) die(ctx, "abw_sam_names_load");
+						names_resident = true;
+					}
+					const int rc = abw_sam_parse(ctx, buf.data(), cut, NULL, NULL, n_scaf, (uint32_t)max_snps, cap_r,
 					                             r_scaf.data(), r_pos.data(), r_len.data(), NULL, NULL, NULL, NULL, NULL, &cnt);
 					if(rc == ABW_ERR_FORMAT || rc == ABW_ERR_LOWER_N) {
 						cerr << "abawaca-build (hip): " << abw_last_error(ctx) << endl;

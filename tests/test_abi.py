@@ -113,3 +113,18 @@ def test_shard_decide_is_the_final_size_check():
     o = mk(dim=-1, key=-1, legal=0)
     L.abw_sep_shard_decide(C.byref(o), 500, 500, 100)
     assert o.split == 0
+
+
+def test_km_chunk_rule_needs_no_gpu_and_is_what_the_adapter_passes():
+    """abw_km_chunk_for (no context, no GPU call): multiples of 32, at most 64 tiles, enough chunks to fill the device; the
+    values integration/ClusterSeparatorKMeans passes for 256 compute units on the bench shapes stay what round 2's runs used
+    (the chunk is part of the result's bits)."""
+    L = _lib.lib()
+    assert L.abw_km_chunk_for(256, 799859, 64) == L.abw_km_chunk_for(256, 799859, 64) > 0
+    assert L.abw_km_chunk_for(256, 3999008, 256) == 1984                     # configs[2] on one GPU (bench: "chunk": 1984)
+    for n in (1, 31, 32, 33, 5000, 799859, 3999008, 2 ** 31 - 64):
+        for R in (1, 8, 32, 33, 64, 96, 256, 1000):
+            for cu in (1, 64, 256, 304):
+                c = L.abw_km_chunk_for(cu, n, R)
+                assert c >= 32 and c % 32 == 0 and c <= 64 * 32
+    assert L.abw_km_chunk_for(0, 100, 8) == 0 and L.abw_km_chunk_for(256, 0, 8) == 0 and L.abw_km_chunk_for(256, 100, 0) == 0

@@ -79,3 +79,18 @@ def test_node_matches_the_long_way(seed, n_scaf, G):
             kmeans.km_node(store, np.array([5, 3], dtype=np.int32), 8, 77, 6)    # not ascending
     finally:
         ctx.close()
+
+
+def test_auto_chunk_is_the_exported_rule_for_this_device():
+    """abw_km_auto_chunk(ctx, n, R) == abw_km_chunk_for(the device's compute units, n, R): the adapter's device-independent
+    default (256 units) is the library's own rule, not a copy of it."""
+    import torch
+    ctx = _lib.Context(0)
+    try:
+        cu = torch.cuda.get_device_properties(0).multi_processor_count
+        L = _lib.lib()
+        for n in (32, 4097, 200_000, 799_859, 3_999_008):
+            for R in (1, 16, 32, 64, 100, 256):
+                assert kmeans.auto_chunk(ctx, n, R) == L.abw_km_chunk_for(cu, n, R)
+    finally:
+        ctx.close()

@@ -153,3 +153,37 @@ def test_capacity_is_checked(ctx):
     assert rc == -3 and cnt.records == 500 and cnt.lines == 506            # ABW_ERR_CAPACITY, counts filled: call again with room
     with pytest.raises(_lib.AbwError):
         ctx.check(rc)
+
+
+def test_the_resident_name_table_gives_the_same_records():
+    """abw_sam_names_load once, then pieces of a file and a second file with names == NULL: the arrays of the calls that
+    pass the names; a table of another size, or none, is refused with ABW_ERR_STATE; other work between the pieces (it
+    uses the context's scratch buffers) does not disturb the table."""
+    c = _lib.Context(0)
+    try:
+        names = ["scaffold_%d" % i for i in range(700)] + ["scaffold_1"]
+        with pytest.raises(_lib.AbwError) as e:
+            coverage.parse_sam(c, _random_sam(5, 10, names, False), len(names))
+        assert e.value.code == _lib.ABW_ERR_STATE
+        n = coverage.sam_names_load(c, names)
+        for seed, n_lines in ((6, 4000), (7, 900)):
+            text = _random_sam(seed, n_lines, names, False)
+            want, ev_w = coverage.parse_sam(c, text, names, every_record=True)
+            cut = int(np.flatnonzero(text == 10)[len(names) // 2 + n_lines // 2]) + 1          # a line end in the middle
+            got = []
+            for piece in (text[:cut], text[cut:]):
+                kept, ev = coverage.parse_sam(c, piece, n, every_record=True)
+                got.append((kept, ev))
+                coverage.parse_sam(c, piece, ["another", "table", "in", "scratch"])           # the per-call table lives elsewhere
+            for k in range(3):
+                assert np.array_equal(np.concatenate([g[0][k] for g in got]), want[k])
+            for key in ("scaf", "pos0", "len", "flag", "nsnps"):
+                assert np.array_equal(np.concatenate([g[1][key] for g in got]), ev_w[key])
+        with pytest.raises(_lib.AbwError) as e:
+            coverage.parse_sam(c, text, n - 1)
+        assert e.value.code == _lib.ABW_ERR_STATE
+        coverage.sam_names_load(c, [])                                                           # dropped
+        with pytest.raises(_lib.AbwError):
+            coverage.parse_sam(c, text, n)
+    finally:
+        c.close()

@@ -63,6 +63,45 @@ def test_static_entry_matches_segment_dev_twice():
         ctx.close()
 
 
+def test_static_entry_allocates_nothing_and_does_not_wait():
+    """What the entry point is for: the device's free memory (hipMemGetInfo, which sees the library's allocations and
+    torch's alike) is the same before and after static calls on inputs and outputs that already exist, also for a larger
+    input than any before (the context's grow-only buffers would grow), and the call returns without a synchronisation:
+    nothing comes back to the host but the status."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx = _lib.Context(0)
+    try:
+        cases = []
+        for seed, n_scaf in ((11, 200), (12, 4000), (13, 900)):    # small (warm-up), larger than anything before, smaller
+            blob, off = _assembly(seed, n_scaf)
+            total = len(blob)
+            t_ascii = torch.from_numpy(np.concatenate([blob, np.zeros((-total) % 16 + 16, np.uint8)])).to(dev)
+            t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+            cap = total // 2000 + len(off) + 32
+            outs = got_like(dev, cap)
+            res = torch.full((2,), -1, dtype=torch.int64, device=dev)
+            cases.append((t_ascii, total, t_off, outs, res, blob, off))
+        signature.segment_static(ctx, cases[0][0], cases[0][1], cases[0][2], 2000, *cases[0][3], cases[0][4])   # code object loaded
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info(0)[0]
+        for t_ascii, total, t_off, outs, res, _b, _o in cases[1:]:
+            signature.segment_static(ctx, t_ascii, total, t_off, 2000, *outs, res)
+        free1 = torch.cuda.mem_get_info(0)[0]
+        ctx.synchronize()
+        assert free1 == free0 and torch.cuda.mem_get_info(0)[0] == free0
+        for t_ascii, total, t_off, outs, res, blob, off in cases[1:]:       # and the results are the other entry point's
+            ref = got_like(dev, len(outs[0]))
+            n = signature.segment_dev(ctx, t_ascii, total, t_off, 2000, *ref)
+            ctx.synchronize()
+            assert int(res[0]) == n and int(res[1]) == 0
+            for a, b in zip(ref, outs):
+                assert torch.equal(a, b)
+    finally:
+        ctx.close()
+
+
 def test_static_entry_rules():
     import torch
     ctx = _lib.Context(0)
