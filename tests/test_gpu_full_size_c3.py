@@ -9,6 +9,11 @@ oracle-sized cases of test_gpu_signature.py pin the kernels bit for bit):
              len - k + 1 (k = 1..4), with N strictly fewer 4-mers; over the assembly the monomer counts sum to the
              bases the segments hold, nseg x (nonN // nseg) per scaffold (a checksum of checksums)
   rows     : the four normalised blocks of every row sum to 4 (|error| <= 1e-12)
+  coverage : on those 4.98 M segments (reference src/abawaca-build.cpp:231-244): 10^8 reads of 100 bp that tile every
+             scaffold give every segment the coverage 1 (every coordinate of it once; the reference's 0-based read positions
+             against 1-based segment coordinates leave a scaffold's last coordinate out); the same reads shifted by 50 bases,
+             added to the same sums in a second call, give 2 less the coordinates below 50 (|error| <= 1e-9: the sums are
+             fp64 additions of overlap / length in read order)
 """
 import os
 import sys
@@ -17,6 +22,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import ctypes as C  # noqa: E402
+
 import bench  # noqa: E402
 from abawaca_amd import _lib, signature  # noqa: E402
 
@@ -88,5 +95,34 @@ def test_signature_10gbp_of_configs3():
         # rows: four normalised blocks
         err = (t_dims.sum(1) - 4.0).abs().max()
         assert float(err) <= 1e-12
+        del t_dims, t_counts, tot, seg_nonN, ends_on_base, want
+        # coverage of the same segments
+        RL = 100
+        n_reads = total // RL
+        i = torch.arange(n_reads, device=dev, dtype=torch.int64)
+        r_scaf = (i // (L // RL)).to(torch.int32)
+        r_pos = (i % (L // RL)) * RL
+        r_len = torch.full((n_reads,), RL, dtype=torch.int32, device=dev)
+        del i
+        t_cov = torch.zeros(n, dtype=torch.float64, device=dev)
+        pv = lambda t: C.c_void_p(t.data_ptr())
+        cov_call = lambda pos: ctx.check(_lib.lib().abw_cov_accumulate_dev(ctx.handle, pv(t_scaf), pv(t_st), pv(t_en), n, n_scaf, pv(r_scaf), pv(pos),
+                                                                          pv(r_len), n_reads, pv(t_cov)))
+        # The reference compares a read's 0-based position with the segments' 1-based coordinates as they are (ref
+        # src/ReadMapping.cpp:41, src/abawaca-build.cpp:177-185, 231-244): the tiling reads cover the coordinates 0 .. L - 1,
+        # so a segment that ends on coordinate L misses one base; the shifted reads cover 50 .. L + 49.
+        flen = length.to(torch.float64)
+        cov_call(r_pos)
+        ctx.synchronize()
+        expect = 1.0 - (en == L).to(torch.float64) / flen
+        assert float((t_cov - expect).abs().max()) <= 1e-9
+        assert 0 < int((en == L).sum()) <= n_scaf
+        r_pos2 = r_pos + RL // 2
+        cov_call(r_pos2)                                                # continues the sums
+        ctx.synchronize()
+        missing = torch.clamp(RL // 2 - st, min=0).to(torch.float64)    # coordinates st .. 49
+        expect = expect + 1.0 - missing / flen
+        assert float((t_cov - expect).abs().max()) <= 1e-9
+        assert int((missing > 0).sum()) == n_scaf
     finally:
         ctx.close()
