@@ -361,20 +361,32 @@ __global__ __launch_bounds__(256) void seg_blockcount_kernel(const uint8_t* __re
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t b = wave; b < nblk; b += nwaves) {
-        const uint64_t A = b * SEGBLK + (uint64_t)lane * 16;
-        uint32_t nN = 0, nn = 0, len = 0;
-        if (A + 16 <= total_len) {
-            const uint4 v = *reinterpret_cast<const uint4*>(ascii + A);
-            nN = count_byte_eq(v.x, 0x4E4E4E4Eu) + count_byte_eq(v.y, 0x4E4E4E4Eu) + count_byte_eq(v.z, 0x4E4E4E4Eu) + count_byte_eq(v.w, 0x4E4E4E4Eu);
-            nn = count_byte_eq(v.x, 0x6E6E6E6Eu) + count_byte_eq(v.y, 0x6E6E6E6Eu) + count_byte_eq(v.z, 0x6E6E6E6Eu) + count_byte_eq(v.w, 0x6E6E6E6Eu);
-            len = 16;
-        } else {
-            for (uint64_t i = A; i < total_len; i++) { nN += ascii[i] == 'N'; nn += ascii[i] == 'n'; len++; }
+    // four blocks per turn: four 16-byte loads in flight per lane before the first reduction (one at a time: 4.6 TB/s)
+    for (uint64_t b0 = 4 * wave; b0 < nblk; b0 += 4 * nwaves) {
+        uint4 v[4];
+        bool whole[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t b = b0 + (uint64_t)u, A = b * SEGBLK + (uint64_t)lane * 16;
+            whole[u] = b < nblk && A + 16 <= total_len;
+            v[u] = whole[u] ? *reinterpret_cast<const uint4*>(ascii + A) : make_uint4(0, 0, 0, 0);
         }
-        uint32_t nonN = wave_sum(len - nN);
-        if (nn) atomicOr(flag_lower_n, 1);
-        if (lane == 0) blk_nonN[b] = nonN;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t b = b0 + (uint64_t)u, A = b * SEGBLK + (uint64_t)lane * 16;
+            if (b >= nblk) break;                              // uniform for the wave
+            uint32_t nN = 0, nn = 0, len = 0;
+            if (whole[u]) {
+                nN = count_byte_eq(v[u].x, 0x4E4E4E4Eu) + count_byte_eq(v[u].y, 0x4E4E4E4Eu) + count_byte_eq(v[u].z, 0x4E4E4E4Eu) + count_byte_eq(v[u].w, 0x4E4E4E4Eu);
+                nn = count_byte_eq(v[u].x, 0x6E6E6E6Eu) + count_byte_eq(v[u].y, 0x6E6E6E6Eu) + count_byte_eq(v[u].z, 0x6E6E6E6Eu) + count_byte_eq(v[u].w, 0x6E6E6E6Eu);
+                len = 16;
+            } else {
+                for (uint64_t i = A; i < total_len; i++) { nN += ascii[i] == 'N'; nn += ascii[i] == 'n'; len++; }
+            }
+            const uint32_t nonN = wave_sum(len - nN);
+            if (nn) atomicOr(flag_lower_n, 1);
+            if (lane == 0) blk_nonN[b] = nonN;
+        }
     }
 }
 
