@@ -544,11 +544,13 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* sh
 
 // pass 1: sums of every position tile (live positions only; a tile's count and tot share a word: both < 2^32).
 // grid (position tiles, wide dimensions)
-__global__ __launch_bounds__(256) void tree_wide_sums_kernel(TreeDev Tr, const Tile* __restrict__ tiles, int32_t n_tiles, const uint32_t* __restrict__ wword,
-                                                            int64_t wstride, WSums4* __restrict__ tile_sums)
+// grid (tiles to sum, wide dimensions); which: the tiles' indices (NULL: all of them); the sums go to tile_sums[w * ostride + tile]
+__global__ __launch_bounds__(256) void tree_wide_sums_kernel(TreeDev Tr, const Tile* __restrict__ tiles, const int32_t* __restrict__ which, const uint32_t* __restrict__ wword,
+                                                            int64_t wstride, WSums4* __restrict__ tile_sums, int64_t ostride)
 {
     __shared__ unsigned long long sh[8];
-    const Tile t = tiles[blockIdx.x];
+    const int tile = which ? which[blockIdx.x] : (int)blockIdx.x;
+    const Tile t = tiles[tile];
     const int w = blockIdx.y;
     const uint32_t* __restrict__ words = wword + (int64_t)w * wstride;
     WSums4 a = {0, 0, 0, 0};
@@ -565,21 +567,36 @@ __global__ __launch_bounds__(256) void tree_wide_sums_kernel(TreeDev Tr, const T
     }
     const unsigned long long s0 = block_sum_u64(a.size | (a.tot << 32), sh);           // inside a tile every sum fits 32 bits (see the eval kernel)
     const unsigned long long s1 = block_sum_u64(a.tp1 | (a.bp << 32), sh + 4);
-    if (threadIdx.x == 0) tile_sums[(int64_t)w * n_tiles + blockIdx.x] = WSums4{s0 & 0xFFFFFFFFull, s1 & 0xFFFFFFFFull, s0 >> 32, s1 >> 32};
+    if (threadIdx.x == 0) tile_sums[(int64_t)w * ostride + tile] = WSums4{s0 & 0xFFFFFFFFull, s1 & 0xFFFFFFFFull, s0 >> 32, s1 >> 32};
+}
+
+// pass 1a for the tiles of a node that KEPT its parent's segment: last level's sums less what left in last level's partition
+// (tree_part_scatter_kernel leaves that per tile) -- the giant of a caterpillar is not summed again.  grid (blocks), src[tile] < 0: a fresh tile
+__global__ void tree_wide_inherit_kernel(const int32_t* __restrict__ src, int32_t n_tiles, int32_t n_wide, const WSums4* __restrict__ prev,
+                                         const WSums4* __restrict__ left, WSums4* __restrict__ cur, int64_t stride)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)n_tiles * n_wide; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i / n_tiles), t = (int)(i - (int64_t)w * n_tiles);
+        const int from = src[t];
+        if (from < 0) continue;
+        const WSums4 a = prev[(int64_t)w * stride + from], b = left[(int64_t)w * stride + from];
+        cur[(int64_t)w * stride + t] = WSums4{a.size - b.size, a.tp1 - b.tp1, a.tot - b.tot, a.bp - b.bp};
+    }
 }
 
 // pass 1b: exclusive scan of the tile sums inside every node; node totals.  grid (nodes, wide dimensions), one wave
-__global__ __launch_bounds__(64) void tree_wide_scan_kernel(const NodeDev* __restrict__ nodes, int32_t n_tiles, WSums4* __restrict__ tile_sums,
-                                                           WSums4* __restrict__ node_total, int32_t K)
+__global__ __launch_bounds__(64) void tree_wide_scan_kernel(const NodeDev* __restrict__ nodes, int32_t n_tiles, const WSums4* __restrict__ raw, int64_t rstride,
+                                                           WSums4* __restrict__ tile_sums, WSums4* __restrict__ node_total, int32_t K)
 {
     const int k = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
     const NodeDev nd = nodes[k];
+    const WSums4* __restrict__ in = raw + (int64_t)w * rstride;
     WSums4* ts = tile_sums + (int64_t)w * n_tiles;
     WSums4 run = {0, 0, 0, 0};
     for (int i0 = nd.ptile_begin; i0 < nd.ptile_end; i0 += 64) {
         const int i = i0 + lane;
         WSums4 v = {0, 0, 0, 0};
-        if (i < nd.ptile_end) v = ts[i];
+        if (i < nd.ptile_end) v = in[i];
         WSums4 x = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -1161,9 +1178,11 @@ __global__ __launch_bounds__(256) void tree_part_scatter_kernel(const Tile* __re
                                                                const int32_t* __restrict__ items2, int64_t istride,
                                                                const uint16_t* __restrict__ mask, const unsigned long long* __restrict__ tile_cnt,
                                                                uint32_t* __restrict__ out, int32_t* __restrict__ out2,
-                                                               uint32_t* __restrict__ marks, int scaf, int32_t* __restrict__ scaf2cluster, int32_t* __restrict__ scaf_slot)
+                                                               uint32_t* __restrict__ marks, int scaf, int32_t* __restrict__ scaf2cluster, int32_t* __restrict__ scaf_slot,
+                                                               TreeDev Tr, WSums4* __restrict__ left, int64_t lstride)
 {
     __shared__ unsigned long long sh[5];
+    __shared__ unsigned long long shs[8];
     const Tile t = tiles[blockIdx.x];
     const NodePart np = part[t.node];
     const uint32_t* __restrict__ it = items + (int64_t)blockIdx.y * istride;
@@ -1207,6 +1226,30 @@ __global__ __launch_bounds__(256) void tree_part_scatter_kernel(const Tile* __re
             if (scaf) scaf_slot[v[i]] = one ? np.slot1 : np.slot2;
             ones_before += one; alive_before++;
         }
+    }
+    // One child keeps the segment: the sums of what leaves this tile, for tree_wide_inherit_kernel at the next level (the
+    // tile's new sums are its old ones less these).  Uniform for the workgroup.
+    if (left && (base1 < 0) != (base2 < 0)) {
+        const int w = blockIdx.y;
+        WSums4 a = {0, 0, 0, 0};
+        if (__syncthreads_or(moving != 0)) {
+            if (!moving) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = W_DEAD;             // (this thread loaded nothing)
+            }
+            uint32_t pk[8];
+            load_packs(Tr, w, v, moving, pk);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if ((moving >> i) & 1u) {
+                    const WSums r = pack_wsums(Tr, w, v[i], pk[i], true);
+                    a.size += 1u; a.tp1 += r.tp1; a.tot += r.tot; a.bp += r.bp;
+                }
+            }
+            const unsigned long long s0 = block_sum_u64(a.size | (a.tot << 32), shs), s1 = block_sum_u64(a.tp1 | (a.bp << 32), shs + 4);
+            a = WSums4{s0 & 0xFFFFFFFFull, s1 & 0xFFFFFFFFull, s0 >> 32, s1 >> 32};
+        }
+        if (threadIdx.x == 0) left[(int64_t)w * lstride + blockIdx.x] = a;
     }
 }
 
@@ -1294,7 +1337,7 @@ int tree_static_build(abw_ctx* ctx, SepHost& H, const SepDev& P, const int32_t* 
 
 // ---- the recursion as a sequence of levels that a caller can interleave with an exchange ------------------------------
 // node of a level: id, size, and where its histogram comes from
-struct HostNode { int32_t id; int32_t m; int64_t n; int32_t parent; int64_t seg_begin, seg_len; bool root_seg; };   // parent: its slot in the previous level
+struct HostNode { int32_t id; int32_t m; int64_t n; int32_t parent; int64_t seg_begin, seg_len; bool root_seg; int32_t inherit; };   // inherit: the slot (previous level) whose segment it keeps, or -1   // parent: its slot in the previous level
                                                                           // (-1: the root); seg: its segment of the wide position arrays
 
 struct TreeRun {
@@ -1340,9 +1383,21 @@ struct TreeRun {
     // the sides to the children's sizes -- one read-back and one wait per level instead of three -- and the partition runs on
     // while the host lays out the next level
     bool solo = false;
+    // the tiles' own sums (before the scan), kept from level to level: a node that keeps its parent's segment inherits them
+    // (tree_wide_inherit_kernel) -- buffers of the run's own, the context's scratch slots are re-reserved by every level
+    WSums4* raw[2] = {nullptr, nullptr};    // [n_wide][raw_cap], this level's / the previous level's
+    WSums4* left = nullptr;                 // [n_wide][raw_cap] what left every tile in the last partition
+    int64_t raw_cap = 0;
+    int rcur = 0;
+    bool prev_raw = false;                  // raw[rcur ^ 1] and left hold the previous level
+    std::vector<int32_t> prev_tb, tile_begin;   // first position tile of every slot of the previous level / of this one (and the count behind the last)
     hipEvent_t ev_part = nullptr;           // the level's NodePart records have left the pinned block
     bool part_pending = false;
-    ~TreeRun() { if (ev_part) (void)hipEventDestroy(ev_part); }
+    ~TreeRun()
+    {
+        if (ev_part) (void)hipEventDestroy(ev_part);
+        for (void* q : {(void*)raw[0], (void*)raw[1], (void*)left}) if (q) (void)hipFree(q);
+    }
     int begin(int32_t min_ndps_, int64_t max_nodes_);
     int eval(abw_tree_winner* best, int64_t cap, int64_t* n_level);
     int assign(const abw_tree_winner* winners, int64_t n);
@@ -1407,7 +1462,7 @@ int TreeRun::begin(int32_t min_ndps_, int64_t max_nodes_)
         ABW_HIP(ctx, hipMemcpy2DAsync(wword[0], (size_t)Wp * 4, H.d_wword, (size_t)Np * 4, (size_t)N * 4, (size_t)n_wide, hipMemcpyDeviceToDevice, st));
 
     }
-    level.assign(1, HostNode{1, S, N, -1, 0, N, true});        // root_seg: still in the static order, where pos_of holds
+    level.assign(1, HostNode{1, S, N, -1, 0, N, true, -1});        // root_seg: still in the static order, where pos_of holds
     nodes.clear();
     next_id = 2; visited = 0; cur = 0; wcur = 0; arena_end = N; phase = 0;
     return ABW_OK;
@@ -1457,9 +1512,30 @@ int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
     }
     n_st = (int32_t)stiles.size(); n_pt = (int32_t)ptiles.size();
     const int32_t n_at = (int32_t)atiles.size();
+    // position tiles: inherited from the previous level (same segment, same cuts) or fresh
+    if (n_wide && n_pt > raw_cap) {                              // (grow-only; a level that grows them inherits nothing)
+        ABW_HIP(ctx, hipStreamSynchronize(st));
+        for (WSums4** q : {&raw[0], &raw[1], &left}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+        raw_cap = (int64_t)n_pt + n_pt / 2 + 64;
+        for (WSums4** q : {&raw[0], &raw[1], &left}) ABW_HIP(ctx, hipMalloc((void**)q, (size_t)n_wide * raw_cap * sizeof(WSums4)));
+        prev_raw = false;
+    }
+    std::vector<int32_t> src_tile((size_t)n_pt, -1), fresh;
+    tile_begin.assign((size_t)K + 1, n_pt);
+    for (int32_t k = 0; k < K && n_wide; k++) {
+        const int32_t from = level[k].inherit;
+        const int32_t cnt = nd[k].ptile_end - nd[k].ptile_begin;
+        tile_begin[(size_t)k] = nd[k].ptile_begin;
+        const bool ok = prev_raw && from >= 0 && from + 1 < (int32_t)prev_tb.size() && prev_tb[(size_t)from + 1] - prev_tb[(size_t)from] == cnt;
+        for (int32_t j = 0; j < cnt; j++) {
+            if (ok) src_tile[(size_t)nd[k].ptile_begin + j] = prev_tb[(size_t)from] + j;
+            else fresh.push_back(nd[k].ptile_begin + j);
+        }
+    }
+    const int32_t n_fresh = (int32_t)fresh.size();
     std::vector<uint8_t> blob;
     const size_t o_nodes = pack(blob, nd), o_st = pack(blob, stiles), o_pt = pack(blob, ptiles), o_at = pack(blob, atiles),
-                 o_zero = pack(blob, zero_slots), o_sub = pack(blob, subs);
+                 o_zero = pack(blob, zero_slots), o_sub = pack(blob, subs), o_src = pack(blob, src_tile), o_fresh = pack(blob, fresh);
     const size_t lvl_bytes = (blob.size() + 63) & ~(size_t)63;
     o_res = lvl_bytes; o_part = o_res + (((size_t)K * sizeof(NodeRes) + 63) & ~(size_t)63);
     const size_t all_bytes = o_part + (size_t)K * sizeof(NodePart) + 64;
@@ -1475,6 +1551,8 @@ int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
     const Tile* d_atiles = (const Tile*)(dl + o_at);
     const int32_t* d_zero = (const int32_t*)(dl + o_zero);
     const SubJob* d_subs = (const SubJob*)(dl + o_sub);
+    const int32_t* d_src_tile = (const int32_t*)(dl + o_src);
+    const int32_t* d_fresh = (const int32_t*)(dl + o_fresh);
     d_res = (NodeRes*)(dl + o_res);
     d_part = (NodePart*)(dl + o_part);
 
@@ -1554,9 +1632,17 @@ int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
         ABW_PROF(ctx, "sep_wide");
         hipLaunchKernelGGL(tree_bar_kernel, dim3((unsigned)K), dim3(64), 0, st, Tr, d_cand, d_bar);
         ABW_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(tree_wide_sums_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, wword[wcur], Wp, d_tsums);
-        ABW_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(tree_wide_scan_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, d_nodes, n_pt, d_tsums, d_ntot, K);
+        if (n_fresh < n_pt) {
+            hipLaunchKernelGGL(tree_wide_inherit_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)n_pt * n_wide + 255) / 256, (int64_t)ctx->num_cu * 4)), dim3(256), 0, st,
+                               d_src_tile, n_pt, n_wide, (const WSums4*)raw[rcur ^ 1], (const WSums4*)left, raw[rcur], raw_cap);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        if (n_fresh) {
+            hipLaunchKernelGGL(tree_wide_sums_kernel, dim3((unsigned)n_fresh, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_fresh < n_pt ? d_fresh : (const int32_t*)nullptr,
+                               wword[wcur], Wp, raw[rcur], raw_cap);
+            ABW_LAUNCH_CHECK(ctx);
+        }
+        hipLaunchKernelGGL(tree_wide_scan_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, d_nodes, n_pt, (const WSums4*)raw[rcur], raw_cap, d_tsums, d_ntot, K);
         ABW_LAUNCH_CHECK(ctx);
         ABW_HIP(ctx, hipMemsetAsync(d_wlist_n, 0, 4, st));
         hipLaunchKernelGGL(tree_wide_screen_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, d_nodes, min_ndps,
@@ -1681,8 +1767,8 @@ int TreeRun::advance()
             np.scaf_base1 = nsb; np.scaf_base2 = nsb + (int32_t)r.m1;
             np.slot1 = (int32_t)next.size(); np.slot2 = np.slot1 + 1;
             nsb += (int32_t)(r.m1 + r.m2);
-            next.push_back(HostNode{o.child1, (int32_t)r.m1, (int64_t)r.n1, k, 0, 0, false});
-            next.push_back(HostNode{o.child2, (int32_t)r.m2, (int64_t)r.n2, k, 0, 0, false});
+            next.push_back(HostNode{o.child1, (int32_t)r.m1, (int64_t)r.n1, k, 0, 0, false, -1});
+            next.push_back(HostNode{o.child2, (int32_t)r.m2, (int64_t)r.n2, k, 0, 0, false, -1});
             split_nodes.push_back(k);
         }
         nodes.push_back(o);
@@ -1711,9 +1797,9 @@ int TreeRun::advance()
             const int kp = compact ? 0 : keeps(k);
             HostNode &c1 = next[(size_t)np.slot1], &c2 = next[(size_t)np.slot2];
             if (kp && level[k].root_seg) { np.bits = 1; n_leavers = (int32_t)(kp == 1 ? r.m2 : r.m1); leavers_at = kp == 1 ? np.scaf_base2 : np.scaf_base1; (kp == 1 ? c1 : c2).root_seg = true; }
-            if (kp == 1) { np.dp_base1 = -1; c1.seg_begin = level[k].seg_begin; c1.seg_len = level[k].seg_len; }
+            if (kp == 1) { np.dp_base1 = -1; c1.seg_begin = level[k].seg_begin; c1.seg_len = level[k].seg_len; c1.inherit = k; }
             else { np.dp_base1 = (int32_t)at; c1.seg_begin = at; c1.seg_len = (int64_t)r.n1; at += (int64_t)r.n1; }
-            if (kp == 2) { np.dp_base2 = -1; c2.seg_begin = level[k].seg_begin; c2.seg_len = level[k].seg_len; }
+            if (kp == 2) { np.dp_base2 = -1; c2.seg_begin = level[k].seg_begin; c2.seg_len = level[k].seg_len; c2.inherit = k; }
             else { np.dp_base2 = (int32_t)at; c2.seg_begin = at; c2.seg_len = (int64_t)r.n2; at += (int64_t)r.n2; }
         }
         arena_end = at;
@@ -1734,7 +1820,7 @@ int TreeRun::advance()
         ABW_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(tree_part_scatter_kernel, dim3((unsigned)n_st, 1), dim3(256), 0, st, d_stiles, n_st, d_nodes, d_part, (const uint32_t*)order[cur],
                            (const int32_t*)nullptr, (int64_t)0, d_smask, d_scnt, order[cur ^ 1], (int32_t*)nullptr,
-                           (uint32_t*)nullptr, 1, (int32_t*)ctx->scratch[9].p, d_scaf_slot);
+                           (uint32_t*)nullptr, 1, (int32_t*)ctx->scratch[9].p, d_scaf_slot, Tr, (WSums4*)nullptr, (int64_t)0);
         ABW_LAUNCH_CHECK(ctx);
         if (n_wide && !next.empty()) {
             if (n_leavers > 0) {
@@ -1751,7 +1837,7 @@ int TreeRun::advance()
             const int wto = compact ? (wcur ^ 1) : wcur;
             hipLaunchKernelGGL(tree_part_scatter_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, d_ptiles, n_pt, d_nodes, d_part, (const uint32_t*)wword[wcur],
                                (const int32_t*)wbin[wcur], Wp, d_pmask, d_pcnt, wword[wto], wbin[wto],
-                               compact ? (uint32_t*)nullptr : wword[wcur], 0, (int32_t*)nullptr, (int32_t*)nullptr);
+                               compact ? (uint32_t*)nullptr : wword[wcur], 0, (int32_t*)nullptr, (int32_t*)nullptr, Tr, compact ? (WSums4*)nullptr : left, raw_cap);
             ABW_LAUNCH_CHECK(ctx);
             wcur = wto;
         }
@@ -1760,6 +1846,10 @@ int TreeRun::advance()
     // eval waits for ev_part instead, and the partition runs on behind the host)
     if (!solo) ABW_HIP(ctx, hipStreamSynchronize(st));
     cur ^= 1;
+    // what the next level may inherit: this level's tile sums (raw[rcur]) and what left every tile (left)
+    prev_tb = tile_begin;
+    prev_raw = n_wide > 0 && !compact;
+    rcur ^= 1;
     level.swap(next);
     phase = (level.empty() || visited >= max_nodes) ? 3 : 0;
     return ABW_OK;
