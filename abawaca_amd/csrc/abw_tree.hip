@@ -609,20 +609,79 @@ __global__ __launch_bounds__(64) void tree_wide_scan_kernel(const NodeDev* __res
     if (lane == 0) node_total[(int64_t)w * K + k] = run;
 }
 
+// Pass 2a', the screen of the screen: can ANY run end of a tile reach the node's bar?  Along a segment the four sums only grow,
+// so inside a tile size1, TP1 and tot1 lie between the tile's carry and carry + the tile's own sums, and
+// TP^2 / (TOT x SZ) of either side of the split is at most (largest TP)^2 / (smallest TOT x smallest SZ).  A tile whose bound
+// stays below the bar (with the margin of screen32) is done without reading one of its positions: next to the best
+// threshold of a dimension the bound is tight, everywhere else it is far below -- a few per cent of the tiles remain.
+// The same for the size check (ref ...Specificity.cpp:151): no run end of the tile leaves both sides their minimum.
+// c: the tile's carry, o: its own sums.  -> the tile must be looked at
+__device__ __forceinline__ bool tile_may_reach(const WSums4& c, const WSums4& o, long long n, int32_t min_ndps, double bar)
+{
+    const long long size_lo = (long long)c.size, size_hi = (long long)(c.size + o.size);
+    if (size_hi < min_ndps || n - size_lo < min_ndps) return false;            // size1 <= size_hi, size2 <= n - size_lo
+    if (!(bar > 0.0)) return true;
+    const double need = bar * (1.0 - 1e-5);
+    const double tp_hi = (double)(c.tp1 + o.tp1), tot_lo = (double)c.tot, tot_hi = (double)(c.tot + o.tot), dn = (double)n;
+    // Only the SMALLER side of a threshold is scored (ref :155; a tie scores side 2): side 1 where 2 size1 < n.
+    // the side "<= threshold": TP1 <= tp_hi, tot1 >= tot_lo, size1 >= size_lo
+    if (2 * size_lo < n) {
+        const double den1 = tot_lo * (double)size_lo;
+        if (!(den1 > 0.0) || tp_hi * tp_hi >= need * den1) return true;
+    }
+    // the other side: TP2 = n - size1 - tot1 + TP1, tot2 = n - tot1, size2 = n - size1
+    if (2 * size_hi >= n) {
+        const double tp2_hi = dn - (double)size_lo - tot_lo + tp_hi, den2 = (dn - tot_hi) * (dn - (double)size_hi);
+        if (!(den2 > 0.0) || tp2_hi * tp2_hi >= need * den2) return true;
+    }
+    return false;
+}
+
+// grid: blocks over (position tiles x wide dimensions).  Lists the tiles to look at; every tile's best starts as "none".
+__global__ __launch_bounds__(256) void tree_wide_tilescreen_kernel(const Tile* __restrict__ tiles, int32_t n_tiles, int32_t n_wide, const NodeDev* __restrict__ nodes,
+                                                                  int32_t K, int32_t min_ndps, const WSums4* __restrict__ tile_carry, const WSums4* __restrict__ node_total,
+                                                                  const double* __restrict__ bar, Cand* __restrict__ tile_best, int32_t* __restrict__ list,
+                                                                  int32_t* __restrict__ list_n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (i < (int64_t)n_tiles * n_wide) {
+        const int w = (int)(i / n_tiles), t = (int)(i - (int64_t)w * n_tiles);
+        const Tile tl = tiles[t];
+        const NodeDev nd = nodes[tl.node];
+        const WSums4 c = tile_carry[i];
+        const WSums4 e = (t + 1 < nd.ptile_end) ? tile_carry[i + 1] : node_total[(int64_t)w * K + tl.node];      // the carry behind the tile
+        keep = tile_may_reach(c, WSums4{e.size - c.size, e.tp1 - c.tp1, e.tot - c.tot, e.bp - c.bp}, nd.n, min_ndps, bar[tl.node]);
+        tile_best[i] = Cand{0.0, 0, 0, 0.0, 0.0, 0};
+    }
+    const unsigned long long m = __ballot(keep);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(list_n, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (keep) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+    }
+}
+
 // pass 2a, the screen: rescan every tile with its carry and ask at every run end (the last position of a bin inside the
 // node's segment) whether its threshold could reach the node's bar at all (screen32).  The tiles where one does -- a few, once
 // the narrow dimensions have set a bar -- are listed for pass 2b; the others are done.  Kept lean (no candidate, no SCG lists,
 // no fp64: 8 waves per SIMD), because a block lives about as long as a handful of memory round trips.
-// grid (position tiles, wide dimensions)
+// grid: any; the workgroups take the tiles listed by tree_wide_tilescreen_kernel in turn
 __global__ __launch_bounds__(256) void tree_wide_screen_kernel(TreeDev Tr, const Tile* __restrict__ tiles, int32_t n_tiles, const NodeDev* __restrict__ nodes,
                                                               int32_t min_ndps, const int32_t* __restrict__ wbin, const uint32_t* __restrict__ wword,
                                                               int64_t wstride, const WSums4* __restrict__ tile_carry, const double* __restrict__ bar,
-                                                              Cand* __restrict__ tile_best, int32_t* __restrict__ list, int32_t* __restrict__ list_n)
+                                                              const int32_t* __restrict__ todo, const int32_t* __restrict__ todo_n,
+                                                              int32_t* __restrict__ list, int32_t* __restrict__ list_n)
 {
     __shared__ unsigned long long sh[5];
     __shared__ uint32_t sh32[4];
-    const Tile t = tiles[blockIdx.x];
-    const int w = blockIdx.y;
+    const int n_todo = *todo_n;
+  for (int li = blockIdx.x; li < n_todo; li += gridDim.x) {           // (a workgroup's turns are separated by the barrier of the vote below)
+    const int entry = todo[li];
+    const int w = entry / n_tiles, tile = entry - w * n_tiles;
+    const Tile t = tiles[tile];
     const int32_t* __restrict__ bins = wbin + (int64_t)w * wstride;
     const uint32_t* __restrict__ words = wword + (int64_t)w * wstride;
     const int i0 = (t.begin & ~(TILE_P - 1)) + 8 * threadIdx.x;
@@ -637,7 +696,7 @@ __global__ __launch_bounds__(256) void tree_wide_screen_kernel(TreeDev Tr, const
     }
     const int next_bin = bins[min((int64_t)i0 + 8, wstride - 1)];   // (not behind the node's record: one round trip less)
     const NodeDev nd = nodes[t.node];
-    const WSums4 carry = tile_carry[(int64_t)w * n_tiles + blockIdx.x];
+    const WSums4 carry = tile_carry[(int64_t)w * n_tiles + tile];
     const double node_bar = bar[t.node];
     load_packs<true>(Tr, w, wd, 0xFFu, pk);
     b[8] = (i0 + 8 < nd.dp_end) ? next_bin : -1;                  // -1 past the segment's end (where a partial tile ends, too): the last run ends there
@@ -669,10 +728,8 @@ __global__ __launch_bounds__(256) void tree_wide_screen_kernel(TreeDev Tr, const
         __builtin_amdgcn_sched_barrier(0);                      // one position after the other: eight at once cost 20 registers
     }
     const int any = __syncthreads_or(hit);
-    if (threadIdx.x == 0) {
-        tile_best[(int64_t)w * n_tiles + blockIdx.x] = none;
-        if (any) list[atomicAdd(list_n, 1)] = w * n_tiles + (int)blockIdx.x;
-    }
+    if (threadIdx.x == 0 && any) list[atomicAdd(list_n, 1)] = entry;
+  }
 }
 
 // pass 2b: the listed tiles again, with everything: evaluate the threshold at every run end (the last position of a bin inside
@@ -1567,7 +1624,7 @@ int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
                  t_cnt = ((size_t)(std::max(1, n_wide) * (size_t)n_pt + n_st) * 8 + 63) & ~(size_t)63,
                  t_mask = (((size_t)std::max(1, n_wide) * n_pt + n_st) * 512 + 63) & ~(size_t)63;
     if ((int64_t)std::max(1, n_wide) * n_pt >= ((int64_t)1 << 31)) return abw_fail(ctx, ABW_ERR_ARG, "abw_sep_tree: too many position tiles");
-    if ((rc = abw_reserve(ctx, b_tile, t_cand + t_sums + t_best + t_tot + t_cnt + t_mask + (size_t)K * 8 + 64 + (size_t)std::max(1, n_wide) * n_pt * 4))) return rc;
+    if ((rc = abw_reserve(ctx, b_tile, t_cand + t_sums + t_best + t_tot + t_cnt + t_mask + (size_t)K * 8 + 64 + 2 * (size_t)std::max(1, n_wide) * n_pt * 4))) return rc;
     Cand* d_cand = (Cand*)b_tile.p;
     WSums4* d_tsums = (WSums4*)((uint8_t*)b_tile.p + t_cand);
     Cand* d_tbest = (Cand*)((uint8_t*)b_tile.p + t_cand + t_sums);
@@ -1578,7 +1635,8 @@ int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
     d_smask = d_pmask + (size_t)std::max(1, n_wide) * n_pt * 256;
     double* d_bar = (double*)((uint8_t*)d_pmask + t_mask);
     int32_t* d_wlist_n = (int32_t*)(d_bar + K);                                             // tiles listed by the screen for the full evaluation
-    int32_t* d_wlist = d_wlist_n + 16;
+    int32_t* d_wlist = d_wlist_n + 16;                                                      // (d_wlist_n[1]: the tiles listed for the screen itself)
+    int32_t* d_wtodo = d_wlist + (size_t)std::max(1, n_wide) * n_pt;
     if (scg_n > 0 && (int64_t)K * s.n_scg <= SCG_LEVEL_LDS) {
         hipLaunchKernelGGL(tree_scg_lds_kernel, dim3((unsigned)D), dim3(256), 0, st, Tr, H.d_carriers, H.n_carriers, d_scaf_slot, K, d_scg_lo, d_scg_hi);
         ABW_LAUNCH_CHECK(ctx);
@@ -1644,9 +1702,13 @@ int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
         }
         hipLaunchKernelGGL(tree_wide_scan_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, d_nodes, n_pt, (const WSums4*)raw[rcur], raw_cap, d_tsums, d_ntot, K);
         ABW_LAUNCH_CHECK(ctx);
-        ABW_HIP(ctx, hipMemsetAsync(d_wlist_n, 0, 4, st));
-        hipLaunchKernelGGL(tree_wide_screen_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, Tr, d_ptiles, n_pt, d_nodes, min_ndps,
-                           wbin[wcur], wword[wcur], Wp, d_tsums, d_bar, d_tbest, d_wlist, d_wlist_n);
+        ABW_HIP(ctx, hipMemsetAsync(d_wlist_n, 0, 8, st));
+        const int64_t n_items = (int64_t)n_pt * n_wide;
+        hipLaunchKernelGGL(tree_wide_tilescreen_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, d_ptiles, n_pt, n_wide, d_nodes, K, min_ndps,
+                           (const WSums4*)d_tsums, (const WSums4*)d_ntot, (const double*)d_bar, d_tbest, d_wtodo, d_wlist_n + 1);
+        ABW_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(tree_wide_screen_kernel, dim3((unsigned)std::min<int64_t>(n_items, (int64_t)ctx->num_cu * 6)), dim3(256), 0, st, Tr, d_ptiles, n_pt, d_nodes, min_ndps,
+                           wbin[wcur], wword[wcur], Wp, d_tsums, d_bar, (const int32_t*)d_wtodo, (const int32_t*)(d_wlist_n + 1), d_wlist, d_wlist_n);
         ABW_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(tree_wide_eval_kernel, dim3((unsigned)std::min<int64_t>((int64_t)n_pt * n_wide, (int64_t)ctx->num_cu * 4)), dim3(256), 0, st, Tr, d_ptiles, n_pt, d_nodes, K, min_ndps,
                            wbin[wcur], wword[wcur], Wp, d_tsums, d_ntot, d_scg_lo, d_scg_hi, d_bar, d_tbest, (const int32_t*)d_wlist, (const int32_t*)d_wlist_n);
