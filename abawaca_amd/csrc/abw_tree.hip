@@ -923,23 +923,51 @@ __device__ __forceinline__ void eval_threshold_lazy(long long size1, long long t
     if (pass) best = Cand{prod, bin, 1, sens, spec, size1};
 }
 
-// pass 2a, the screen (as tree_wide_screen_kernel): which tiles hold a static run end whose threshold could reach the node's
-// bar.  grid (position tiles, wide dimensions)
+// pass 2a' (as tree_wide_tilescreen_kernel): the tiles whose sums could reach the bar at all.  grid: blocks over (tiles x wide dimensions)
+__global__ __launch_bounds__(256) void node_wide_tilescreen_kernel(int32_t n_tiles, int32_t n_wide, int32_t min_ndps, const WSums4* __restrict__ tile_carry,
+                                                                  const WSums4* __restrict__ total, const double* __restrict__ bar, Cand* __restrict__ tile_best,
+                                                                  int32_t* __restrict__ list, int32_t* __restrict__ list_n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (i < (int64_t)n_tiles * n_wide) {
+        const int w = (int)(i / n_tiles), t = (int)(i - (int64_t)w * n_tiles);
+        const WSums4 c = tile_carry[i], tot = total[w];
+        const WSums4 e = (t + 1 < n_tiles) ? tile_carry[i + 1] : tot;
+        keep = tile_may_reach(c, WSums4{e.size - c.size, e.tp1 - c.tp1, e.tot - c.tot, e.bp - c.bp}, (long long)tot.size, min_ndps, bar[0]);
+        tile_best[i] = Cand{0.0, 0, 0, 0.0, 0.0, 0};
+    }
+    const unsigned long long m = __ballot(keep);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(list_n, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (keep) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+    }
+}
+
+// pass 2a, the screen (as tree_wide_screen_kernel): which of those tiles hold a static run end whose threshold could reach
+// the node's bar.  grid: any; the workgroups take the listed tiles in turn
 template <bool MASKED>
 __global__ __launch_bounds__(256) void node_wide_screen_kernel(TreeDev Tr, int32_t N, int32_t n_tiles, int32_t min_ndps, const uint32_t* __restrict__ wword,
                                                               int64_t wstride, const uint8_t* __restrict__ member, const WSums4* __restrict__ tile_carry,
-                                                              const WSums4* __restrict__ total, const double* __restrict__ bar, Cand* __restrict__ tile_best,
+                                                              const WSums4* __restrict__ total, const double* __restrict__ bar,
+                                                              const int32_t* __restrict__ todo, const int32_t* __restrict__ todo_n,
                                                               int32_t* __restrict__ list, int32_t* __restrict__ list_n)
 {
     __shared__ unsigned long long sh[5];
     __shared__ uint32_t sh32[4];
-    const int w = blockIdx.y;
+    const int n_todo = *todo_n;
+  for (int li = blockIdx.x; li < n_todo; li += gridDim.x) {
+    const int entry = todo[li];
+    const int w = entry / n_tiles, tile = entry - w * n_tiles;
     const uint32_t* __restrict__ words = wword + (int64_t)w * wstride;
-    const int begin = blockIdx.x * TILE_P, end = min(N, begin + TILE_P);
+    const int begin = tile * TILE_P, end = min(N, begin + TILE_P);
     const int i0 = begin + 8 * threadIdx.x;
     uint32_t wd[8], pk[8];
     load8_stream(words, i0, begin, end, wd, 0u);
-    const WSums4 carry = tile_carry[(int64_t)w * n_tiles + blockIdx.x];
+    const WSums4 carry = tile_carry[(int64_t)w * n_tiles + tile];
     const uint32_t n32 = (uint32_t)total[w].size;
     const double node_bar = bar[0];
     uint32_t in = 0;
@@ -978,10 +1006,8 @@ __global__ __launch_bounds__(256) void node_wide_screen_kernel(TreeDev Tr, int32
         __builtin_amdgcn_sched_barrier(0);
     }
     const int any = __syncthreads_or(hit);
-    if (threadIdx.x == 0) {
-        tile_best[(int64_t)w * n_tiles + blockIdx.x] = none;
-        if (any) list[atomicAdd(list_n, 1)] = w * n_tiles + (int)blockIdx.x;
-    }
+    if (threadIdx.x == 0 && any) list[atomicAdd(list_n, 1)] = entry;
+  }
 }
 
 // pass 2b: the listed tiles (list == NULL: every tile) again with everything; evaluate at the static run ends.  grid: any
@@ -1968,7 +1994,7 @@ int abw_tree_static_ensure(abw_ctx* ctx)
 
 // ---- abw_sep_node's wide dimensions (see node_wide_*_kernel): host side --------------------------------------------------
 namespace {
-struct NodeWide { TreeDev Tr; int32_t n_tiles, n_wide; WSums4 *tile_sums, *total; Cand* tile_best; double* bar; int32_t *list_n, *list; };
+struct NodeWide { TreeDev Tr; int32_t n_tiles, n_wide; WSums4 *tile_sums, *total; Cand* tile_best; double* bar; int32_t *list_n, *list, *todo; };
 
 int node_wide_plan(abw_ctx* ctx, NodeWide& W)
 {
@@ -1978,7 +2004,7 @@ int node_wide_plan(abw_ctx* ctx, NodeWide& W)
     W.n_tiles = (int32_t)((s.N + TILE_P - 1) / TILE_P);
     const size_t o_sums = 0, o_tot = o_sums + (size_t)W.n_wide * W.n_tiles * sizeof(WSums4),
                  o_best = o_tot + (size_t)W.n_wide * sizeof(WSums4), o_bar = o_best + (size_t)W.n_wide * W.n_tiles * sizeof(Cand), o_list = o_bar + 64,
-                 bytes = o_list + 64 + (size_t)W.n_wide * W.n_tiles * 4;
+                 bytes = o_list + 64 + 2 * (size_t)W.n_wide * W.n_tiles * 4;
     if (H.nw_cap < bytes) {
         if (H.d_nw) { ABW_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(H.d_nw); H.d_nw = nullptr; H.nw_cap = 0; }
         ABW_HIP(ctx, hipMalloc(&H.d_nw, bytes));
@@ -1986,7 +2012,7 @@ int node_wide_plan(abw_ctx* ctx, NodeWide& W)
     }
     uint8_t* p = (uint8_t*)H.d_nw;
     W.tile_sums = (WSums4*)(p + o_sums); W.total = (WSums4*)(p + o_tot); W.tile_best = (Cand*)(p + o_best); W.bar = (double*)(p + o_bar);
-    W.list_n = (int32_t*)(p + o_list); W.list = W.list_n + 16;
+    W.list_n = (int32_t*)(p + o_list); W.list = W.list_n + 16; W.todo = W.list + (size_t)W.n_wide * W.n_tiles;      // list_n[1]: the length of todo
     memset(&W.Tr, 0, sizeof(W.Tr));
     W.Tr.P = static_params(s);
     W.Tr.narrow = H.d_nsort; W.Tr.n_narrow = (int32_t)H.narrow_dims.size();
@@ -2045,11 +2071,15 @@ int abw_node_wide_eval(abw_ctx* ctx, const uint8_t* d_member, bool exact_per_dim
     const int64_t all = (int64_t)W.n_tiles * W.n_wide;
     const int32_t* list = nullptr;
     if (!exact_per_dim) {                                       // with a bar most tiles are done after the screen
-        ABW_HIP(ctx, hipMemsetAsync(W.list_n, 0, 4, st));
-        if (d_member) hipLaunchKernelGGL(node_wide_screen_kernel<true>, grid, dim3(256), 0, st, W.Tr, (int32_t)s.N, W.n_tiles, min_ndps, (const uint32_t*)H.d_wword, Np, d_member,
-                                         (const WSums4*)W.tile_sums, (const WSums4*)W.total, (const double*)W.bar, W.tile_best, W.list, W.list_n);
-        else hipLaunchKernelGGL(node_wide_screen_kernel<false>, grid, dim3(256), 0, st, W.Tr, (int32_t)s.N, W.n_tiles, min_ndps, (const uint32_t*)H.d_wword, Np, (const uint8_t*)nullptr,
-                                (const WSums4*)W.tile_sums, (const WSums4*)W.total, (const double*)W.bar, W.tile_best, W.list, W.list_n);
+        ABW_HIP(ctx, hipMemsetAsync(W.list_n, 0, 8, st));
+        hipLaunchKernelGGL(node_wide_tilescreen_kernel, dim3((unsigned)((all + 255) / 256)), dim3(256), 0, st, W.n_tiles, W.n_wide, min_ndps, (const WSums4*)W.tile_sums,
+                           (const WSums4*)W.total, (const double*)W.bar, W.tile_best, W.todo, W.list_n + 1);
+        ABW_LAUNCH_CHECK(ctx);
+        const dim3 sgrid((unsigned)std::min<int64_t>(all, (int64_t)ctx->num_cu * 6));
+        if (d_member) hipLaunchKernelGGL(node_wide_screen_kernel<true>, sgrid, dim3(256), 0, st, W.Tr, (int32_t)s.N, W.n_tiles, min_ndps, (const uint32_t*)H.d_wword, Np, d_member,
+                                         (const WSums4*)W.tile_sums, (const WSums4*)W.total, (const double*)W.bar, (const int32_t*)W.todo, (const int32_t*)(W.list_n + 1), W.list, W.list_n);
+        else hipLaunchKernelGGL(node_wide_screen_kernel<false>, sgrid, dim3(256), 0, st, W.Tr, (int32_t)s.N, W.n_tiles, min_ndps, (const uint32_t*)H.d_wword, Np, (const uint8_t*)nullptr,
+                                (const WSums4*)W.tile_sums, (const WSums4*)W.total, (const double*)W.bar, (const int32_t*)W.todo, (const int32_t*)(W.list_n + 1), W.list, W.list_n);
         ABW_LAUNCH_CHECK(ctx);
         list = W.list;
     }
