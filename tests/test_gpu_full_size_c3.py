@@ -37,6 +37,7 @@ def test_signature_10gbp_of_configs3():
     t_ascii, total, t_off = bench.make_assembly_blob_gpu(20243, MBP, dev)
     n_scaf = MBP * 100
     assert total == n_scaf * L == 10_000_000_000
+    torch.cuda.synchronize()             # torch made the inputs on ITS stream; the library works on its own
     ctx = _lib.Context(0)
     try:
         cap = total // 2000 + n_scaf + 16
@@ -112,12 +113,14 @@ def test_signature_10gbp_of_configs3():
         # src/ReadMapping.cpp:41, src/abawaca-build.cpp:177-185, 231-244): the tiling reads cover the coordinates 0 .. L - 1,
         # so a segment that ends on coordinate L misses one base; the shifted reads cover 50 .. L + 49.
         flen = length.to(torch.float64)
+        torch.cuda.synchronize()
         cov_call(r_pos)
         ctx.synchronize()
         expect = 1.0 - (en == L).to(torch.float64) / flen
         assert float((t_cov - expect).abs().max()) <= 1e-9
         assert 0 < int((en == L).sum()) <= n_scaf
         r_pos2 = r_pos + RL // 2
+        torch.cuda.synchronize()
         cov_call(r_pos2)                                                # continues the sums
         ctx.synchronize()
         missing = torch.clamp(RL // 2 - st, min=0).to(torch.float64)    # coordinates st .. 49

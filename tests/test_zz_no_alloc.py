@@ -93,6 +93,7 @@ def test_static_entry_allocates_nothing_and_does_not_wait():
         assert free1 == free0 and torch.cuda.mem_get_info(0)[0] == free0
         for t_ascii, total, t_off, outs, res, blob, off in cases[1:]:       # and the results are the other entry point's
             ref = got_like(dev, len(outs[0]))
+            torch.cuda.synchronize()                            # (torch fills on its own stream)
             n = signature.segment_dev(ctx, t_ascii, total, t_off, 2000, *ref)
             ctx.synchronize()
             assert int(res[0]) == n and int(res[1]) == 0
