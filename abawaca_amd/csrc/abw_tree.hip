@@ -1284,6 +1284,13 @@ __global__ __launch_bounds__(256) void tree_part_scatter_kernel(const Tile* __re
     const uint32_t m1 = mk & 0xFFu, ma = mk >> 8;
     // the items are read only by the threads that have one to copy: where a child keeps the segment, almost none do
     const uint32_t moving = (base1 >= 0 ? m1 : 0u) | (base2 >= 0 ? (ma & ~m1) : 0u);
+    // a tile of a kept segment that nothing leaves (most tiles of a caterpillar's giant) is done here
+    const bool one_keeps = !scaf && (base1 < 0) != (base2 < 0);
+    const int any_moving = one_keeps ? __syncthreads_or(moving != 0) : 1;
+    if (!any_moving) {
+        if (left && threadIdx.x == 0) left[(int64_t)blockIdx.y * lstride + blockIdx.x] = WSums4{0, 0, 0, 0};
+        return;
+    }
     int32_t v2[8];
     if (moving || scaf) {
         load8(it, i0, t.begin, t.end, v, W_DEAD);
@@ -1312,10 +1319,10 @@ __global__ __launch_bounds__(256) void tree_part_scatter_kernel(const Tile* __re
     }
     // One child keeps the segment: the sums of what leaves this tile, for tree_wide_inherit_kernel at the next level (the
     // tile's new sums are its old ones less these).  Uniform for the workgroup.
-    if (left && (base1 < 0) != (base2 < 0)) {
+    if (left && one_keeps) {
         const int w = blockIdx.y;
         WSums4 a = {0, 0, 0, 0};
-        if (__syncthreads_or(moving != 0)) {
+        {
             if (!moving) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) v[i] = W_DEAD;             // (this thread loaded nothing)
