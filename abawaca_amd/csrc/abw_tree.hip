@@ -323,7 +323,8 @@ __global__ __launch_bounds__(256) void tree_scg_lds_kernel(TreeDev Tr, const int
 }
 
 constexpr int SCG_LDS = 256;
-struct ScgView { const int32_t* lo; const int32_t* hi; int n; bool compact; };
+struct ScgView { const int32_t* lo; const int32_t* hi; int n; bool compact; };     // compact: lo / hi are LDS arrays holding the present SCGs only
+typedef const __attribute__((address_space(3))) int32_t* LdsI32;
 
 // One threshold of a (node, dimension): size check, small side, sensitivity x specificity in fp64 exactly as the
 // reference's doubles, the SCG / size gate (ref ...Specificity.cpp:146-161, ClusterQuality.cpp:96-136).
@@ -353,7 +354,10 @@ __device__ __forceinline__ void eval_threshold(long long size1, long long tp1, l
     if (!cand_better(cnd, best)) return;
     int cl = 0, chh = 0, ng = scg.n;
     if (scg.compact) {
-        for (int g = 0; g < scg.n; g++) { cl += scg.lo[g] <= bin; chh += scg.hi[g] <= bin; }
+        // the staged lists live in LDS: say so, or every read is a flat load that waits on both memory paths
+        const LdsI32 lo3 = (LdsI32)scg.lo, hi3 = (LdsI32)scg.hi;
+#pragma unroll 4
+        for (int g = 0; g < scg.n; g++) { cl += lo3[g] <= bin; chh += hi3[g] <= bin; }
     } else {
         ng = 0;
         for (int g = 0; g < scg.n; g++) { const int l = scg.lo[g]; if (l != INT_MAX) { ng++; cl += l <= bin; chh += scg.hi[g] <= bin; } }
@@ -911,7 +915,10 @@ __device__ __forceinline__ void eval_threshold_lazy(long long size1, long long t
     const int bin = get_bin();
     int cl = 0, chh = 0, ng = scg.n;
     if (scg.compact) {
-        for (int g = 0; g < scg.n; g++) { cl += scg.lo[g] <= bin; chh += scg.hi[g] <= bin; }
+        // the staged lists live in LDS: say so, or every read is a flat load that waits on both memory paths
+        const LdsI32 lo3 = (LdsI32)scg.lo, hi3 = (LdsI32)scg.hi;
+#pragma unroll 4
+        for (int g = 0; g < scg.n; g++) { cl += lo3[g] <= bin; chh += hi3[g] <= bin; }
     } else {
         ng = 0;
         for (int g = 0; g < scg.n; g++) { const int l = scg.lo[g]; if (l != INT_MAX) { ng++; cl += l <= bin; chh += scg.hi[g] <= bin; } }
