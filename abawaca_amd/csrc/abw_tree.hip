@@ -1597,16 +1597,21 @@ int TreeRun::eval(abw_tree_winner* best, int64_t cap, int64_t* n_level)
     }
     // children come in pairs (2j, 2j + 1) of one parent: the smaller is accumulated, the bigger subtracted; a node without
     // its sibling in this (cut) level, and the root, are accumulated
+    // (a level that accumulates few scaffolds -- the smaller children of a caterpillar -- cuts them into smaller tiles: the
+    // kernel is a chain of dependent loads per scaffold, and a few hundred workgroups do not fill the device)
+    std::vector<int32_t> acc_nodes;
+    int64_t acc_scaf = 0;
     for (int32_t k = 0; k < K; k++) {
         const int32_t sib = (level[k].parent >= 0) ? (k ^ 1) : -1;
         const bool has_sib = sib >= 0 && sib < K && level[sib].parent == level[k].parent;
         const bool bigger = has_sib && (level[k].n > level[sib].n || (level[k].n == level[sib].n && k > sib));
         if (bigger) subs.push_back(SubJob{k, level[k].parent, sib});
-        else {
-            zero_slots.push_back(k);
-            int32_t tb, te;
-            make_tiles(atiles, k, nd[k].scaf_begin, nd[k].scaf_end, TILE_A, tb, te);
-        }
+        else { zero_slots.push_back(k); acc_nodes.push_back(k); acc_scaf += level[k].m; }
+    }
+    const int tile_a = acc_scaf * std::max(1, n_groups) <= (int64_t)TILE_A * ctx->num_cu * 8 ? TILE_A / 4 : TILE_A;
+    for (int32_t k : acc_nodes) {
+        int32_t tb, te;
+        make_tiles(atiles, k, nd[k].scaf_begin, nd[k].scaf_end, tile_a, tb, te);
     }
     n_st = (int32_t)stiles.size(); n_pt = (int32_t)ptiles.size();
     const int32_t n_at = (int32_t)atiles.size();
