@@ -1209,7 +1209,7 @@ __global__ __launch_bounds__(256) void tree_count_kernel(TreeDev Tr, const Tile*
 // cluster 1" when cluster 1 leaves, as "live, not cluster 1" when cluster 2 does, so that the scatter's ranks come out the same.
 __global__ __launch_bounds__(256) void tree_part_count_kernel(const Tile* __restrict__ tiles, int32_t n_tiles, const NodePart* __restrict__ part,
                                                              const uint32_t* __restrict__ items, int64_t istride,
-                                                             const uint8_t* __restrict__ side, uint32_t sc_mask, const uint8_t* __restrict__ bits,
+                                                             const uint8_t* __restrict__ side, uint32_t sc_mask, uint8_t* __restrict__ bits,
                                                              unsigned long long* __restrict__ tile_cnt, uint16_t* __restrict__ mask)
 {
     __shared__ unsigned long long sh[4];
@@ -1219,7 +1219,9 @@ __global__ __launch_bounds__(256) void tree_part_count_kernel(const Tile* __rest
     const int i0 = (t.begin & ~2047) + 8 * threadIdx.x;
     uint32_t m1 = 0, ma = 0;
     if (bits && np.bits) {
-        uint32_t m = bits[((int64_t)blockIdx.y * istride + i0) >> 3];
+        uint8_t* __restrict__ mine = bits + (((int64_t)blockIdx.y * istride + i0) >> 3);      // read by this thread alone: left clear for the next level
+        uint32_t m = *mine;
+        if (m) *mine = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) if (i0 + i < t.begin || i0 + i >= t.end) m &= ~(1u << i);
         ma = m; m1 = np.dp_base1 >= 0 ? m : 0u;
@@ -1539,6 +1541,7 @@ int TreeRun::begin(int32_t min_ndps_, int64_t max_nodes_)
         abw_devbuf& b_bits = ctx->scratch[3];
         if ((rc = abw_reserve(ctx, b_bits, (size_t)n_wide * (Wp / 8) + 64))) return rc;
         bits = (uint32_t*)b_bits.p;
+        ABW_HIP(ctx, hipMemsetAsync(bits, 0, (size_t)n_wide * (Wp / 8), st));      // once: tree_part_count_kernel clears what it reads
     }
     Tr.narrow = H.d_nsort; Tr.n_narrow = n_narrow; Tr.toffn = H.d_toffn; Tr.TBn = TBn;
     Tr.groups = H.d_groups; Tr.n_groups = n_groups; Tr.nk16 = (const uint4*)H.d_nk16; Tr.ts8 = (const uint4*)H.d_ts8; Tr.srec = (const int4*)H.d_srec;
@@ -1892,7 +1895,7 @@ int TreeRun::advance()
         auto keeps = [&](int32_t k) -> int {                   // 1 / 2: that child keeps the segment; 0: both are copied out
             const NodeRes& r = h_res[k];
             const int64_t big = (int64_t)std::max(r.n1, r.n2);
-            if (2 * big < level[k].seg_len) return 0;
+            if (2 * big < level[k].seg_len) return 0;          // (keeping the root's segment longer -- down to 1/16 live -- was slower: 88 -> 95 ms at 2M scaffolds)
             return r.n1 > r.n2 ? 1 : 2;
         };
         int64_t need = 0;
@@ -1922,7 +1925,7 @@ int TreeRun::advance()
     {
         ABW_PROF(ctx, "sep_partition");
         hipLaunchKernelGGL(tree_part_count_kernel, dim3((unsigned)n_st, 1), dim3(256), 0, st, d_stiles, n_st, d_part, (const uint32_t*)order[cur], (int64_t)0, d_scaf_side,
-                           W_SC, (const uint8_t*)nullptr, d_scnt, d_smask);
+                           W_SC, (uint8_t*)nullptr, d_scnt, d_smask);
         ABW_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(tree_part_scan_kernel, dim3((unsigned)K, 1), dim3(64), 0, st, d_nodes, d_part, n_st, d_scnt, 1);
         ABW_LAUNCH_CHECK(ctx);
@@ -1932,13 +1935,12 @@ int TreeRun::advance()
         ABW_LAUNCH_CHECK(ctx);
         if (n_wide && !next.empty()) {
             if (n_leavers > 0) {
-                ABW_HIP(ctx, hipMemset2DAsync(bits, (size_t)(Wp / 8), 0, (size_t)(((N + 63) / 64) * 8), (size_t)n_wide, st));
                 hipLaunchKernelGGL(tree_mark_kernel, dim3((unsigned)((n_leavers + 255) / 256), (unsigned)n_wide), dim3(256), 0, st, Tr, (const int32_t*)(order[cur ^ 1] + leavers_at), n_leavers,
                                    (const int32_t*)abw_sep_host(ctx).d_posof, N, bits, Wp / 32);
                 ABW_LAUNCH_CHECK(ctx);
             }
             hipLaunchKernelGGL(tree_part_count_kernel, dim3((unsigned)n_pt, (unsigned)n_wide), dim3(256), 0, st, d_ptiles, n_pt, d_part, (const uint32_t*)wword[wcur], Wp, d_scaf_side,
-                               Tr.sc_mask, n_leavers > 0 ? (const uint8_t*)bits : (const uint8_t*)nullptr, d_pcnt, d_pmask);
+                               Tr.sc_mask, n_leavers > 0 ? (uint8_t*)bits : (uint8_t*)nullptr, d_pcnt, d_pmask);
             ABW_LAUNCH_CHECK(ctx);
             hipLaunchKernelGGL(tree_part_scan_kernel, dim3((unsigned)K, (unsigned)n_wide), dim3(64), 0, st, d_nodes, d_part, n_pt, d_pcnt, 0);
             ABW_LAUNCH_CHECK(ctx);
