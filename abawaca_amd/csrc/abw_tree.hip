@@ -1150,21 +1150,40 @@ __global__ __launch_bounds__(64) void tree_winner_kernel(TreeDev Tr, const NodeD
 // ---- scaffold sides (ref ClusterSeparator.cpp:35-53,94-122): cluster1 = the raw side with fewer dps (tie: the "<=" side), a
 // scaffold goes to cluster1 iff at least half of its dps are there.  Only the nodes whose winner is THIS context's
 // (res.win.legal set by the host: a legal winner in one of its dimensions) are assigned here.  grid (scaffold tiles)
+// COUNT (one context decides every node: abw_sep_tree): the children's sizes in the same pass (tree_count_kernel's sums).
+template <bool COUNT>
 __global__ __launch_bounds__(256) void tree_assign_kernel(TreeDev Tr, const Tile* __restrict__ tiles, const int32_t* __restrict__ order,
-                                                         const NodeRes* __restrict__ res, uint8_t* __restrict__ scaf_side)
+                                                         NodeRes* __restrict__ res, uint8_t* __restrict__ scaf_side)
 {
+    __shared__ unsigned long long b[4];
     const Tile t = tiles[blockIdx.x];
     const GlobalRes win = res[t.node].win;
     if (!win.legal) return;                                   // uniform for the tile: nothing to reconstruct (ref :27-28), or not mine
+    if (COUNT) { if (threadIdx.x < 4) b[threadIdx.x] = 0; __syncthreads(); }
     const bool swap = win.n - win.size1 < win.size1;
     const int32_t* __restrict__ col = Tr.P.bins + (int64_t)win.dim * Tr.P.N;
+    unsigned long long n1 = 0, n2 = 0, m1 = 0, m2 = 0;
     for (int ls = t.begin + threadIdx.x; ls < t.end; ls += 256) {
         const int s = order[ls];
         const int f = Tr.P.scaf_first[s], tot = Tr.P.scaf_ndps[s];
         int c = 0;
         for (int i = 0; i < tot; i++) c += col[f + i] <= win.bin;
         const int c1 = swap ? tot - c : c;
-        scaf_side[s] = (c1 > 0 && 2 * (long long)c1 >= tot) ? 1 : 2;
+        const bool one = c1 > 0 && 2 * (long long)c1 >= tot;
+        scaf_side[s] = one ? 1 : 2;
+        if (COUNT) { if (one) { n1 += (unsigned long long)tot; m1++; } else { n2 += (unsigned long long)tot; m2++; } }
+    }
+    if (COUNT) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { n1 += __shfl_xor(n1, o, 64); n2 += __shfl_xor(n2, o, 64); m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&b[0], n1); atomicAdd(&b[1], n2); atomicAdd(&b[2], m1); atomicAdd(&b[3], m2); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (b[0]) atomicAdd(&res[t.node].n1, b[0]);
+            if (b[1]) atomicAdd(&res[t.node].n2, b[1]);
+            if (b[2]) atomicAdd(&res[t.node].m1, (uint32_t)b[2]);
+            if (b[3]) atomicAdd(&res[t.node].m2, (uint32_t)b[3]);
+        }
     }
 }
 
@@ -1796,7 +1815,7 @@ int TreeRun::assign(const abw_tree_winner* winners, int64_t n)
     if (solo) {                                                 // every winner is this context's own, and already where the kernel reads it
         ABW_HIP(ctx, hipMemsetAsync(d_scaf_side, 0, (size_t)S, st));
         ABW_PROF(ctx, "sep_eval");
-        hipLaunchKernelGGL(tree_assign_kernel, dim3((unsigned)n_st), dim3(256), 0, st, Tr, d_stiles, (const int32_t*)order[cur], (const NodeRes*)d_res, d_scaf_side);
+        hipLaunchKernelGGL(tree_assign_kernel<true>, dim3((unsigned)n_st), dim3(256), 0, st, Tr, d_stiles, (const int32_t*)order[cur], d_res, d_scaf_side);
         ABW_LAUNCH_CHECK(ctx);
         phase = 2;
         return ABW_OK;
@@ -1817,7 +1836,7 @@ int TreeRun::assign(const abw_tree_winner* winners, int64_t n)
     ABW_HIP(ctx, hipMemsetAsync(d_scaf_side, 0, (size_t)S, st));
     {
         ABW_PROF(ctx, "sep_eval");
-        hipLaunchKernelGGL(tree_assign_kernel, dim3((unsigned)n_st), dim3(256), 0, st, Tr, d_stiles, (const int32_t*)order[cur], (const NodeRes*)d_res, d_scaf_side);
+        hipLaunchKernelGGL(tree_assign_kernel<false>, dim3((unsigned)n_st), dim3(256), 0, st, Tr, d_stiles, (const int32_t*)order[cur], d_res, d_scaf_side);
         ABW_LAUNCH_CHECK(ctx);
     }
     phase = 2;
@@ -1832,7 +1851,7 @@ int TreeRun::advance()
     if (phase != 2) return abw_fail(ctx, ABW_ERR_STATE, "abw_sep_tree_advance: no assigned level (abw_sep_tree_assign)");
     uint8_t* hp = (uint8_t*)ctx->pinned;
     NodeRes* h_res = (NodeRes*)(hp + o_res);
-    {
+    if (!solo) {                                                // (solo: counted with the sides, tree_assign_kernel<true>)
         ABW_PROF(ctx, "sep_eval");
         hipLaunchKernelGGL(tree_count_kernel, dim3((unsigned)n_st), dim3(256), 0, st, Tr, d_stiles, (const int32_t*)order[cur], (const uint8_t*)d_scaf_side, d_res);
         ABW_LAUNCH_CHECK(ctx);
