@@ -65,6 +65,7 @@ def parse():
                     "bin of the table per NODE (abw_sep_shard_*), as separator_sharded_node_by_node")
     ap.add_argument("--sep-nodes-dims", type=int, default=0, help="N > 1: nodes of the dimension-sharded recursion to run (0 = all)")
     ap.add_argument("--no-c2", action="store_true", help="N = 1: skip the configs[2] job on the one GPU")
+    ap.add_argument("--no-c4", action="store_true", help="N = 1: skip configs[4]'s recursion (2M scaffolds) on the one GPU")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--chunk", type=int, default=0, help="points per fp32 partial sum; 0 = the library's choice (abw_km_auto_chunk)")
     ap.add_argument("--sig-mbp", type=int, default=1000, help="signature side bench: assembly size in Mbp")
@@ -833,6 +834,19 @@ def configs2_on_one_gpu(ctx, dev, args):
     return res
 
 
+def configs4_on_one_gpu(ctx, dev, args):
+    """configs[4]'s table (2M scaffolds, 20 samples, 400 planted genomes) on ONE GPU: the root node and the whole recursive
+    binning, node by node and in one abw_sep_tree call -- the base of the scaffold-sharded runs of N > 1."""
+    import torch
+    keys_t, dp2scaf, scaf_len, genome, G = make_points(20245, args.sep_scaffolds, 20, dev, 400)
+    keys_host = keys_t.cpu().numpy()
+    del keys_t
+    torch.cuda.empty_cache()
+    res = separator_leg(ctx, keys_host, dp2scaf, scaf_len, genome, G, 20246, "configs[4]")
+    res.pop("cpu_baseline", None)
+    return res
+
+
 def free_port():
     import socket
     with socket.socket() as s:
@@ -1365,6 +1379,9 @@ def main():
         x_t = keys_t = None
         torch.cuda.empty_cache()
         out["configs2_one_gpu"] = side_leg("configs2_one_gpu", configs2_on_one_gpu, ctx, dev, args)
+
+    if world == 1 and not args.no_c4 and not args.no_extras:
+        out["configs4_one_gpu"] = side_leg("configs4_one_gpu", configs4_on_one_gpu, ctx, dev, args)
 
     # ---------------- optional: configs[0], the reference's own CPU-runnable case, end to end -----------------
     if args.c1 and world == 1:
