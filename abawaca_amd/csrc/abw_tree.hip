@@ -389,6 +389,18 @@ __device__ __forceinline__ bool screen32(uint32_t size1, uint32_t tp1, uint32_t 
     return !(tp * tp < need * ((float)TOT * (float)SZ));
 }
 
+// the same with the quantity itself returned (fp32, for ORDERING candidates only): TP^2 / (TOT x SZ) of the scored side, -1 where
+// the sizes fail
+__device__ __forceinline__ float screen_est32(uint32_t size1, uint32_t tp1, uint32_t tot1, uint32_t n, uint32_t min_ndps)
+{
+    const uint32_t size2 = n - size1;
+    if (size1 < min_ndps || size2 < min_ndps) return -1.0f;
+    const bool small1 = size1 < size2;
+    const uint32_t TP = small1 ? tp1 : n - (size1 + tot1 - tp1), TOT = small1 ? tot1 : n - tot1, SZ = small1 ? size1 : size2;
+    const float tp = (float)TP, den = (float)TOT * (float)SZ;
+    return den > 0.0f ? tp * tp / den : 3.0e38f;
+}
+
 // SCGs present in the (node, dimension): lo != INT_MAX.  Up to SCG_LDS SCGs are compacted into LDS (the gate of a candidate
 // then walks the present ones only); a table with more is read in place.  Call by all threads.
 __device__ __forceinline__ ScgView stage_scgs(const int32_t* __restrict__ lo, const int32_t* __restrict__ hi, int n_scg, int32_t* s_lo, int32_t* s_hi, int* s_ng)
@@ -801,14 +813,37 @@ __global__ __launch_bounds__(256) void tree_wide_eval_kernel(TreeDev Tr, const T
     float need = screen_need(best, node_bar);
     const int64_t sg = ((int64_t)t.node * Tr.D + d) * Tr.P.n_scg;
     const ScgView scg = stage_scgs(scg_lo + sg, scg_hi + sg, Tr.P.n_scg, s_lo, s_hi, &s_ng);
+    // The thread's run ends (threshold = the bin): the one that looks best first (fp32 estimate), then the others against what it
+    // set -- near a dimension's best threshold the products rise from run end to run end, and in walking order every one of
+    // a thread's eight would go through the two IEEE divisions and the gate.  Any order gives the same best (cand_better).
+    uint32_t p_sz[8], p_tp[8], p_tot[8];
+    unsigned long long p_bp[8];
+    uint32_t todo = 0;
+    float e_best = -2.0f;
+    int i_best = -1;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        if (i0 + i >= t.begin && i0 + i < t.end) {
-            size1 += (wd[i] & W_DEAD) ? 0u : 1u; tp1 += r_tp[i]; tot1 += r_tot[i]; bp1 += r_bp[i];
-            if (b[i + 1] != b[i] && screen32(size1, tp1, tot1, n32, mn32, need)) {       // a run end: threshold = this bin
-                eval_threshold((long long)size1, (long long)tp1, (long long)tot1, bp1, n, bp_total, min_ndps, b[i], scg, best, node_bar);
-                need = screen_need(best, node_bar);
-            }
+        size1 += (wd[i] & W_DEAD) ? 0u : 1u; tp1 += r_tp[i]; tot1 += r_tot[i]; bp1 += r_bp[i];       // (nothing outside the tile: dead words there)
+        p_sz[i] = size1; p_tp[i] = tp1; p_tot[i] = tot1; p_bp[i] = bp1;
+        if (i0 + i >= t.begin && i0 + i < t.end && b[i + 1] != b[i] && screen32(size1, tp1, tot1, n32, mn32, need)) {
+            todo |= 1u << i;
+            const float e = screen_est32(size1, tp1, tot1, n32, mn32);
+            if (e > e_best) { e_best = e; i_best = i; }
+        }
+    }
+    if (i_best >= 0) {
+        uint32_t sz = 0, tp = 0, tt = 0; unsigned long long bp = 0; int bin = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (i == i_best) { sz = p_sz[i]; tp = p_tp[i]; tt = p_tot[i]; bp = p_bp[i]; bin = b[i]; }
+        eval_threshold((long long)sz, (long long)tp, (long long)tt, bp, n, bp_total, min_ndps, bin, scg, best, node_bar);
+        need = screen_need(best, node_bar);
+        todo &= ~(1u << i_best);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (((todo >> i) & 1u) && screen32(p_sz[i], p_tp[i], p_tot[i], n32, mn32, need)) {
+            eval_threshold((long long)p_sz[i], (long long)p_tp[i], (long long)p_tot[i], p_bp[i], n, bp_total, min_ndps, b[i], scg, best, node_bar);
+            need = screen_need(best, node_bar);
         }
     }
     const Cand bb = block_best(best, wbest);
@@ -892,8 +927,7 @@ __global__ __launch_bounds__(64) void node_wide_scan_kernel(int32_t n_tiles, WSu
     if (lane == 0) total[w] = run;
 }
 
-// eval_threshold for a walk in ascending order of bins (a later threshold of the same thread must be strictly better), the
-// bin fetched by get_bin() only when the candidate reaches the gate
+// eval_threshold with the bin fetched by get_bin() only when the candidate gets past the product test
 template <typename BinFn>
 __device__ __forceinline__ void eval_threshold_lazy(long long size1, long long tp1, long long tot1, unsigned long long bp1, long long n,
                                                     unsigned long long bp_total, int32_t min_ndps, BinFn get_bin, const ScgView& scg, Cand& best, double bar)
@@ -912,8 +946,9 @@ __device__ __forceinline__ void eval_threshold_lazy(long long size1, long long t
     const double spec = (double)(int)TP / (double)(int)SZ;         // ref .h:74
     const double prod = sens * spec;
     if (!(prod == prod)) return;                                   // NaN is never better (ref .h:28)
-    if (best.found && !(prod > best.prod)) return;                 // equal products keep the smaller threshold
+    if (best.found && prod < best.prod) return;
     const int bin = get_bin();
+    if (best.found && prod == best.prod && bin >= best.bin) return;   // equal products keep the smaller threshold (the walk may come in any order)
     int cl = 0, chh = 0, ng = scg.n;
     if (scg.compact) {
         // the staged lists live in LDS: say so, or every read is a flat load that waits on both memory paths
@@ -1077,14 +1112,35 @@ __global__ __launch_bounds__(256) void node_wide_eval_kernel(TreeDev Tr, int32_t
     float need = screen_need(best, node_bar);
     const int64_t sg = (int64_t)d * Tr.P.n_scg;
     const ScgView scg = stage_scgs(scg_lo + sg, scg_hi + sg, Tr.P.n_scg, s_lo, s_hi, &s_ng);
+    // (the most promising run end first, as in tree_wide_eval_kernel)
+    uint32_t p_sz[8], p_tp[8], p_tot[8];
+    unsigned long long p_bp[8];
+    uint32_t todo = 0;
+    float e_best = -2.0f;
+    int i_best = -1;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        if (i0 + i < end) {
-            if (in & (1u << i)) { size1++; tp1 += r_tp[i]; tot1 += r_tot[i]; bp1 += r_bp[i]; }
-            if ((wd[i] & W_END) && screen32(size1, tp1, tot1, n32, mn32, need)) {
-                eval_threshold_lazy((long long)size1, (long long)tp1, (long long)tot1, bp1, n, tot.bp, min_ndps, [&]() { return bins[i0 + i]; }, scg, best, node_bar);
-                need = screen_need(best, node_bar);
-            }
+        if (in & (1u << i)) { size1++; tp1 += r_tp[i]; tot1 += r_tot[i]; bp1 += r_bp[i]; }
+        p_sz[i] = size1; p_tp[i] = tp1; p_tot[i] = tot1; p_bp[i] = bp1;
+        if (i0 + i < end && (wd[i] & W_END) && screen32(size1, tp1, tot1, n32, mn32, need)) {
+            todo |= 1u << i;
+            const float e = screen_est32(size1, tp1, tot1, n32, mn32);
+            if (e > e_best) { e_best = e; i_best = i; }
+        }
+    }
+    if (i_best >= 0) {
+        uint32_t sz = 0, tp = 0, tt = 0; unsigned long long bp = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (i == i_best) { sz = p_sz[i]; tp = p_tp[i]; tt = p_tot[i]; bp = p_bp[i]; }
+        eval_threshold_lazy((long long)sz, (long long)tp, (long long)tt, bp, n, tot.bp, min_ndps, [&]() { return bins[i0 + i_best]; }, scg, best, node_bar);
+        need = screen_need(best, node_bar);
+        todo &= ~(1u << i_best);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (((todo >> i) & 1u) && screen32(p_sz[i], p_tp[i], p_tot[i], n32, mn32, need)) {
+            eval_threshold_lazy((long long)p_sz[i], (long long)p_tp[i], (long long)p_tot[i], p_bp[i], n, tot.bp, min_ndps, [&]() { return bins[i0 + i]; }, scg, best, node_bar);
+            need = screen_need(best, node_bar);
         }
     }
     const Cand bb = block_best(best, wbest);
