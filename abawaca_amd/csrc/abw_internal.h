@@ -95,6 +95,7 @@ struct abw_ctx {
     bool        scratch_quiet = false; // API of abw_sep_tree keeps its level in scratch[] between calls and checks the count
     abw_devbuf  km_buf[3];             // state of a k-means run in progress (abw_km_shard_*): lives across calls
     int         num_cu = 256;
+    int         km_arith = 0;          // ABW_KM_ARITH_*: what abw_km_shard_step's non-final passes compute in (abw_km_set_arith)
     void*       pinned = nullptr;      // grow-only pinned host staging (results of a call leave the GPU in one batch)
     size_t      pinned_cap = 0;
     abw_sig_pipe* sig_pipe = nullptr;
@@ -151,3 +152,6 @@ struct abw_device_guard {
     explicit abw_device_guard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
     ~abw_device_guard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
+
+// abw_km_b3.hip: the k-means step on three bf16 planes; 1 = launched on ctx->stream, 0 = no such kernel for this shape
+int abw_km_step_b3(abw_ctx* ctx, const float* x, int64_t N, int d, const float* dT, int Rp, int chunk, int64_t nchunks, float* slabs);

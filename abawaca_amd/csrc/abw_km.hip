@@ -615,6 +615,14 @@ int32_t abw_km_auto_chunk(const abw_ctx* ctx, int64_t N, int32_t R)
     return ctx ? abw_km_chunk_for(ctx->num_cu, N, R) : 0;
 }
 
+int abw_km_set_arith(abw_ctx* ctx, int32_t arith)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (arith != ABW_KM_ARITH_F32 && arith != ABW_KM_ARITH_BF16X3) return abw_fail(ctx, ABW_ERR_ARG, "abw_km_set_arith: unknown arithmetic %d", arith);
+    ctx->km_arith = arith;
+    return ABW_OK;
+}
+
 int abw_km_shard_begin(abw_ctx* ctx, const float* d_x, int64_t N_local, int64_t first_point, int64_t N_total, int32_t d,
                        int32_t R, uint32_t base_seed, int32_t chunk, abw_km_exchange* ex)
 {
@@ -691,7 +699,10 @@ int abw_km_shard_step(abw_ctx* ctx, uint8_t* d_assign)
     const StepArgs a = { k.x, k.N, k.d, k.dT, k.Rp, k.chunk, k.nchunks, k.slabs, d_assign, k.R };
     {
         ABW_PROF(ctx, "km_step");
-        switch (k.DT) {
+        // the split-bf16 arithmetic runs the passes that only feed the centroid update; the final assign pass is the exact one
+        const bool split = ctx->km_arith == ABW_KM_ARITH_BF16X3 && !d_assign &&
+                           abw_km_step_b3(ctx, k.x, k.N, k.d, k.dT, k.Rp, k.chunk, k.nchunks, k.slabs);
+        if (!split) switch (k.DT) {
             case 1: launch_step<1>(ctx, a); break;
             case 2: launch_step<2>(ctx, a); break;
             case 3: launch_step<3>(ctx, a); break;

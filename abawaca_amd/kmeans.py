@@ -27,6 +27,15 @@ def kmeans_restarts(ctx: Context, x_dn: np.ndarray, R: int, base_seed: int, iter
     return assign, cent, inertia
 
 
+ARITH_F32, ARITH_BF16X3 = 0, 1
+
+
+def set_arith(ctx: Context, arith: int) -> None:
+    """What the Lloyd passes compute in from now on (abw_km_set_arith): ARITH_F32, the exact default, or ARITH_BF16X3, the
+    three-plane bf16 split held to the documented Lloyd tolerance instead of bit parity."""
+    ctx.check(lib().abw_km_set_arith(ctx.handle, int(arith)))
+
+
 def auto_chunk(ctx: Context, N: int, R: int) -> int:
     """The chunk length the library picks for chunk = 0 on this device (abw_km_auto_chunk)."""
     return int(lib().abw_km_auto_chunk(ctx.handle, int(N), int(R)))

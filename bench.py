@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--sep-node-by-node", action="store_true", help="N > 1: also the older scaffold-sharded separator that exchanges every histogram "
                     "bin of the table per NODE (abw_sep_shard_*), as separator_sharded_node_by_node")
     ap.add_argument("--sep-nodes-dims", type=int, default=0, help="N > 1: nodes of the dimension-sharded recursion to run (0 = all)")
+    ap.add_argument("--no-split", action="store_true", help="N = 1: skip the same job in the split-bf16 arithmetic (abw_km_set_arith)")
     ap.add_argument("--no-c2", action="store_true", help="N = 1: skip the configs[2] job on the one GPU")
     ap.add_argument("--no-c4", action="store_true", help="N = 1: skip configs[4]'s recursion (2M scaffolds) on the one GPU")
     ap.add_argument("--iters", type=int, default=20)
@@ -826,6 +827,17 @@ def configs2_on_one_gpu(ctx, dev, args):
                value=N * R * iters * steps / elapsed, unit="point*iterations/s", ms_per_step=elapsed / steps * 1e3, chunk=chunk,
                roofline=dict(kernel="km_step_kernel", bound="mfma", achieved=round(tf, 3), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                              frac=round(tf / FP32_MFMA_PEAK_TFLOPS, 4), ms_per_launch=round(ms_avg, 4), traffic=None))
+    if not args.no_split:
+        in_exact = t_in.clone()
+        kmeans.set_arith(ctx, kmeans.ARITH_BF16X3)
+        try:
+            el_s, n_s, ms_s = timed_steps(step, 1, steps, barrier, ctx)
+        finally:
+            kmeans.set_arith(ctx, kmeans.ARITH_F32)
+        res["km_split_bf16x3"] = dict(value=N * R * iters * steps / el_s, unit="point*iterations/s", ms_per_step=el_s / steps * 1e3,
+                                      speedup_over_exact=round(elapsed / el_s, 3), km_step_ms_per_launch_avg=round(ms_s / max(n_s, 1), 4),
+                                      same_best_restart=bool(int(t_in.argmin()) == int(in_exact.argmin())),
+                                      worst_inertia_rel_diff=float(((t_in - in_exact).abs() / in_exact).max()))
     del t_as, x_t
     if not args.no_extras:
         keys_host = keys_t.cpu().numpy()
@@ -952,6 +964,26 @@ def main():
         value = N * R * iters * args.steps / elapsed
         kernel_N, kernel_R = N, R
         parallelism, scaling = "single GPU", "weak"
+        # ---- the same job with the Lloyd passes on three bf16 planes (abw_km_set_arith, abw_km_b3.hip).  Not the headline:
+        #      that arithmetic is held to the documented tolerance (tests/test_gpu_kmeans_lloyd.py), not to bit parity.
+        km_split = None
+        if not args.no_split:
+            in_exact, a_exact = t_inertia.clone(), t_assign[int(winner[0])].clone()
+            kmeans.set_arith(ctx, kmeans.ARITH_BF16X3)
+            try:
+                el_s, n_s, ms_s = timed_steps(step, args.warmup, args.steps, barrier, ctx)
+            finally:
+                kmeans.set_arith(ctx, kmeans.ARITH_F32)
+            w_s = multi.best_restart(t_inertia.cpu(), first_restart)
+            km_split = dict(arith="x and D as three bf16 planes each, six plane products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; "
+                                  "final assign pass, reductions and update exact",
+                            value=N * R * iters * args.steps / el_s, unit="point*iterations/s", ms_per_step=el_s / args.steps * 1e3,
+                            speedup_over_exact=round(elapsed / el_s, 3), km_step_ms_per_launch_avg=round(ms_s / max(n_s, 1), 4),
+                            launches=n_s, best_restart=dict(id=int(w_s[0]), inertia=float(w_s[1])),
+                            same_best_restart=bool(int(w_s[0]) == int(winner[0])),
+                            worst_inertia_rel_diff=float(((t_inertia - in_exact).abs() / in_exact).max()),
+                            best_restart_points_in_other_cluster=int((t_assign[int(winner[0])] != a_exact).sum()))
+            del in_exact, a_exact
         del t_assign
     else:
         # ---- leg A, "restarts": rank k owns restart ids [first, first + R_a) of the job's R_job, points replicated
@@ -1245,6 +1277,8 @@ def main():
                                     f"(z-scored), {G} planted genomes, k=2, ONE job of {R} restarts x {iters} Lloyd iterations, chunk {args.chunk}",
                            parallelism=parallelism),
                roofline=roofline, best_restart=dict(id=int(winner[0]), inertia=float(winner[1]), rank=int(winner[2])))
+    if world == 1 and km_split is not None:
+        out["km_split_bf16x3"] = km_split
     if legs:
         out["partitions"] = legs
     if weak is not None:

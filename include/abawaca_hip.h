@@ -434,6 +434,19 @@ int32_t abw_km_auto_chunk(const abw_ctx* ctx, int64_t N, int32_t R);
  * whatever the device is.  abw_km_auto_chunk(ctx, N, R) == abw_km_chunk_for(the context's compute units, N, R). */
 int32_t abw_km_chunk_for(int32_t num_cu, int64_t N, int32_t R);
 
+/* The arithmetic of the Lloyd passes that feed the centroid update (abw_km_run_dev, abw_km_shard_step, abw_km_node):
+ *   ABW_KM_ARITH_F32    (default) exact fp32 fmaf chains on the fp32 matrix cores: bit-identical to the CPU restatement;
+ *   ABW_KM_ARITH_BF16X3 points and discriminant split exactly into three bf16 planes each, the six plane products of weight
+ *                       >= 2^-16 on the bf16 matrix cores with fp32 accumulation (about fp32 accuracy, hardware summation
+ *                       order): 1.8x - 2.3x the step rate, held to the documented Lloyd tolerance (per pass <= 1e-5 of the
+ *                       points in the other cluster, final inertia to 1e-6 relative) instead of bit parity.  Shapes without
+ *                       such a kernel (fewer than 33 restarts, d + 1 < 129, 64 restarts with d > 191) run the exact one.
+ * The final assign pass, the fp64 reductions, the centroid update and the inertia are the exact path's either way.
+ * Stays set on the context until changed.  (No reference counterpart.) */
+#define ABW_KM_ARITH_F32    0
+#define ABW_KM_ARITH_BF16X3 1
+int abw_km_set_arith(abw_ctx* ctx, int32_t arith);
+
 /* d_x: device [d][N] fp32 dimension-major points, d <= 223.  k = 2.  R restarts are run
  * together; restart r seeds TinyMT32 with base_seed + r.  chunk: points per fp32 partial sum
  * (multiple of 32; 0 = abw_km_auto_chunk).  Outputs are device pointers (any may be NULL):

@@ -27,32 +27,41 @@ FLIP_TOL = 1e-5        # share of points in the other cluster than the float64 r
 INERTIA_TOL = 1e-6     # relative difference of the final inertia (measured r2: 4.1e-8)
 
 
-def test_twenty_iterations_against_float64_lloyd():
+def _against_float64_lloyd(samples, R, check, arith, outname):
     import torch
     dev = torch.device("cuda", 0)
-    keys_t, _dp2scaf, _len, _genome, _G = bench.make_points(20241, 200_000, 10, dev)
-    x_t = bench.standardise(keys_t)                               # fp32 [189, N], what bench.py clusters
+    keys_t, _dp2scaf, _len, _genome, _G = bench.make_points(20241, 200_000, samples, dev)
+    x_t = bench.standardise(keys_t)                               # fp32 [179 + samples, N], what bench.py clusters
     torch.cuda.synchronize()          # the library runs on its own stream: x_t must be complete before it reads it
     D, N = x_t.shape
     x64 = x_t.to(torch.float64)
-    R, iters, seed = 4, 20, 20240
+    iters, seed = 20, 20240
     ctx = _lib.Context(0)
     try:
         chunk = kmeans.auto_chunk(ctx, N, R)
+        kmeans.set_arith(ctx, arith)
         # the library's assignment after `it` iterations, for every it (a run of `it` iterations ends with an assign pass)
-        lib_assign, lib_inertia = [], None
+        lib_assign, lib_inertia, lib_cent = [], None, None
         for it in range(iters + 1):
             a = torch.empty((R, N), dtype=torch.uint8, device=dev)
             i = torch.empty(R, dtype=torch.float64, device=dev)
-            kmeans.kmeans_restarts_dev(ctx, x_t, N, D, R, seed, it, chunk, a, None, i)
+            c = torch.empty((R, 2, D), dtype=torch.float32, device=dev)
+            kmeans.kmeans_restarts_dev(ctx, x_t, N, D, R, seed, it, chunk, a, c, i)
             ctx.synchronize()
-            lib_assign.append(a)
-            lib_inertia = i
+            lib_assign.append(a[check].clone())
+            lib_inertia, lib_cent = i, c
+        if arith != kmeans.ARITH_F32:
+            # the split arithmetic really ran: its centroids are close to the exact path's, and not the same bits
+            kmeans.set_arith(ctx, kmeans.ARITH_F32)
+            c32 = torch.empty((R, 2, D), dtype=torch.float32, device=dev)
+            kmeans.kmeans_restarts_dev(ctx, x_t, N, D, R, seed, iters, chunk, None, c32, None)
+            ctx.synchronize()
+            assert not torch.equal(c32, lib_cent)
         worst_flip, worst_inertia, flips = 0.0, 0.0, []
-        for r in range(R):
+        for k, r in enumerate(check):
             row = []
             for it, mem, _c0, _c1, inert in lt.lloyd(torch, x64, seed, r, iters):
-                frac = float((mem != lib_assign[it][r].to(torch.bool)).double().mean())
+                frac = float((mem != lib_assign[it][k].to(torch.bool)).double().mean())
                 row.append(frac)
             flips.append(row)
             worst_flip = max(worst_flip, max(row))
@@ -60,9 +69,25 @@ def test_twenty_iterations_against_float64_lloyd():
             assert 0 < int(mem.sum()) < N
         out = os.path.join(ROOT, "gpurun_out")
         if os.path.isdir(out):
-            json.dump(dict(N=N, D=D, R=R, iters=iters, chunk=chunk, worst_flip_fraction=worst_flip, worst_inertia_rel=worst_inertia,
-                           flip_fraction_per_restart_and_iteration=flips), open(os.path.join(out, "lloyd_tolerance.json"), "w"))
+            json.dump(dict(N=N, D=D, R=R, restarts_checked=list(check), arith=["f32", "bf16x3"][arith], iters=iters, chunk=chunk,
+                           worst_flip_fraction=worst_flip, worst_inertia_rel=worst_inertia,
+                           flip_fraction_per_restart_and_iteration=flips), open(os.path.join(out, outname), "w"))
         assert worst_flip <= FLIP_TOL, flips
         assert worst_inertia <= INERTIA_TOL
     finally:
         ctx.close()
+
+
+def test_twenty_iterations_against_float64_lloyd():
+    _against_float64_lloyd(10, 4, [0, 1, 2, 3], kmeans.ARITH_F32, "lloyd_tolerance.json")
+
+
+def test_split_bf16_arithmetic_keeps_the_same_tolerance_at_configs1():
+    """abw_km_set_arith(ABW_KM_ARITH_BF16X3), the shape of configs[1] (64 restarts = two restart tiles per workgroup, 189
+    dims): restarts of both tiles, first, middle and last lanes."""
+    _against_float64_lloyd(10, 64, [0, 1, 31, 32, 62, 63], kmeans.ARITH_BF16X3, "lloyd_tolerance_bf16x3_c1.json")
+
+
+def test_split_bf16_arithmetic_keeps_the_same_tolerance_at_199_dims():
+    """The other kernel shape (four restart tiles per workgroup, 199 dims as configs[2]): 128 restarts, one checked per tile."""
+    _against_float64_lloyd(20, 128, [0, 33, 70, 127], kmeans.ARITH_BF16X3, "lloyd_tolerance_bf16x3_199.json")
