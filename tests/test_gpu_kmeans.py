@@ -46,6 +46,31 @@ def test_kmeans_bit_exact_vs_oracle(ctx, N, d, R, iters, chunk):
     assert np.array_equal(inert, oi)                                     # fp64 inertia identical
 
 
+@pytest.mark.parametrize("N,d,R,iters,chunk", [(6000, 189, 64, 3, 512),      # two restart tiles, two point lanes (configs[1]'s kernel)
+                                                  (2101, 130, 40, 3, 96),       # ragged N, padded restarts, last chunk short
+                                                  (5003, 199, 100, 3, 160),     # four restart tiles, the last one partly padding
+                                                  (4000, 150, 96, 2, 128),      # three restart tiles: one wave of the workgroup idle
+                                                  (3000, 189, 256, 2, 256)])    # two workgroup rows of restarts
+def test_split_bf16_arithmetic_agrees_with_the_exact_path(ctx, N, d, R, iters, chunk):
+    """abw_km_set_arith(ABW_KM_ARITH_BF16X3) on every kernel shape it has, ragged edges included: the Lloyd passes run on three
+    bf16 planes, so the bits differ from the exact path's -- centroids to 1e-5 of the data's scale, inertia to 1e-6, and on
+    separated blobs the same assignments but for near ties."""
+    x, _ = _blobs(N + d, N, d)
+    a0, c0, i0 = kmeans.kmeans_restarts(ctx, x, R, base_seed=20240, iters=iters, chunk=chunk)
+    kmeans.set_arith(ctx, kmeans.ARITH_BF16X3)
+    try:
+        a1, c1, i1 = kmeans.kmeans_restarts(ctx, x, R, base_seed=20240, iters=iters, chunk=chunk)
+    finally:
+        kmeans.set_arith(ctx, kmeans.ARITH_F32)
+    assert not np.array_equal(c0.view(np.uint32), c1.view(np.uint32))   # the other arithmetic really ran
+    scale = float(np.abs(x).max())
+    assert np.abs(c1.astype(np.float64) - c0.astype(np.float64)).max() <= 1e-5 * scale
+    assert (np.abs(i1 - i0) / i0).max() <= 1e-6
+    assert (a0 != a1).sum(axis=1).max() <= max(1, N // 1000)
+    with pytest.raises(_lib.AbwError):
+        kmeans.set_arith(ctx, 7)
+
+
 def test_kmeans_recovers_planted_clusters(ctx):
     x, lab = _blobs(7, 20000, 50, sep=3.0)
     a, c, inert = kmeans.kmeans_restarts(ctx, x, 8, base_seed=1, iters=10)
