@@ -29,14 +29,17 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 
 union Frag { bf16x8 v; s16x4 h[2]; uint32_t w[4]; uint2 d2[2]; uint4 q; };
 
+// h, m, l: words whose UPPER halves are the three bf16 planes of v (the lower halves are whatever is left: hi2 drops them)
 __device__ __forceinline__ void split3(float v, uint32_t& h, uint32_t& m, uint32_t& l)
 {
-    h = __float_as_uint(v) & 0xFFFF0000u;
-    const float r1 = v - __uint_as_float(h);                  // built with -fno-slp-vectorize: v_pk_add_f32 beside MFMAs is slow
-    m = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(m);
-    l = __float_as_uint(r2) & 0xFFFF0000u;
+    h = __float_as_uint(v);
+    const float r1 = v - __uint_as_float(h & 0xFFFF0000u);    // built with -fno-slp-vectorize: v_pk_add_f32 beside MFMAs is slow
+    m = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(m & 0xFFFF0000u);
+    l = __float_as_uint(r2);
 }
+// the upper halves of two words as one: a's in the low half, b's in the high half (v_perm_b32)
+__device__ __forceinline__ uint32_t hi2(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
 // XOR applied to the 16-byte chunk index (0..3) of row j of the x image
 __device__ __forceinline__ int sigma(int j) { return (j >> 2) & 3; }
@@ -68,9 +71,9 @@ __global__ __launch_bounds__(256) void km_step_b3_kernel(const float* __restrict
         for (int i = 0; i < 8; i++) split3(dT[(int64_t)(16 * s + 8 * half + i) * Rp + r0c + col], h[i], m[i], l[i]);
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            dreg[0][s].w[w] = (h[2 * w] >> 16) | h[2 * w + 1];
-            dreg[1][s].w[w] = (m[2 * w] >> 16) | m[2 * w + 1];
-            dreg[2][s].w[w] = (l[2 * w] >> 16) | l[2 * w + 1];
+            dreg[0][s].w[w] = hi2(h[2 * w], h[2 * w + 1]);
+            dreg[1][s].w[w] = hi2(m[2 * w], m[2 * w + 1]);
+            dreg[2][s].w[w] = hi2(l[2 * w], l[2 * w + 1]);
         }
     }
 
@@ -88,9 +91,9 @@ __global__ __launch_bounds__(256) void km_step_b3_kernel(const float* __restrict
 #pragma unroll
         for (int e = 0; e < 4; e++) split3(v[e], h[e], m[e], l[e]);
         uint8_t* q = ximg + ((k / DT) * 2 + buf) * XTILE + row * 64 + (((sq >> 1) ^ sigma(row)) << 4) + ((sq & 1) << 3);
-        *(uint2*)(q) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
-        *(uint2*)(q + XPLANE) = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
-        *(uint2*)(q + 2 * XPLANE) = make_uint2((l[0] >> 16) | l[1], (l[2] >> 16) | l[3]);
+        *(uint2*)(q) = make_uint2(hi2(h[0], h[1]), hi2(h[2], h[3]));
+        *(uint2*)(q + XPLANE) = make_uint2(hi2(m[0], m[1]), hi2(m[2], m[3]));
+        *(uint2*)(q + 2 * XPLANE) = make_uint2(hi2(l[0], l[1]), hi2(l[2], l[3]));
     };
     auto tile_origin = [&](int64_t t0, int64_t end) { return min(t0, end - 32); };
 
@@ -133,9 +136,6 @@ __global__ __launch_bounds__(256) void km_step_b3_kernel(const float* __restrict
         for (int ti = 0; ti < ntiles; ti++) {
             const int64_t tile = p_begin + 32 * (int64_t)ti;
             const uint8_t* xw = ximg + (pl * 2 + cur) * XTILE;
-            const float* nxt[PT];
-#pragma unroll
-            for (int q = 0; q < PT; q++) nxt[q] = point_at(q, ti + 2);
             // ---- discriminant: x fragments one k-step ahead
             auto read_xa = [&](Frag* xa, int s) {
 #pragma unroll
@@ -155,16 +155,25 @@ __global__ __launch_bounds__(256) void km_step_b3_kernel(const float* __restrict
                     xa[P].h[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a);
                 }
             };
-            // sums group gi = (s2 = gi / 3, plane P = 2 - gi % 3): fragment of column tile t
-            auto read_xb1 = [&](Frag* xb, int gi, int t) {
-                const int s2 = gi / 3, P = 2 - gi % 3;
-                xb[t].q = *(const uint4*)(xw + (32 * t + col) * 64 + P * XPLANE + (((2 * s2 + half) ^ sg) << 4));
+            // sums: MFMA n = (group gi = n / DT, column tile t = n % DT), group gi = (point half s2 = gi / 3, plane P = 2 - gi % 3);
+            // its x fragment is read three MFMAs ahead into a ring of four
+            constexpr int NM = 6 * DT;
+            constexpr int RB = 4;
+            Frag xb[RB];
+            auto read_xbn = [&](int n) {
+                if (n >= NM) return;
+                const int gi = n / DT, t = n % DT, s2 = gi / 3, P = 2 - gi % 3;
+                xb[n % RB].q = *(const uint4*)(xw + (32 * t + col) * 64 + P * XPLANE + (((2 * s2 + half) ^ sg) << 4));
             };
-            Frag xa[2][3], xb[2][DT];
+            Frag xa[2][3];
             f32x16 S0, S1;
 #pragma unroll
             for (int e = 0; e < 16; e++) { S0[e] = 0.0f; S1[e] = 0.0f; }
             read_xa(xa[0], 0);
+            SB();                                             // the first fragments are on their way: now the address arithmetic
+            const float* nxt[PT];
+#pragma unroll
+            for (int q = 0; q < PT; q++) nxt[q] = point_at(q, ti + 2);
             // ---- discriminant: two chains; between two MFMAs one sixth of the k-step's other work: the x fragments of the
             //      next k-step, and staging load s of tile ti+1 split into planes, stored, and re-issued for tile ti+2
 #pragma unroll
@@ -179,17 +188,17 @@ __global__ __launch_bounds__(256) void km_step_b3_kernel(const float* __restrict
                 SB();
                 S0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2].v, dreg[0][s].v, S0, 0, 0, 0);
                 SB();
-                if (s + 1 < NS) read_xa1(nx, s + 1, 0); else { read_xb1(xb[0], 0, 0); if (DT > 1) read_xb1(xb[0], 0, 1); }
+                if (s + 1 < NS) read_xa1(nx, s + 1, 0); else { read_xbn(0); if (RB > 4) read_xbn(3); }
                 if (st) split3(v[0], h[0], m[0], l[0]);
                 SB();
                 S1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, dreg[2][s].v, S1, 0, 0, 0);
                 SB();
-                if (s + 1 < NS) read_xa1(nx, s + 1, 1); else { if (DT > 2) read_xb1(xb[0], 0, 2); if (DT > 3) read_xb1(xb[0], 0, 3); }
+                if (s + 1 < NS) read_xa1(nx, s + 1, 1); else { read_xbn(1); if (RB > 5) read_xbn(4); }
                 if (st) split3(v[1], h[1], m[1], l[1]);
                 SB();
                 S0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, dreg[1][s].v, S0, 0, 0, 0);
                 SB();
-                if (s + 1 < NS) read_xa1(nx, s + 1, 2); else { if (DT > 4) read_xb1(xb[0], 0, 4); if (DT > 5) read_xb1(xb[0], 0, 5); if (DT > 6) read_xb1(xb[0], 0, 6); }
+                if (s + 1 < NS) read_xa1(nx, s + 1, 2); else { read_xbn(2); if (RB > 6) read_xbn(5); if (RB > 7) read_xbn(6); }
                 if (st) split3(v[2], h[2], m[2], l[2]);
                 SB();
                 S1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, dreg[0][s].v, S1, 0, 0, 0);
@@ -200,14 +209,17 @@ __global__ __launch_bounds__(256) void km_step_b3_kernel(const float* __restrict
                 S0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, dreg[1][s].v, S0, 0, 0, 0);
                 SB();
                 if (st) {
-                    *(uint2*)(q) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
-                    *(uint2*)(q + XPLANE) = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
-                    *(uint2*)(q + 2 * XPLANE) = make_uint2((l[0] >> 16) | l[1], (l[2] >> 16) | l[3]);
+                    *(uint2*)(q) = make_uint2(hi2(h[0], h[1]), hi2(h[2], h[3]));
+                    *(uint2*)(q + XPLANE) = make_uint2(hi2(m[0], m[1]), hi2(m[2], m[3]));
                 }
                 SB();
                 S1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, dreg[0][s].v, S1, 0, 0, 0);
                 SB();
-                if (st) { ldp[s / DT] = nxt[s / DT]; load_k(s); }
+                if (st) {
+                    *(uint2*)(q + 2 * XPLANE) = make_uint2(hi2(l[0], l[1]), hi2(l[2], l[3]));
+                    ldp[s / DT] = nxt[s / DT];
+                    load_k(s);
+                }
                 SB();
             }
             // ---- memberships: register e of lane (col, half) is tile point 16(e>>3) + 8 half + (e&7)
@@ -230,17 +242,16 @@ __global__ __launch_bounds__(256) void km_step_b3_kernel(const float* __restrict
             members(0);
             // ---- sums: six groups (point half s2 x plane), each one MFMA per column tile: no MFMA waits for the one before
 #pragma unroll
-            for (int gi = 0; gi < 6; gi++) {
-                const int s2 = gi / 3;
-#pragma unroll
-                for (int t = 0; t < DT; t++) {
-                    SB();
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf[s2].v, xb[gi & 1][t].v, acc2[t], 0, 0, 0);
-                    SB();
-                    if (gi + 1 < 6) read_xb1(xb[(gi + 1) & 1], gi + 1, t);
-                    if (gi == 0 && t == 0) members(1);
-                }
+            for (int n = 0; n < NM; n++) {
+                SB();
+                read_xbn(n + RB - 1);
+                if (n == 0) members(1);
+                SB();
+                acc2[n % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf[n / (3 * DT)].v, xb[n % RB].v, acc2[n % DT], 0, 0, 0);
             }
+            // the discriminant's accumulators stay allocated until here: left to itself the allocator gives them the registers
+            // of two sums accumulators and copies those away and back around every tile (64 v_accvgpr_mov)
+            asm volatile("; S0, S1 live to here %0 %1" :: "a"(S0), "a"(S1));
             SB();
             __syncthreads();
             cur ^= 1;
@@ -257,7 +268,6 @@ __global__ __launch_bounds__(256) void km_step_b3_kernel(const float* __restrict
         }
     }
 }
-
 
 template <int DT, int CW>
 int launch_b3(abw_ctx* ctx, const float* x, int64_t N, int d, const float* dT, int Rp, int chunk, int64_t nchunks, float* slabs)

@@ -4,6 +4,7 @@
 #include "ClusterSeparatorKMeans.h"
 #include "abawaca_hip.h"
 #include <stdlib.h>
+#include <string.h>
 // the GPU this process works on: ABW_DEVICE in the environment (default 0)
 static inline int abw_env_device() { const char* e = getenv("ABW_DEVICE"); return e ? atoi(e) : 0; }
 #include <algorithm>
@@ -48,6 +49,11 @@ void km_load(const ScafDpData& scaf_db, const ClusterData& root)
 	KmStore& st = g_km;
 	if(!st.ctx && abw_ctx_create(abw_env_device(), &st.ctx) != ABW_OK)
 		throw std::runtime_error("ClusterSeparatorKMeans: no MI355X / HIP device available");
+	// ABW_KM_ARITH=bf16x3: the Lloyd passes on three bf16 planes (include/abawaca_hip.h, abw_km_set_arith); it takes effect
+	// from 33 restarts on (set_parameters) -- with the default 16 there is one restart tile and the exact kernel runs
+	if(const char* e = getenv("ABW_KM_ARITH"))
+		if(abw_km_set_arith(st.ctx, strcmp(e, "bf16x3") == 0 ? ABW_KM_ARITH_BF16X3 : ABW_KM_ARITH_F32) != ABW_OK)
+			throw std::runtime_error(abw_last_error(st.ctx));
 	const size_t N = scaf_db.ndps(), D = root.ndimensions();
 	if(root.ndps() != N)
 		throw std::invalid_argument("ClusterSeparatorKMeans: the first node must hold every datapoint (root of the recursion)");
