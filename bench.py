@@ -1032,6 +1032,23 @@ def main():
                               identical_on_all_ranks=bool(torch.equal(chk, t_i2)),
                               exchange_bytes_per_pass=int(8 * ((R_job + 31) // 32 * 32) * Wp), passes_per_step=iters + 1,
                               collective=f"all-gather + rank-ordered fp64 adds per pass over {args.backend}")
+        # the same partition with the Lloyd passes on three bf16 planes (abw_km_set_arith): all R_job restarts are on every
+        # GPU, so the split kernel applies whatever the world size; the exchange and the final pass are the exact path's
+        if not args.no_split:
+            in_exact = t_i2.clone()
+            kmeans.set_arith(ctx, kmeans.ARITH_BF16X3)
+            ctx.use_torch_stream(args.backend == "nccl")
+            try:
+                el_s, nl_s, ms_s = timed_steps(step_b, args.warmup, args.steps, barrier, ctx)
+            finally:
+                ctx.use_torch_stream(False)
+                kmeans.set_arith(ctx, kmeans.ARITH_F32)
+            el_s = multi.max_elapsed(el_s, dist, dev)
+            legs["points_split_bf16x3"] = dict(value=N * R_job * iters * args.steps / el_s, ms_per_step=el_s / args.steps * 1e3,
+                                               speedup_over_exact_points=round(el_b / el_s, 3), km_step_ms=round(ms_s / max(nl_s, 1), 4),
+                                               same_best_restart=bool(int(t_i2.argmin()) == int(in_exact.argmin())),
+                                               worst_inertia_rel_diff=float(((t_i2 - in_exact).abs() / in_exact).max()),
+                                               note="not a candidate for `value`: held to the Lloyd tolerance, not to bit parity")
         del t_a, x_loc
         dist.barrier()
         best = "points" if legs["points"]["value"] >= legs["restarts"]["value"] else "restarts"
