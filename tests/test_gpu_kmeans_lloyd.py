@@ -27,10 +27,10 @@ FLIP_TOL = 1e-5        # share of points in the other cluster than the float64 r
 INERTIA_TOL = 1e-6     # relative difference of the final inertia (measured r2: 4.1e-8)
 
 
-def _against_float64_lloyd(samples, R, check, arith, outname):
+def _against_float64_lloyd(samples, R, check, arith, outname, scaffolds=200_000):
     import torch
     dev = torch.device("cuda", 0)
-    keys_t, _dp2scaf, _len, _genome, _G = bench.make_points(20241, 200_000, samples, dev)
+    keys_t, _dp2scaf, _len, _genome, _G = bench.make_points(20241, scaffolds, samples, dev)
     x_t = bench.standardise(keys_t)                               # fp32 [179 + samples, N], what bench.py clusters
     torch.cuda.synchronize()          # the library runs on its own stream: x_t must be complete before it reads it
     D, N = x_t.shape
@@ -91,3 +91,11 @@ def test_split_bf16_arithmetic_keeps_the_same_tolerance_at_configs1():
 def test_split_bf16_arithmetic_keeps_the_same_tolerance_at_199_dims():
     """The other kernel shape (four restart tiles per workgroup, 199 dims as configs[2]): 128 restarts, one checked per tile."""
     _against_float64_lloyd(20, 128, [0, 33, 70, 127], kmeans.ARITH_BF16X3, "lloyd_tolerance_bf16x3_199.json")
+
+
+@pytest.mark.parametrize("arith", [kmeans.ARITH_F32, kmeans.ARITH_BF16X3])
+def test_configs2_size_against_float64_lloyd(arith):
+    """configs[2] at its stated size -- 1M scaffolds -> 4.0 M points x 199 dims, ONE job of 256 restarts x 20 iterations -- in
+    both arithmetics: three restarts (first, middle, last restart tile) followed through every iteration by the float64
+    textbook run, same bounds."""
+    _against_float64_lloyd(20, 256, [0, 100, 255], arith, "lloyd_tolerance_c2_%s.json" % ["f32", "bf16x3"][arith], scaffolds=1_000_000)
