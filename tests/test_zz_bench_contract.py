@@ -30,6 +30,9 @@ def test_default_run_prints_the_contract_line():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     for leg in ("separator", "signature", "coverage", "lrn"):
         assert leg in d and d[leg]["value"] > 0
+    sp = d["km_split_bf16x3"]                                    # the opt-in arithmetic beside the headline, never in its place
+    assert sp["value"] > d["value"] and sp["same_best_restart"] and sp["worst_inertia_rel_diff"] <= 1e-6
+    assert d["roofline"]["kernel"] == "km_step_kernel"
 
 
 def test_bare_gpus_2_starts_its_own_ranks():
@@ -45,7 +48,10 @@ def test_bare_gpus_2_starts_its_own_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "configs[2]" in d["config"]["workload"]
-    assert set(d["partitions"]) == {"restarts", "points"} and d["partitions"]["points"]["identical_on_all_ranks"]
+    assert set(d["partitions"]) == {"restarts", "points", "points_split_bf16x3"} and d["partitions"]["points"]["identical_on_all_ranks"]
+    sp = d["partitions"]["points_split_bf16x3"]                  # the opt-in arithmetic: never the headline, same winner, same inertia to 1e-6
+    assert d["value"] in (d["partitions"]["restarts"]["value"], d["partitions"]["points"]["value"])
+    assert sp["same_best_restart"] and sp["worst_inertia_rel_diff"] <= 1e-6
     assert d["separator_dimension_sharded"]["same_tree_on_all_ranks"]
     sh = d["separator_sharded"]                                  # scaffold-sharded, level by level: the same recursion, a small exchange
     assert sh["same_tree_on_all_ranks"] and sh["nodes"] == d["separator_dimension_sharded"]["nodes"]
