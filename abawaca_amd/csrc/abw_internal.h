@@ -154,4 +154,5 @@ struct abw_device_guard {
 };
 
 // abw_km_b3.hip: the k-means step on three bf16 planes; 1 = launched on ctx->stream, 0 = no such kernel for this shape
+int abw_km_b3_has(int d, int Rp);
 int abw_km_step_b3(abw_ctx* ctx, const float* x, int64_t N, int d, const float* dT, int Rp, int chunk, int64_t nchunks, float* slabs);

@@ -698,10 +698,10 @@ int abw_km_shard_step(abw_ctx* ctx, uint8_t* d_assign)
     abw_km_state& k = ctx->km;
     const StepArgs a = { k.x, k.N, k.d, k.dT, k.Rp, k.chunk, k.nchunks, k.slabs, d_assign, k.R };
     {
-        ABW_PROF(ctx, "km_step");
         // the split-bf16 arithmetic runs the passes that only feed the centroid update; the final assign pass is the exact one
-        const bool split = ctx->km_arith == ABW_KM_ARITH_BF16X3 && !d_assign &&
-                           abw_km_step_b3(ctx, k.x, k.N, k.d, k.dT, k.Rp, k.chunk, k.nchunks, k.slabs);
+        const bool want_split = ctx->km_arith == ABW_KM_ARITH_BF16X3 && !d_assign && abw_km_b3_has(k.d, k.Rp);
+        ABW_PROF(ctx, want_split ? "km_step_b3" : "km_step");
+        const bool split = want_split && abw_km_step_b3(ctx, k.x, k.N, k.d, k.dT, k.Rp, k.chunk, k.nchunks, k.slabs);
         if (!split) switch (k.DT) {
             case 1: launch_step<1>(ctx, a); break;
             case 2: launch_step<2>(ctx, a); break;

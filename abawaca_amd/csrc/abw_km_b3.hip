@@ -284,12 +284,19 @@ int launch_b3(abw_ctx* ctx, const float* x, int64_t N, int d, const float* dT, i
 
 }  // namespace
 
+// whether abw_km_step_b3 has a kernel for d dimensions and Rp (padded) restarts
+int abw_km_b3_has(int d, int Rp)
+{
+    const int DT = (d + 1 + 31) / 32, tiles = Rp / 32;
+    return (Rp & 31) == 0 && ((tiles == 2 && (DT == 5 || DT == 6)) || (tiles >= 3 && DT >= 5 && DT <= 7));
+}
+
 // 1: launched; 0: no kernel of this arithmetic for the shape (the caller runs the exact one).  Shapes: 2 restart tiles with
 // 128 <= d + 1 <= 192 (two point lanes, 144 KiB), 3 or more restart tiles with 128 <= d + 1 <= 224.
 int abw_km_step_b3(abw_ctx* ctx, const float* x, int64_t N, int d, const float* dT, int Rp, int chunk, int64_t nchunks, float* slabs)
 {
     const int DT = (d + 1 + 31) / 32, tiles = Rp / 32;
-    if (N < 32 || chunk < 32 || (chunk & 31) || (Rp & 31)) return 0;
+    if (N < 32 || chunk < 32 || (chunk & 31) || !abw_km_b3_has(d, Rp)) return 0;
     if (tiles == 2) {
         if (DT == 5) return launch_b3<5, 2>(ctx, x, N, d, dT, Rp, chunk, nchunks, slabs);
         if (DT == 6) return launch_b3<6, 2>(ctx, x, N, d, dT, Rp, chunk, nchunks, slabs);

@@ -831,11 +831,11 @@ def configs2_on_one_gpu(ctx, dev, args):
         in_exact = t_in.clone()
         kmeans.set_arith(ctx, kmeans.ARITH_BF16X3)
         try:
-            el_s, n_s, ms_s = timed_steps(step, 1, steps, barrier, ctx)
+            el_s, n_s, ms_s = timed_steps(step, 1, steps, barrier, ctx, prof_name="km_step_b3")
         finally:
             kmeans.set_arith(ctx, kmeans.ARITH_F32)
         res["km_split_bf16x3"] = dict(value=N * R * iters * steps / el_s, unit="point*iterations/s", ms_per_step=el_s / steps * 1e3,
-                                      speedup_over_exact=round(elapsed / el_s, 3), km_step_ms_per_launch_avg=round(ms_s / max(n_s, 1), 4),
+                                      speedup_over_exact=round(elapsed / el_s, 3), km_step_b3_ms_per_launch=round(ms_s / max(n_s, 1), 4),
                                       same_best_restart=bool(int(t_in.argmin()) == int(in_exact.argmin())),
                                       worst_inertia_rel_diff=float(((t_in - in_exact).abs() / in_exact).max()))
     del t_as, x_t
@@ -971,15 +971,22 @@ def main():
             in_exact, a_exact = t_inertia.clone(), t_assign[int(winner[0])].clone()
             kmeans.set_arith(ctx, kmeans.ARITH_BF16X3)
             try:
-                el_s, n_s, ms_s = timed_steps(step, args.warmup, args.steps, barrier, ctx)
+                el_s, n_s, ms_s = timed_steps(step, args.warmup, args.steps, barrier, ctx, prof_name="km_step_b3")
             finally:
                 kmeans.set_arith(ctx, kmeans.ARITH_F32)
             w_s = multi.best_restart(t_inertia.cpu(), first_restart)
+            tf_s = N * R * 4.0 * (D + 1) / (ms_s / max(n_s, 1) * 1e-3) / 1e12
             km_split = dict(arith="x and D as three bf16 planes each, six plane products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; "
                                   "final assign pass, reductions and update exact",
                             value=N * R * iters * args.steps / el_s, unit="point*iterations/s", ms_per_step=el_s / args.steps * 1e3,
-                            speedup_over_exact=round(elapsed / el_s, 3), km_step_ms_per_launch_avg=round(ms_s / max(n_s, 1), 4),
-                            launches=n_s, best_restart=dict(id=int(w_s[0]), inertia=float(w_s[1])),
+                            speedup_over_exact=round(elapsed / el_s, 3),
+                            roofline=dict(kernel="km_step_b3_kernel", bound="mfma", achieved=round(tf_s, 3), peak=FP32_MFMA_PEAK_TFLOPS,
+                                          unit="TFLOP/s", frac=round(tf_s / FP32_MFMA_PEAK_TFLOPS, 4), ms_per_launch=round(ms_s / max(n_s, 1), 4),
+                                          launches=n_s, traffic=None,
+                                          note="priced like the exact kernel: the 4(d+1) fp32 flops per unit the step needs, against the fp32 "
+                                               "matrix peak (frac > 1 is the point of the split); as executed: 18(d+1) bf16 flops per unit = "
+                                               f"{round(4.5 * tf_s / 2500.0, 3)} of the 2.5 PFLOP/s bf16 peak; the kernel sits at the power limit (DESIGN 3.5b)"),
+                            best_restart=dict(id=int(w_s[0]), inertia=float(w_s[1])),
                             same_best_restart=bool(int(w_s[0]) == int(winner[0])),
                             worst_inertia_rel_diff=float(((t_inertia - in_exact).abs() / in_exact).max()),
                             best_restart_points_in_other_cluster=int((t_assign[int(winner[0])] != a_exact).sum()))
@@ -1039,7 +1046,7 @@ def main():
             kmeans.set_arith(ctx, kmeans.ARITH_BF16X3)
             ctx.use_torch_stream(args.backend == "nccl")
             try:
-                el_s, nl_s, ms_s = timed_steps(step_b, args.warmup, args.steps, barrier, ctx)
+                el_s, nl_s, ms_s = timed_steps(step_b, args.warmup, args.steps, barrier, ctx, prof_name="km_step_b3")
             finally:
                 ctx.use_torch_stream(False)
                 kmeans.set_arith(ctx, kmeans.ARITH_F32)

@@ -71,6 +71,20 @@ def test_split_bf16_arithmetic_agrees_with_the_exact_path(ctx, N, d, R, iters, c
         kmeans.set_arith(ctx, 7)
 
 
+@pytest.mark.parametrize("N,d,R", [(3000, 189, 16), (3000, 60, 64), (3000, 199, 64)])
+def test_split_bf16_arithmetic_runs_the_exact_kernel_where_it_has_none(ctx, N, d, R):
+    """One restart tile, fewer than 128 columns, or 64 restarts with more than 191 dims: no split kernel -- the exact one runs
+    and the bits are the exact path's."""
+    x, _ = _blobs(N + d, N, d)
+    a0, c0, i0 = kmeans.kmeans_restarts(ctx, x, R, base_seed=7, iters=3, chunk=128)
+    kmeans.set_arith(ctx, kmeans.ARITH_BF16X3)
+    try:
+        a1, c1, i1 = kmeans.kmeans_restarts(ctx, x, R, base_seed=7, iters=3, chunk=128)
+    finally:
+        kmeans.set_arith(ctx, kmeans.ARITH_F32)
+    assert np.array_equal(c0.view(np.uint32), c1.view(np.uint32)) and np.array_equal(a0, a1) and np.array_equal(i0, i1)
+
+
 def test_kmeans_recovers_planted_clusters(ctx):
     x, lab = _blobs(7, 20000, 50, sep=3.0)
     a, c, inert = kmeans.kmeans_restarts(ctx, x, 8, base_seed=1, iters=10)
