@@ -976,13 +976,19 @@ def main():
                 kmeans.set_arith(ctx, kmeans.ARITH_F32)
             w_s = multi.best_restart(t_inertia.cpu(), first_restart)
             tf_s = N * R * 4.0 * (D + 1) / (ms_s / max(n_s, 1) * 1e-3) / 1e12
+            split_traffic = None
+            if (args.scaffolds, args.samples, R) == (200000, 10, 64):
+                try:
+                    split_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_r03.json")))["km_step_b3_kernel"]["hbm_bytes_per_launch"]
+                except Exception:
+                    split_traffic = None
             km_split = dict(arith="x and D as three bf16 planes each, six plane products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; "
                                   "final assign pass, reductions and update exact",
                             value=N * R * iters * args.steps / el_s, unit="point*iterations/s", ms_per_step=el_s / args.steps * 1e3,
                             speedup_over_exact=round(elapsed / el_s, 3),
                             roofline=dict(kernel="km_step_b3_kernel", bound="mfma", achieved=round(tf_s, 3), peak=FP32_MFMA_PEAK_TFLOPS,
                                           unit="TFLOP/s", frac=round(tf_s / FP32_MFMA_PEAK_TFLOPS, 4), ms_per_launch=round(ms_s / max(n_s, 1), 4),
-                                          launches=n_s, traffic=None,
+                                          launches=n_s, traffic=split_traffic,
                                           note="priced like the exact kernel: the 4(d+1) fp32 flops per unit the step needs, against the fp32 "
                                                "matrix peak (frac > 1 is the point of the split); as executed: 18(d+1) bf16 flops per unit = "
                                                f"{round(4.5 * tf_s / 2500.0, 3)} of the 2.5 PFLOP/s bf16 peak; the kernel sits at the power limit (DESIGN 3.5b)"),
