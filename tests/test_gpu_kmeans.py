@@ -119,3 +119,38 @@ def test_argument_and_state_errors_are_reported_not_faulted(ctx):
     same = np.ones((3, 96), dtype=np.float32)
     asg, cen, ine = kmeans.kmeans_restarts(ctx, same, 2, base_seed=3, iters=2, chunk=32)
     assert np.all(asg == 0) and np.all(ine == 0.0) and np.all(cen == 1.0)
+
+
+def test_a_captured_graph_of_the_job_replays_to_the_same_bits():
+    """abw_km_run_dev allocates nothing once its buffers are sized and only launches on the context's stream, so a caller may
+    capture the whole job -- the 21 passes' launches -- into a HIP graph and replay it (experiments/km_graph.py: 1 - 4 % faster than
+    issuing them; the gaps between dependent kernels are not the launches')."""
+    import torch
+    dev = torch.device("cuda", 0)
+    N, d, R, iters = 40_000, 150, 64, 4
+    x = torch.randn((d, N), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    x[:, : N // 2] += 1.5
+    inert = torch.empty(R, dtype=torch.float64, device=dev)
+    asg = torch.empty((R, N), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    c = _lib.Context(0)
+    try:
+        def job():
+            kmeans.kmeans_restarts_dev(c, x, N, d, R, 11, iters, 512, asg, None, inert)
+        job(); c.synchronize()
+        want_i, want_a = inert.clone(), asg.clone()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            c.use_torch_stream(True)
+            job(); torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                job()
+            c.use_torch_stream(False)
+        torch.cuda.synchronize()
+        for _ in range(2):
+            inert.zero_(); asg.zero_()
+            g.replay(); torch.cuda.synchronize()
+            assert torch.equal(inert, want_i) and torch.equal(asg, want_a)
+    finally:
+        c.close()
