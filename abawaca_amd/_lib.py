@@ -178,7 +178,8 @@ class Context:
         self.shares_torch_stream = bool(on)
 
     def prof_enable(self, on=True):
-        self.check(lib().abw_prof_enable(self._h, 1 if on else 0))
+        """on: False / True (every launch bracketed by events) or an int n > 1 (every n-th launch of a family: a sample)."""
+        self.check(lib().abw_prof_enable(self._h, int(on)))
 
     def prof_reset(self):
         self.check(lib().abw_prof_reset(self._h))

@@ -68,7 +68,8 @@ abw_prof_scope::abw_prof_scope(abw_ctx* c, const char* name) : ctx(c)
     if (!ctx || !ctx->prof.on) return;
     int id = -1;
     for (size_t i = 0; i < ctx->prof.names.size(); i++) if (ctx->prof.names[i] == name) { id = (int)i; break; }
-    if (id < 0) { id = (int)ctx->prof.names.size(); ctx->prof.names.push_back(name); }
+    if (id < 0) { id = (int)ctx->prof.names.size(); ctx->prof.names.push_back(name); ctx->prof.seen.push_back(0); }
+    if (ctx->prof.seen[id]++ % ctx->prof.period) return;      // a sampled measurement: this scope of the name is not one of the timed ones
     hipEvent_t a = prof_event(ctx);
     b = prof_event(ctx);
     if (!a || !b) { b = nullptr; return; }
@@ -87,6 +88,7 @@ int abw_prof_enable(abw_ctx* ctx, int on)
 {
     if (!ctx) return ABW_ERR_ARG;
     ctx->prof.on = on != 0;
+    ctx->prof.period = on > 1 ? (uint32_t)on : 1u;
     return ABW_OK;
 }
 
@@ -97,6 +99,7 @@ int abw_prof_reset(abw_ctx* ctx)
     ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& r : ctx->prof.recs) { ctx->prof.pool.push_back(r.a); ctx->prof.pool.push_back(r.b); }
     ctx->prof.recs.clear();
+    for (auto& n : ctx->prof.seen) n = 0;
     return ABW_OK;
 }
 

@@ -52,6 +52,8 @@ struct abw_sep_state {
 struct abw_prof_rec { int id; hipEvent_t a, b; };
 struct abw_prof {
     bool on = false;
+    uint32_t period = 1;                    // every period-th scope of a name is bracketed (abw_prof_enable(ctx, period))
+    std::vector<uint32_t> seen;             // scopes of names[i] met since the last reset
     std::vector<std::string> names;
     std::vector<abw_prof_rec> recs;
     std::vector<hipEvent_t> pool;

@@ -588,15 +588,19 @@ CONFIGS = {1: dict(scaffolds=200_000, samples=10, genomes=100, restarts=64),
            4: dict(scaffolds=2_000_000, samples=20, genomes=400)}
 
 
+PROF_PERIOD = 3     # the timed region brackets every 3rd launch of a kernel family with HIP events: a pair costs the stream ~9 us
+                    # (experiments/km_prof_cost.py: 7.9 -> 8.3 ms per configs[1] job with every launch bracketed)
+
+
 def timed_steps(step, warmup, steps, barrier, ctx, prof_name="km_step"):
     """The bench contract: `warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides.
-    -> (elapsed seconds of this rank, launches of `prof_name`, their summed ms)"""
+    -> (elapsed seconds of this rank, launches of `prof_name` that were timed -- every PROF_PERIOD-th --, their summed ms)"""
     import torch
     for _ in range(warmup):
         step()
     barrier()
     ctx.prof_reset()
-    ctx.prof_enable(True)
+    ctx.prof_enable(PROF_PERIOD)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -1293,7 +1297,8 @@ def main():
     traffic = pmc_all.get("km_step_kernel", {}).get("hbm_bytes_per_launch") if default_workload else None
     roofline = dict(kernel="km_step_kernel", bound="mfma", achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TFLOPS,
                     unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
-                    launches=n_launch, ms_per_launch=round(ms_avg, 4), flops_per_unit=flops_per_unit,
+                    launches=n_launch, launches_timed="every %d-th launch of the timed region is bracketed by HIP events" % PROF_PERIOD,
+                    ms_per_launch=round(ms_avg, 4), flops_per_unit=flops_per_unit,
                     survey_flops_per_unit=7 * D,
                     achieved_at_survey_count=round(kernel_N * kernel_R * 7.0 * D / (ms_avg * 1e-3) / 1e12, 3),
                     hbm_algorithmic_GBs=round((4.0 * kernel_N * D + 4.0 * kernel_R * (D + 1)) / (ms_avg * 1e-3) / 1e9, 1),

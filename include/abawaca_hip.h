@@ -53,7 +53,9 @@ int  abw_abi_version(void);
  * kernel launches with HIP events recorded on the context's stream.  abw_prof_read synchronises
  * the stream and returns, for the kernel family `name` ("sig_count", "sig_segment", "sep_accum",
  * "sep_eval", "km_step", "km_update"), the number of launches and their summed duration since the
- * last abw_prof_reset.  Used by bench.py for the roofline figure. */
+ * last abw_prof_reset.  Used by bench.py for the roofline figure.  An event pair costs the stream about 9 us (it is a
+ * dependency of its own between two launches): on = 1 brackets every launch; on = n > 1 brackets every n-th launch of a
+ * family, a sample -- abw_prof_read's count is then the number of launches that were timed. */
 int  abw_prof_enable(abw_ctx* ctx, int on);
 int  abw_prof_reset(abw_ctx* ctx);
 int  abw_prof_read(abw_ctx* ctx, const char* name, uint64_t* launches, double* total_ms);
