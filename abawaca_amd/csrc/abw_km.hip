@@ -127,13 +127,14 @@ __device__ __forceinline__ int rowpoint(int i) { return 2 * ((i & 3) + 4 * (i >>
 // and left to itself the allocator parks it in the AGPRs of the sums accumulators, paying 64 copies
 // per tile.  Inline asm is invisible to the hazard recogniser: mfma_v_done() supplies the 18 wait
 // states a 16-pass MFMA result needs before VALU may read it.
+// b: the discriminant operand D[r][j] of this lane, held in an accumulation register for the whole launch (KM_BREG)
 __device__ __forceinline__ void mfma_v_first(f32x16& c, float a, float b)
 {
-    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
 }
 __device__ __forceinline__ void mfma_v(f32x16& c, float a, float b)
 {
-    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
 }
 __device__ __forceinline__ void mfma_v_done(f32x16& c0, f32x16& c1)
 {
@@ -160,10 +161,9 @@ __device__ unsigned long long km_tim[10];
 template <int DT, int CW> struct KmCfg {
     static constexpr int W = DT * 32;
     static constexpr int PT = 4 / CW;                        // point lanes (chunks walked side by side)
-    static constexpr int CS_FLOATS = CW * W * 32;            // discriminant operand [ct][j][col]
     static constexpr int TILE_FLOATS = W * XS;               // one staged x tile
-    // two buffers per point lane when they fit beside the operand in 160 KiB, else one
-    static constexpr int NBUF = ((CS_FLOATS + PT * 2 * TILE_FLOATS) * 4 <= 160 * 1024) ? 2 : 1;
+    // two buffers per point lane when they fit in 160 KiB, else one (the discriminant operand lives in registers)
+    static constexpr int NBUF = (PT * 2 * TILE_FLOATS * 4 <= 160 * 1024) ? 2 : 1;
 };
 
 template <int DT, int CW, bool ASSIGN>
@@ -174,7 +174,6 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
     using C = KmCfg<DT, CW>;
     constexpr int W = C::W, PT = C::PT, NBUF = C::NBUF;
     constexpr int NS = 16 * DT;                              // k-steps of the discriminant product = MFMAs of either product
-    __shared__ float cs[C::CS_FLOATS];
     __shared__ float xs[PT * NBUF][C::TILE_FLOATS];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
@@ -183,11 +182,10 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
     // a wave past the last restart tile recomputes the last one and stores nothing: keeps every
     // wave on one straight-line MFMA stream and inside the workgroup barriers
     const bool wave_cols = r0 < Rp;
-    for (int i = threadIdx.x; i < CW * W * 32; i += 256) {
-        const int t = i / (W * 32), j = (i >> 5) % W, c = i & 31;
-        cs[i] = dT[(int64_t)j * Rp + min(((int)blockIdx.y * CW + t) * 32, Rp - 32) + c];
-    }
-    const float* bop = cs + ct * W * 32 + half * 32 + col;   // + 64*s for k-step s
+    // the discriminant operand of this wave's restarts: k-step s needs D[r0 + col][2s + half] -- one register per k-step
+    float breg[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) breg[s] = dT[(int64_t)(2 * s + half) * Rp + min(r0, Rp - 32) + col];
     const int rp = rowpoint(col);
     const int sq = threadIdx.x & 7;                          // staging: this thread's point quad within a tile
     const int sr = threadIdx.x >> 3;                         //          and its first row (then every 32nd)
@@ -278,25 +276,23 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
                 // the first one runs, so the next batch's LDS reads and the staging loads are dealt out
                 // one or two per MFMA instead of in a block (a block of ~16 costs a bubble per batch).
                 const float* aop = xt + half * XS + rp;      // + 2*XS*s for k-step s
-                float a[2][8], b[2][8];
+                float a[2][8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) { a[0][u] = aop[2 * XS * u]; b[0][u] = bop[64 * u]; }
+                for (int u = 0; u < 8; u++) a[0][u] = aop[2 * XS * u];
 #pragma unroll
                 for (int bt = 0; bt < NS / 8; bt++) {
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         const int m = 8 * bt + u;                        // index of this MFMA
-                        const int s1 = 8 * (bt + 1) + (u & ~1);          // k-step pair fetched behind it
                         if (bt + 1 < NS / 8) {
-                            if (!(u & 1)) { a[(bt + 1) & 1][u] = aop[2 * XS * s1]; a[(bt + 1) & 1][u + 1] = aop[2 * XS * (s1 + 1)]; }
-                            else          { b[(bt + 1) & 1][u - 1] = bop[64 * s1]; b[(bt + 1) & 1][u] = bop[64 * (s1 + 1)]; }
+                            a[(bt + 1) & 1][u] = aop[2 * XS * (8 * (bt + 1) + u)];       // one operand read per MFMA
                         } else if (u < DT) {
                             bb[0][u] = sop[32 * XS * u];                 // first operands of the sums product
                         }
                         if ((m * PT) % 16 == 0) load_k(m * PT / 16);      // next tiles -> registers, also with one buffer
                         __builtin_amdgcn_sched_barrier(0);
-                        if (bt == 0 && u < 2) mfma_v_first((u & 1) ? acc1b : acc1, a[0][u], b[0][u]);
-                        else                  mfma_v((u & 1) ? acc1b : acc1, a[bt & 1][u], b[bt & 1][u]);
+                        if (bt == 0 && u < 2) mfma_v_first((u & 1) ? acc1b : acc1, a[0][u], breg[m]);
+                        else                  mfma_v((u & 1) ? acc1b : acc1, a[bt & 1][u], breg[m]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
