@@ -161,7 +161,11 @@ __device__ unsigned long long km_tim[10];
 template <int DT, int CW> struct KmCfg {
     static constexpr int W = DT * 32;
     static constexpr int PT = 4 / CW;                        // point lanes (chunks walked side by side)
-    static constexpr int TILE_FLOATS = W * XS;               // one staged x tile
+    // One staged x tile: row j = sr + 32 kk of the tile lies at LDS row sr * DTP + kk, so the DT rows a staging thread fills
+    // are neighbours and its stores need no address arithmetic (an instruction between two MFMAs costs the pipe ~14
+    // cycles); DTP odd keeps the second product's reads -- row col * DTP + t for lane col -- on 32 different banks.
+    static constexpr int DTP = DT | 1;
+    static constexpr int TILE_FLOATS = 32 * DTP * XS;
     // two buffers per point lane when they fit in 160 KiB, else one (the discriminant operand lives in registers)
     static constexpr int NBUF = (PT * 2 * TILE_FLOATS * 4 <= 160 * 1024) ? 2 : 1;
 };
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
                                                      float* __restrict__ slabs, uint8_t* __restrict__ assign, int R)
 {
     using C = KmCfg<DT, CW>;
-    constexpr int W = C::W, PT = C::PT, NBUF = C::NBUF;
+    constexpr int W = C::W, PT = C::PT, NBUF = C::NBUF, DTP = C::DTP;
     constexpr int NS = 16 * DT;                              // k-steps of the discriminant product = MFMAs of either product
     __shared__ float xs[PT * NBUF][C::TILE_FLOATS];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
             const float cst = (row == d) ? 1.0f : 0.0f;
             if (row >= d) v = f32x4u{cst, cst, cst, cst};
         }
-        float* q = stq[k / DT] + 32 * kk * XS;
+        float* q = stq[k / DT] + kk * XS;
         q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
     };
     // A tile that would run past its chunk's end (only the last tile of the data can) is moved back to
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
 #pragma unroll
         for (int q = 0; q < PT; q++) {
             ldp[q] = x + tile_origin(pb[q], pe[q]) + 4 * sq;
-            stq[q] = xs[q * NBUF] + sr * XS + 4 * sq;
+            stq[q] = xs[q * NBUF] + sr * DTP * XS + 4 * sq;
         }
 #pragma unroll
         for (int k = 0; k < NL; k++) load_k(k);
@@ -261,10 +265,10 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
 #pragma unroll
             for (int q = 0; q < PT; q++) {
                 ldp[q] = x + tile_origin(pb[q] + 32 * (int64_t)(have_next ? ti + 1 : ti), pe[q]) + 4 * sq;
-                stq[q] = xs[q * NBUF + (NBUF == 2 ? (cur ^ 1) : 0)] + sr * XS + 4 * sq;
+                stq[q] = xs[q * NBUF + (NBUF == 2 ? (cur ^ 1) : 0)] + sr * DTP * XS + 4 * sq;
             }
             const float* xt = xs[pl * NBUF + (NBUF == 2 ? cur : 0)];
-            const float* sop = xt + col * XS + half;         // sums operand: + 32*XS*t + 2*e
+            const float* sop = xt + col * DTP * XS + half;   // sums operand: + XS*t + 2*e
             float bb[2][DT];
             KM_T(2);
             // ---- discriminant: g[p][r] = sum_j x[p][j] D[r][j] + e[r]; operands read 8 k-steps ahead.
@@ -275,19 +279,20 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
                 // One wave per SIMD: whatever is issued between two MFMAs has to fit into the 64 cycles
                 // the first one runs, so the next batch's LDS reads and the staging loads are dealt out
                 // one or two per MFMA instead of in a block (a block of ~16 costs a bubble per batch).
-                const float* aop = xt + half * XS + rp;      // + 2*XS*s for k-step s
+                const float* aop = xt + half * DTP * XS + rp; // + arow(s) for k-step s: dims 2s, 2s+1 = LDS rows ((2s)%32 + half) DTP + (2s)/32
+                auto arow = [](int s_) { return (((2 * s_) % 32) * DTP + (2 * s_) / 32) * XS; };
                 float a[2][8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) a[0][u] = aop[2 * XS * u];
+                for (int u = 0; u < 8; u++) a[0][u] = aop[arow(u)];
 #pragma unroll
                 for (int bt = 0; bt < NS / 8; bt++) {
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         const int m = 8 * bt + u;                        // index of this MFMA
                         if (bt + 1 < NS / 8) {
-                            a[(bt + 1) & 1][u] = aop[2 * XS * (8 * (bt + 1) + u)];       // one operand read per MFMA
+                            a[(bt + 1) & 1][u] = aop[arow(8 * (bt + 1) + u)];            // one operand read per MFMA
                         } else if (u < DT) {
-                            bb[0][u] = sop[32 * XS * u];                 // first operands of the sums product
+                            bb[0][u] = sop[XS * u];                      // first operands of the sums product
                         }
                         if ((m * PT) % 16 == 0) load_k(m * PT / 16);      // next tiles -> registers, also with one buffer
                         __builtin_amdgcn_sched_barrier(0);
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int t = 0; t < DT; t++) {
                     const int m = e * DT + t;
-                    if (e + 1 < 16) bb[(e + 1) & 1][t] = sop[32 * XS * t + 2 * (e + 1)];
+                    if (e + 1 < 16) bb[(e + 1) & 1][t] = sop[XS * t + 2 * (e + 1)];
                     if (NBUF == 2 && (m * PT) % 16 == 0) store_k(m * PT / 16);
                     if (e + 1 < 16 && t == 0) mem[e + 1] = member(e + 1);
                     __builtin_amdgcn_sched_barrier(0);
