@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
             //      point q = 2e + half of the tile, restart r0 + col.  g = chain0 + chain1; member of
             //      cluster 1 iff g > 0.
             // ---- sums: S1[r][j] += sum_p mem[p][r] x[p][j]; operands read one point pair ahead;
-            //      membership e+1 is computed in the shadow of the MFMAs of point pair e.
+            //      the sixteen memberships are computed in a block in front of it.
             KM_T(3);
             const int64_t tile0 = tile_origin(tile, p_end);                       // where the staged tile really starts
             const int skip = (int)min((int64_t)32, tile - tile0);                 // its leading points that are not ours
@@ -319,7 +319,10 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
                 return (valid && in1) ? 1.0f : 0.0f;
             };
             mfma_v_done(acc1, acc1b);
-            mem[0] = member(0);
+            // all sixteen at once, before the second product: between its MFMAs every one of these instructions costs the
+            // matrix pipe ~14 cycles (760 cycles per tile), here their issue slots (600) -- experiments/README.md, round 3
+#pragma unroll
+            for (int e = 0; e < 16; e++) mem[e] = member(e);
             KM_T(4);
 #pragma unroll
             for (int e = 0; e < 16; e++) {
@@ -328,7 +331,6 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
                     const int m = e * DT + t;
                     if (e + 1 < 16) bb[(e + 1) & 1][t] = sop[XS * t + 2 * (e + 1)];
                     if (NBUF == 2 && (m * PT) % 16 == 0) store_k(m * PT / 16);
-                    if (e + 1 < 16 && t == 0) mem[e + 1] = member(e + 1);
                     __builtin_amdgcn_sched_barrier(0);
                     acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(mem[e], bb[e & 1][t], acc2[t], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
