@@ -19,6 +19,7 @@
 // registers), so memberships never leave registers.  fp32 partial sums run over one chunk of points
 // in point order, one slab per chunk; slabs are added in fp64 in chunk order (km_group / km_update).
 #include "abw_internal.h"
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -170,7 +171,7 @@ template <int DT, int CW> struct KmCfg {
     static constexpr int NBUF = (PT * 2 * TILE_FLOATS * 4 <= 160 * 1024) ? 2 : 1;
 };
 
-template <int DT, int CW, bool ASSIGN>
+template <int DT, int CW, bool ASSIGN, bool OFF32>
 __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ x, int64_t N, int d,
                                                      const float* __restrict__ dT, int Rp, int chunk, int64_t nchunks,
                                                      float* __restrict__ slabs, uint8_t* __restrict__ assign, int R)
@@ -209,7 +210,23 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
     f32x4u stg[NL];
     const float* ldp[PT];                                    // per point lane: x + first point of the quad being fetched
     float* stq[PT];                                          // per point lane: destination buffer + (sr, 4sq)
-    auto load_k = [&](int k) { stg[k] = *(const f32x4u*)(ldp[k / DT] + (int64_t)min(sr + 32 * (k % DT), d - 1) * N); };
+    // OFF32 (every byte offset inside a tile's d rows fits 32 bits: (d - 1) N + 31 < 2^30, what launch_step_cw checks): the
+    // tile's first point is a uniform address -- a raw buffer descriptor in scalar registers -- and a thread's offsets to its
+    // rows never change, so a staging load is ONE instruction.  With 64-bit pointers every load also paid a 64-bit vector add,
+    // and those twelve adds per tile were all that kept the first product off the matrix pipe's rate (6 546 -> 6 121 cycles
+    // per tile, the pipe's 6 144 less the first tile's share; experiments/README.md).
+    uint32_t voff[DT];
+#pragma unroll
+    for (int kk = 0; kk < DT; kk++) voff[kk] = OFF32 ? (uint32_t)(((int64_t)min(sr + 32 * kk, d - 1) * N + 4 * sq) * 4) : 0u;
+    auto load_k = [&](int k) {
+        if (OFF32) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ldp[k / DT], 0, 0xFFFFFFFFu, 0x00027000);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[k % DT], 0, 0);
+            stg[k] = f32x4u{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+        } else {
+            stg[k] = *(const f32x4u*)(ldp[k / DT] + (int64_t)min(sr + 32 * (k % DT), d - 1) * N);
+        }
+    };
     auto store_k = [&](int k) {
         const int kk = k % DT;
         f32x4u v = stg[k];
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
         __syncthreads();                                      // previous group's last tiles fully consumed
 #pragma unroll
         for (int q = 0; q < PT; q++) {
-            ldp[q] = x + tile_origin(pb[q], pe[q]) + 4 * sq;
+            ldp[q] = x + tile_origin(pb[q], pe[q]) + (OFF32 ? 0 : 4 * sq);
             stq[q] = xs[q * NBUF] + sr * DTP * XS + 4 * sq;
         }
 #pragma unroll
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
             // step of a group the same code re-fetches the current tiles into the idle buffers (harmless)
 #pragma unroll
             for (int q = 0; q < PT; q++) {
-                ldp[q] = x + tile_origin(pb[q] + 32 * (int64_t)(have_next ? ti + 1 : ti), pe[q]) + 4 * sq;
+                ldp[q] = x + tile_origin(pb[q] + 32 * (int64_t)(have_next ? ti + 1 : ti), pe[q]) + (OFF32 ? 0 : 4 * sq);
                 stq[q] = xs[q * NBUF + (NBUF == 2 ? (cur ^ 1) : 0)] + sr * DTP * XS + 4 * sq;
             }
             const float* xt = xs[pl * NBUF + (NBUF == 2 ? cur : 0)];
@@ -536,10 +553,17 @@ void launch_step_cw(abw_ctx* ctx, const StepArgs& a)
     const unsigned gy = (unsigned)((a.Rp / 32 + CW - 1) / CW);
     const unsigned gx = (unsigned)std::min<int64_t>((a.nchunks + PT - 1) / PT, (int64_t)ctx->num_cu * 8);
     const dim3 grid(gx, gy);
-    if (a.assign)
-        hipLaunchKernelGGL((km_step_kernel<DT, CW, true>), grid, dim3(256), 0, ctx->stream, a.x, a.N, a.d, a.dT, a.Rp, a.chunk, a.nchunks, a.slabs, a.assign, a.R);
+    // byte offsets inside a tile's rows in 32 bits (the staging's one-instruction loads); ABW_KM_PTR64=1 forces the other path (tests)
+    static const bool force64 = getenv("ABW_KM_PTR64") != nullptr;
+    const bool off32 = !force64 && (int64_t)(a.d - 1) * a.N + 31 < (1ll << 30);
+    if (a.assign && off32)
+        hipLaunchKernelGGL((km_step_kernel<DT, CW, true, true>), grid, dim3(256), 0, ctx->stream, a.x, a.N, a.d, a.dT, a.Rp, a.chunk, a.nchunks, a.slabs, a.assign, a.R);
+    else if (a.assign)
+        hipLaunchKernelGGL((km_step_kernel<DT, CW, true, false>), grid, dim3(256), 0, ctx->stream, a.x, a.N, a.d, a.dT, a.Rp, a.chunk, a.nchunks, a.slabs, a.assign, a.R);
+    else if (off32)
+        hipLaunchKernelGGL((km_step_kernel<DT, CW, false, true>), grid, dim3(256), 0, ctx->stream, a.x, a.N, a.d, a.dT, a.Rp, a.chunk, a.nchunks, a.slabs, a.assign, a.R);
     else
-        hipLaunchKernelGGL((km_step_kernel<DT, CW, false>), grid, dim3(256), 0, ctx->stream, a.x, a.N, a.d, a.dT, a.Rp, a.chunk, a.nchunks, a.slabs, a.assign, a.R);
+        hipLaunchKernelGGL((km_step_kernel<DT, CW, false, false>), grid, dim3(256), 0, ctx->stream, a.x, a.N, a.d, a.dT, a.Rp, a.chunk, a.nchunks, a.slabs, a.assign, a.R);
 }
 
 // Column tiles per workgroup: as many as there are restart tiles (up to 4), the remaining waves

@@ -154,3 +154,29 @@ def test_a_captured_graph_of_the_job_replays_to_the_same_bits():
             assert torch.equal(inert, want_i) and torch.equal(asg, want_a)
     finally:
         c.close()
+
+
+def test_the_64_bit_pointer_staging_path_gives_the_same_bits():
+    """Tables whose row offsets do not fit 32 bits ((d - 1) N >= 2^30) take the step kernel's other staging path (64-bit pointers
+    instead of a buffer descriptor + 32-bit offsets).  ABW_KM_PTR64=1 forces it on a small table, in a process of its own (the
+    switch is read once): bit-identical to the CPU restatement there too."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import _oracle as orc\n"
+        "from abawaca_amd import _lib, kmeans\n"
+        "rng = np.random.default_rng(3)\n"
+        "for N, d, R, chunk in ((6000, 189, 64, 512), (2100, 199, 32, 160), (4097, 33, 16, 256)):\n"
+        "    x = np.ascontiguousarray((rng.normal(0, 1, (N, d)) + 3.0 * rng.integers(0, 2, (N, 1))).astype(np.float32).T)\n"
+        "    c = _lib.Context(0)\n"
+        "    a, ce, i = kmeans.kmeans_restarts(c, x, R, base_seed=20240, iters=3, chunk=chunk)\n"
+        "    oa, oc, oi = orc.kmeans(x, R, 20240, 3, chunk)\n"
+        "    assert np.array_equal(ce.view(np.uint32), oc.view(np.uint32)) and np.array_equal(a, oa) and np.array_equal(i, oi)\n"
+        "    c.close()\n"
+        "print('same bits')\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, ABW_KM_PTR64="1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and "same bits" in p.stdout, p.stderr[-2000:]
