@@ -88,7 +88,16 @@ __global__ __launch_bounds__(256) void km_step_b3_kernel(const float* __restrict
     constexpr int NL = PT * DT;
     f32x4u stg[NL];
     const float* ldp[PT];
-    auto load_k = [&](int k) { stg[k] = *(const f32x4u*)(ldp[k / DT] + (int64_t)min(sr + 32 * (k % DT), d - 1) * N); };
+    // the tile's first point as a raw buffer descriptor in scalar registers + the thread's constant 32-bit row offsets: a
+    // staging load is one instruction (the launcher refuses tables whose row offsets need more than 32 bits)
+    uint32_t voff[DT];
+#pragma unroll
+    for (int kk = 0; kk < DT; kk++) voff[kk] = (uint32_t)(((int64_t)min(sr + 32 * kk, d - 1) * N + 4 * sq) * 4);
+    auto load_k = [&](int k) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ldp[k / DT], 0, 0xFFFFFFFFu, 0x00027000);
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[k % DT], 0, 0);
+        stg[k] = f32x4u{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+    };
     auto store_k = [&](int k, int buf) {
         const int kk = k % DT, row = sr + 32 * kk;
         f32x4u v = stg[k];
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(256) void km_step_b3_kernel(const float* __restrict
         const int64_t ch = cg * PT + pl;
         const int64_t p_begin = pb[pl], p_end = pe[pl];
         const int ntiles = (int)((pe[0] - pb[0] + 31) >> 5);
-        auto point_at = [&](int q, int t) { return x + tile_origin(pb[q] + 32 * (int64_t)min(t, ntiles - 1), pe[q]) + 4 * sq; };
+        auto point_at = [&](int q, int t) { return x + tile_origin(pb[q] + 32 * (int64_t)min(t, ntiles - 1), pe[q]); };
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PT; q++) ldp[q] = point_at(q, 0);
