@@ -338,8 +338,20 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
             mfma_v_done(acc1, acc1b);
             // all sixteen at once, before the second product: between its MFMAs every one of these instructions costs the
             // matrix pipe ~14 cycles (760 cycles per tile), here their issue slots (600) -- experiments/README.md, round 3
+            // ... and a tile whose 32 points are all ours (every tile but a chunk's last) does not ask for validity: three
+            // instructions per point pair instead of six.  The branch is around this block only (around the loop of the second
+            // product as well it made the allocator spill 300 registers).
+            if (__builtin_amdgcn_readfirstlane(skip) == 0) {
 #pragma unroll
-            for (int e = 0; e < 16; e++) mem[e] = member(e);
+                for (int e = 0; e < 16; e++) {
+                    const bool in1 = acc1[e] + acc1b[e] > 0.0f;
+                    if (ASSIGN) abits |= in1 ? (1u << e) : 0u;
+                    mem[e] = in1 ? 1.0f : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; e++) mem[e] = member(e);
+            }
             KM_T(4);
 #pragma unroll
             for (int e = 0; e < 16; e++) {
