@@ -209,7 +209,10 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
     constexpr int NL = PT * DT;                              // staging loads (and stores) per thread per step
     f32x4u stg[NL];
     const float* ldp[PT];                                    // per point lane: x + first point of the quad being fetched
-    float* stq[PT];                                          // per point lane: destination buffer + (sr, 4sq)
+    // per point lane: LDS byte address of destination buffer + (sr, 4sq), each in a register of its own (left to itself the
+    // compiler keeps one and adds the lanes' constant distance in front of every store: a vector add between two MFMAs)
+    typedef __attribute__((address_space(3))) float lds_float;
+    uint32_t stq[PT];
     // OFF32 (every byte offset inside a tile's d rows fits 32 bits: (d - 1) N + 31 < 2^30, what launch_step_cw checks): the
     // tile's first point is a uniform address -- a raw buffer descriptor in scalar registers -- and a thread's offsets to its
     // rows never change, so a staging load is ONE instruction.  With 64-bit pointers every load also paid a 64-bit vector add,
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
             const float cst = (row == d) ? 1.0f : 0.0f;
             if (row >= d) v = f32x4u{cst, cst, cst, cst};
         }
-        float* q = stq[k / DT] + kk * XS;
+        lds_float* q = (lds_float*)(size_t)stq[k / DT] + kk * XS;
         q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
     };
     // A tile that would run past its chunk's end (only the last tile of the data can) is moved back to
@@ -260,7 +263,8 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
 #pragma unroll
         for (int q = 0; q < PT; q++) {
             ldp[q] = x + tile_origin(pb[q], pe[q]) + (OFF32 ? 0 : 4 * sq);
-            stq[q] = xs[q * NBUF] + sr * DTP * XS + 4 * sq;
+            stq[q] = (uint32_t)(size_t)(lds_float*)(xs[q * NBUF] + sr * DTP * XS + 4 * sq);
+            asm volatile("" : "+v"(stq[q]));
         }
 #pragma unroll
         for (int k = 0; k < NL; k++) load_k(k);
@@ -282,7 +286,8 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
 #pragma unroll
             for (int q = 0; q < PT; q++) {
                 ldp[q] = x + tile_origin(pb[q] + 32 * (int64_t)(have_next ? ti + 1 : ti), pe[q]) + (OFF32 ? 0 : 4 * sq);
-                stq[q] = xs[q * NBUF + (NBUF == 2 ? (cur ^ 1) : 0)] + sr * DTP * XS + 4 * sq;
+                stq[q] = (uint32_t)(size_t)(lds_float*)(xs[q * NBUF + (NBUF == 2 ? (cur ^ 1) : 0)] + sr * DTP * XS + 4 * sq);
+                asm volatile("" : "+v"(stq[q]));
             }
             const float* xt = xs[pl * NBUF + (NBUF == 2 ? cur : 0)];
             const float* sop = xt + col * DTP * XS + half;   // sums operand: + XS*t + 2*e
