@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
 #pragma unroll
     for (int s = 0; s < NS; s++) breg[s] = dT[(int64_t)(2 * s + half) * Rp + min(r0, Rp - 32) + col];
     const int rp = rowpoint(col);
+    const int ns_used = (d + 2) >> 1;                        // k-steps of the first product that touch a row <= d
     const int sq = threadIdx.x & 7;                          // staging: this thread's point quad within a tile
     const int sr = threadIdx.x >> 3;                         //          and its first row (then every 32nd)
 
@@ -318,8 +319,10 @@ __global__ __launch_bounds__(256) void km_step_kernel(const float* __restrict__ 
                         }
                         if ((m * PT) % 16 == 0) load_k(m * PT / 16);      // next tiles -> registers, also with one buffer
                         __builtin_amdgcn_sched_barrier(0);
-                        if (bt == 0 && u < 2) mfma_v_first((u & 1) ? acc1b : acc1, a[0][u], breg[m]);
-                        else                  mfma_v((u & 1) ? acc1b : acc1, a[bt & 1][u], breg[m]);
+                        // k-step m multiplies rows 2m, 2m+1 of the tile: past row d (the ones row that meets e[r]) both operands are
+                        // zero, and the last row group's k-steps beyond it are skipped (d = 199: 12 of 112; uniform branches)
+                        if (bt == 0 && u < 2)                          mfma_v_first((u & 1) ? acc1b : acc1, a[0][u], breg[m]);
+                        else if (m < 16 * (DT - 1) || m < ns_used)     mfma_v((u & 1) ? acc1b : acc1, a[bt & 1][u], breg[m]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
