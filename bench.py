@@ -588,8 +588,9 @@ CONFIGS = {1: dict(scaffolds=200_000, samples=10, genomes=100, restarts=64),
            4: dict(scaffolds=2_000_000, samples=20, genomes=400)}
 
 
-PROF_PERIOD = 3     # the timed region brackets every 3rd launch of a kernel family with HIP events: a pair costs the stream ~9 us
-                    # (experiments/km_prof_cost.py: 7.9 -> 8.3 ms per configs[1] job with every launch bracketed)
+PROF_PERIOD = 7     # the timed region brackets every 7th launch of a kernel family with HIP events (three of a job's 21 passes): a
+                    # pair costs the stream ~9 us (experiments/km_prof_cost.py: 7.9 -> 8.3 ms per configs[1] job with every launch
+                    # bracketed); the launches of a family all do the same work
 
 
 def timed_steps(step, warmup, steps, barrier, ctx, prof_name="km_step"):
