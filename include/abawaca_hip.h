@@ -442,7 +442,7 @@ int32_t abw_km_chunk_for(int32_t num_cu, int64_t N, int32_t R);
  *                       >= 2^-16 on the bf16 matrix cores with fp32 accumulation (about fp32 accuracy, hardware summation
  *                       order): twice the step rate, held to the documented Lloyd tolerance (per pass <= 1e-5 of the
  *                       points in the other cluster, final inertia to 1e-6 relative) instead of bit parity.  Shapes without
- *                       such a kernel (fewer than 33 restarts, d + 1 < 129, 64 restarts with d > 191) run the exact one.
+ *                       such a kernel (fewer than 33 restarts, d + 1 < 129, 64 restarts with d > 191, (d - 1) N >= 2^30) run the exact one.
  * The final assign pass, the fp64 reductions, the centroid update and the inertia are the exact path's either way.
  * Stays set on the context until changed.  (No reference counterpart.) */
 #define ABW_KM_ARITH_F32    0
