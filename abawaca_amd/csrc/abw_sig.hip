@@ -354,6 +354,16 @@ __device__ __forceinline__ uint32_t count_byte_eq(uint32_t x, uint32_t pat)   //
     return __popc(z);
 }
 
+// 0x80 in every byte of x that equals the byte replicated in pat (exact)
+__device__ __forceinline__ uint32_t bytes_eq(uint32_t x, uint32_t pat)
+{
+    const uint32_t t = x ^ pat;
+    return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+}
+
+#ifndef SEGU
+#define SEGU 8
+#endif
 __global__ __launch_bounds__(256) void seg_blockcount_kernel(const uint8_t* __restrict__ ascii, uint64_t total_len,
                                                             uint32_t* __restrict__ blk_nonN, uint64_t nblk,
                                                             int* __restrict__ flag_lower_n)
@@ -361,33 +371,51 @@ __global__ __launch_bounds__(256) void seg_blockcount_kernel(const uint8_t* __re
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    // four blocks per turn: four 16-byte loads in flight per lane before the first reduction (one at a time: 4.6 TB/s)
-    for (uint64_t b0 = 4 * wave; b0 < nblk; b0 += 4 * nwaves) {
-        uint4 v[4];
-        bool whole[4];
+    uint32_t any_n = 0;
+    // SEGU blocks per turn: that many 16-byte loads in flight per lane before the first reduction (one at a time: 4.6 TB/s).
+    // The pass is close to vector-instruction-bound beside the reads: the 'N's are counted (one population count per
+    // word), a lower-case 'n' is only looked for (its detector words are ORed, one test at the end), and the four blocks'
+    // counts travel through two wave reductions, two 16-bit counts in a word.
+    for (uint64_t b0 = SEGU * wave; b0 < nblk; b0 += SEGU * nwaves) {
+        uint4 v[SEGU];
+        bool whole[SEGU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < SEGU; u++) {
             const uint64_t b = b0 + (uint64_t)u, A = b * SEGBLK + (uint64_t)lane * 16;
             whole[u] = b < nblk && A + 16 <= total_len;
-            v[u] = whole[u] ? *reinterpret_cast<const uint4*>(ascii + A) : make_uint4(0, 0, 0, 0);
+            typedef uint32_t u32x4n __attribute__((ext_vector_type(4)));
+            if (whole[u]) {
+                const u32x4n t = __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(ascii + A));
+                v[u] = make_uint4(t[0], t[1], t[2], t[3]);
+            } else {
+                v[u] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        uint32_t nonN[SEGU];
+#pragma unroll
+        for (int u = 0; u < SEGU; u++) {
+            const uint64_t b = b0 + (uint64_t)u, A = b * SEGBLK + (uint64_t)lane * 16;
+            uint32_t nN = 0, len = 0;
+            if (whole[u]) {
+                nN = __popc(bytes_eq(v[u].x, 0x4E4E4E4Eu)) + __popc(bytes_eq(v[u].y, 0x4E4E4E4Eu)) + __popc(bytes_eq(v[u].z, 0x4E4E4E4Eu)) +
+                     __popc(bytes_eq(v[u].w, 0x4E4E4E4Eu));
+                any_n |= bytes_eq(v[u].x, 0x6E6E6E6Eu) | bytes_eq(v[u].y, 0x6E6E6E6Eu) | bytes_eq(v[u].z, 0x6E6E6E6Eu) | bytes_eq(v[u].w, 0x6E6E6E6Eu);
+                len = 16;
+            } else if (b < nblk) {
+                for (uint64_t i = A; i < total_len; i++) { nN += ascii[i] == 'N'; any_n |= ascii[i] == 'n'; len++; }
+            }
+            nonN[u] = len - nN;                                 // <= 16 per lane, <= 1024 per block: 16 bits hold a block's sum
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint64_t b = b0 + (uint64_t)u, A = b * SEGBLK + (uint64_t)lane * 16;
-            if (b >= nblk) break;                              // uniform for the wave
-            uint32_t nN = 0, nn = 0, len = 0;
-            if (whole[u]) {
-                nN = count_byte_eq(v[u].x, 0x4E4E4E4Eu) + count_byte_eq(v[u].y, 0x4E4E4E4Eu) + count_byte_eq(v[u].z, 0x4E4E4E4Eu) + count_byte_eq(v[u].w, 0x4E4E4E4Eu);
-                nn = count_byte_eq(v[u].x, 0x6E6E6E6Eu) + count_byte_eq(v[u].y, 0x6E6E6E6Eu) + count_byte_eq(v[u].z, 0x6E6E6E6Eu) + count_byte_eq(v[u].w, 0x6E6E6E6Eu);
-                len = 16;
-            } else {
-                for (uint64_t i = A; i < total_len; i++) { nN += ascii[i] == 'N'; nn += ascii[i] == 'n'; len++; }
+        for (int u = 0; u < SEGU; u += 2) {
+            const uint32_t s2 = wave_sum(nonN[u] | (nonN[u + 1] << 16));
+            if (lane == 0) {
+                if (b0 + u < nblk) blk_nonN[b0 + u] = s2 & 0xFFFFu;
+                if (b0 + u + 1 < nblk) blk_nonN[b0 + u + 1] = s2 >> 16;
             }
-            const uint32_t nonN = wave_sum(len - nN);
-            if (nn) atomicOr(flag_lower_n, 1);
-            if (lane == 0) blk_nonN[b] = nonN;
         }
     }
+    if (any_n) atomicOr(flag_lower_n, 1);
 }
 
 // exclusive scan -> uint64, three small launches: per-1024 group totals, scan of the group totals
