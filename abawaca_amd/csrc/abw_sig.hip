@@ -346,14 +346,6 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int SEGBLK = 1024;
 
-__device__ __forceinline__ uint32_t count_byte_eq(uint32_t x, uint32_t pat)   // pat = byte replicated 4x
-{
-    uint32_t t = x ^ pat;
-    // exact zero-byte detector: 0x80 in every byte of t that is zero
-    uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
-    return __popc(z);
-}
-
 // 0x80 in every byte of x that equals the byte replicated in pat (exact)
 __device__ __forceinline__ uint32_t bytes_eq(uint32_t x, uint32_t pat)
 {
