@@ -214,8 +214,13 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
         const uint64_t seg_e = sb + seg_end[s];                 // absolute, exclusive
         const uint64_t a0 = seg_b & ~(uint64_t)15;
 
+        // the four bytes in front of a lane's piece (its 3-base halo) are the last word of the lane below's piece: they come
+        // over by a wave shift, and lane 0 gets the last word of lane 63's piece of the step before (one scalar load per
+        // segment for the first step) -- not a second load and its 64-bit address per lane and step
+        uint32_t prev_tail = (a0 >= 4) ? *reinterpret_cast<const uint32_t*>(ascii + a0 - 4) : 0u;
         for (uint64_t base = a0; base < seg_e; base += 1024) {
             const uint64_t A = base + (uint64_t)lane * 16;
+            uint32_t q3 = 0;
             // segment bounds relative to window 0 of lane 0 (base - 3), clamped so that 32-bit lane math is exact
             const int rel_b = (int)max((int64_t)-(1 << 20), min((int64_t)(1 << 20), (int64_t)(seg_b - base) + 3));
             const int rel_e = (int)max((int64_t)-(1 << 20), min((int64_t)(1 << 20), (int64_t)(seg_e - base) + 3));
@@ -228,7 +233,8 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
                     q[0] = q[1] = q[2] = q[3] = 0;
                     for (uint64_t i = 0; A + i < total_len; i++) q[i >> 2] |= (uint32_t)ascii[A + i] << (8 * (i & 3));
                 }
-                const uint32_t halo = (A >= 4) ? *reinterpret_cast<const uint32_t*>(ascii + A - 4) : 0;
+                q3 = q[3];
+                const uint32_t halo = (uint32_t)__builtin_amdgcn_update_dpp((int)prev_tail, (int)q3, 0x138, 0xF, 0xF, false);   // wave_shr:1
                 // Window t = 0..18 is the base at A - 3 + t (3-base halo, then the 16 bases of this
                 // piece).  Code stream S (2 bits per base) and validity stream V (1 bit per base),
                 // both with the newest base in the lowest bits: base t sits at bit 18 - t of V.
@@ -273,6 +279,7 @@ __global__ __launch_bounds__(256) void sig_count_kernel(
                     } while (H1 | H2 | H3);
                 }
             }
+            prev_tail = (uint32_t)__builtin_amdgcn_readlane((int)q3, 63);   // (a next step exists only if lane 63 had a piece)
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
