@@ -199,8 +199,9 @@ static __device__ __forceinline__ void accum_group_tile(const NGroup& G, const u
         // (16-byte loads side by side), then a thread per scaffold for what lands on bin t_s.
         const int4 r0 = srec[begin], r1 = srec[end - 1];
         for (int dp = r0.x + (int)threadIdx.x; dp < r1.x + r1.y; dp += 256) {
-            const uint4 c = codes[dp];
-            const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+            typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+            const u32x4s c = __builtin_nontemporal_load(reinterpret_cast<const u32x4s*>(codes + dp));    // read once per node: streamed
+            const uint32_t cw[4] = {c[0], c[1], c[2], c[3]};
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 if (q < G.cnt) {
