@@ -22,7 +22,7 @@ EXPORTS = [
     "abw_abi_version", "abw_prof_enable", "abw_prof_reset", "abw_prof_read", "abw_sig_dim_names", "abw_sig_segment_host", "abw_sig_segment_dev", "abw_sig_segment_static", "abw_sig_count_dev", "abw_sig_selftest_division",
     "abw_sig_build", "abw_sep_load", "abw_sep_load_dev", "abw_km_sum_ordered", "abw_sam_parse", "abw_sam_parse_dev", "abw_sam_names_load", "abw_sep_node", "abw_sep_node_assign", "abw_sep_tree", "abw_sep_dev_keys", "abw_km_run_dev", "abw_km_run",
     "abw_km_features_from_keys", "abw_km_tinymt_selftest", "abw_km_auto_chunk", "abw_km_chunk_for", "abw_km_set_arith",
-    "abw_cov_accumulate", "abw_cov_accumulate_dev", "abw_km_load", "abw_km_node", "abw_lrn_header", "abw_lrn_parse", "abw_lrn_emit", "abw_lrn_emit_rows", "abw_lrn_emit_rows_dev", "abw_lrn_table_load",
+    "abw_cov_accumulate", "abw_cov_accumulate_dev", "abw_km_load", "abw_km_node", "abw_lrn_header", "abw_lrn_parse", "abw_lrn_emit", "abw_lrn_emit_rows", "abw_lrn_emit_rows_dev", "abw_lrn_table_load", "abw_lrn_table_load_dev",
     "abw_sep_shard_load", "abw_sep_shard_accum", "abw_sep_shard_eval", "abw_sep_shard_decide", "abw_sep_shard_combine", "abw_device_count",
     "abw_sep_tree_begin", "abw_sep_tree_eval", "abw_sep_tree_assign", "abw_sep_tree_advance", "abw_sep_tree_result", "abw_sep_tree_merge",
     "abw_sep_tree_level", "abw_sep_narrow_bins", "abw_sep_stree_begin", "abw_sep_stree_accum", "abw_sep_stree_eval", "abw_sep_stree_assign",
@@ -132,6 +132,7 @@ def lib():
     L.abw_lrn_emit.argtypes = [vp, vp, i64, i32, u64, vp, u64, C.POINTER(u64)]
     L.abw_lrn_emit_rows.argtypes = [vp, vp, i64, i32, vp, i64, vp, u64, C.POINTER(u64)]
     L.abw_lrn_table_load.argtypes = [vp, vp, i64, i32]
+    L.abw_lrn_table_load_dev.argtypes = [vp, vp, i64, i32]
     L.abw_lrn_emit_rows_dev.argtypes = [vp, vp, i64, i32, vp, i64, vp, u64, C.POINTER(u64), vp]
     L.abw_km_load.argtypes = [vp, vp, i32, i64, vp, i32]
     L.abw_km_node.argtypes = [vp, vp, i32, i32, u32, i32, i32, i32, C.POINTER(KmSplit), vp, vp]

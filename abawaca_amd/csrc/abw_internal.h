@@ -104,7 +104,7 @@ struct abw_ctx {
     void*       sig_static = nullptr;  // this device's address of abw_sig.hip's static workspace (abw_sig_segment_static)
     abw_devbuf  sam_names;             // resident hash table of the scaffold names (abw_sam_names_load): slot_hash | name_off | slot_id | blob
     uint64_t    sam_n_scaf = 0, sam_slots = 0;   // sam_slots = 0: none loaded
-    abw_devbuf  lrn_table;             // resident [n_cols][ld] doubles of the cluster writer (abw_lrn_table_load)
+    abw_devbuf  lrn_table;             // resident [ld][n_cols] doubles of the cluster writer (abw_lrn_table_load[_dev]: transposed at load)
     int64_t     lrn_ld = 0;
     int32_t     lrn_cols = 0;
 };

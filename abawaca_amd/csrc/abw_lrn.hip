@@ -503,69 +503,217 @@ __device__ __forceinline__ int dec_digits64(uint64_t v)
 }
 __device__ __forceinline__ uint32_t field6_len(const Fix6& f) { return 1u + f.neg + (uint32_t)dec_digits64(f.q / 1000000ull) + 7u; }
 
+constexpr int EMIT_LDS_MAX = 80 * 1024;                        // a workgroup's rows in LDS: two workgroups per CU
 constexpr int EMIT6_FIELD_MAX = 23;                           // "\t-" + 13 digits + "." + 6 decimals, rounded up
 
-__global__ __launch_bounds__(256) void lrn_rowlen6_kernel(const double* __restrict__ values, int64_t ld, int32_t n_cols,
-                                                         const int64_t* __restrict__ dps, int64_t n_rows, uint32_t* __restrict__ row_len,
-                                                         unsigned long long* __restrict__ err)
+// ---- a field of the cluster writer without loops (|value| < 1e8: eight integer digits at most) ----------------------
+__device__ __forceinline__ uint32_t digits4(uint32_t y)      // y < 10000 -> its four digits as bytes, byte 0 = the thousands
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
-    int64_t dp = dps[row];
-    if (dp < 1 || dp > ld) { if (lane == 0) atomicMin(err, (unsigned long long)(row + 1) << 8 | 1); dp = 1; }
-    uint32_t len = 0;
-    for (int c = lane; c < n_cols; c += 64) {
-        const Fix6 f = fix6_of(values[(int64_t)c * ld + dp - 1]);
-        if (f.bad) atomicMin(err, (unsigned long long)(row + 1) << 8 | 2);
-        len += field6_len(f);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
-    if (lane == 0) row_len[row] = len + (uint32_t)key_len((unsigned long long)dp) + 1u;
+    const uint32_t a = (y * 5243u) >> 19, b = y - a * 100u;                 // y / 100 (exact below 43 699), y % 100
+    const uint32_t t = a | (b << 16);
+    const uint32_t tens = ((t * 103u) >> 10) & 0x000F000Fu;                 // both halves / 10 (exact below 179)
+    return tens | ((t - tens * 10u) << 8);
+}
+struct Field6 { uint64_t head, tail; uint32_t head_hi, len, tail_at; };
+// head (+ head_hi): "\t", "-" if negative, the integer digits -- 12 bytes of which the first tail_at count; tail: ".",
+// six decimals and the "\t" that starts the next field (the row's last field: its place takes the "\n" afterwards).
+__device__ __forceinline__ Field6 field6_of(uint32_t ip, uint32_t fr, uint32_t neg)
+{
+    const uint32_t hi4 = ip / 10000u, lo4 = ip - hi4 * 10000u;
+    const uint64_t dig = (uint64_t)digits4(hi4) | (uint64_t)digits4(lo4) << 32;           // byte 0 = the highest of eight
+    const uint32_t lead = (uint32_t)__builtin_ctzll(dig | 1ull << 56) >> 3;               // leading zeros, 7 at most
+    const uint64_t body = (dig + 0x3030303030303030ull) >> (8u * lead);
+    const uint32_t nd = 8u - lead, p = 1u + neg;
+    const uint32_t fh = fr / 10000u, fl = fr - fh * 10000u, ft = (fh * 103u) >> 10;
+    Field6 r;
+    r.head = (uint64_t)(neg ? 0x2D09u : 0x09u) | body << (8u * p);
+    r.head_hi = (uint32_t)(body >> (64u - 8u * p));
+    r.tail = 0x2Eull | (uint64_t)(0x30u + ft) << 8 | (uint64_t)(0x30u + fh - ft * 10u) << 16 | (uint64_t)(digits4(fl) + 0x30303030u) << 24 | 0x09ull << 56;
+    r.tail_at = p + nd;
+    r.len = p + nd + 7u;
+    return r;
+}
+// LDS takes a wave's stores in program order, so a byte keeps what the LAST instruction that touches it writes.  The head's
+// 12 bytes hold rubbish behind the digits: in the lane's own field (the tail, stored later, covers it) or, for a
+// 9-byte field, in the first three bytes of the next lane's field -- which that lane's `head` store, one instruction
+// after every lane's `head_hi`, covers.  The tail holds no rubbish (its eighth byte is the next field's tab).
+__device__ __forceinline__ void field6_store(uint8_t* p, const Field6& f)
+{
+    __builtin_memcpy(p + 8, &f.head_hi, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_memcpy(p, &f.head, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_memcpy(p + f.tail_at, &f.tail, 8);
+}
+// wave64 prefix sum and sum in DPP steps (rows of 16: shifts by 1, 2, 4, 8; then lane 15 of a row to the next row, lane
+// 31 to the upper half)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(x), 63); }
+
+// One launch per call (round 3; before: a length pass, a three-launch scan and a print pass, the table gathered twice).
+// A workgroup takes the next four rows by ticket, prints each into LDS -- which also gives its length --, publishes the
+// four lengths' sum and finds the bytes in front of it by a decoupled look-back over the workgroups with lower tickets
+// (state word: bit 62 = "my sum", bit 63 = "everything up to and including me", value below; a wave reads 64 predecessors
+// at a time).  Every workgroup with a lower ticket has started and publishes its sum without waiting for anyone, so every
+// wait ends.  The text goes out in aligned 16-byte stores (the row's place is known only after it is printed: the LDS
+// words are shifted by the wave-uniform byte offset with v_alignbyte).  TEXT = false: lengths and offsets only.
+constexpr uint64_t LB_SUM = 1ull << 62, LB_ALL = 1ull << 63, LB_VAL = (1ull << 62) - 1ull;
+enum { CTL_TICKET = 0, CTL_ERR = 1, CTL_TOTAL = 2, CTL_WORDS = 4 };      // CTL_ERR: the maximum of ~(row + 1 << 8 | code), 0 = none
+
+__device__ __forceinline__ void emit6_report(unsigned long long* ctl, int64_t row, unsigned code)
+{
+    atomicMax(ctl + CTL_ERR, ~((unsigned long long)(row + 1) << 8 | code));
 }
 
-__global__ __launch_bounds__(256) void lrn_emit6_kernel(const double* __restrict__ values, int64_t ld, int32_t n_cols,
-                                                       const int64_t* __restrict__ dps, int64_t n_rows,
-                                                       const uint64_t* __restrict__ row_off, uint8_t* __restrict__ text)
+// ROWMAJ: the table is the resident copy, [ld][n_cols] (a datapoint's values side by side: a row is one coalesced read
+// instead of n_cols lines of 128 bytes for 8 bytes each -- what bounds the other form).
+template <bool TEXT, int WPB, bool ROWMAJ>                    // WPB rows (waves) per workgroup
+__global__ __launch_bounds__(64 * WPB) void lrn_emit6_kernel(const double* __restrict__ values, int64_t ld, int32_t n_cols,
+                                                       const int64_t* __restrict__ dps, int64_t n_rows, uint32_t row_stride,
+                                                       unsigned long long* __restrict__ ctl, unsigned long long* __restrict__ state,
+                                                       uint8_t* __restrict__ text, uint64_t text_cap, uint64_t* __restrict__ row_off)
 {
-    __shared__ uint8_t buf[4][EMIT_ROW_MAX];
+    extern __shared__ __align__(16) uint8_t emit6_lds[];
+    __shared__ unsigned long long s_bid, s_excl;
+    __shared__ uint32_t s_len[WPB];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int64_t row = (int64_t)blockIdx.x * 4 + wid;
-    if (row >= n_rows) return;
-    uint8_t* lb = buf[wid];
-    int64_t dp = dps[row];
-    if (dp < 1 || dp > ld) dp = 1;                           // reported by the length pass; the text is not handed out
-    const int klen = key_len((unsigned long long)dp);
-    if (lane == 0) { unsigned long long k = (unsigned long long)dp; for (int i = klen - 1; i >= 0; i--) { lb[i] = (uint8_t)('0' + k % 10ull); k /= 10ull; } }
-    uint32_t carry = (uint32_t)klen;
-    for (int c0 = 0; c0 < n_cols; c0 += 64) {
-        const int c = c0 + lane;
-        Fix6 f;
-        f.q = 0; f.neg = 0; f.bad = 0;
-        if (c < n_cols) f = fix6_of(values[(int64_t)c * ld + dp - 1]);
-        const uint32_t len = (c < n_cols) ? field6_len(f) : 0u;
-        const uint32_t incl = wave_incl_scan_u32(len, lane);
-        if (c < n_cols) {
-            uint8_t* p = lb + carry + incl - len;
-            uint64_t ip = f.q / 1000000ull;
-            uint32_t fr = (uint32_t)(f.q - ip * 1000000ull);
-            *p++ = '\t';
-            if (f.neg) *p++ = '-';
-            const int nd = dec_digits64(ip);
-            for (int i = nd - 1; i >= 0; i--) { p[i] = (uint8_t)('0' + ip % 10ull); ip /= 10ull; }
-            p += nd;
-            *p++ = '.';
-            for (int i = 5; i >= 0; i--) { p[i] = (uint8_t)('0' + fr % 10u); fr /= 10u; }
+    if (threadIdx.x == 0) s_bid = atomicAdd(ctl + CTL_TICKET, 1ull);
+    __syncthreads();
+    const uint64_t bid = s_bid;
+    const int64_t row = (int64_t)bid * WPB + wid;
+    uint8_t* lb = emit6_lds + (size_t)wid * row_stride;
+    uint32_t total = 0;
+    if (row < n_rows) {
+        int64_t dp = dps[row];
+        if (dp < 1 || dp > ld) { if (lane == 0) emit6_report(ctl, row, 1); dp = 1; }
+        const int klen = key_len((unsigned long long)dp);
+        if (TEXT && lane == 0) { unsigned long long k = (unsigned long long)dp; for (int i = klen - 1; i >= 0; i--) { lb[i] = (uint8_t)('0' + k % 10ull); k /= 10ull; } }
+        uint32_t carry = (uint32_t)klen;
+        for (int cb = 0; cb < n_cols; cb += 256) {           // four gathers in flight per lane
+            double vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int c = cb + 64 * u + lane; vv[u] = c < n_cols ? (ROWMAJ ? values[(dp - 1) * (int64_t)n_cols + c] : values[(int64_t)c * ld + dp - 1]) : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int c0 = cb + 64 * u, c = c0 + lane;
+                if (c0 >= n_cols) break;
+                const Fix6 f = fix6_of(vv[u]);
+                if (f.bad) emit6_report(ctl, row, 2);
+                uint64_t ip = f.q / 1000000ull;
+                const uint32_t fr = (uint32_t)(f.q - ip * 1000000ull);
+                if (__ballot(ip >= 100000000ull) == 0) {
+                    // the usual wave: every |value| below 1e8.  No loop over the digits and no byte stores: the field
+                    // is put together in registers and leaves in four stores -- see field6_store for their order
+                    const Field6 fd = field6_of((uint32_t)ip, fr, f.neg);
+                    const uint32_t len = (c < n_cols) ? fd.len : 0u;
+                    if (TEXT) {
+                        const uint32_t incl = wave_incl_scan_dpp(len);
+                        if (c < n_cols) field6_store(lb + carry + incl - len, fd);
+                        carry += __shfl(incl, 63, 64);
+                    } else {
+                        carry += wave_sum_dpp(len);
+                    }
+                    continue;
+                }
+                const int nd = ip < 0x100000000ull ? dec_digits((uint32_t)ip) : dec_digits64(ip);
+                const uint32_t len = (c < n_cols) ? 1u + f.neg + (uint32_t)nd + 7u : 0u;
+                if (TEXT) {
+                    const uint32_t incl = wave_incl_scan_dpp(len);
+                    if (c < n_cols) {
+                        uint8_t* p = lb + carry + incl - len;
+                        uint32_t r6 = fr;
+                        *p++ = '\t';
+                        if (f.neg) *p++ = '-';
+                        for (int i = nd - 1; i >= 0; i--) { p[i] = (uint8_t)('0' + ip % 10ull); ip /= 10ull; }
+                        p += nd;
+                        *p++ = '.';
+                        for (int i = 5; i >= 0; i--) { p[i] = (uint8_t)('0' + r6 % 10u); r6 /= 10u; }
+                    }
+                    carry += __shfl(incl, 63, 64);
+                } else {
+                    carry += wave_sum_dpp(len);
+                }
+            }
         }
-        carry += __shfl(incl, 63, 64);
+        if (TEXT && lane == 0) lb[carry] = '\n';
+        total = carry + 1u;
     }
-    if (lane == 0) lb[carry] = '\n';
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint64_t o = row_off[row];
-    const uint32_t total = carry + 1u;
-    for (uint32_t i = lane; i < total; i += 64) text[o + i] = lb[i];
+    if (lane == 0) s_len[wid] = total;
+    __syncthreads();
+    if (wid == 0) {
+        uint64_t sum = lane < WPB ? (uint64_t)s_len[lane] : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        uint64_t excl = 0;
+        if (bid > 0) {
+            if (lane == 0) __hip_atomic_store(state + bid, LB_SUM | sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t top = (int64_t)bid - 1;                  // the nearest workgroup not yet added
+            for (;;) {
+                const int64_t idx = top - lane;
+                const uint64_t v = idx >= 0 ? __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_ALL;
+                const uint64_t have_all = __ballot((v & LB_ALL) != 0), nothing = __ballot((v >> 62) == 0);
+                const int stop = have_all ? __builtin_ctzll(have_all) : 64;        // the nearest that knows everything below it
+                const uint64_t below = stop >= 64 ? ~0ull : (2ull << stop) - 1ull;
+                if (nothing & below) { __builtin_amdgcn_s_sleep(2); continue; }    // one of them has not published yet
+                uint64_t t = lane <= stop ? (v & LB_VAL) : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                excl += t;
+                if (stop < 64) break;
+                top -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(state + bid, LB_ALL | (excl + sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+            if ((int64_t)bid == (n_rows + WPB - 1) / WPB - 1) { ctl[CTL_TOTAL] = excl + sum; if (row_off) row_off[n_rows] = excl + sum; }
+        }
+    }
+    __syncthreads();
+    if (row >= n_rows) return;
+    uint64_t o = s_excl;
+    for (int w = 0; w < wid; w++) o += s_len[w];
+    if (row_off && lane == 0) row_off[row] = o;
+    if (!TEXT || o + total > text_cap) return;
+    // head up to the first 16-byte boundary of the text, aligned 16-byte pieces, tail
+    const uint32_t h = min(total, (uint32_t)__builtin_amdgcn_readfirstlane((int)((16u - (uint32_t)(o & 15ull)) & 15u)));
+    const uint32_t nvec = (total - h) >> 4, r = h & 3u;
+    if ((uint32_t)lane < h) text[o + lane] = lb[lane];
+    const uint32_t* lw = reinterpret_cast<const uint32_t*>(lb) + (h >> 2);
+    uint4* tv = reinterpret_cast<uint4*>(text + o + h);
+    for (uint32_t k = lane; k < nvec; k += 64) {
+        const uint32_t* q = lw + 4 * k;
+        const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+        uint4 out;
+        out.x = __builtin_amdgcn_alignbyte(w1, w0, r); out.y = __builtin_amdgcn_alignbyte(w2, w1, r);
+        out.z = __builtin_amdgcn_alignbyte(w3, w2, r); out.w = __builtin_amdgcn_alignbyte(w4, w3, r);
+        tv[k] = out;
+    }
+    const uint32_t done = h + (nvec << 4);
+    if (done + (uint32_t)lane < total) text[o + done + lane] = lb[done + lane];
+}
+
+// [n_cols][ld] -> [ld][n_cols], 32 x 32 tiles through LDS (the resident copy of the cluster writer's table)
+__global__ __launch_bounds__(256) void lrn_transpose_kernel(const double* __restrict__ in, int64_t ld, int32_t n_cols, double* __restrict__ out)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t dp0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < n_cols && dp0 + tx < ld) tile[j][tx] = in[(int64_t)(c0 + j) * ld + dp0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (dp0 + j < ld && c0 + tx < n_cols) out[(dp0 + j) * (int64_t)n_cols + c0 + tx] = tile[tx][j];
 }
 
 // header: the first four lines, on the host (ref :36-111)
@@ -757,55 +905,100 @@ int abw_lrn_emit(abw_ctx* ctx, const int32_t* milli, int64_t n_rows, int32_t n_c
     return ABW_OK;
 }
 
-int abw_lrn_emit_rows_dev(abw_ctx* ctx, const double* d_values, int64_t ld, int32_t n_cols, const int64_t* d_dps, int64_t n_rows,
+// d_values: [n_cols][ld], or with row_major the resident copy [ld][n_cols]
+static int emit_rows_core(abw_ctx* ctx, const double* d_values, bool row_major, int64_t ld, int32_t n_cols, const int64_t* d_dps, int64_t n_rows,
                           uint8_t* d_text, uint64_t text_cap, uint64_t* text_len, uint64_t* d_row_off)
 {
-    if (!ctx) return ABW_ERR_ARG;
     if (!d_values || !text_len || n_rows < 0 || ld < 1 || n_cols < 1 || (n_rows > 0 && !d_dps))
         return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_emit_rows: bad argument");
-    if ((uint64_t)n_cols * EMIT6_FIELD_MAX + 24 > (uint64_t)EMIT_ROW_MAX)
-        return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_emit_rows: rows of %d columns do not fit the staging buffer (at most %d)", n_cols, (EMIT_ROW_MAX - 24) / EMIT6_FIELD_MAX);
+    if ((uint64_t)n_cols * EMIT6_FIELD_MAX + 24 + 16 + 15 > (uint64_t)EMIT_ROW_MAX)
+        return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_emit_rows: rows of %d columns do not fit the staging buffer (at most %d)", n_cols, (EMIT_ROW_MAX - 24 - 31) / EMIT6_FIELD_MAX);
     *text_len = 0;
     if (n_rows == 0) return ABW_OK;
     abw_device_guard g(ctx->device);
     hipStream_t st = ctx->stream;
     int rc;
-    // scratch[4]: row_len u32 + row_off u64 + err
-    const size_t lb = ((size_t)n_rows * 4 + 15) & ~(size_t)7;
-    if ((rc = abw_reserve(ctx, ctx->scratch[4], lb + ((size_t)n_rows + 2) * 8 + 8))) return rc;
-    uint32_t* row_len = (uint32_t*)ctx->scratch[4].p;
-    uint64_t* row_off = (uint64_t*)((uint8_t*)row_len + lb);
-    unsigned long long* d_err = (unsigned long long*)(row_off + n_rows + 2);
-    ABW_HIP(ctx, hipMemsetAsync(d_err, 0xFF, 8, st));
-    const unsigned gr = (unsigned)((n_rows + 3) / 4);
+    // scratch[4]: ticket, error, total | one look-back word per workgroup.  As many rows (waves) per workgroup as keep two
+    // workgroups' rows in a CU's LDS, at most 16: fewer workgroups, a shorter look-back (a 2 000-row cluster: 125 instead of 500)
+    const uint32_t row_stride = (uint32_t)(((uint64_t)n_cols * EMIT6_FIELD_MAX + 24 + 16 + 15) & ~15ull);      // 16: what a store may write behind the row's end
+    const int wpb = 16 * row_stride <= EMIT_LDS_MAX ? 16 : 8 * row_stride <= EMIT_LDS_MAX ? 8 : 4;
+    const uint64_t nblk = ((uint64_t)n_rows + wpb - 1) / wpb;
+    const size_t sb = (CTL_WORDS + (size_t)nblk) * 8;
+    if ((rc = abw_reserve(ctx, ctx->scratch[4], sb))) return rc;
+    unsigned long long* ctl = (unsigned long long*)ctx->scratch[4].p;
+    unsigned long long* state = ctl + CTL_WORDS;
+    const bool with_text = d_text && text_cap > 0;
+    auto launch = [&](auto kern, size_t lds) -> int {
+        if (lds > 65536) ABW_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, EMIT_LDS_MAX));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * wpb), lds, st, d_values, ld, n_cols, d_dps, n_rows,
+                           row_stride, ctl, state, with_text ? d_text : (uint8_t*)nullptr, with_text ? text_cap : (uint64_t)0, d_row_off);
+        return ABW_OK;
+    };
     {
         ABW_PROF(ctx, "lrn_emit_rows");
-        hipLaunchKernelGGL(lrn_rowlen6_kernel, dim3(gr), dim3(256), 0, st, d_values, ld, n_cols, d_dps, n_rows, row_len, d_err);
+        ABW_HIP(ctx, hipMemsetAsync(ctl, 0, sb, st));
+        const size_t lds = (size_t)wpb * row_stride;
+#define EMIT6_PICK(T, R, L) (wpb == 16 ? launch(lrn_emit6_kernel<T, 16, R>, L) : wpb == 8 ? launch(lrn_emit6_kernel<T, 8, R>, L) : launch(lrn_emit6_kernel<T, 4, R>, L))
+        if (with_text) rc = row_major ? EMIT6_PICK(true, true, lds) : EMIT6_PICK(true, false, lds);
+        else rc = row_major ? EMIT6_PICK(false, true, 0) : EMIT6_PICK(false, false, 0);
+#undef EMIT6_PICK
+        if (rc) return rc;
         ABW_LAUNCH_CHECK(ctx);
-        if ((rc = abw_device_scan_u32(ctx, row_len, (uint64_t)n_rows, row_off))) return rc;
     }
-    uint64_t total = 0;
-    unsigned long long err = 0;
-    ABW_HIP(ctx, hipMemcpyAsync(&total, row_off + n_rows, 8, hipMemcpyDeviceToHost, st));
-    ABW_HIP(ctx, hipMemcpyAsync(&err, d_err, 8, hipMemcpyDeviceToHost, st));
+    unsigned long long h_ctl[CTL_WORDS] = {0, 0, 0, 0};
+    ABW_HIP(ctx, hipMemcpyAsync(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));
-    if (err != ~0ull) {
+    if (h_ctl[CTL_ERR] != 0) {
+        const unsigned long long err = ~h_ctl[CTL_ERR];
         if ((err & 0xFF) == 1) return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_emit_rows: row %llu names a datapoint outside [1, %lld]", (unsigned long long)(err >> 8), (long long)ld);
         return abw_fail(ctx, ABW_ERR_FORMAT, "abw_lrn_emit_rows: row %llu holds a value that is not finite or not below 9.2e12", (unsigned long long)(err >> 8));
     }
+    const uint64_t total = h_ctl[CTL_TOTAL];
     *text_len = total;
-    if (d_row_off) ABW_HIP(ctx, hipMemcpyAsync(d_row_off, row_off, ((size_t)n_rows + 1) * 8, hipMemcpyDeviceToDevice, st));
-    if (!d_text || total > text_cap) {
-        ABW_HIP(ctx, hipStreamSynchronize(st));
+    if (!d_text || total > text_cap)
         return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_lrn_emit_rows: the rows take %llu bytes, capacity %llu", (unsigned long long)total, (unsigned long long)text_cap);
-    }
-    {
-        ABW_PROF(ctx, "lrn_emit_rows");
-        hipLaunchKernelGGL(lrn_emit6_kernel, dim3(gr), dim3(256), 0, st, d_values, ld, n_cols, d_dps, n_rows, row_off, d_text);
-        ABW_LAUNCH_CHECK(ctx);
-    }
-    ABW_HIP(ctx, hipStreamSynchronize(st));
     return ABW_OK;
+}
+
+static int resident_table(abw_ctx* ctx, int64_t ld, int32_t n_cols)
+{
+    if (ctx->lrn_ld != ld || ctx->lrn_cols != n_cols)
+        return abw_fail(ctx, ABW_ERR_STATE, "abw_lrn_emit_rows: no values given and no resident table of %lld x %d (abw_lrn_table_load)", (long long)ld, n_cols);
+    return ABW_OK;
+}
+
+int abw_lrn_emit_rows_dev(abw_ctx* ctx, const double* d_values, int64_t ld, int32_t n_cols, const int64_t* d_dps, int64_t n_rows,
+                          uint8_t* d_text, uint64_t text_cap, uint64_t* text_len, uint64_t* d_row_off)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    if (d_values) return emit_rows_core(ctx, d_values, false, ld, n_cols, d_dps, n_rows, d_text, text_cap, text_len, d_row_off);
+    if (!text_len || ld < 1 || n_cols < 1) return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_emit_rows: bad argument");
+    int rc;
+    if ((rc = resident_table(ctx, ld, n_cols))) return rc;
+    return emit_rows_core(ctx, (const double*)ctx->lrn_table.p, true, ld, n_cols, d_dps, n_rows, d_text, text_cap, text_len, d_row_off);
+}
+
+// the resident copy: [ld][n_cols], transposed on the device from the caller's [n_cols][ld]
+static int table_keep(abw_ctx* ctx, const double* d_src, int64_t ld, int32_t n_cols)
+{
+    int rc;
+    if ((rc = abw_reserve(ctx, ctx->lrn_table, (size_t)ld * (size_t)n_cols * 8))) return rc;
+    hipLaunchKernelGGL(lrn_transpose_kernel, dim3((unsigned)((ld + 31) / 32), (unsigned)((n_cols + 31) / 32)), dim3(256), 0, ctx->stream,
+                       d_src, ld, n_cols, (double*)ctx->lrn_table.p);
+    ABW_LAUNCH_CHECK(ctx);
+    ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->lrn_ld = ld; ctx->lrn_cols = n_cols;
+    return ABW_OK;
+}
+
+int abw_lrn_table_load_dev(abw_ctx* ctx, const double* d_values, int64_t ld, int32_t n_cols)
+{
+    if (!ctx) return ABW_ERR_ARG;
+    abw_device_guard g(ctx->device);
+    ctx->lrn_ld = 0; ctx->lrn_cols = 0;
+    if (!d_values) { abw_release(ctx->lrn_table); return ABW_OK; }        // unload
+    if (ld < 1 || n_cols < 1 || n_cols > 65535 * 32) return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_table_load: bad argument");
+    return table_keep(ctx, d_values, ld, n_cols);
 }
 
 int abw_lrn_table_load(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_cols)
@@ -814,14 +1007,12 @@ int abw_lrn_table_load(abw_ctx* ctx, const double* values, int64_t ld, int32_t n
     abw_device_guard g(ctx->device);
     ctx->lrn_ld = 0; ctx->lrn_cols = 0;
     if (!values) { abw_release(ctx->lrn_table); return ABW_OK; }          // unload
-    if (ld < 1 || n_cols < 1) return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_table_load: bad argument");
+    if (ld < 1 || n_cols < 1 || n_cols > 65535 * 32) return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_table_load: bad argument");
     const size_t vb = (size_t)ld * (size_t)n_cols * 8;
     int rc;
-    if ((rc = abw_reserve(ctx, ctx->lrn_table, vb))) return rc;
-    ABW_HIP(ctx, hipMemcpyAsync(ctx->lrn_table.p, values, vb, hipMemcpyHostToDevice, ctx->stream));
-    ABW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->lrn_ld = ld; ctx->lrn_cols = n_cols;
-    return ABW_OK;
+    if ((rc = abw_reserve(ctx, ctx->scratch[6], vb))) return rc;
+    ABW_HIP(ctx, hipMemcpyAsync(ctx->scratch[6].p, values, vb, hipMemcpyHostToDevice, ctx->stream));
+    return table_keep(ctx, (const double*)ctx->scratch[6].p, ld, n_cols);
 }
 
 int abw_lrn_emit_rows(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_cols, const int64_t* dps, int64_t n_rows,
@@ -830,13 +1021,12 @@ int abw_lrn_emit_rows(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_
     if (!ctx) return ABW_ERR_ARG;
     if (!text_len || n_rows < 0 || ld < 1 || n_cols < 1 || (n_rows > 0 && !dps))
         return abw_fail(ctx, ABW_ERR_ARG, "abw_lrn_emit_rows: bad argument");
-    if (!values && (ctx->lrn_ld != ld || ctx->lrn_cols != n_cols))
-        return abw_fail(ctx, ABW_ERR_STATE, "abw_lrn_emit_rows: no values given and no resident table of %lld x %d (abw_lrn_table_load)", (long long)ld, n_cols);
+    int rc;
+    if (!values && (rc = resident_table(ctx, ld, n_cols))) return rc;
     *text_len = 0;
     if (n_rows == 0) return ABW_OK;
     abw_device_guard g(ctx->device);
     hipStream_t st = ctx->stream;
-    int rc;
     // scratch[6]: the table (unless resident) | scratch[5]: the datapoint list | scratch[0]: text
     const size_t vb = (size_t)ld * (size_t)n_cols * 8, db = (size_t)n_rows * 8;
     const double* d_values = (const double*)ctx->lrn_table.p;
@@ -847,15 +1037,19 @@ int abw_lrn_emit_rows(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_
     }
     if ((rc = abw_reserve(ctx, ctx->scratch[5], db))) return rc;
     ABW_HIP(ctx, hipMemcpyAsync(ctx->scratch[5].p, dps, db, hipMemcpyHostToDevice, st));
-    // the length pass sizes the text
+    // printed straight away into a device buffer of the caller's capacity (at most what the rows can take); without a
+    // buffer, or when it is too small, the call only sizes the text
     uint64_t need = 0;
-    rc = abw_lrn_emit_rows_dev(ctx, d_values, ld, n_cols, (const int64_t*)ctx->scratch[5].p, n_rows, NULL, 0, &need, NULL);
-    if (rc != ABW_ERR_CAPACITY) return rc;
+    uint8_t* d_text = NULL;
+    uint64_t cap = 0;
+    if (text && text_cap > 0) {
+        cap = std::min<uint64_t>(text_cap, (uint64_t)n_rows * ((uint64_t)n_cols * EMIT6_FIELD_MAX + 24));
+        if ((rc = abw_reserve(ctx, ctx->scratch[0], cap + 64))) return rc;
+        d_text = (uint8_t*)ctx->scratch[0].p;
+    }
+    rc = emit_rows_core(ctx, d_values, !values, ld, n_cols, (const int64_t*)ctx->scratch[5].p, n_rows, d_text, cap, &need, NULL);
     *text_len = need;
-    if (!text || need > text_cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_lrn_emit_rows: the rows take %llu bytes, capacity %llu", (unsigned long long)need, (unsigned long long)text_cap);
-    if ((rc = abw_reserve(ctx, ctx->scratch[0], need + 64))) return rc;
-    if ((rc = abw_lrn_emit_rows_dev(ctx, d_values, ld, n_cols, (const int64_t*)ctx->scratch[5].p, n_rows,
-                                    (uint8_t*)ctx->scratch[0].p, need, &need, NULL))) return rc;
+    if (rc) return rc;
     ABW_HIP(ctx, hipMemcpyAsync(text, ctx->scratch[0].p, need, hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));
     return ABW_OK;

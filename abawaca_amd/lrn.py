@@ -68,14 +68,37 @@ def lrn_emit_rows(ctx: Context, values: np.ndarray, dps: np.ndarray) -> np.ndarr
     return text[:n.value]
 
 
-def lrn_emit_rows_dev(ctx: Context, t_values, t_dps, t_text=None, t_row_off=None):
+def lrn_emit_rows_dev(ctx: Context, t_values, t_dps, t_text=None, t_row_off=None, resident=None):
     """Device-resident form: torch tensors values f64 [n_cols, ld], dps int64 [n_rows], text uint8 (or None: size only),
-    row_off int64/uint64 [n_rows + 1] (or None).  -> number of bytes the rows take."""
-    n_cols, ld = t_values.shape
+    row_off int64/uint64 [n_rows + 1] (or None).  t_values None + resident = (n_cols, ld): print from the copy
+    lrn_table_load_dev keeps.  -> number of bytes the rows take."""
+    n_cols, ld = t_values.shape if t_values is not None else resident
     n = C.c_uint64(0)
-    rc = lib().abw_lrn_emit_rows_dev(ctx.handle, C.c_void_p(t_values.data_ptr()), ld, n_cols, C.c_void_p(t_dps.data_ptr()), t_dps.numel(),
+    rc = lib().abw_lrn_emit_rows_dev(ctx.handle, C.c_void_p(t_values.data_ptr()) if t_values is not None else None, ld, n_cols,
+                                     C.c_void_p(t_dps.data_ptr()), t_dps.numel(),
                                      C.c_void_p(t_text.data_ptr()) if t_text is not None else None, t_text.numel() if t_text is not None else 0, C.byref(n),
                                      C.c_void_p(t_row_off.data_ptr()) if t_row_off is not None else None)
     if not (t_text is None and rc == -3):
         ctx.check(rc)
     return int(n.value)
+
+
+def lrn_table_load_dev(ctx: Context, t_values):
+    """Keeps a (transposed) copy of the device table f64 [n_cols, ld] for lrn_emit_rows_dev(ctx, None, ..., resident=shape);
+    None drops it.  -> the shape to pass as `resident`."""
+    if t_values is None:
+        ctx.check(lib().abw_lrn_table_load_dev(ctx.handle, None, 0, 0))
+        return None
+    n_cols, ld = t_values.shape
+    ctx.check(lib().abw_lrn_table_load_dev(ctx.handle, C.c_void_p(t_values.data_ptr()), ld, n_cols))
+    return (n_cols, ld)
+
+
+def lrn_emit_rows_dev_host_check(ctx: Context, dps: np.ndarray, resident) -> np.ndarray:
+    """abw_lrn_emit_rows (host pointers) from the resident copy, whichever call loaded it: values = NULL."""
+    n_cols, ld = resident
+    d = np.ascontiguousarray(dps, dtype=np.int64)
+    text = np.empty(len(d) * (23 * n_cols + 24), dtype=np.uint8)
+    n = C.c_uint64(0)
+    ctx.check(lib().abw_lrn_emit_rows(ctx.handle, None, ld, n_cols, C.c_void_p(d.ctypes.data), len(d), C.c_void_p(text.ctypes.data), len(text), C.byref(n)))
+    return text[:n.value]

@@ -443,12 +443,13 @@ def lrn_bench(ctx, with_cpu):
     nc, msc = ctx.prof_read("lrn_emit_rows")
     ctx.prof_enable(False)
     c_s = msc * 1e-3
+    alg_c = 8.0 * D * N + cbytes                              # every value read once, the text written once (one launch since round 3)
     res["cluster_writer"] = dict(value=cbytes / c_s / 1e9, unit="GB/s of text (kernels)", clusters=n_cl, rows_per_cluster=per, text_mb=round(cbytes / 1e6, 1),
                                  ms_kernels=round(c_s * 1e3, 3), ms_wall_text_left_on_device=round(wall_c * 1e3, 2),
-                                 roofline=dict(kernel="lrn_emit6_kernel (+ row lengths)", bound="hbm", achieved=round((16.0 * D * N + cbytes) / c_s / 1e9, 1),
-                                               peak=HBM_PEAK_GBS, unit="GB/s", frac=round((16.0 * D * N + cbytes) / c_s / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
-                                               note="algorithmic bytes: every value read twice (length pass, print pass) + the text once"))
-    # the same clusters in ONE call (concatenated lists, row offsets back): no longer bound by five launches per cluster
+                                 roofline=dict(kernel="lrn_emit6_kernel", bound="hbm", achieved=round(alg_c / c_s / 1e9, 1),
+                                               peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg_c / c_s / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
+                                               note="algorithmic bytes: every value once + the text once; one call per cluster of 2 000 rows is launch-bound"))
+    # the same clusters in ONE call (concatenated lists, row offsets back)
     t_all = torch.empty(cbytes, dtype=torch.uint8, device="cuda")
     t_off = torch.empty(n_cl * per + 1, dtype=torch.int64, device="cuda")
     lrn.lrn_emit_rows_dev(ctx, t_vals, perm[:n_cl * per], t_all, t_off)
@@ -459,7 +460,38 @@ def lrn_bench(ctx, with_cpu):
     ctx.prof_enable(False)
     o_s = mso / reps * 1e-3
     res["cluster_writer"]["one_call"] = dict(value=cbytes / o_s / 1e9, unit="GB/s of text (kernels)", ms_kernels=round(o_s * 1e3, 3),
-                                             roofline_frac=round((16.0 * D * N + cbytes) / o_s / 1e9 / HBM_PEAK_GBS, 4))
+                                             roofline_frac=round(alg_c / o_s / 1e9 / HBM_PEAK_GBS, 4),
+                                             note="the caller's [columns][datapoints] table: a 128-byte line per value read")
+    # from the resident copy (abw_lrn_table_load_dev keeps the table transposed: a row is one coalesced read) -- what
+    # integration/ClusterEsomWriterHip prints from
+    shape = lrn.lrn_table_load_dev(ctx, t_vals)
+    def clusters_resident():
+        tot = 0
+        for c in range(n_cl):
+            tot += lrn.lrn_emit_rows_dev(ctx, None, perm[c * per:(c + 1) * per], t_out, resident=shape)
+        return tot
+    clusters_resident()
+    ctx.prof_reset(); ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    rbytes = clusters_resident()
+    wall_r = time.perf_counter() - t0
+    nr, msr = ctx.prof_read("lrn_emit_rows")
+    t_chk = torch.empty(cbytes, dtype=torch.uint8, device="cuda")
+    lrn.lrn_emit_rows_dev(ctx, None, perm[:n_cl * per], t_chk, t_off, resident=shape)
+    ctx.prof_reset()
+    for _ in range(reps):
+        lrn.lrn_emit_rows_dev(ctx, None, perm[:n_cl * per], t_chk, t_off, resident=shape)
+    nro, msro = ctx.prof_read("lrn_emit_rows")
+    ctx.prof_enable(False)
+    assert rbytes == cbytes and torch.equal(t_chk, t_all)
+    r_s, ro_s = msr * 1e-3, msro / reps * 1e-3
+    res["cluster_writer"]["resident_copy"] = dict(
+        value=cbytes / r_s / 1e9, unit="GB/s of text (kernels)", ms_kernels=round(r_s * 1e3, 3), ms_wall_text_left_on_device=round(wall_r * 1e3, 2),
+        roofline_frac=round(alg_c / r_s / 1e9 / HBM_PEAK_GBS, 4),
+        one_call=dict(value=cbytes / ro_s / 1e9, unit="GB/s of text (kernels)", ms_kernels=round(ro_s * 1e3, 3),
+                      roofline_frac=round(alg_c / ro_s / 1e9 / HBM_PEAK_GBS, 4)))
+    lrn.lrn_table_load_dev(ctx, None)
+    del t_chk
     del t_all, t_off
     if with_cpu:
         import _oracle as orc

@@ -408,20 +408,26 @@ int abw_lrn_emit(abw_ctx* ctx, const int32_t* milli, int64_t n_rows, int32_t n_c
  * (six decimals of the binary value, round to nearest, ties to even).  values: [n_cols][ld] doubles, dimension-major, the
  * value of datapoint dp (1-based internal id) in column c at values[c*ld + dp-1]; dps: the cluster's datapoints in the
  * order of the rows (the reference walks an unordered_set: the order is the caller's); the four header lines (ref :81-90)
- * stay with the caller.  *text_len = bytes the rows take, also when they do not fit text_cap (ABW_ERR_CAPACITY, nothing
- * written; text may then be NULL).  A dp outside [1, ld]: ABW_ERR_ARG; a value that is not finite or not below 9.2e12 in
- * magnitude: ABW_ERR_FORMAT.  _dev: values, dps and text are device pointers (the table stays resident between clusters);
- * d_row_off (device, n_rows + 1 entries, or NULL) receives the byte offset of every row, so that one call can print the
- * concatenated datapoint lists of many clusters and the caller cuts the text at the clusters' first rows.
- * The other form takes host pointers and copies. */
+ * stay with the caller.  *text_len = bytes the rows take, also when they do not fit text_cap (ABW_ERR_CAPACITY; text may
+ * then be NULL: the call only sizes).  One launch prints and sizes, so a caller that passes a buffer of a safe size --
+ * n_rows * (23 n_cols + 24) at most -- needs one call; after ABW_ERR_CAPACITY, ABW_ERR_ARG (a dp outside [1, ld]) or
+ * ABW_ERR_FORMAT (a value that is not finite or not below 9.2e12 in magnitude) the first text_cap bytes of text are
+ * unspecified, nothing behind them is touched.  _dev: values, dps and text are device pointers (the table stays resident
+ * between clusters); d_row_off (device, n_rows + 1 entries, or NULL) receives the byte offset of every row, so that one
+ * call can print the concatenated datapoint lists of many clusters and the caller cuts the text at the clusters' first
+ * rows.  The other form takes host pointers and copies.  n_cols <= 710. */
 int abw_lrn_emit_rows_dev(abw_ctx* ctx, const double* d_values, int64_t ld, int32_t n_cols, const int64_t* d_dps, int64_t n_rows,
                           uint8_t* d_text, uint64_t text_cap, uint64_t* text_len, uint64_t* d_row_off);
 int abw_lrn_emit_rows(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_cols, const int64_t* dps, int64_t n_rows,
                       uint8_t* text, uint64_t text_cap, uint64_t* text_len);
-/* Keeps a copy of the table on the device for the host-pointer form: after abw_lrn_table_load, abw_lrn_emit_rows with
- * values == NULL (and the same ld, n_cols) prints from the resident copy -- what a driver that writes one .lrn per
- * cluster of the recursion (ref: src/abawaca.cpp:161-182) wants.  values == NULL here drops the copy. */
+/* Keeps a copy of the table on the device: after abw_lrn_table_load (host pointer) or abw_lrn_table_load_dev (device
+ * pointer; same [n_cols][ld] layout), abw_lrn_emit_rows and abw_lrn_emit_rows_dev with values == NULL (and the same ld,
+ * n_cols) print from the resident copy -- what a driver that writes one .lrn per cluster of the recursion (ref:
+ * src/abawaca.cpp:161-182) wants.  The copy is kept TRANSPOSED, a datapoint's values side by side: a row is then one
+ * coalesced read, where the [n_cols][ld] form costs a 128-byte line per value (2.4 times the rows per second, DESIGN.md
+ * 3.7).  values == NULL here drops the copy. */
 int abw_lrn_table_load(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_cols);
+int abw_lrn_table_load_dev(abw_ctx* ctx, const double* d_values, int64_t ld, int32_t n_cols);
 
 /* ---- extension: k-means restarts (NO counterpart in the reference, see DESIGN.md "K-means";
  *      RNG = TinyMT32, ref: src/misc.cpp:24-36, src/TinyMT-src-1.0.1/tinymt/tinymt32.{c,h}) -------- */

@@ -74,12 +74,18 @@ void ClusterEsomWriterHip::write_clustering_info_file(const ClusterData& cluster
 	// the rows (:92-98) in the order the reference walks the cluster's datapoints
 	const unordered_set<size_t>& dps = clustering_db.datapoints();
 	std::vector<int64_t> list(dps.begin(), dps.end());
+	// one call prints and sizes: the buffer is kept between clusters and starts at a guess of 12 bytes per value; a
+	// cluster that takes more (ABW_ERR_CAPACITY carries the size) is printed again into a buffer of that size
+	static std::vector<uint8_t> text;
+	const uint64_t guess = (uint64_t)list.size() * ((uint64_t)st.D * 12 + 24);
+	if(text.size() < guess) text.resize(guess);
 	uint64_t len = 0;
-	int rc = abw_lrn_emit_rows(st.ctx, NULL, (int64_t)st.N, (int32_t)st.D, list.data(), (int64_t)list.size(), NULL, 0, &len);
-	if(rc != ABW_OK && rc != ABW_ERR_CAPACITY)
-		throw std::runtime_error(std::string("ClusterEsomWriterHip: abw_lrn_emit_rows failed: ") + abw_last_error(st.ctx));
-	std::vector<uint8_t> text(len);
-	if(len > 0 && abw_lrn_emit_rows(st.ctx, NULL, (int64_t)st.N, (int32_t)st.D, list.data(), (int64_t)list.size(), text.data(), len, &len) != ABW_OK)
+	int rc = list.empty() ? ABW_OK : abw_lrn_emit_rows(st.ctx, NULL, (int64_t)st.N, (int32_t)st.D, list.data(), (int64_t)list.size(), text.data(), text.size(), &len);
+	if(rc == ABW_ERR_CAPACITY) {
+		text.resize(len);
+		rc = abw_lrn_emit_rows(st.ctx, NULL, (int64_t)st.N, (int32_t)st.D, list.data(), (int64_t)list.size(), text.data(), text.size(), &len);
+	}
+	if(rc != ABW_OK)
 		throw std::runtime_error(std::string("ClusterEsomWriterHip: abw_lrn_emit_rows failed: ") + abw_last_error(st.ctx));
 	fwrite(text.data(), 1, len, fp);
 	fclose(fp);

@@ -1,5 +1,6 @@
 """GPU .lrn loader (abw_lrn_parse, row N4) against the golden vectors of the reference's own loader, against the
 oracle on a large table, and its error behaviour."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -135,7 +136,9 @@ def _wild_table(rng, D, N):
     return v
 
 
-@pytest.mark.parametrize("N,D,n_rows", [(4000, 189, 2500), (50, 700, 50), (1, 1, 1), (300, 64, 900)])
+@pytest.mark.parametrize("N,D,n_rows", [(4000, 189, 2500), (50, 700, 50), (1, 1, 1), (300, 64, 900),
+                                        (600, 300, 700),          # eight rows per workgroup (16 / 8 / 4 by row width)
+                                        (20000, 8, 70001)])       # 4 376 workgroups: the look-back over many windows
 def test_cluster_writer_matches_oracle(ctx, N, D, n_rows):
     rng = np.random.default_rng(N + D)
     v = _wild_table(rng, D, N)
@@ -170,6 +173,57 @@ def test_cluster_writer_resident_table(ctx):
     for dl in lists:
         assert np.array_equal(text[off[first]:off[first + len(dl)]], orc.lrn_emit_rows(v, dl))
         first += len(dl)
+
+
+def test_cluster_writer_buffer_too_small_or_too_large(ctx):
+    """One launch prints and sizes: a buffer that is too small gives ABW_ERR_CAPACITY with the size and nothing behind
+    its end is touched; one that is larger than needed is filled up to the size."""
+    import torch
+    rng = np.random.default_rng(17)
+    v = _wild_table(rng, 40, 3000)
+    dps = rng.integers(1, 3001, size=5000).astype(np.int64)
+    want = orc.lrn_emit_rows(v, dps)
+    t_v, t_d = torch.from_numpy(v).cuda(), torch.from_numpy(dps).cuda()
+    cap = len(want) // 3
+    t_text = torch.full((len(want) + 999,), 0xAB, dtype=torch.uint8, device="cuda")
+    n = C.c_uint64(0)
+    rc = _lib.lib().abw_lrn_emit_rows_dev(ctx.handle, C.c_void_p(t_v.data_ptr()), 3000, 40, C.c_void_p(t_d.data_ptr()), len(dps),
+                                          C.c_void_p(t_text.data_ptr()), cap, C.byref(n), None)
+    assert rc == _lib.ABW_ERR_CAPACITY and n.value == len(want)
+    assert bool((t_text[cap:] == 0xAB).all())
+    assert lrn.lrn_emit_rows_dev(ctx, t_v, t_d, t_text) == len(want)
+    got = t_text.cpu().numpy()
+    assert np.array_equal(got[:len(want)], want) and (got[len(want):] == 0xAB).all()
+    # host form, one pass: a buffer with room to spare
+    big = np.full(len(want) + 5000, 0xCD, dtype=np.uint8)
+    ctx.check(_lib.lib().abw_lrn_emit_rows(ctx.handle, C.c_void_p(v.ctypes.data), 3000, 40, C.c_void_p(dps.ctypes.data), len(dps),
+                                           C.c_void_p(big.ctypes.data), len(big), C.byref(n)))
+    assert n.value == len(want) and np.array_equal(big[:len(want)], want) and (big[len(want):] == 0xCD).all()
+
+
+def test_cluster_writer_resident_device_copy(ctx):
+    """abw_lrn_table_load_dev + abw_lrn_emit_rows_dev(values = NULL): the transposed resident copy prints the same bytes
+    (widths that are no multiple of the transposition's tiles included)."""
+    import torch
+    for D, N in ((37, 1000), (189, 2001), (1, 5), (300, 33)):
+        rng = np.random.default_rng(D)
+        v = _wild_table(rng, D, N)
+        t_v = torch.from_numpy(v).cuda()
+        dps = rng.integers(1, N + 1, size=777).astype(np.int64)
+        t_d = torch.from_numpy(dps).cuda()
+        with pytest.raises(_lib.AbwError) as e:
+            lrn.lrn_emit_rows_dev(ctx, None, t_d, None, resident=(D + 1, N))               # no such copy
+        assert e.value.code == _lib.ABW_ERR_STATE
+        shape = lrn.lrn_table_load_dev(ctx, t_v)
+        want = orc.lrn_emit_rows(v, dps)
+        assert lrn.lrn_emit_rows_dev(ctx, None, t_d, None, resident=shape) == len(want)
+        t_text = torch.zeros(len(want), dtype=torch.uint8, device="cuda")
+        lrn.lrn_emit_rows_dev(ctx, None, t_d, t_text, resident=shape)
+        assert np.array_equal(t_text.cpu().numpy(), want)
+        assert np.array_equal(lrn.lrn_emit_rows_dev_host_check(ctx, dps, shape), want)
+    lrn.lrn_table_load_dev(ctx, None)
+    with pytest.raises(_lib.AbwError):
+        lrn.lrn_emit_rows_dev(ctx, None, t_d, None, resident=shape)
 
 
 def test_cluster_writer_errors(ctx):
