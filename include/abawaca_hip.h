@@ -424,7 +424,7 @@ int abw_lrn_emit_rows(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_
  * pointer; same [n_cols][ld] layout), abw_lrn_emit_rows and abw_lrn_emit_rows_dev with values == NULL (and the same ld,
  * n_cols) print from the resident copy -- what a driver that writes one .lrn per cluster of the recursion (ref:
  * src/abawaca.cpp:161-182) wants.  The copy is kept TRANSPOSED, a datapoint's values side by side: a row is then one
- * coalesced read, where the [n_cols][ld] form costs a 128-byte line per value (2.4 times the rows per second, DESIGN.md
+ * coalesced read, where the [n_cols][ld] form costs a 128-byte line per value (1.6 times the rows per second, DESIGN.md
  * 3.7).  values == NULL here drops the copy. */
 int abw_lrn_table_load(abw_ctx* ctx, const double* values, int64_t ld, int32_t n_cols);
 int abw_lrn_table_load_dev(abw_ctx* ctx, const double* d_values, int64_t ld, int32_t n_cols);
