@@ -399,59 +399,6 @@ __device__ __forceinline__ int key_len(unsigned long long key)
 constexpr int EMIT_COLS_PER_LANE = 16;                        // up to 1024 columns
 constexpr int EMIT_ROW_MAX = 16384;                           // bytes of one row staged in LDS
 
-__global__ __launch_bounds__(256) void lrn_rowlen_kernel(const int32_t* __restrict__ milli, int64_t n_rows, int32_t n_cols, uint64_t first_key,
-                                                        uint32_t* __restrict__ row_len)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
-    const int32_t* r = milli + row * n_cols;
-    uint32_t len = 0;
-    for (int c = lane; c < n_cols; c += 64) len += (uint32_t)field_len(r[c]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
-    if (lane == 0) row_len[row] = len + (uint32_t)key_len(first_key + (uint64_t)row) + 1u;       // + key + "\n"
-}
-
-__global__ __launch_bounds__(256) void lrn_emit_kernel(const int32_t* __restrict__ milli, int64_t n_rows, int32_t n_cols, uint64_t first_key,
-                                                      const uint64_t* __restrict__ row_off, uint8_t* __restrict__ text)
-{
-    __shared__ uint8_t buf[4][EMIT_ROW_MAX];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int64_t row = (int64_t)blockIdx.x * 4 + wid;
-    if (row >= n_rows) return;
-    uint8_t* lb = buf[wid];
-    const int32_t* r = milli + row * n_cols;
-    const uint64_t key = first_key + (uint64_t)row;
-    const int klen = key_len(key);
-    if (lane == 0) { unsigned long long k = key; for (int i = klen - 1; i >= 0; i--) { lb[i] = (uint8_t)('0' + k % 10ull); k /= 10ull; } }
-    uint32_t carry = (uint32_t)klen;
-    for (int c0 = 0; c0 < n_cols; c0 += 64) {                // columns c0 .. c0+63, one per lane, in order
-        const int c = c0 + lane;
-        const int32_t k = (c < n_cols) ? r[c] : 0;
-        const uint32_t len = (c < n_cols) ? (uint32_t)field_len(k) : 0u;
-        const uint32_t incl = wave_incl_scan_u32(len, lane);
-        if (c < n_cols) {
-            uint8_t* p = lb + carry + incl - len;
-            const uint32_t a = k < 0 ? 0u - (uint32_t)k : (uint32_t)k;
-            uint32_t q = a / 1000u, f = a % 1000u;
-            *p++ = '\t';
-            if (k < 0) *p++ = '-';
-            const int nd = dec_digits(q);
-            for (int i = nd - 1; i >= 0; i--) { p[i] = (uint8_t)('0' + q % 10u); q /= 10u; }
-            p += nd;
-            p[0] = '.'; p[1] = (uint8_t)('0' + f / 100u); p[2] = (uint8_t)('0' + (f / 10u) % 10u); p[3] = (uint8_t)('0' + f % 10u);
-        }
-        carry += __shfl(incl, 63, 64);
-    }
-    if (lane == 0) lb[carry] = '\n';
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint64_t o = row_off[row];
-    const uint32_t total = carry + 1u;
-    for (uint32_t i = lane; i < total; i += 64) text[o + i] = lb[i];
-}
-
 // ---- cluster writer (ref src/ClusterWriter.cpp:92-98): rows "<dp>\t%lf\t%lf...\n" ---------------------------------
 // "%lf" prints six decimals of the EXACT binary value, rounded to nearest, ties to even (the C library's conversion,
 // which is what the reference's fprintf does).  |v| = m * 2^e exactly with m < 2^53, so v * 10^6 = (m * 10^6) * 2^e with
@@ -540,9 +487,9 @@ __device__ __forceinline__ Field6 field6_of(uint32_t ip, uint32_t fr, uint32_t n
 __device__ __forceinline__ void field6_store(uint8_t* p, const Field6& f)
 {
     __builtin_memcpy(p + 8, &f.head_hi, 4);
-    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");                           // three instructions, in this order
     __builtin_memcpy(p, &f.head, 8);
-    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
     __builtin_memcpy(p + f.tail_at, &f.tail, 8);
 }
 // wave64 prefix sum and sum in DPP steps (rows of 16: shifts by 1, 2, 4, 8; then lane 15 of a row to the next row, lane
@@ -574,6 +521,138 @@ __device__ __forceinline__ void emit6_report(unsigned long long* ctl, int64_t ro
     atomicMax(ctl + CTL_ERR, ~((unsigned long long)(row + 1) << 8 | code));
 }
 
+// What follows a row's printing, for both writers: the workgroup's rows find their place in the text (look-back over the
+// workgroups with lower tickets), the last ticket stores the total, the rows leave in aligned 16-byte stores.
+template <int WPB, bool TEXT>
+__device__ __forceinline__ void emit_place_and_store(uint64_t bid, int64_t row, int64_t n_rows, uint32_t total, const uint8_t* lb,
+                                                     unsigned long long* __restrict__ ctl, unsigned long long* __restrict__ state,
+                                                     uint8_t* __restrict__ text, uint64_t text_cap, uint64_t* __restrict__ row_off)
+{
+    __shared__ unsigned long long s_excl;
+    __shared__ uint32_t s_len[WPB];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) s_len[wid] = total;
+    __syncthreads();
+    if (wid == 0) {
+        uint64_t sum = lane < WPB ? (uint64_t)s_len[lane] : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        uint64_t excl = 0;
+        if (bid > 0) {
+            if (lane == 0) __hip_atomic_store(state + bid, LB_SUM | sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t top = (int64_t)bid - 1;                  // the nearest workgroup not yet added
+            for (;;) {
+                const int64_t idx = top - lane;
+                const uint64_t v = idx >= 0 ? __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_ALL;
+                const uint64_t have_all = __ballot((v & LB_ALL) != 0), nothing = __ballot((v >> 62) == 0);
+                const int stop = have_all ? __builtin_ctzll(have_all) : 64;        // the nearest that knows everything below it
+                const uint64_t below = stop >= 64 ? ~0ull : (2ull << stop) - 1ull;
+                if (nothing & below) { __builtin_amdgcn_s_sleep(2); continue; }    // one of them has not published yet
+                uint64_t t = lane <= stop ? (v & LB_VAL) : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                excl += t;
+                if (stop < 64) break;
+                top -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(state + bid, LB_ALL | (excl + sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+            if ((int64_t)bid == (n_rows + WPB - 1) / WPB - 1) { ctl[CTL_TOTAL] = excl + sum; if (row_off) row_off[n_rows] = excl + sum; }
+        }
+    }
+    __syncthreads();
+    if (row >= n_rows) return;
+    uint64_t o = s_excl;
+    for (int w = 0; w < wid; w++) o += s_len[w];
+    if (row_off && lane == 0) row_off[row] = o;
+    if (!TEXT || o + total > text_cap) return;
+    // head up to the first 16-byte boundary of the text, aligned 16-byte pieces, tail
+    const uint32_t h = min(total, (uint32_t)__builtin_amdgcn_readfirstlane((int)((16u - (uint32_t)(o & 15ull)) & 15u)));
+    const uint32_t nvec = (total - h) >> 4, r = h & 3u;
+    if ((uint32_t)lane < h) text[o + lane] = lb[lane];
+    const uint32_t* lw = reinterpret_cast<const uint32_t*>(lb) + (h >> 2);
+    uint4* tv = reinterpret_cast<uint4*>(text + o + h);
+    for (uint32_t k = lane; k < nvec; k += 64) {
+        const uint32_t* q = lw + 4 * k;
+        const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+        uint4 out;
+        out.x = __builtin_amdgcn_alignbyte(w1, w0, r); out.y = __builtin_amdgcn_alignbyte(w2, w1, r);
+        out.z = __builtin_amdgcn_alignbyte(w3, w2, r); out.w = __builtin_amdgcn_alignbyte(w4, w3, r);
+        tv[k] = out;
+    }
+    const uint32_t done = h + (nvec << 4);
+    if (done + (uint32_t)lane < total) text[o + done + lane] = lb[done + lane];
+}
+
+template <int WPB>
+__device__ __forceinline__ uint64_t emit_ticket(unsigned long long* __restrict__ ctl)
+{
+    __shared__ unsigned long long s_bid;
+    if (threadIdx.x == 0) s_bid = atomicAdd(ctl + CTL_TICKET, 1ull);
+    __syncthreads();
+    return s_bid;
+}
+
+// The build writer's rows in the same one launch (round 3; before: lengths, a three-launch scan, the print).  A field is
+// "\t[-]<|k| / 1000>" -- 12 bytes of which the first 2 .. 9 count -- and ".ddd"; the head leaves in three 4-byte LDS stores
+// from the highest down, the tail after every lane's head: a field has at least six bytes, so the rubbish of a head lies
+// in the lane's own tail or in the NEXT lane's field, in a word that lane stores in a later instruction.
+template <bool TEXT, int WPB>
+__global__ __launch_bounds__(64 * WPB) void lrn_emit3_kernel(const int32_t* __restrict__ milli, int64_t n_rows, int32_t n_cols, uint64_t first_key,
+                                                            uint32_t row_stride, unsigned long long* __restrict__ ctl, unsigned long long* __restrict__ state,
+                                                            uint8_t* __restrict__ text, uint64_t text_cap)
+{
+    extern __shared__ __align__(16) uint8_t emit3_lds[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint64_t bid = emit_ticket<WPB>(ctl);
+    const int64_t row = (int64_t)bid * WPB + wid;
+    uint8_t* lb = emit3_lds + (size_t)wid * row_stride;
+    uint32_t total = 0;
+    if (row < n_rows) {
+        const int32_t* r = milli + row * n_cols;
+        const uint64_t key = first_key + (uint64_t)row;
+        const int klen = key_len(key);
+        if (TEXT && lane == 0) { unsigned long long k = key; for (int i = klen - 1; i >= 0; i--) { lb[i] = (uint8_t)('0' + k % 10ull); k /= 10ull; } }
+        uint32_t carry = (uint32_t)klen;
+        for (int c0 = 0; c0 < n_cols; c0 += 64) {            // columns c0 .. c0+63, one per lane, in order
+            const int c = c0 + lane;
+            const int32_t k = (c < n_cols) ? r[c] : 0;
+            const uint32_t neg = k < 0, a = neg ? 0u - (uint32_t)k : (uint32_t)k;
+            const uint32_t q = a / 1000u, f = a - q * 1000u;                         // q < 2 147 484: seven digits
+            const uint32_t hi4 = q / 10000u, lo4 = q - hi4 * 10000u;
+            const uint64_t dig = (uint64_t)digits4(hi4) | (uint64_t)digits4(lo4) << 32;
+            const uint32_t lead = (uint32_t)__builtin_ctzll(dig | 1ull << 56) >> 3;
+            const uint64_t body = (dig + 0x3030303030303030ull) >> (8u * lead);
+            const uint32_t p = 1u + neg, at = p + 8u - lead;
+            const uint32_t len = (c < n_cols) ? at + 4u : 0u;
+            if (TEXT) {
+                const uint32_t incl = wave_incl_scan_dpp(len);
+                if (c < n_cols) {
+                    uint8_t* dst = lb + carry + incl - len;
+                    const uint64_t head = (uint64_t)(neg ? 0x2D09u : 0x09u) | body << (8u * p);
+                    const uint32_t h2 = (uint32_t)(body >> (64u - 8u * p)), h1 = (uint32_t)(head >> 32), h0 = (uint32_t)head;
+                    const uint32_t tail = (digits4(f) + 0x30303000u) | 0x2Eu;
+                    __builtin_memcpy(dst + 8, &h2, 4);
+                    asm volatile("" ::: "memory");           // four instructions, in this order: merged into wider stores, two
+                    __builtin_memcpy(dst + 4, &h1, 4);       // lanes would write the same byte in one instruction
+                    asm volatile("" ::: "memory");
+                    __builtin_memcpy(dst, &h0, 4);
+                    asm volatile("" ::: "memory");
+                    __builtin_memcpy(dst + at, &tail, 4);
+                }
+                carry += __shfl(incl, 63, 64);
+            } else {
+                carry += wave_sum_dpp(len);
+            }
+        }
+        if (TEXT && lane == 0) lb[carry] = '\n';
+        total = carry + 1u;
+    }
+    emit_place_and_store<WPB, TEXT>(bid, row, n_rows, total, lb, ctl, state, text, text_cap, nullptr);
+}
+
 // ROWMAJ: the table is the resident copy, [ld][n_cols] (a datapoint's values side by side: a row is one coalesced read
 // instead of n_cols lines of 128 bytes for 8 bytes each -- what bounds the other form).
 template <bool TEXT, int WPB, bool ROWMAJ>                    // WPB rows (waves) per workgroup
@@ -583,12 +662,8 @@ __global__ __launch_bounds__(64 * WPB) void lrn_emit6_kernel(const double* __res
                                                        uint8_t* __restrict__ text, uint64_t text_cap, uint64_t* __restrict__ row_off)
 {
     extern __shared__ __align__(16) uint8_t emit6_lds[];
-    __shared__ unsigned long long s_bid, s_excl;
-    __shared__ uint32_t s_len[WPB];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_bid = atomicAdd(ctl + CTL_TICKET, 1ull);
-    __syncthreads();
-    const uint64_t bid = s_bid;
+    const uint64_t bid = emit_ticket<WPB>(ctl);
     const int64_t row = (int64_t)bid * WPB + wid;
     uint8_t* lb = emit6_lds + (size_t)wid * row_stride;
     uint32_t total = 0;
@@ -647,59 +722,7 @@ __global__ __launch_bounds__(64 * WPB) void lrn_emit6_kernel(const double* __res
         if (TEXT && lane == 0) lb[carry] = '\n';
         total = carry + 1u;
     }
-    if (lane == 0) s_len[wid] = total;
-    __syncthreads();
-    if (wid == 0) {
-        uint64_t sum = lane < WPB ? (uint64_t)s_len[lane] : 0ull;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        uint64_t excl = 0;
-        if (bid > 0) {
-            if (lane == 0) __hip_atomic_store(state + bid, LB_SUM | sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int64_t top = (int64_t)bid - 1;                  // the nearest workgroup not yet added
-            for (;;) {
-                const int64_t idx = top - lane;
-                const uint64_t v = idx >= 0 ? __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_ALL;
-                const uint64_t have_all = __ballot((v & LB_ALL) != 0), nothing = __ballot((v >> 62) == 0);
-                const int stop = have_all ? __builtin_ctzll(have_all) : 64;        // the nearest that knows everything below it
-                const uint64_t below = stop >= 64 ? ~0ull : (2ull << stop) - 1ull;
-                if (nothing & below) { __builtin_amdgcn_s_sleep(2); continue; }    // one of them has not published yet
-                uint64_t t = lane <= stop ? (v & LB_VAL) : 0ull;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-                excl += t;
-                if (stop < 64) break;
-                top -= 64;
-            }
-        }
-        if (lane == 0) {
-            __hip_atomic_store(state + bid, LB_ALL | (excl + sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_excl = excl;
-            if ((int64_t)bid == (n_rows + WPB - 1) / WPB - 1) { ctl[CTL_TOTAL] = excl + sum; if (row_off) row_off[n_rows] = excl + sum; }
-        }
-    }
-    __syncthreads();
-    if (row >= n_rows) return;
-    uint64_t o = s_excl;
-    for (int w = 0; w < wid; w++) o += s_len[w];
-    if (row_off && lane == 0) row_off[row] = o;
-    if (!TEXT || o + total > text_cap) return;
-    // head up to the first 16-byte boundary of the text, aligned 16-byte pieces, tail
-    const uint32_t h = min(total, (uint32_t)__builtin_amdgcn_readfirstlane((int)((16u - (uint32_t)(o & 15ull)) & 15u)));
-    const uint32_t nvec = (total - h) >> 4, r = h & 3u;
-    if ((uint32_t)lane < h) text[o + lane] = lb[lane];
-    const uint32_t* lw = reinterpret_cast<const uint32_t*>(lb) + (h >> 2);
-    uint4* tv = reinterpret_cast<uint4*>(text + o + h);
-    for (uint32_t k = lane; k < nvec; k += 64) {
-        const uint32_t* q = lw + 4 * k;
-        const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
-        uint4 out;
-        out.x = __builtin_amdgcn_alignbyte(w1, w0, r); out.y = __builtin_amdgcn_alignbyte(w2, w1, r);
-        out.z = __builtin_amdgcn_alignbyte(w3, w2, r); out.w = __builtin_amdgcn_alignbyte(w4, w3, r);
-        tv[k] = out;
-    }
-    const uint32_t done = h + (nvec << 4);
-    if (done + (uint32_t)lane < total) text[o + done + lane] = lb[done + lane];
+    emit_place_and_store<WPB, TEXT>(bid, row, n_rows, total, lb, ctl, state, text, text_cap, row_off);
 }
 
 // [n_cols][ld] -> [ld][n_cols], 32 x 32 tiles through LDS (the resident copy of the cluster writer's table)
@@ -874,33 +897,44 @@ int abw_lrn_emit(abw_ctx* ctx, const int32_t* milli, int64_t n_rows, int32_t n_c
     abw_device_guard g(ctx->device);
     hipStream_t st = ctx->stream;
     int rc;
-    // scratch[6]: milli | scratch[4]: row_len u32 + row_off u64 | scratch[0]: text
+    // scratch[6]: milli | scratch[4]: ticket, total + one look-back word per workgroup | scratch[0]: text, of the caller's
+    // capacity (at most what the rows can take): one launch prints and sizes
     const size_t mb = (size_t)n_rows * n_cols * 4;
+    const uint32_t row_stride = (uint32_t)(((uint64_t)n_cols * 13 + 24 + 16 + 15) & ~15ull);
+    const int wpb = 8 * row_stride <= EMIT_LDS_MAX ? 8 : 4;
+    const uint64_t nblk = ((uint64_t)n_rows + wpb - 1) / wpb;
+    const size_t sb = (CTL_WORDS + (size_t)nblk) * 8;
+    const bool with_text = text && text_cap > 0;
+    const uint64_t cap = with_text ? std::min<uint64_t>(text_cap, (uint64_t)n_rows * ((uint64_t)n_cols * 13 + 21)) : 0;
     if ((rc = abw_reserve(ctx, ctx->scratch[6], mb))) return rc;
-    if ((rc = abw_reserve(ctx, ctx->scratch[4], (((size_t)n_rows * 4 + 15) & ~(size_t)7) + ((size_t)n_rows + 2) * 8))) return rc;
+    if ((rc = abw_reserve(ctx, ctx->scratch[4], sb))) return rc;
+    if (with_text && (rc = abw_reserve(ctx, ctx->scratch[0], cap + 64))) return rc;
     int32_t* d_milli = (int32_t*)ctx->scratch[6].p;
-    uint32_t* row_len = (uint32_t*)ctx->scratch[4].p;
-    uint64_t* row_off = (uint64_t*)((uint8_t*)row_len + (((size_t)n_rows * 4 + 15) & ~(size_t)7));
+    unsigned long long* ctl = (unsigned long long*)ctx->scratch[4].p;
+    unsigned long long* state = ctl + CTL_WORDS;
+    uint8_t* d_text = with_text ? (uint8_t*)ctx->scratch[0].p : nullptr;
     ABW_HIP(ctx, hipMemcpyAsync(d_milli, milli, mb, hipMemcpyHostToDevice, st));
-    const unsigned gr = (unsigned)((n_rows + 3) / 4);
+    auto launch = [&](auto kern, size_t lds) -> int {
+        if (lds > 65536) ABW_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, EMIT_LDS_MAX));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * wpb), lds, st, (const int32_t*)d_milli, n_rows, n_cols, first_key, row_stride, ctl, state, d_text, cap);
+        return ABW_OK;
+    };
     {
         ABW_PROF(ctx, "lrn_emit");
-        hipLaunchKernelGGL(lrn_rowlen_kernel, dim3(gr), dim3(256), 0, st, d_milli, n_rows, n_cols, first_key, row_len);
+        ABW_HIP(ctx, hipMemsetAsync(ctl, 0, sb, st));
+        const size_t lds = (size_t)wpb * row_stride;
+        if (with_text) rc = wpb == 8 ? launch(lrn_emit3_kernel<true, 8>, lds) : launch(lrn_emit3_kernel<true, 4>, lds);
+        else rc = wpb == 8 ? launch(lrn_emit3_kernel<false, 8>, 0) : launch(lrn_emit3_kernel<false, 4>, 0);
+        if (rc) return rc;
         ABW_LAUNCH_CHECK(ctx);
-        if ((rc = abw_device_scan_u32(ctx, row_len, (uint64_t)n_rows, row_off))) return rc;
     }
-    uint64_t total = 0;
-    ABW_HIP(ctx, hipMemcpyAsync(&total, row_off + n_rows, 8, hipMemcpyDeviceToHost, st));
+    unsigned long long h_ctl[CTL_WORDS] = {0, 0, 0, 0};
+    ABW_HIP(ctx, hipMemcpyAsync(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));
+    const uint64_t total = h_ctl[CTL_TOTAL];
     *text_len = total;
     if (!text || total > text_cap) return abw_fail(ctx, ABW_ERR_CAPACITY, "abw_lrn_emit: the rows take %llu bytes, capacity %llu", (unsigned long long)total, (unsigned long long)text_cap);
-    if ((rc = abw_reserve(ctx, ctx->scratch[0], total + 64))) return rc;
-    {
-        ABW_PROF(ctx, "lrn_emit");
-        hipLaunchKernelGGL(lrn_emit_kernel, dim3(gr), dim3(256), 0, st, d_milli, n_rows, n_cols, first_key, row_off, (uint8_t*)ctx->scratch[0].p);
-        ABW_LAUNCH_CHECK(ctx);
-    }
-    ABW_HIP(ctx, hipMemcpyAsync(text, ctx->scratch[0].p, total, hipMemcpyDeviceToHost, st));
+    ABW_HIP(ctx, hipMemcpyAsync(text, d_text, total, hipMemcpyDeviceToHost, st));
     ABW_HIP(ctx, hipStreamSynchronize(st));
     return ABW_OK;
 }
@@ -918,10 +952,11 @@ static int emit_rows_core(abw_ctx* ctx, const double* d_values, bool row_major, 
     abw_device_guard g(ctx->device);
     hipStream_t st = ctx->stream;
     int rc;
-    // scratch[4]: ticket, error, total | one look-back word per workgroup.  As many rows (waves) per workgroup as keep two
-    // workgroups' rows in a CU's LDS, at most 16: fewer workgroups, a shorter look-back (a 2 000-row cluster: 125 instead of 500)
+    // scratch[4]: ticket, error, total | one look-back word per workgroup.  Eight rows (waves) per workgroup when two
+    // workgroups' rows fit a CU's LDS, else four.  Measured at 189 columns, 4 / 8 / 16 rows per workgroup: 24.9 / 20.4 / 23.5 us
+    // per 2 000-row cluster and 0.66 / 0.57 / 0.58 ms per 200 000 rows -- a workgroup's ticket and look-back are what costs
     const uint32_t row_stride = (uint32_t)(((uint64_t)n_cols * EMIT6_FIELD_MAX + 24 + 16 + 15) & ~15ull);      // 16: what a store may write behind the row's end
-    const int wpb = 16 * row_stride <= EMIT_LDS_MAX ? 16 : 8 * row_stride <= EMIT_LDS_MAX ? 8 : 4;
+    const int wpb = 8 * row_stride <= EMIT_LDS_MAX ? 8 : 4;
     const uint64_t nblk = ((uint64_t)n_rows + wpb - 1) / wpb;
     const size_t sb = (CTL_WORDS + (size_t)nblk) * 8;
     if ((rc = abw_reserve(ctx, ctx->scratch[4], sb))) return rc;
@@ -938,7 +973,7 @@ static int emit_rows_core(abw_ctx* ctx, const double* d_values, bool row_major, 
         ABW_PROF(ctx, "lrn_emit_rows");
         ABW_HIP(ctx, hipMemsetAsync(ctl, 0, sb, st));
         const size_t lds = (size_t)wpb * row_stride;
-#define EMIT6_PICK(T, R, L) (wpb == 16 ? launch(lrn_emit6_kernel<T, 16, R>, L) : wpb == 8 ? launch(lrn_emit6_kernel<T, 8, R>, L) : launch(lrn_emit6_kernel<T, 4, R>, L))
+#define EMIT6_PICK(T, R, L) (wpb == 8 ? launch(lrn_emit6_kernel<T, 8, R>, L) : launch(lrn_emit6_kernel<T, 4, R>, L))
         if (with_text) rc = row_major ? EMIT6_PICK(true, true, lds) : EMIT6_PICK(true, false, lds);
         else rc = row_major ? EMIT6_PICK(false, true, 0) : EMIT6_PICK(false, false, 0);
 #undef EMIT6_PICK

@@ -120,6 +120,33 @@ def test_writer_round_trip_and_format(ctx, N, D, first):
         assert np.array_equal(names, first + np.arange(N)) and np.array_equal(keys.T, m)
 
 
+def test_writer_short_and_long_fields_side_by_side(ctx):
+    """The one-launch writer stores a field's head as 12 bytes whatever its length: rows of the shortest fields (6 bytes),
+    the longest (13), every digit-count boundary and both int32 ends, in every neighbourhood; a buffer that is too small
+    answers with the size and nothing behind its end is written."""
+    rng = np.random.default_rng(23)
+    edge = np.array([0, 1, -1, 9, 10, 999, 1000, -999, -1000, 9999, 10_000, 99_999, 100_000, 999_999, 1_000_000, 9_999_999, 10_000_000,
+                     99_999_999, 100_000_000, 999_999_999, 1_000_000_000, 2 ** 31 - 1, -2 ** 31, -2 ** 31 + 1, 2_147_483_000], dtype=np.int64)
+    m = edge[rng.integers(0, len(edge), size=(700, 131))]
+    m[0, :] = 0                                                                # a row of 6-byte fields
+    m[1, :] = -2 ** 31                                                         # a row of 13-byte fields
+    m[2, ::2], m[2, 1::2] = 0, -2 ** 31
+    m[3, :len(edge)] = edge
+    text = lrn.lrn_emit(ctx, m.astype(np.int32), 18_446_744_073_709_550_000)    # 20-digit keys
+    want = "".join(str(18_446_744_073_709_550_000 + r) + "".join("\t%s%d.%03d" % ((("-" if v < 0 else ""),) + divmod(abs(int(v)), 1000)) for v in m[r]) + "\n"
+                   for r in range(len(m))).encode()
+    assert bytes(text) == want
+    mi = np.ascontiguousarray(m.astype(np.int32))
+    buf = np.full(len(want) + 100, 0xEE, dtype=np.uint8)
+    n = C.c_uint64(0)
+    rc = _lib.lib().abw_lrn_emit(ctx.handle, C.c_void_p(mi.ctypes.data), 700, 131, 18_446_744_073_709_550_000, C.c_void_p(buf.ctypes.data), len(want) // 2, C.byref(n))
+    assert rc == _lib.ABW_ERR_CAPACITY and n.value == len(want) and (buf == 0xEE).all()
+    rc = _lib.lib().abw_lrn_emit(ctx.handle, C.c_void_p(mi.ctypes.data), 700, 131, 18_446_744_073_709_550_000, None, 0, C.byref(n))
+    assert rc == _lib.ABW_ERR_CAPACITY and n.value == len(want)
+    ctx.check(_lib.lib().abw_lrn_emit(ctx.handle, C.c_void_p(mi.ctypes.data), 700, 131, 18_446_744_073_709_550_000, C.c_void_p(buf.ctypes.data), len(buf), C.byref(n)))
+    assert bytes(buf[:n.value]) == want and (buf[n.value:] == 0xEE).all()
+
+
 # ---- cluster writer: ClusterEsomWriter::write_clustering_info_file (reference src/ClusterWriter.cpp:92-98) --------
 def test_cluster_writer_reproduces_the_reference_file(ctx, golden_dir):
     g = np.load(os.path.join(golden_dir, "lrn_c.npz"))
@@ -137,7 +164,7 @@ def _wild_table(rng, D, N):
 
 
 @pytest.mark.parametrize("N,D,n_rows", [(4000, 189, 2500), (50, 700, 50), (1, 1, 1), (300, 64, 900),
-                                        (600, 300, 700),          # eight rows per workgroup (16 / 8 / 4 by row width)
+                                        (600, 300, 700), (90, 500, 333),   # eight rows per workgroup up to 442 columns, four above
                                         (20000, 8, 70001)])       # 4 376 workgroups: the look-back over many windows
 def test_cluster_writer_matches_oracle(ctx, N, D, n_rows):
     rng = np.random.default_rng(N + D)
