@@ -417,63 +417,7 @@ __global__ __launch_bounds__(256) void seg_blockcount_kernel(const uint8_t* __re
     if (any_n) atomicOr(flag_lower_n, 1);
 }
 
-// exclusive scan -> uint64, three small launches: per-1024 group totals, scan of the group totals
-// (one workgroup; n/1024 entries), rescan of every group with its carry.  out has n + 1 entries.
-template <typename TIN>
-__global__ __launch_bounds__(1024) void scan_group_totals_kernel(const TIN* __restrict__ in, uint64_t n, uint64_t* __restrict__ gtot)
-{
-    __shared__ uint64_t w[16];
-    const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
-    uint64_t v = (i < n) ? (uint64_t)in[i] : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint64_t t = 0; for (int k = 0; k < 16; k++) t += w[k]; gtot[blockIdx.x] = t; }
-}
-
-__global__ __launch_bounds__(1024) void scan_single_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t n)
-{
-    __shared__ uint64_t wsum[16];
-    __shared__ uint64_t carry_s;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint64_t base = 0; base < n; base += 1024) {
-        const uint64_t i = base + threadIdx.x;
-        uint64_t v = (i < n) ? in[i] : 0, x = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { uint64_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-        if (lane == 63) wsum[wid] = x;
-        __syncthreads();
-        uint64_t woff = 0;
-        for (int k = 0; k < wid; k++) woff += wsum[k];
-        const uint64_t carry = carry_s;
-        if (i < n) out[i] = carry + woff + x - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + x;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[n] = carry_s;
-}
-
-template <typename TIN>
-__global__ __launch_bounds__(1024) void scan_apply_kernel(const TIN* __restrict__ in, uint64_t n, const uint64_t* __restrict__ goff,
-                                                         uint64_t ngroups, uint64_t* __restrict__ out)
-{
-    __shared__ uint64_t wsum[16];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
-    uint64_t v = (i < n) ? (uint64_t)in[i] : 0, x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { uint64_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-    if (lane == 63) wsum[wid] = x;
-    __syncthreads();
-    uint64_t woff = goff[blockIdx.x];
-    for (int k = 0; k < wid; k++) woff += wsum[k];
-    if (i < n) out[i] = woff + x - v;
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = goff[ngroups];
-}
+// exclusive scan -> uint64: scan_lookback_kernel (below, with device_scan_tmp).  out has n + 1 entries.
 
 // rank (number of non-N bytes) of blob prefix [0, pos): whole blocks from blk_prefix + a partial block
 __device__ __forceinline__ uint64_t prefix_nonN(const uint8_t* __restrict__ ascii, const uint64_t* __restrict__ blk_prefix,
@@ -623,18 +567,91 @@ __global__ __launch_bounds__(256) void seg_emit_kernel(const uint8_t* __restrict
     }
 }
 
-// tmp: (2 * ceil(n / 1024) + 2) uint64 for the group totals / offsets of the two-level scan
+// Round 3: ONE pass (plus the memset of its look-back words) instead of three launches.  A workgroup takes the next 4096
+// elements by ticket, scans them (a thread owns four consecutive ones), publishes their sum and finds what lies in front by a
+// decoupled look-back over the workgroups with lower tickets (state word: bit 62 "my sum", bit 63 "everything up to and
+// including me", the value below; a wave reads 64 predecessors per step).  A lower ticket has started and publishes its
+// sum without waiting for anyone, so every wait ends.  Sums stay below 2^62 (they count bytes, segments, records).
+constexpr uint64_t SCAN_SUM = 1ull << 62, SCAN_ALL = 1ull << 63, SCAN_VAL = (1ull << 62) - 1ull;
+constexpr int SCAN_ITEMS = 4, SCAN_TILE = 1024 * SCAN_ITEMS;
+
+template <typename TIN>
+__global__ __launch_bounds__(1024) void scan_lookback_kernel(const TIN* __restrict__ in, uint64_t n, uint64_t* __restrict__ out,
+                                                            unsigned long long* __restrict__ tmp)
+{
+    __shared__ unsigned long long s_bid, s_excl;
+    __shared__ uint64_t wsum[16];
+    unsigned long long* state = tmp + 2;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_bid = atomicAdd(tmp, 1ull);
+    __syncthreads();
+    const uint64_t bid = s_bid;
+    const uint64_t i0 = bid * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS];
+    if (sizeof(TIN) == 4 && i0 + SCAN_ITEMS <= n && ((uintptr_t)in & 15) == 0) {
+        const uint4 q = *reinterpret_cast<const uint4*>(in + i0);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) v[k] = (i0 + k < n) ? (uint64_t)in[i0 + k] : 0ull;
+    }
+    const uint64_t mine = v[0] + v[1] + v[2] + v[3];
+    uint64_t x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint64_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    if (wid == 0) {
+        uint64_t sum = lane < 16 ? wsum[lane] : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        uint64_t excl = 0;
+        if (bid > 0) {
+            if (lane == 0) __hip_atomic_store(state + bid, SCAN_SUM | sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t top = (int64_t)bid - 1;                  // the nearest workgroup not yet added
+            for (;;) {
+                const int64_t idx = top - lane;
+                const uint64_t w = idx >= 0 ? __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SCAN_ALL;
+                const uint64_t have_all = __ballot((w & SCAN_ALL) != 0), nothing = __ballot((w >> 62) == 0);
+                const int stop = have_all ? __builtin_ctzll(have_all) : 64;        // the nearest that knows everything below it
+                const uint64_t below = stop >= 64 ? ~0ull : (2ull << stop) - 1ull;
+                if (nothing & below) { __builtin_amdgcn_s_sleep(2); continue; }    // one of them has not published yet
+                uint64_t t = lane <= stop ? (w & SCAN_VAL) : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                excl += t;
+                if (stop < 64) break;
+                top -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(state + bid, SCAN_ALL | (excl + sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+            if (bid == (n + SCAN_TILE - 1) / SCAN_TILE - 1) out[n] = excl + sum;
+        }
+    }
+    __syncthreads();
+    uint64_t before = s_excl + x - mine;                     // everything in front of this thread's four
+    for (int k = 0; k < wid; k++) before += wsum[k];
+    if (i0 + SCAN_ITEMS <= n && ((uintptr_t)out & 15) == 0) {
+        ulonglong2 a, b2;
+        a.x = before; a.y = before + v[0]; b2.x = a.y + v[1]; b2.y = b2.x + v[2];
+        reinterpret_cast<ulonglong2*>(out + i0)[0] = a;
+        reinterpret_cast<ulonglong2*>(out + i0)[1] = b2;
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) { if (i0 + k < n) out[i0 + k] = before; before += v[k]; }
+    }
+}
+
+// tmp: (2 * ceil(n / 1024) + 2) uint64 (the size the two-level scan of rounds 1-2 needed; this one uses ceil(n / 4096) + 2)
 template <typename TIN>
 int device_scan_tmp(abw_ctx* ctx, const TIN* in, uint64_t n, uint64_t* out, uint64_t* tmp)
 {
-    const uint64_t ngroups = (n + 1023) / 1024;
-    uint64_t* gtot = tmp;
-    uint64_t* goff = gtot + ngroups;
-    hipLaunchKernelGGL(scan_group_totals_kernel<TIN>, dim3((unsigned)ngroups), dim3(1024), 0, ctx->stream, in, n, gtot);
-    ABW_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(1024), 0, ctx->stream, gtot, goff, ngroups);
-    ABW_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(scan_apply_kernel<TIN>, dim3((unsigned)ngroups), dim3(1024), 0, ctx->stream, in, n, goff, ngroups, out);
+    if (n == 0) { ABW_HIP(ctx, hipMemsetAsync(out, 0, 8, ctx->stream)); return ABW_OK; }
+    const uint64_t nblk = (n + SCAN_TILE - 1) / SCAN_TILE;
+    ABW_HIP(ctx, hipMemsetAsync(tmp, 0, (nblk + 2) * 8, ctx->stream));
+    hipLaunchKernelGGL(scan_lookback_kernel<TIN>, dim3((unsigned)nblk), dim3(1024), 0, ctx->stream, in, n, out, (unsigned long long*)tmp);
     ABW_LAUNCH_CHECK(ctx);
     return ABW_OK;
 }
