@@ -58,12 +58,23 @@ __device__ __forceinline__ uint32_t eq_mask16(const uint8_t* __restrict__ p, uin
     return m;
 }
 
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x, int lane)
+// wave64 prefix sum in DPP steps (rows of 16: shifts by 1, 2, 4, 8; then lane 15 of a row to the next row, lane 31 to the
+// upper half) -- six adds, where six shuffles through the LDS crossbar cost five instructions each
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
     return x;
 }
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(x), 63); }
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x, int) { return wave_incl_scan_dpp(x); }
+// the value of the lane above / below (the last / first lane keeps its own, as __shfl_down / __shfl_up by one do)
+__device__ __forceinline__ uint32_t lane_above(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x130, 0xF, 0xF, false); }   // wave_shl:1
+__device__ __forceinline__ uint32_t lane_below(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x138, 0xF, 0xF, false); }   // wave_shr:1
 
 // per block: newlines, and the tabs after its last newline (all its tabs when it has none)
 __global__ __launch_bounds__(256) void lrn_nlcount_kernel(const uint8_t* __restrict__ text, uint64_t len, uint32_t* __restrict__ blk_nl,
@@ -227,12 +238,12 @@ __global__ __launch_bounds__(256) void lrn_blocks_kernel(const uint8_t* __restri
         // character classes of this lane's 16 bytes (bit i = byte i); the 16 bytes behind them are the next lane's
         const uint32_t tab16 = eq_mask16r(mine, 0x09090909u), nl16 = eq_mask16r(mine, 0x0A0A0A0Au);
         const uint32_t dig16 = digit_mask16(mine), dot16 = eq_mask16r(mine, 0x2E2E2E2Eu), min16 = eq_mask16r(mine, 0x2D2D2D2Du);
-        const uint32_t sep32 = (tab16 | nl16) | (__shfl_down(tab16 | nl16, 1, 64) << 16);
-        const uint32_t nl32 = nl16 | (__shfl_down(nl16, 1, 64) << 16);
-        const uint32_t dig32 = dig16 | (__shfl_down(dig16, 1, 64) << 16);
-        const uint32_t dot32 = dot16 | (__shfl_down(dot16, 1, 64) << 16);
+        const uint32_t sep32 = (tab16 | nl16) | (lane_above(tab16 | nl16) << 16);
+        const uint32_t nl32 = nl16 | (lane_above(nl16) << 16);
+        const uint32_t dig32 = dig16 | (lane_above(dig16) << 16);
+        const uint32_t dot32 = dot16 | (lane_above(dot16) << 16);
         const uint32_t W0 = mine.x, W1 = mine.y, W2 = mine.z, W3 = mine.w;
-        const uint32_t W4 = __shfl_down(mine.x, 1, 64), W5 = __shfl_down(mine.y, 1, 64), W6 = __shfl_down(mine.z, 1, 64);
+        const uint32_t W4 = lane_above(mine.x), W5 = lane_above(mine.y), W6 = lane_above(mine.z);
         const int live = (lane == 63 || A >= len) ? 0 : (len - A >= 16 ? 16 : (int)(len - A));
         const uint32_t lm = (1u << live) - 1u;
         const uint32_t tabs = tab16 & lm, nls = nl16 & lm;
@@ -242,19 +253,21 @@ __global__ __launch_bounds__(256) void lrn_blocks_kernel(const uint8_t* __restri
         // field of this lane's first byte: tabs since the last newline -- a segmented exclusive scan over the lanes ...
         uint32_t seg_t = nls ? __popc(tabs >> (32 - __builtin_clz(nls))) : __popc(tabs);     // this lane's tabs after its last newline
         uint32_t seg_f = nls ? 1u : 0u;                                                      // ... which restart the count
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(seg_t, o, 64), f = __shfl_up(seg_f, o, 64);
-            if (lane >= o) { if (!seg_f) seg_t += t; seg_f |= f; }
-        }
-        uint32_t in_t = __shfl_up(seg_t, 1, 64), in_f = __shfl_up(seg_f, 1, 64);
+        // (the same six DPP steps as the prefix sum; a lane without a source receives t = 0, f = 0: the identity)
+#define SEG_STEP(CTRL, ROWS, BOUND) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)seg_t, CTRL, ROWS, 0xF, BOUND), \
+                                      f = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)seg_f, CTRL, ROWS, 0xF, BOUND); \
+                                      seg_t += seg_f ? 0u : t; seg_f |= f; }
+        SEG_STEP(0x111, 0xF, true) SEG_STEP(0x112, 0xF, true) SEG_STEP(0x114, 0xF, true) SEG_STEP(0x118, 0xF, true)
+        SEG_STEP(0x142, 0xA, false) SEG_STEP(0x143, 0xC, false)
+#undef SEG_STEP
+        uint32_t in_t = lane_below(seg_t), in_f = lane_below(seg_f);
         if (lane == 0) { in_t = 0; in_f = 0; }
         // ... plus, while no newline of this block lies before the lane, the tabs between the start of the line and the block
         uint32_t carry = 0;
         for (uint64_t j = b; j-- > 0;) { carry += blk_tail[j]; if (blk_nl[j]) break; }      // wave-uniform; a line spans at most 9 blocks
         const uint32_t field0 = in_t + (in_f ? 0u : carry);
         // a field starts at the first byte of the text and after every tab or newline
-        uint32_t prev_sep = (__shfl_up(tab16 | nl16, 1, 64) >> 15) & 1u;                     // (all lanes take part in the shuffle)
+        uint32_t prev_sep = (lane_below(tab16 | nl16) >> 15) & 1u;                     // (all lanes take part in the shuffle)
         if (lane == 0) prev_sep = (A == 0) ? 1u : (uint32_t)(text[A - 1] == '\t' || text[A - 1] == '\n');
         uint32_t starts = (((tabs | nls) << 1) | prev_sep) & lm;
         uint64_t cur_line = ~0ull, row = 0;
@@ -492,19 +505,6 @@ __device__ __forceinline__ void field6_store(uint8_t* p, const Field6& f)
     asm volatile("" ::: "memory");
     __builtin_memcpy(p + f.tail_at, &f.tail, 8);
 }
-// wave64 prefix sum and sum in DPP steps (rows of 16: shifts by 1, 2, 4, 8; then lane 15 of a row to the next row, lane
-// 31 to the upper half)
-__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x)
-{
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
-    return x;
-}
-__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(x), 63); }
 
 // One launch per call (round 3; before: a length pass, a three-launch scan and a print pass, the table gathered twice).
 // A workgroup takes the next four rows by ticket, prints each into LDS -- which also gives its length --, publishes the
