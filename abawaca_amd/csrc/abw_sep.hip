@@ -398,14 +398,8 @@ __global__ __launch_bounds__(256) void sep_wide_hist_kernel(SepDev P, WideDev W,
 // ---- chunked scan + evaluation ----------------------------------------------------------------
 __device__ __forceinline__ Sums wave_incl_scan(Sums x, int lane)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        Sums y;
-        y.size = __shfl_up(x.size, o, 64); y.tp1 = __shfl_up(x.tp1, o, 64);
-        y.tot = __shfl_up(x.tot, o, 64); y.bp = __shfl_up(x.bp, o, 64);
-        if (lane >= o) x = sums_add(x, y);
-    }
-    return x;
+    (void)lane;
+    return Sums{wave_prefix_u64(x.size), wave_prefix_u64(x.tp1), wave_prefix_u64(x.tot), wave_prefix_u64(x.bp)};
 }
 
 // phase A: per-chunk totals

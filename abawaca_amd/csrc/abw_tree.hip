@@ -107,9 +107,7 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
 __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long long v, unsigned long long* sh, unsigned long long* total)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    unsigned long long x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    const unsigned long long x = wave_prefix_u64(v);
     __syncthreads();
     if (lane == 63) sh[wid] = x;
     __syncthreads();
@@ -548,9 +546,7 @@ __device__ __forceinline__ void load_scaf_bytes(const uint8_t* __restrict__ tab,
 __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* sh)          // sh: 4 words
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint32_t x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    const uint32_t x = wave_prefix_u32(v);
     __syncthreads();
     if (lane == 63) sh[wid] = x;
     __syncthreads();
@@ -610,18 +606,15 @@ __global__ __launch_bounds__(64) void tree_wide_scan_kernel(const NodeDev* __res
     const WSums4* __restrict__ in = raw + (int64_t)w * rstride;
     WSums4* ts = tile_sums + (int64_t)w * n_tiles;
     WSums4 run = {0, 0, 0, 0};
+    const WSums4 none = {0, 0, 0, 0};
+    WSums4 nxt = (nd.ptile_begin + lane < nd.ptile_end) ? in[nd.ptile_begin + lane] : none;      // the next 64 tiles are on their way during the scan
     for (int i0 = nd.ptile_begin; i0 < nd.ptile_end; i0 += 64) {
         const int i = i0 + lane;
-        WSums4 v = {0, 0, 0, 0};
-        if (i < nd.ptile_end) v = in[i];
-        WSums4 x = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long z = __shfl_up(x.size, o, 64), a = __shfl_up(x.tp1, o, 64), b = __shfl_up(x.tot, o, 64), c = __shfl_up(x.bp, o, 64);
-            if (lane >= o) { x.size += z; x.tp1 += a; x.tot += b; x.bp += c; }
-        }
+        const WSums4 v = nxt;
+        nxt = (i + 64 < nd.ptile_end) ? in[i + 64] : none;
+        const WSums4 x = {wave_prefix_u64(v.size), wave_prefix_u64(v.tp1), wave_prefix_u64(v.tot), wave_prefix_u64(v.bp)};
         if (i < nd.ptile_end) ts[i] = WSums4{run.size + x.size - v.size, run.tp1 + x.tp1 - v.tp1, run.tot + x.tot - v.tot, run.bp + x.bp - v.bp};
-        run.size += __shfl(x.size, 63, 64); run.tp1 += __shfl(x.tp1, 63, 64); run.tot += __shfl(x.tot, 63, 64); run.bp += __shfl(x.bp, 63, 64);
+        run.size += wave_last_u64(x.size); run.tp1 += wave_last_u64(x.tp1); run.tot += wave_last_u64(x.tot); run.bp += wave_last_u64(x.bp);
     }
     if (lane == 0) node_total[(int64_t)w * K + k] = run;
 }
@@ -911,18 +904,15 @@ __global__ __launch_bounds__(64) void node_wide_scan_kernel(int32_t n_tiles, WSu
     const int w = blockIdx.x, lane = threadIdx.x;
     WSums4* ts = tile_sums + (int64_t)w * n_tiles;
     WSums4 run = {0, 0, 0, 0};
+    const WSums4 none = {0, 0, 0, 0};
+    WSums4 nxt = (lane < n_tiles) ? ts[lane] : none;          // the next 64 tiles are on their way during the scan (they lie behind what this turn writes)
     for (int i0 = 0; i0 < n_tiles; i0 += 64) {
         const int i = i0 + lane;
-        WSums4 v = {0, 0, 0, 0};
-        if (i < n_tiles) v = ts[i];
-        WSums4 x = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long a = __shfl_up(x.size, o, 64), b = __shfl_up(x.tp1, o, 64), c = __shfl_up(x.tot, o, 64), e = __shfl_up(x.bp, o, 64);
-            if (lane >= o) { x.size += a; x.tp1 += b; x.tot += c; x.bp += e; }
-        }
+        const WSums4 v = nxt;
+        nxt = (i + 64 < n_tiles) ? ts[i + 64] : none;
+        const WSums4 x = {wave_prefix_u64(v.size), wave_prefix_u64(v.tp1), wave_prefix_u64(v.tot), wave_prefix_u64(v.bp)};
         if (i < n_tiles) ts[i] = WSums4{run.size + x.size - v.size, run.tp1 + x.tp1 - v.tp1, run.tot + x.tot - v.tot, run.bp + x.bp - v.bp};
-        run.size += __shfl(x.size, 63, 64); run.tp1 += __shfl(x.tp1, 63, 64); run.tot += __shfl(x.tot, 63, 64); run.bp += __shfl(x.bp, 63, 64);
+        run.size += wave_last_u64(x.size); run.tp1 += wave_last_u64(x.tp1); run.tot += wave_last_u64(x.tot); run.bp += wave_last_u64(x.bp);
     }
     if (lane == 0) total[w] = run;
 }
@@ -1327,14 +1317,14 @@ __global__ __launch_bounds__(64) void tree_part_scan_kernel(const NodeDev* __res
     const int tb = scaf ? nd.stile_begin : nd.ptile_begin, te = scaf ? nd.stile_end : nd.ptile_end;
     unsigned long long* tc = tile_cnt + (int64_t)blockIdx.y * n_tiles;
     unsigned long long run = 0;
+    unsigned long long nxt = (tb + lane < te) ? tc[tb + lane] : 0;
     for (int i0 = tb; i0 < te; i0 += 64) {
         const int i = i0 + lane;
-        const unsigned long long v = (i < te) ? tc[i] : 0;
-        unsigned long long x = v;                              // both halves stay below 2^31: no carry between them
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        const unsigned long long v = nxt;
+        nxt = (i + 64 < te) ? tc[i + 64] : 0;
+        const unsigned long long x = wave_prefix_u64(v);       // both halves stay below 2^31: no carry between them
         if (i < te) tc[i] = run + x - v;
-        run += __shfl(x, 63, 64);
+        run += wave_last_u64(x);
     }
 }
 
