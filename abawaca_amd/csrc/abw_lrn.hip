@@ -606,51 +606,59 @@ __global__ __launch_bounds__(64 * WPB) void lrn_emit3_kernel(const int32_t* __re
 {
     extern __shared__ __align__(16) uint8_t emit3_lds[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const uint64_t bid = emit_ticket<WPB>(ctl);
-    const int64_t row = (int64_t)bid * WPB + wid;
-    uint8_t* lb = emit3_lds + (size_t)wid * row_stride;
-    uint32_t total = 0;
-    if (row < n_rows) {
-        const int32_t* r = milli + row * n_cols;
-        const uint64_t key = first_key + (uint64_t)row;
-        const int klen = key_len(key);
-        if (TEXT && lane == 0) { unsigned long long k = key; for (int i = klen - 1; i >= 0; i--) { lb[i] = (uint8_t)('0' + k % 10ull); k /= 10ull; } }
-        uint32_t carry = (uint32_t)klen;
-        for (int c0 = 0; c0 < n_cols; c0 += 64) {            // columns c0 .. c0+63, one per lane, in order
-            const int c = c0 + lane;
-            const int32_t k = (c < n_cols) ? r[c] : 0;
-            const uint32_t neg = k < 0, a = neg ? 0u - (uint32_t)k : (uint32_t)k;
-            const uint32_t q = a / 1000u, f = a - q * 1000u;                         // q < 2 147 484: seven digits
-            const uint32_t hi4 = q / 10000u, lo4 = q - hi4 * 10000u;
-            const uint64_t dig = (uint64_t)digits4(hi4) | (uint64_t)digits4(lo4) << 32;
-            const uint32_t lead = (uint32_t)__builtin_ctzll(dig | 1ull << 56) >> 3;
-            const uint64_t body = (dig + 0x3030303030303030ull) >> (8u * lead);
-            const uint32_t p = 1u + neg, at = p + 8u - lead;
-            const uint32_t len = (c < n_cols) ? at + 4u : 0u;
-            if (TEXT) {
-                const uint32_t incl = wave_incl_scan_dpp(len);
-                if (c < n_cols) {
-                    uint8_t* dst = lb + carry + incl - len;
-                    const uint64_t head = (uint64_t)(neg ? 0x2D09u : 0x09u) | body << (8u * p);
-                    const uint32_t h2 = (uint32_t)(body >> (64u - 8u * p)), h1 = (uint32_t)(head >> 32), h0 = (uint32_t)head;
-                    const uint32_t tail = (digits4(f) + 0x30303000u) | 0x2Eu;
-                    __builtin_memcpy(dst + 8, &h2, 4);
-                    asm volatile("" ::: "memory");           // four instructions, in this order: merged into wider stores, two
-                    __builtin_memcpy(dst + 4, &h1, 4);       // lanes would write the same byte in one instruction
-                    asm volatile("" ::: "memory");
-                    __builtin_memcpy(dst, &h0, 4);
-                    asm volatile("" ::: "memory");
-                    __builtin_memcpy(dst + at, &tail, 4);
+    // persistent workgroups (as many as the chip holds at once) take tile after tile by ticket: 25 000 workgroups of eight
+    // rows each were started slower than they finish -- on average fewer than six waves per CU were in flight (PMC)
+    const uint64_t nblk = ((uint64_t)n_rows + WPB - 1) / WPB;
+    for (;;) {
+        const uint64_t bid = emit_ticket<WPB>(ctl);
+        if (bid >= nblk) break;                               // uniform: every thread of the workgroup read the same ticket
+        const int64_t row = (int64_t)bid * WPB + wid;
+        uint8_t* lb = emit3_lds + (size_t)wid * row_stride;
+        uint32_t total = 0;
+        if (row < n_rows) {
+            const int32_t* r = milli + row * n_cols;
+            const uint64_t key = first_key + (uint64_t)row;
+            const int klen = key_len(key);
+            if (TEXT && lane == 0) { unsigned long long k = key; for (int i = klen - 1; i >= 0; i--) { lb[i] = (uint8_t)('0' + k % 10ull); k /= 10ull; } }
+            uint32_t carry = (uint32_t)klen;
+            for (int c0 = 0; c0 < n_cols; c0 += 64) {            // columns c0 .. c0+63, one per lane, in order
+                const int c = c0 + lane;
+                const int32_t k = (c < n_cols) ? r[c] : 0;
+                const uint32_t neg = k < 0, a = neg ? 0u - (uint32_t)k : (uint32_t)k;
+                const uint32_t q = a / 1000u, f = a - q * 1000u;                         // q < 2 147 484: seven digits
+                const uint32_t hi4 = q / 10000u, lo4 = q - hi4 * 10000u;
+                const uint64_t dig = (uint64_t)digits4(hi4) | (uint64_t)digits4(lo4) << 32;
+                const uint32_t lead = (uint32_t)__builtin_ctzll(dig | 1ull << 56) >> 3;
+                const uint64_t body = (dig + 0x3030303030303030ull) >> (8u * lead);
+                const uint32_t p = 1u + neg, at = p + 8u - lead;
+                const uint32_t len = (c < n_cols) ? at + 4u : 0u;
+                if (TEXT) {
+                    const uint32_t incl = wave_incl_scan_dpp(len);
+                    if (c < n_cols) {
+                        uint8_t* dst = lb + carry + incl - len;
+                        const uint64_t head = (uint64_t)(neg ? 0x2D09u : 0x09u) | body << (8u * p);
+                        const uint32_t h2 = (uint32_t)(body >> (64u - 8u * p)), h1 = (uint32_t)(head >> 32), h0 = (uint32_t)head;
+                        const uint32_t tail = (digits4(f) + 0x30303000u) | 0x2Eu;
+                        __builtin_memcpy(dst + 8, &h2, 4);
+                        asm volatile("" ::: "memory");           // four instructions, in this order: merged into wider stores, two
+                        __builtin_memcpy(dst + 4, &h1, 4);       // lanes would write the same byte in one instruction
+                        asm volatile("" ::: "memory");
+                        __builtin_memcpy(dst, &h0, 4);
+                        asm volatile("" ::: "memory");
+                        __builtin_memcpy(dst + at, &tail, 4);
+                    }
+                    carry += __shfl(incl, 63, 64);
+                } else {
+                    carry += wave_sum_dpp(len);
                 }
-                carry += __shfl(incl, 63, 64);
-            } else {
-                carry += wave_sum_dpp(len);
             }
+            if (TEXT && lane == 0) lb[carry] = '\n';
+            total = carry + 1u;
         }
-        if (TEXT && lane == 0) lb[carry] = '\n';
-        total = carry + 1u;
+        emit_place_and_store<WPB, TEXT>(bid, row, n_rows, total, lb, ctl, state, text, text_cap, nullptr);
+        if ((uint64_t)gridDim.x >= nblk) break;               // a workgroup per tile: no second ticket to learn that
     }
-    emit_place_and_store<WPB, TEXT>(bid, row, n_rows, total, lb, ctl, state, text, text_cap, nullptr);
+
 }
 
 // ROWMAJ: the table is the resident copy, [ld][n_cols] (a datapoint's values side by side: a row is one coalesced read
@@ -663,66 +671,74 @@ __global__ __launch_bounds__(64 * WPB) void lrn_emit6_kernel(const double* __res
 {
     extern __shared__ __align__(16) uint8_t emit6_lds[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const uint64_t bid = emit_ticket<WPB>(ctl);
-    const int64_t row = (int64_t)bid * WPB + wid;
-    uint8_t* lb = emit6_lds + (size_t)wid * row_stride;
-    uint32_t total = 0;
-    if (row < n_rows) {
-        int64_t dp = dps[row];
-        if (dp < 1 || dp > ld) { if (lane == 0) emit6_report(ctl, row, 1); dp = 1; }
-        const int klen = key_len((unsigned long long)dp);
-        if (TEXT && lane == 0) { unsigned long long k = (unsigned long long)dp; for (int i = klen - 1; i >= 0; i--) { lb[i] = (uint8_t)('0' + k % 10ull); k /= 10ull; } }
-        uint32_t carry = (uint32_t)klen;
-        for (int cb = 0; cb < n_cols; cb += 256) {           // four gathers in flight per lane
-            double vv[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int c = cb + 64 * u + lane; vv[u] = c < n_cols ? (ROWMAJ ? values[(dp - 1) * (int64_t)n_cols + c] : values[(int64_t)c * ld + dp - 1]) : 0.0; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int c0 = cb + 64 * u, c = c0 + lane;
-                if (c0 >= n_cols) break;
-                const Fix6 f = fix6_of(vv[u]);
-                if (f.bad) emit6_report(ctl, row, 2);
-                uint64_t ip = f.q / 1000000ull;
-                const uint32_t fr = (uint32_t)(f.q - ip * 1000000ull);
-                if (__ballot(ip >= 100000000ull) == 0) {
-                    // the usual wave: every |value| below 1e8.  No loop over the digits and no byte stores: the field
-                    // is put together in registers and leaves in four stores -- see field6_store for their order
-                    const Field6 fd = field6_of((uint32_t)ip, fr, f.neg);
-                    const uint32_t len = (c < n_cols) ? fd.len : 0u;
+    // persistent workgroups (as many as the chip holds at once) take tile after tile by ticket: 25 000 workgroups of eight
+    // rows each were started slower than they finish -- on average fewer than six waves per CU were in flight (PMC)
+    const uint64_t nblk = ((uint64_t)n_rows + WPB - 1) / WPB;
+    for (;;) {
+        const uint64_t bid = emit_ticket<WPB>(ctl);
+        if (bid >= nblk) break;                               // uniform: every thread of the workgroup read the same ticket
+        const int64_t row = (int64_t)bid * WPB + wid;
+        uint8_t* lb = emit6_lds + (size_t)wid * row_stride;
+        uint32_t total = 0;
+        if (row < n_rows) {
+            int64_t dp = dps[row];
+            if (dp < 1 || dp > ld) { if (lane == 0) emit6_report(ctl, row, 1); dp = 1; }
+            const int klen = key_len((unsigned long long)dp);
+            if (TEXT && lane == 0) { unsigned long long k = (unsigned long long)dp; for (int i = klen - 1; i >= 0; i--) { lb[i] = (uint8_t)('0' + k % 10ull); k /= 10ull; } }
+            uint32_t carry = (uint32_t)klen;
+            for (int cb = 0; cb < n_cols; cb += 256) {           // four gathers in flight per lane
+                double vv[4];
+    #pragma unroll
+                for (int u = 0; u < 4; u++) { const int c = cb + 64 * u + lane; vv[u] = c < n_cols ? (ROWMAJ ? values[(dp - 1) * (int64_t)n_cols + c] : values[(int64_t)c * ld + dp - 1]) : 0.0; }
+    #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int c0 = cb + 64 * u, c = c0 + lane;
+                    if (c0 >= n_cols) break;
+                    const Fix6 f = fix6_of(vv[u]);
+                    if (f.bad) emit6_report(ctl, row, 2);
+                    uint64_t ip = f.q / 1000000ull;
+                    const uint32_t fr = (uint32_t)(f.q - ip * 1000000ull);
+                    if (__ballot(ip >= 100000000ull) == 0) {
+                        // the usual wave: every |value| below 1e8.  No loop over the digits and no byte stores: the field
+                        // is put together in registers and leaves in four stores -- see field6_store for their order
+                        const Field6 fd = field6_of((uint32_t)ip, fr, f.neg);
+                        const uint32_t len = (c < n_cols) ? fd.len : 0u;
+                        if (TEXT) {
+                            const uint32_t incl = wave_incl_scan_dpp(len);
+                            if (c < n_cols) field6_store(lb + carry + incl - len, fd);
+                            carry += __shfl(incl, 63, 64);
+                        } else {
+                            carry += wave_sum_dpp(len);
+                        }
+                        continue;
+                    }
+                    const int nd = ip < 0x100000000ull ? dec_digits((uint32_t)ip) : dec_digits64(ip);
+                    const uint32_t len = (c < n_cols) ? 1u + f.neg + (uint32_t)nd + 7u : 0u;
                     if (TEXT) {
                         const uint32_t incl = wave_incl_scan_dpp(len);
-                        if (c < n_cols) field6_store(lb + carry + incl - len, fd);
+                        if (c < n_cols) {
+                            uint8_t* p = lb + carry + incl - len;
+                            uint32_t r6 = fr;
+                            *p++ = '\t';
+                            if (f.neg) *p++ = '-';
+                            for (int i = nd - 1; i >= 0; i--) { p[i] = (uint8_t)('0' + ip % 10ull); ip /= 10ull; }
+                            p += nd;
+                            *p++ = '.';
+                            for (int i = 5; i >= 0; i--) { p[i] = (uint8_t)('0' + r6 % 10u); r6 /= 10u; }
+                        }
                         carry += __shfl(incl, 63, 64);
                     } else {
                         carry += wave_sum_dpp(len);
                     }
-                    continue;
-                }
-                const int nd = ip < 0x100000000ull ? dec_digits((uint32_t)ip) : dec_digits64(ip);
-                const uint32_t len = (c < n_cols) ? 1u + f.neg + (uint32_t)nd + 7u : 0u;
-                if (TEXT) {
-                    const uint32_t incl = wave_incl_scan_dpp(len);
-                    if (c < n_cols) {
-                        uint8_t* p = lb + carry + incl - len;
-                        uint32_t r6 = fr;
-                        *p++ = '\t';
-                        if (f.neg) *p++ = '-';
-                        for (int i = nd - 1; i >= 0; i--) { p[i] = (uint8_t)('0' + ip % 10ull); ip /= 10ull; }
-                        p += nd;
-                        *p++ = '.';
-                        for (int i = 5; i >= 0; i--) { p[i] = (uint8_t)('0' + r6 % 10u); r6 /= 10u; }
-                    }
-                    carry += __shfl(incl, 63, 64);
-                } else {
-                    carry += wave_sum_dpp(len);
                 }
             }
+            if (TEXT && lane == 0) lb[carry] = '\n';
+            total = carry + 1u;
         }
-        if (TEXT && lane == 0) lb[carry] = '\n';
-        total = carry + 1u;
+        emit_place_and_store<WPB, TEXT>(bid, row, n_rows, total, lb, ctl, state, text, text_cap, row_off);
+        if ((uint64_t)gridDim.x >= nblk) break;               // a workgroup per tile: no second ticket to learn that
     }
-    emit_place_and_store<WPB, TEXT>(bid, row, n_rows, total, lb, ctl, state, text, text_cap, row_off);
+
 }
 
 // [n_cols][ld] -> [ld][n_cols], 32 x 32 tiles through LDS (the resident copy of the cluster writer's table)
@@ -885,6 +901,13 @@ int abw_lrn_parse(abw_ctx* ctx, const uint8_t* text, uint64_t len, int64_t ndps,
     return ABW_OK;
 }
 
+// persistent workgroups of the writers: as many per CU as its 32 wave slots and its LDS hold
+static unsigned emit_wgs_per_cu(int wpb, uint32_t row_stride)
+{
+    const unsigned by_waves = 32u / (unsigned)wpb, by_lds = (unsigned)((160u * 1024u) / ((size_t)wpb * row_stride + 256));
+    return std::max(1u, std::min(by_waves, by_lds));
+}
+
 int abw_lrn_emit(abw_ctx* ctx, const int32_t* milli, int64_t n_rows, int32_t n_cols, uint64_t first_key,
                  uint8_t* text, uint64_t text_cap, uint64_t* text_len)
 {
@@ -904,6 +927,7 @@ int abw_lrn_emit(abw_ctx* ctx, const int32_t* milli, int64_t n_rows, int32_t n_c
     const int wpb = 8 * row_stride <= EMIT_LDS_MAX ? 8 : 4;
     const uint64_t nblk = ((uint64_t)n_rows + wpb - 1) / wpb;
     const size_t sb = (CTL_WORDS + (size_t)nblk) * 8;
+    const unsigned grid = (unsigned)std::min<uint64_t>(nblk, (uint64_t)ctx->num_cu * emit_wgs_per_cu(wpb, row_stride));
     const bool with_text = text && text_cap > 0;
     const uint64_t cap = with_text ? std::min<uint64_t>(text_cap, (uint64_t)n_rows * ((uint64_t)n_cols * 13 + 21)) : 0;
     if ((rc = abw_reserve(ctx, ctx->scratch[6], mb))) return rc;
@@ -916,7 +940,7 @@ int abw_lrn_emit(abw_ctx* ctx, const int32_t* milli, int64_t n_rows, int32_t n_c
     ABW_HIP(ctx, hipMemcpyAsync(d_milli, milli, mb, hipMemcpyHostToDevice, st));
     auto launch = [&](auto kern, size_t lds) -> int {
         if (lds > 65536) ABW_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, EMIT_LDS_MAX));
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * wpb), lds, st, (const int32_t*)d_milli, n_rows, n_cols, first_key, row_stride, ctl, state, d_text, cap);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpb), lds, st, (const int32_t*)d_milli, n_rows, n_cols, first_key, row_stride, ctl, state, d_text, cap);
         return ABW_OK;
     };
     {
@@ -959,13 +983,14 @@ static int emit_rows_core(abw_ctx* ctx, const double* d_values, bool row_major, 
     const int wpb = 8 * row_stride <= EMIT_LDS_MAX ? 8 : 4;
     const uint64_t nblk = ((uint64_t)n_rows + wpb - 1) / wpb;
     const size_t sb = (CTL_WORDS + (size_t)nblk) * 8;
+    const unsigned grid = (unsigned)std::min<uint64_t>(nblk, (uint64_t)ctx->num_cu * emit_wgs_per_cu(wpb, row_stride));
     if ((rc = abw_reserve(ctx, ctx->scratch[4], sb))) return rc;
     unsigned long long* ctl = (unsigned long long*)ctx->scratch[4].p;
     unsigned long long* state = ctl + CTL_WORDS;
     const bool with_text = d_text && text_cap > 0;
     auto launch = [&](auto kern, size_t lds) -> int {
         if (lds > 65536) ABW_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, EMIT_LDS_MAX));
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * wpb), lds, st, d_values, ld, n_cols, d_dps, n_rows,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpb), lds, st, d_values, ld, n_cols, d_dps, n_rows,
                            row_stride, ctl, state, with_text ? d_text : (uint8_t*)nullptr, with_text ? text_cap : (uint64_t)0, d_row_off);
         return ABW_OK;
     };
