@@ -158,3 +158,36 @@ struct abw_device_guard {
 // abw_km_b3.hip: the k-means step on three bf16 planes; 1 = launched on ctx->stream, 0 = no such kernel for this shape
 int abw_km_b3_has(int d, int Rp);
 int abw_km_step_b3(abw_ctx* ctx, const float* x, int64_t N, int d, const float* dT, int Rp, int chunk, int64_t nchunks, float* slabs);
+
+// ---- wave64 prefix sums in DPP steps (round 3) -------------------------------------------------------------------------
+// Rows of 16 lanes: shifts by 1, 2, 4, 8 (a lane without a source adds 0); then lane 15 of a row to the next row and lane 31
+// to the upper half.  Six moves and adds per 32 bits, where __shfl_up costs a trip through the LDS crossbar per step --
+// the one-wave scans of the recursion (tile sums of a node, partition counts) are chains of exactly these, and the
+// parsers and writers of the .lrn files take the field offsets of a row from them.  Every lane of the wave must be active.
+template <int CTRL, int ROWS, bool BOUND>
+__device__ __forceinline__ uint32_t dpp_from_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWS, 0xF, BOUND); }
+template <int CTRL, int ROWS, bool BOUND>
+__device__ __forceinline__ unsigned long long dpp_from_u64(unsigned long long x)
+{
+    return (unsigned long long)dpp_from_u32<CTRL, ROWS, BOUND>((uint32_t)(x >> 32)) << 32 | dpp_from_u32<CTRL, ROWS, BOUND>((uint32_t)x);
+}
+__device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t x)                     // inclusive
+{
+    x += dpp_from_u32<0x111, 0xF, true>(x); x += dpp_from_u32<0x112, 0xF, true>(x); x += dpp_from_u32<0x114, 0xF, true>(x);
+    x += dpp_from_u32<0x118, 0xF, true>(x); x += dpp_from_u32<0x142, 0xA, false>(x); x += dpp_from_u32<0x143, 0xC, false>(x);
+    return x;
+}
+__device__ __forceinline__ unsigned long long wave_prefix_u64(unsigned long long x)   // inclusive
+{
+    x += dpp_from_u64<0x111, 0xF, true>(x); x += dpp_from_u64<0x112, 0xF, true>(x); x += dpp_from_u64<0x114, 0xF, true>(x);
+    x += dpp_from_u64<0x118, 0xF, true>(x); x += dpp_from_u64<0x142, 0xA, false>(x); x += dpp_from_u64<0x143, 0xC, false>(x);
+    return x;
+}
+__device__ __forceinline__ unsigned long long wave_last_u64(unsigned long long x)     // lane 63's value, wave-uniform
+{
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 63) << 32 | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63);
+}
+__device__ __forceinline__ uint32_t wave_last_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, 63); }
+// the value of the lane above / below (the last / first lane keeps its own, as __shfl_down / __shfl_up by one do)
+__device__ __forceinline__ uint32_t lane_above(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x130, 0xF, 0xF, false); }   // wave_shl:1
+__device__ __forceinline__ uint32_t lane_below(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x138, 0xF, 0xF, false); }   // wave_shr:1

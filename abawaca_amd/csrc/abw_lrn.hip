@@ -58,23 +58,10 @@ __device__ __forceinline__ uint32_t eq_mask16(const uint8_t* __restrict__ p, uin
     return m;
 }
 
-// wave64 prefix sum in DPP steps (rows of 16: shifts by 1, 2, 4, 8; then lane 15 of a row to the next row, lane 31 to the
-// upper half) -- six adds, where six shuffles through the LDS crossbar cost five instructions each
-__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x)
-{
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
-    return x;
-}
-__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(x), 63); }
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x, int) { return wave_incl_scan_dpp(x); }
-// the value of the lane above / below (the last / first lane keeps its own, as __shfl_down / __shfl_up by one do)
-__device__ __forceinline__ uint32_t lane_above(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x130, 0xF, 0xF, false); }   // wave_shl:1
-__device__ __forceinline__ uint32_t lane_below(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x138, 0xF, 0xF, false); }   // wave_shr:1
+// (wave_prefix_u32 / wave_last_u32 / lane_above / lane_below: abw_internal.h)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x) { return wave_prefix_u32(x); }
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t x) { return wave_last_u32(wave_prefix_u32(x)); }
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x, int) { return wave_prefix_u32(x); }
 
 // per block: newlines, and the tabs after its last newline (all its tabs when it has none)
 __global__ __launch_bounds__(256) void lrn_nlcount_kernel(const uint8_t* __restrict__ text, uint64_t len, uint32_t* __restrict__ blk_nl,
